@@ -1,0 +1,746 @@
+"""CPU oracle: numpy/scipy fp64 restatement of BayBE's GP recommend() hot path.
+
+TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  PARITY UNPINNED (no botorch /
+gpytorch importable; no golden vectors in the reference's tests).
+
+What is restated, and the reference call site it follows
+---------------------------------------------------------
+* model assembly (Normalize over the numerical columns with the search-space
+  bounds, Standardize(m=1), ConstantMean, Matérn-5/2 ARD *without* outputscale,
+  Gamma(3, 2/e^{sqrt2-3}/sqrt(d)) lengthscale prior with box constraint
+  l >= 0.025, Gamma(2, e^5) noise prior with box constraint s2 >= 1e-4, MLL for one
+  task / LOO pseudo-likelihood for several):
+  ``baybe/surrogates/gaussian_process/core.py:272-341``,
+  ``baybe/surrogates/gaussian_process/presets/baybe.py:56-144,269-281``.
+* ICM task kernel  K((x,t),(x',t')) = k(x,x') * B[t,t'],  B = W W^T + diag(v):
+  ``presets/baybe.py:203-230``, ``components/kernel.py:298-337``,
+  ``baybe/kernels/basic.py:239-248``.
+* fit = scipy L-BFGS-B on -(objective/n) over the raw parameters with box bounds
+  for the un-transformed constraints (botorch.fit.fit_gpytorch_mll, call site
+  ``gaussian_process/core.py:340-341``).
+* exact Cholesky posterior, no observation noise, q-batch joint covariance
+  (botorch Model.posterior via ``surrogates/base.py:249-272``).
+* best_f = max_i objective(posterior mean at training x_i):
+  ``baybe/acquisition/_builder.py:141-161,256-265``.
+* qLogEI (fat=True, tau_relu=1e-6, tau_max=1e-2) with Sobol-normal base samples
+  shared by all candidates; minimisation = factor -1 on the samples:
+  ``baybe/acquisition/acqfs.py:219-223``, ``baybe/objectives/base.py:99-150``,
+  ``baybe/objectives/single.py:65-74``.
+* sequential-greedy optimize_acqf_discrete (chunks of 2048, first-index argmax,
+  unique=True, pending points appended after the candidate):
+  ``baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126``.
+
+[UPSTREAM] marks semantics recalled from botorch 0.16 / gpytorch 1.14 sources.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy import linalg as sla
+from scipy import optimize as sopt
+from scipy.special import gammaln
+
+SQRT3 = math.sqrt(3.0)
+SQRT5 = math.sqrt(5.0)
+TAU_RELU = 1e-6  # [UPSTREAM] botorch.acquisition.logei.TAU_RELU
+TAU_MAX = 1e-2  # [UPSTREAM] botorch.acquisition.logei.TAU_MAX
+FAT_ALPHA_PLUS = 0.1  # [UPSTREAM] botorch.utils.safe_math.fatplus alpha
+FAT_ALPHA_MAX = 2.0  # [UPSTREAM] botorch.utils.safe_math.fatmax alpha
+MIN_INFERRED_NOISE_LEVEL = 1e-4  # [UPSTREAM] botorch.models.utils.gpytorch_modules
+MAX_BATCH_SIZE = 2048  # [UPSTREAM] optimize_acqf_discrete(max_batch_size=2048)
+
+KERNELS = ("matern12", "matern32", "matern52", "rbf")
+
+
+# --------------------------------------------------------------------------------------
+# model specification (what BayBE's factories decide) and parameters (what the fit finds)
+# --------------------------------------------------------------------------------------
+@dataclass
+class GPSpec:
+    """Architecture + priors + constraints of one single-output GP.
+
+    ``baybe_default`` reproduces ``presets/baybe.py`` (the reference default).
+    """
+
+    d: int  # number of comp-rep columns (incl. the task column if any)
+    num_idx: np.ndarray  # numerical columns = kernel active dims = Normalize indices
+    lo: np.ndarray  # scaling bounds of the numerical columns (searchspace.scaling_bounds)
+    hi: np.ndarray
+    kernel: str = "matern52"
+    task_idx: int | None = None
+    n_tasks: int = 1
+    use_outputscale: bool = False  # ScaleKernel wrapper (user kernels); default preset: none
+    ls_constraint: str = "box"  # "box": l >= ls_lower, no transform | "softplus": Positive()
+    ls_lower: float = 2.5e-2
+    ls_prior: tuple | None = None  # ("gamma", concentration, rate)
+    ls_init: float | None = None
+    noise_lower: float = MIN_INFERRED_NOISE_LEVEL
+    noise_prior: tuple | None = None
+    noise_init: float | None = None
+    outputscale_prior: tuple | None = None
+    criterion: str = "mll"  # "mll" | "loo"
+
+    @property
+    def dn(self) -> int:
+        return len(self.num_idx)
+
+    @classmethod
+    def baybe_default(cls, d, lo, hi, task_idx=None, n_tasks=1, kernel="matern52"):
+        """The BAYBE preset (presets/baybe.py:56-144, 203-230, 269-281)."""
+        num_idx = np.array([i for i in range(d) if i != task_idx], dtype=np.int64)
+        dn = len(num_idx)
+        conc = 3.0
+        rate = (conc - 1.0) / math.exp(math.sqrt(2.0) - 3.0) / math.sqrt(dn)
+        nconc = 2.0
+        nrate = (nconc - 1.0) / math.exp(-4.0 - 1.0**2)
+        return cls(
+            d=d,
+            num_idx=num_idx,
+            lo=np.asarray(lo, dtype=np.float64)[num_idx] if len(lo) == d else np.asarray(lo, np.float64),
+            hi=np.asarray(hi, dtype=np.float64)[num_idx] if len(hi) == d else np.asarray(hi, np.float64),
+            kernel=kernel,
+            task_idx=task_idx,
+            n_tasks=n_tasks,
+            ls_prior=("gamma", conc, rate),
+            ls_init=(conc - 1.0) / rate,  # prior mode (presets/baybe.py:100-105)
+            noise_prior=("gamma", nconc, nrate),
+            noise_init=(nconc - 1.0) / nrate,  # prior mode (presets/baybe.py:134-142)
+            criterion="mll" if n_tasks == 1 else "loo",
+        )
+
+
+@dataclass
+class GPParams:
+    """Natural (constrained) hyper-parameters of the standardised/normalised GP."""
+
+    lengthscale: np.ndarray  # [dn]
+    noise: float
+    mean: float = 0.0
+    outputscale: float = 1.0
+    task_W: np.ndarray | None = None  # [T, R]
+    task_v: np.ndarray | None = None  # [T]
+
+    def task_B(self) -> np.ndarray | None:
+        if self.task_W is None:
+            return None
+        return self.task_W @ self.task_W.T + np.diag(self.task_v)
+
+    def copy(self) -> "GPParams":
+        return GPParams(
+            self.lengthscale.copy(),
+            float(self.noise),
+            float(self.mean),
+            float(self.outputscale),
+            None if self.task_W is None else self.task_W.copy(),
+            None if self.task_v is None else self.task_v.copy(),
+        )
+
+
+def softplus(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > 20.0, x, np.log1p(np.exp(np.minimum(x, 20.0))))
+
+
+def inv_softplus(y):
+    y = np.asarray(y, dtype=np.float64)
+    return np.where(y > 20.0, y, np.log(np.expm1(np.minimum(y, 20.0))))
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))
+
+
+def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
+    """Initial values: prior modes for the default preset (presets/baybe.py:100-105,
+    134-142); softplus(0) for Positive()-constrained user kernels [UPSTREAM].
+
+    Task factors: gpytorch draws raw W/v randomly; the oracle (and the HIP path)
+    use a deterministic start (W = task_init * ones, v = softplus(0)) — documented
+    deviation, unpinned.
+    """
+    ls0 = spec.ls_init if spec.ls_init is not None else float(softplus(0.0))
+    nz0 = spec.noise_init if spec.noise_init is not None else 1e-2
+    p = GPParams(
+        lengthscale=np.full(spec.dn, ls0, dtype=np.float64),
+        noise=nz0,
+        mean=0.0,
+        outputscale=float(softplus(0.0)) if spec.use_outputscale else 1.0,
+    )
+    if spec.n_tasks > 1:
+        T = spec.n_tasks
+        p.task_W = np.full((T, T), task_init / math.sqrt(T), dtype=np.float64)
+        p.task_v = np.full(T, float(softplus(0.0)), dtype=np.float64)
+    return p
+
+
+# --------------------------------------------------------------------------------------
+# transforms
+# --------------------------------------------------------------------------------------
+def normalize_inputs(spec: GPSpec, X: np.ndarray) -> np.ndarray:
+    """botorch Normalize(d, bounds, indices) [UPSTREAM A1]; task column untouched."""
+    Xn = np.array(X, dtype=np.float64, copy=True)
+    Xn[:, spec.num_idx] = (Xn[:, spec.num_idx] - spec.lo) / (spec.hi - spec.lo)
+    return Xn
+
+
+def standardize_targets(y: np.ndarray) -> tuple[np.ndarray, float, float]:
+    """botorch Standardize(m=1) [UPSTREAM A2]: Bessel std, std<1e-8 -> 1."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    ybar = float(y.mean())
+    s = float(y.std(ddof=1)) if y.size > 1 else float("nan")
+    if not (s >= 1e-8):
+        s = 1.0
+    return (y - ybar) / s, ybar, s
+
+
+# --------------------------------------------------------------------------------------
+# kernels
+# --------------------------------------------------------------------------------------
+def _scaled_sqdist(XA: np.ndarray, XB: np.ndarray, ls: np.ndarray) -> np.ndarray:
+    A = XA / ls
+    B = XB / ls
+    # direct differences (most accurate form); r^2 >= 0 by construction
+    d2 = np.zeros((A.shape[0], B.shape[0]), dtype=np.float64)
+    for j in range(A.shape[1]):
+        diff = A[:, j : j + 1] - B[None, :, j]
+        d2 += diff * diff
+    return d2
+
+
+def base_kernel_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
+    """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2."""
+    if kernel == "rbf":
+        return np.exp(-0.5 * r2)
+    r = np.sqrt(r2)
+    if kernel == "matern52":
+        return (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * np.exp(-SQRT5 * r)
+    if kernel == "matern32":
+        return (1.0 + SQRT3 * r) * np.exp(-SQRT3 * r)
+    if kernel == "matern12":
+        return np.exp(-r)
+    raise ValueError(kernel)
+
+
+def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
+    """g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3."""
+    if kernel == "rbf":
+        return np.exp(-0.5 * r2)
+    r = np.sqrt(r2)
+    if kernel == "matern52":
+        return (5.0 / 3.0) * (1.0 + SQRT5 * r) * np.exp(-SQRT5 * r)
+    if kernel == "matern32":
+        return 3.0 * np.exp(-SQRT3 * r)
+    if kernel == "matern12":
+        with np.errstate(divide="ignore", invalid="ignore"):
+            g = np.where(r > 0, np.exp(-r) / r, 0.0)
+        return g
+    raise ValueError(kernel)
+
+
+def cross_cov(spec: GPSpec, p: GPParams, XAn: np.ndarray, XBn: np.ndarray) -> np.ndarray:
+    """K(XA, XB) on *normalised* inputs, incl. outputscale and task factor."""
+    r2 = _scaled_sqdist(XAn[:, spec.num_idx], XBn[:, spec.num_idx], p.lengthscale)
+    K = base_kernel_from_r2(spec.kernel, r2)
+    if spec.use_outputscale:
+        K = K * p.outputscale
+    if spec.task_idx is not None:
+        B = p.task_B()
+        ta = XAn[:, spec.task_idx].astype(np.int64)
+        tb = XBn[:, spec.task_idx].astype(np.int64)
+        K = K * B[np.ix_(ta, tb)]
+    return K
+
+
+def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
+    """k(x,x) for each row (1 * outputscale * B[t,t])."""
+    v = np.full(Xn.shape[0], p.outputscale if spec.use_outputscale else 1.0)
+    if spec.task_idx is not None:
+        B = p.task_B()
+        t = Xn[:, spec.task_idx].astype(np.int64)
+        v = v * B[t, t]
+    return v
+
+
+# --------------------------------------------------------------------------------------
+# priors
+# --------------------------------------------------------------------------------------
+def _prior_logp_and_grad(prior, x: np.ndarray) -> tuple[float, np.ndarray]:
+    """sum log p(x) and d/dx; gpytorch GammaPrior / LogNormalPrior [UPSTREAM]."""
+    x = np.asarray(x, dtype=np.float64)
+    if prior is None:
+        return 0.0, np.zeros_like(x)
+    kind = prior[0]
+    if kind == "gamma":
+        _, c, r = prior
+        lp = c * math.log(r) + (c - 1.0) * np.log(x) - r * x - gammaln(c)
+        return float(lp.sum()), (c - 1.0) / x - r
+    if kind == "lognormal":
+        _, mu, sd = prior
+        lx = np.log(x)
+        lp = -lx - math.log(sd) - 0.5 * math.log(2 * math.pi) - 0.5 * ((lx - mu) / sd) ** 2
+        return float(lp.sum()), (-1.0 - (lx - mu) / sd**2) / x
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------------------
+# fit objective: data term (this is what the device computes) + priors (host)
+# --------------------------------------------------------------------------------------
+@dataclass
+class DataTerm:
+    value: float  # log-likelihood (mll) or LOO sum incl. the -n/2 log(2pi) constant
+    g_ls: np.ndarray
+    g_noise: float
+    g_mean: float
+    g_outputscale: float
+    g_task_B: np.ndarray | None  # dL/dB[t,t'] (symmetric accumulation S)
+
+
+def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> DataTerm:
+    """Value + analytic gradient of the data-fit term w.r.t. natural parameters.
+
+    mll:  log N(y | c 1, K + s2 I)                      [UPSTREAM A5, gpytorch ExactMLL]
+    loo:  sum_i log N(y_i | mu_-i, s2_-i)               [UPSTREAM A5, gpytorch LOO-PL]
+    Gradient:  dL/dtheta = sum_ab G_ab dK_ab/dtheta  with
+      mll: G = 0.5 (alpha alpha^T - M),  M = (K + s2 I)^-1
+      loo: G = sym(-M diag(u) M + alpha (M w)^T),  u = 0.5/d + 0.5 alpha^2/d^2,
+           w = alpha/d,  d = diag(M).
+    """
+    n = Xn.shape[0]
+    Kf = cross_cov(spec, p, Xn, Xn)
+    Ky = Kf + p.noise * np.eye(n)
+    L = sla.cholesky(Ky, lower=True)
+    r = ystd - p.mean
+    alpha = sla.cho_solve((L, True), r)
+    Linv = sla.solve_triangular(L, np.eye(n), lower=True)
+    M = Linv.T @ Linv
+    if spec.criterion == "mll":
+        value = -0.5 * float(r @ alpha) - float(np.log(np.diag(L)).sum()) - 0.5 * n * math.log(2 * math.pi)
+        G = 0.5 * (np.outer(alpha, alpha) - M)
+        g_mean = float(alpha.sum())
+    elif spec.criterion == "loo":
+        dg = np.diag(M)
+        value = float((0.5 * np.log(dg) - 0.5 * alpha**2 / dg).sum()) - 0.5 * n * math.log(2 * math.pi)
+        u = 0.5 / dg + 0.5 * alpha**2 / dg**2
+        w = alpha / dg
+        Mw = M @ w
+        G = -(M * u[None, :]) @ M + np.outer(alpha, Mw)
+        G = 0.5 * (G + G.T)
+        g_mean = float(w @ M.sum(axis=1))
+    else:
+        raise ValueError(spec.criterion)
+
+    # kernel-parameter gradients through G
+    Xs = Xn[:, spec.num_idx]
+    r2 = _scaled_sqdist(Xs, Xs, p.lengthscale)
+    gfac = base_kernel_gfac_from_r2(spec.kernel, r2)
+    scale = np.full((n, n), p.outputscale if spec.use_outputscale else 1.0)
+    Bsel = None
+    if spec.task_idx is not None:
+        B = p.task_B()
+        t = Xn[:, spec.task_idx].astype(np.int64)
+        Bsel = B[np.ix_(t, t)]
+        scale = scale * Bsel
+    GW = G * gfac * scale
+    g_ls = np.empty(spec.dn)
+    for j in range(spec.dn):
+        diff = Xs[:, j : j + 1] - Xs[None, :, j]
+        g_ls[j] = float((GW * diff * diff).sum()) / p.lengthscale[j] ** 3
+    g_noise = float(np.trace(G))
+    g_os = float((G * Kf).sum()) / p.outputscale if spec.use_outputscale else 0.0
+    g_B = None
+    if spec.task_idx is not None:
+        kb = base_kernel_from_r2(spec.kernel, r2) * (p.outputscale if spec.use_outputscale else 1.0)
+        T = spec.n_tasks
+        onehot = np.zeros((n, T))
+        onehot[np.arange(n), t] = 1.0
+        g_B = onehot.T @ (G * kb) @ onehot
+    return DataTerm(value, g_ls, g_noise, g_mean, g_os, g_B)
+
+
+# ---- raw <-> natural packing (order = mll.named_parameters(): noise, mean, kernel) ----
+def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
+    parts = [np.array([p.noise]), np.array([p.mean])]
+    if spec.use_outputscale:
+        parts.append(inv_softplus(np.array([p.outputscale])))
+    parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
+    if spec.n_tasks > 1:
+        parts.append(inv_softplus(p.task_W).reshape(-1))
+        parts.append(inv_softplus(p.task_v))
+    return np.concatenate(parts).astype(np.float64)
+
+
+def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
+    raw = np.asarray(raw, dtype=np.float64)
+    i = 0
+    noise = float(raw[i]); i += 1
+    mean = float(raw[i]); i += 1
+    os_ = 1.0
+    if spec.use_outputscale:
+        os_ = float(softplus(raw[i])); i += 1
+    ls_raw = raw[i : i + spec.dn]; i += spec.dn
+    ls = ls_raw.copy() if spec.ls_constraint == "box" else softplus(ls_raw)
+    W = v = None
+    if spec.n_tasks > 1:
+        T = spec.n_tasks
+        W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
+        v = softplus(raw[i : i + T]); i += T
+    return GPParams(ls, noise, mean, os_, W, v)
+
+
+def raw_bounds(spec: GPSpec) -> list[tuple[float | None, float | None]]:
+    """L-BFGS-B bounds: only constraints with transform=None become bounds [UPSTREAM A6]."""
+    b: list[tuple[float | None, float | None]] = [(spec.noise_lower, None), (None, None)]
+    if spec.use_outputscale:
+        b.append((None, None))
+    b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
+    if spec.n_tasks > 1:
+        b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
+    return b
+
+
+def fit_objective(spec: GPSpec, raw: np.ndarray, Xn: np.ndarray, ystd: np.ndarray, data_term_fn=data_term):
+    """-(data term + log priors)/n and its gradient w.r.t. the raw vector.
+
+    gpytorch: ``res = output.log_prob(target); res += sum(prior.log_prob); res / n``.
+    """
+    p = unpack_raw(spec, raw)
+    n = Xn.shape[0]
+    dt = data_term_fn(spec, p, Xn, ystd)
+    lp_ls, glp_ls = _prior_logp_and_grad(spec.ls_prior, p.lengthscale)
+    lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.array([p.noise]))
+    lp_os, glp_os = (0.0, np.zeros(1))
+    if spec.use_outputscale:
+        lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
+    total = dt.value + lp_ls + lp_nz + lp_os
+    g = [np.array([dt.g_noise + glp_nz[0]]), np.array([dt.g_mean])]
+    i = 2
+    if spec.use_outputscale:
+        g.append(np.array([(dt.g_outputscale + glp_os[0]) * float(sigmoid(raw[i]))]))
+        i += 1
+    g_ls = dt.g_ls + glp_ls
+    if spec.ls_constraint != "box":
+        g_ls = g_ls * sigmoid(raw[i : i + spec.dn])
+    g.append(g_ls)
+    i += spec.dn
+    if spec.n_tasks > 1:
+        T = spec.n_tasks
+        S = dt.g_task_B
+        gW = (S + S.T) @ p.task_W
+        g.append((gW * sigmoid(raw[i : i + T * T]).reshape(T, T)).reshape(-1))
+        i += T * T
+        g.append(np.diag(S) * sigmoid(raw[i : i + T]))
+    grad = np.concatenate(g)
+    return -total / n, -grad / n
+
+
+@dataclass
+class FitResult:
+    params: GPParams
+    fun: float
+    nit: int
+    nfev: int
+    status: int
+    message: str
+
+
+def fit_hyperparameters(
+    spec: GPSpec,
+    Xn: np.ndarray,
+    ystd: np.ndarray,
+    p0: GPParams | None = None,
+    data_term_fn=data_term,
+    maxiter: int = 15000,
+) -> FitResult:
+    """botorch.fit.fit_gpytorch_mll -> scipy L-BFGS-B with scipy defaults [UPSTREAM A6]."""
+    p0 = p0 or initial_params(spec)
+    x0 = pack_raw(spec, p0)
+    bounds = raw_bounds(spec)
+
+    def fun(raw):
+        try:
+            return fit_objective(spec, raw, Xn, ystd, data_term_fn)
+        except (np.linalg.LinAlgError, sla.LinAlgError, FloatingPointError):
+            return float("inf"), np.zeros_like(raw)
+
+    res = sopt.minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": maxiter})
+    return FitResult(unpack_raw(spec, res.x), float(res.fun), int(res.nit), int(res.nfev), int(res.status), str(res.message))
+
+
+# --------------------------------------------------------------------------------------
+# fitted model: exact Cholesky posterior
+# --------------------------------------------------------------------------------------
+@dataclass
+class GPModel:
+    spec: GPSpec
+    params: GPParams
+    X_train: np.ndarray  # raw comp-rep rows [n, d]
+    y_train: np.ndarray  # raw targets [n]
+    # derived
+    Xn: np.ndarray = field(init=False)
+    ystd: np.ndarray = field(init=False)
+    ybar: float = field(init=False)
+    ysd: float = field(init=False)
+    L: np.ndarray = field(init=False)
+    alpha: np.ndarray = field(init=False)
+    jitter: float = field(init=False, default=0.0)
+
+    def __post_init__(self):
+        self.X_train = np.ascontiguousarray(self.X_train, dtype=np.float64)
+        self.Xn = normalize_inputs(self.spec, self.X_train)
+        self.ystd, self.ybar, self.ysd = standardize_targets(self.y_train)
+        n = self.Xn.shape[0]
+        Ky = cross_cov(self.spec, self.params, self.Xn, self.Xn) + self.params.noise * np.eye(n)
+        # gpytorch psd_safe_cholesky: retry with jitter 1e-8 * 10^i [UPSTREAM A7]
+        jit = 0.0
+        for attempt in range(4):
+            try:
+                self.L = sla.cholesky(Ky + jit * np.eye(n), lower=True)
+                break
+            except sla.LinAlgError:
+                jit = 1e-8 * 10**attempt
+        else:
+            raise sla.LinAlgError("train covariance not PD even with jitter")
+        self.jitter = jit
+        self.alpha = sla.cho_solve((self.L, True), self.ystd - self.params.mean)
+
+    # posterior of standardised GP at normalised inputs
+    def _std_posterior(self, Xc: np.ndarray, joint: bool):
+        Xcn = normalize_inputs(self.spec, np.atleast_2d(Xc))
+        Ks = cross_cov(self.spec, self.params, Xcn, self.Xn)  # [N, n]
+        mu = self.params.mean + Ks @ self.alpha
+        V = sla.solve_triangular(self.L, Ks.T, lower=True)  # [n, N]
+        if joint:
+            Kss = cross_cov(self.spec, self.params, Xcn, Xcn)
+            return mu, Kss - V.T @ V
+        return mu, prior_var(self.spec, self.params, Xcn) - (V * V).sum(axis=0)
+
+    def posterior(self, Xc: np.ndarray, chunk: int = 8192) -> tuple[np.ndarray, np.ndarray]:
+        """Marginal posterior mean/variance (original target scale), t-batch of q=1."""
+        Xc = np.atleast_2d(np.asarray(Xc, dtype=np.float64))
+        mus, vs = [], []
+        for s in range(0, Xc.shape[0], chunk):
+            mu, v = self._std_posterior(Xc[s : s + chunk], joint=False)
+            mus.append(self.ybar + self.ysd * mu)
+            vs.append(self.ysd**2 * v)
+        return np.concatenate(mus), np.concatenate(vs)
+
+    def posterior_joint(self, Xq: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        mu, cov = self._std_posterior(Xq, joint=True)
+        return self.ybar + self.ysd * mu, self.ysd**2 * cov
+
+
+def fit_gp(spec: GPSpec, X_train, y_train, params: GPParams | None = None, p0: GPParams | None = None) -> GPModel:
+    """Fit (or, with ``params`` given, just factorise) a GP on raw data."""
+    X_train = np.ascontiguousarray(X_train, dtype=np.float64)
+    if params is None:
+        Xn = normalize_inputs(spec, X_train)
+        ystd, _, _ = standardize_targets(y_train)
+        params = fit_hyperparameters(spec, Xn, ystd, p0).params
+    return GPModel(spec, params, X_train, np.asarray(y_train, dtype=np.float64).reshape(-1))
+
+
+# --------------------------------------------------------------------------------------
+# MC acquisition: qLogEI
+# --------------------------------------------------------------------------------------
+def sobol_normal_base_samples(S: int, q: int, seed: int) -> np.ndarray:
+    """botorch SobolQMCNormalSampler base samples [UPSTREAM A8]; uses torch's SobolEngine.
+
+    z = sqrt(2) erfinv(2 v - 1),  v = 0.5 + (1 - eps)(u - 0.5),  u ~ scrambled Sobol(q, seed).
+    Returns [S, q] float64.
+    """
+    import torch
+
+    eng = torch.quasirandom.SobolEngine(dimension=q, scramble=True, seed=int(seed))
+    u = eng.draw(S, dtype=torch.float64)
+    v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
+    z = torch.erfinv(2 * v - 1) * math.sqrt(2)
+    return z.numpy().copy()
+
+
+def draw_sampler_seed() -> int:
+    """MCSampler seed when none is given: torch.randint(0, 1000000, (1,)) [UPSTREAM A8]."""
+    import torch
+
+    return int(torch.randint(0, 1000000, (1,)).item())
+
+
+def log_fatplus(x: np.ndarray, tau: float = TAU_RELU) -> np.ndarray:
+    """log(tau * (softplus(x/tau) + 0.1 / (1 + (x/tau)^2)))  [UPSTREAM A9, safe_math.fatplus]."""
+    t = np.asarray(x, dtype=np.float64) / tau
+    return math.log(tau) + np.log(softplus(t) + FAT_ALPHA_PLUS / (1.0 + t * t))
+
+
+def fatmax(x: np.ndarray, tau: float = TAU_MAX, alpha: float = FAT_ALPHA_MAX, axis: int = -1) -> np.ndarray:
+    """M + tau log sum_j (alpha / (alpha + (M - x_j)/tau))^alpha  [UPSTREAM A9, safe_math.fatmax]."""
+    M = x.max(axis=axis, keepdims=True)
+    s = ((alpha / (alpha + (M - x) / tau)) ** alpha).sum(axis=axis)
+    return np.squeeze(M, axis=axis) + tau * np.log(s)
+
+
+def logmeanexp(x: np.ndarray, axis: int = 0) -> np.ndarray:
+    M = x.max(axis=axis, keepdims=True)
+    return np.squeeze(M, axis=axis) + np.log(np.exp(x - M).mean(axis=axis))
+
+
+def _safe_sqrt_var(v: np.ndarray) -> np.ndarray:
+    """1x1 psd_safe_cholesky: v <= 0 -> add jitter 1e-8, 1e-7, 1e-6 [UPSTREAM A7]."""
+    v = np.asarray(v, dtype=np.float64).copy()
+    for attempt in range(3):
+        bad = ~(v > 0)
+        if not bad.any():
+            break
+        v = np.where(bad, v + 1e-8 * 10**attempt, v)
+    return np.sqrt(np.maximum(v, 0.0))
+
+
+def qlogei_q1(mu: np.ndarray, var: np.ndarray, z: np.ndarray, best_f: float, sign: float = 1.0) -> np.ndarray:
+    """qLogEI of N independent q=1 candidates; z [S] shared base samples."""
+    sd = _safe_sqrt_var(var)
+    obj = sign * (mu[None, :] + sd[None, :] * z.reshape(-1, 1))  # [S, N]
+    li = log_fatplus(obj - best_f)
+    return logmeanexp(li, axis=0)
+
+
+def _safe_cholesky(A: np.ndarray) -> np.ndarray:
+    jit = 0.0
+    for attempt in range(4):
+        try:
+            return sla.cholesky(A + jit * np.eye(A.shape[0]), lower=True)
+        except sla.LinAlgError:
+            jit = 1e-8 * 10**attempt
+    raise sla.LinAlgError("q-batch covariance not PD")
+
+
+def qlogei_joint(mean: np.ndarray, cov: np.ndarray, z: np.ndarray, best_f: float, sign: float = 1.0) -> float:
+    """qLogEI of one q'-batch; z [S, q'] [UPSTREAM A9]."""
+    Lq = _safe_cholesky(cov)
+    samples = mean[None, :] + z @ Lq.T  # [S, q']
+    li = log_fatplus(sign * samples - best_f)
+    return float(logmeanexp(fatmax(li, axis=-1), axis=0))
+
+
+def qlogei_with_pending(
+    model: GPModel, Xc: np.ndarray, pend: np.ndarray, z: np.ndarray, best_f: float, sign: float = 1.0
+) -> np.ndarray:
+    """Vectorised qLogEI of N t-batches [x_i ; pend] (candidate first, then pending).
+
+    Same maths as ``qlogei_joint`` on ``posterior_joint(vstack([x_i, pend]))``; the
+    (1+p)x(1+p) Cholesky is done in block form: l11 = sqrt(var_x), l_P1 = c_xP/l11,
+    L_S = chol(Sigma_PP - l_P1 l_P1^T).
+    """
+    spec, prm = model.spec, model.params
+    Xcn = normalize_inputs(spec, np.atleast_2d(Xc))
+    Pn = normalize_inputs(spec, np.atleast_2d(pend))
+    N, p = Xcn.shape[0], Pn.shape[0]
+    Ks = cross_cov(spec, prm, Xcn, model.Xn)
+    Kp = cross_cov(spec, prm, Pn, model.Xn)
+    Vc = sla.solve_triangular(model.L, Ks.T, lower=True)  # [n, N]
+    Vp = sla.solve_triangular(model.L, Kp.T, lower=True)  # [n, p]
+    s2 = model.ysd**2
+    mu_c = model.ybar + model.ysd * (prm.mean + Ks @ model.alpha)
+    mu_p = model.ybar + model.ysd * (prm.mean + Kp @ model.alpha)
+    var_c = s2 * (prior_var(spec, prm, Xcn) - (Vc * Vc).sum(axis=0))
+    cross = s2 * (cross_cov(spec, prm, Xcn, Pn) - Vc.T @ Vp)  # [N, p]
+    cov_pp = s2 * (cross_cov(spec, prm, Pn, Pn) - Vp.T @ Vp)  # [p, p]
+    out = np.empty(N)
+    l11 = _safe_sqrt_var(var_c)
+    ok = var_c > 0
+    lp1 = cross / l11[:, None]
+    schur = cov_pp[None, :, :] - lp1[:, :, None] * lp1[:, None, :]
+    try:
+        LS = np.linalg.cholesky(schur)
+    except np.linalg.LinAlgError:
+        ok[:] = False
+        LS = None
+    if LS is not None and ok.any():
+        z0 = z[:, 0][:, None]  # [S,1]
+        y0 = mu_c[None, :] + l11[None, :] * z0  # [S,N]
+        yp = mu_p[None, None, :] + lp1[None, :, :] * z0[:, :, None] + np.einsum("nij,sj->sni", LS, z[:, 1:])
+        samples = np.concatenate([y0[:, :, None], yp], axis=2)  # [S,N,1+p]
+        li = log_fatplus(sign * samples - best_f)
+        out[:] = logmeanexp(fatmax(li, axis=-1), axis=0)
+    for i in np.nonzero(~ok)[0]:  # jitter path: exact restatement
+        m, C = model.posterior_joint(np.vstack([np.atleast_2d(Xc)[i : i + 1], pend]))
+        out[i] = qlogei_joint(m, C, z, best_f, sign)
+    return out
+
+
+def best_f_from_model(model: GPModel, sign: float = 1.0) -> float:
+    """max_i objective(posterior mean at training x_i)  (_builder.py:141-161,256-265)."""
+    mu, _ = model.posterior(model.X_train)
+    return float((sign * mu).max())
+
+
+@dataclass
+class GreedyResult:
+    indices: list[int]  # positions into the candidate matrix, in selection order
+    values: list[float]  # acquisition value of each greedy step
+    first_scores: np.ndarray | None = None  # q=1 scores of all candidates (step 0)
+
+
+def optimize_acqf_discrete_qlogei(
+    model: GPModel,
+    Xcand: np.ndarray,
+    q: int,
+    z_by_q: dict[int, np.ndarray] | None = None,
+    seed: int | None = None,
+    S: int = 512,
+    sign: float = 1.0,
+    X_pending: np.ndarray | None = None,
+    best_f: float | None = None,
+    keep_scores: bool = False,
+) -> GreedyResult:
+    """Sequential greedy over a discrete set [UPSTREAM A10] with qLogEI.
+
+    Each greedy step scores every remaining candidate as its own q=1 t-batch,
+    jointly with (base pending + already chosen) points, takes the first-index
+    argmax and removes the row.
+    """
+    Xcand = np.ascontiguousarray(Xcand, dtype=np.float64)
+    N = Xcand.shape[0]
+    if seed is None and z_by_q is None:
+        seed = draw_sampler_seed()
+    if best_f is None:
+        best_f = best_f_from_model(model, sign)
+    base_pending = np.zeros((0, Xcand.shape[1])) if X_pending is None else np.atleast_2d(X_pending)
+    alive = np.ones(N, dtype=bool)
+    chosen: list[int] = []
+    values: list[float] = []
+    first_scores = None
+
+    def get_z(qp: int) -> np.ndarray:
+        if z_by_q is not None:
+            return z_by_q[qp]
+        return sobol_normal_base_samples(S, qp, seed)
+
+    for step in range(q):
+        pend = np.vstack([base_pending, Xcand[chosen]]) if chosen else base_pending
+        p = pend.shape[0]
+        z = get_z(1 + p)
+        scores = np.full(N, -np.inf)
+        idx_alive = np.nonzero(alive)[0]
+        if p == 0:
+            for s in range(0, idx_alive.size, MAX_BATCH_SIZE):
+                ids = idx_alive[s : s + MAX_BATCH_SIZE]
+                mu, var = model.posterior(Xcand[ids])
+                scores[ids] = qlogei_q1(mu, var, z[:, 0], best_f, sign)
+        else:
+            for s in range(0, idx_alive.size, MAX_BATCH_SIZE):
+                ids = idx_alive[s : s + MAX_BATCH_SIZE]
+                scores[ids] = qlogei_with_pending(model, Xcand[ids], pend, z, best_f, sign)
+        if step == 0 and keep_scores:
+            first_scores = scores.copy()
+        best = int(np.argmax(scores))  # first index on ties (torch.argmax)
+        chosen.append(best)
+        values.append(float(scores[best]))
+        alive[best] = False
+    return GreedyResult(chosen, values, first_scores)
+
+
+def topk_first_index(scores: np.ndarray, k: int) -> np.ndarray:
+    """k best q=1 scores, descending, ties -> lower index first (stable)."""
+    order = np.argsort(-scores, kind="stable")
+    return order[:k]
