@@ -1,0 +1,122 @@
+"""ctypes binding of ``libbaybe_hip.so`` (C-ABI declared in ``include/baybe_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing, or no HIP
+device is present, every entry point raises ``HipUnavailableError``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_NAME = "libbaybe_hip.so"
+_lib = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class HipUnavailableError(RuntimeError):
+    """The HIP extension (or a HIP device) is not available; nothing else can run the path."""
+
+
+class HipError(RuntimeError):
+    """A libbaybe_hip call failed."""
+
+
+class ModelDesc(C.Structure):
+    """``bbh_model_desc`` (include/baybe_hip.h)."""
+
+    _fields_ = [
+        ("kernel_kind", C.c_int32),
+        ("d", C.c_int32),
+        ("task_col", C.c_int32),
+        ("n_tasks", C.c_int32),
+        ("use_outputscale", C.c_int32),
+        ("criterion", C.c_int32),
+    ]
+
+
+KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
+CRITERIA = {"mll": 0, "loo": 1}
+MAX_PENDING = 15
+
+# name -> (restype, argtypes); every symbol include/baybe_hip.h declares
+SIGNATURES = {
+    "bbh_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "bbh_destroy": (C.c_int, [C.c_void_p]),
+    "bbh_last_error": (C.c_char_p, [C.c_void_p]),
+    "bbh_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bbh_version": (C.c_int, []),
+    "bbh_selftest": (C.c_int, [C.c_void_p]),
+    "bbh_set_model": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(ModelDesc), C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p],
+    ),
+    "bbh_theta_len": (C.c_int64, [C.c_void_p]),
+    "bbh_get_standardization": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "bbh_fit_value_grad": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "bbh_factorize": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "bbh_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bbh_posterior_unfused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bbh_train_posterior_mean": (C.c_int, [C.c_void_p, c_double_p]),
+    "bbh_qlogei_q1": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double, C.c_double,
+         C.c_void_p, C.c_void_p],
+    ),
+    "bbh_pending_set": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    "bbh_cross_cov": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "bbh_qlogei_pending": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double,
+         C.c_double, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
+    "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
+    "bbh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "bbh_timing_read": (C.c_int, [C.c_void_p, c_double_p, c_int64_p, C.c_int]),
+}
+
+
+def library_path() -> Path:
+    env = os.environ.get("BAYBE_AMD_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent / _LIB_NAME
+
+
+def load_library():
+    """Load the shared library and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise HipUnavailableError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C baybe_amd/csrc`. There is no CPU fallback for this path."
+        )
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as ex:  # missing ROCm runtime etc.
+        raise HipUnavailableError(f"cannot load {path}: {ex}") from ex
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def is_available() -> bool:
+    """True iff the library loads AND a HIP device can be opened."""
+    try:
+        lib = load_library()
+    except (HipUnavailableError, AttributeError):
+        return False
+    h = C.c_void_p()
+    rc = lib.bbh_create(0, C.byref(h))
+    if rc != 0:
+        return False
+    lib.bbh_destroy(h)
+    return True

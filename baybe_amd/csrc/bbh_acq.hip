@@ -1,0 +1,352 @@
+// Monte-Carlo acquisition (qLogEI) and selection kernels.
+//
+// qLogExpectedImprovement as BayBE builds it (baybe/acquisition/acqfs.py:219-223,
+// baybe/acquisition/_builder.py:195-265): fat=True, tau_relu=1e-6, tau_max=1e-2, Sobol-normal
+// base samples shared by all candidates; objective = sign * sample (minimisation = -1,
+// baybe/objectives/base.py:99-105).  Maths restated in oracle/gp_oracle.py (log_fatplus, fatmax,
+// logmeanexp, psd_safe_cholesky jitter).
+#include <math.h>
+#include <string.h>
+
+#include "bbh_common.h"
+
+#define TAU_RELU 1e-6
+#define TAU_MAX 1e-2
+
+// fatplus(x; tau) / tau = softplus(t) + 0.1 / (1 + t^2),  t = x / tau; torch softplus threshold 20
+__device__ __forceinline__ double bbh_fatplus_core(double t) {
+  double sp;
+  if (t > 20.0)
+    sp = t;
+  else if (t < -750.0)
+    sp = 0.0;
+  else
+    sp = log1p(exp(t));
+  return sp + 0.1 / fma(t, t, 1.0);
+}
+
+// 1x1 psd_safe_cholesky: v <= 0 (or NaN) -> add jitter 1e-8, 1e-7, 1e-6
+__device__ __forceinline__ double bbh_safe_sd(double v) {
+  if (!(v > 0.0)) {
+    v += 1e-8;
+    if (!(v > 0.0)) {
+      v += 1e-7;
+      if (!(v > 0.0)) v += 1e-6;
+    }
+  }
+  return sqrt(fmax(v, 0.0));
+}
+
+// q' = 1:  score = log( mean_s fatplus(sign (mu + sd z_s) - best_f) )
+//               = logmeanexp_s log_fatplus(...)   (all terms positive, no cancellation)
+__global__ __launch_bounds__(256) void bbh_qlogei_q1_kernel(const double* __restrict__ mean,
+                                                            const double* __restrict__ var, int64_t N,
+                                                            const double* __restrict__ z, int S, double best_f,
+                                                            double sign, const uint8_t* __restrict__ alive,
+                                                            double* __restrict__ scores) {
+  extern __shared__ double s_z[];
+  for (int s = threadIdx.x; s < S; s += blockDim.x) s_z[s] = z[s];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  const double inv_tau = 1.0 / TAU_RELU;
+  const double a = (sign * mean[i] - best_f) * inv_tau;
+  const double b = sign * bbh_safe_sd(var[i]) * inv_tau;
+  double sum = 0.0;
+  for (int s = 0; s < S; s++) sum += bbh_fatplus_core(fma(b, s_z[s], a));
+  scores[i] = log(TAU_RELU) + log(sum) - log((double)S);
+}
+
+// q' = 1 + p with pending points.  Thread-private packed lower-triangular Cholesky in LDS
+// (element e of thread t at s_L[e * 64 + t]); exact psd_safe_cholesky semantics (jitter retries).
+#define QMAX 16
+#define QTRI (QMAX * (QMAX + 1) / 2)
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+__global__ __launch_bounds__(64) void bbh_qlogei_pending_kernel(
+    const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ cross, int64_t N, int p,
+    const double* __restrict__ mean_p, const double* __restrict__ cov_pp, const double* __restrict__ z, int S,
+    double best_f, double sign, const uint8_t* __restrict__ alive, double* __restrict__ scores) {
+  __shared__ double s_L[QTRI * 64];
+  __shared__ double s_mp[QMAX];
+  __shared__ double s_cpp[QMAX * QMAX];
+  const int t = threadIdx.x;
+  const int q = p + 1;
+  for (int e = t; e < p; e += 64) s_mp[e] = mean_p[e];
+  for (int e = t; e < p * p; e += 64) s_cpp[e] = cov_pp[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 64 + t;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  double* L = s_L + t;  // L[tri(i,j) * 64]
+  const double v0 = var[i];
+  // Cholesky of Sigma = [[v0, c^T], [c, cov_pp]] with diagonal jitter retries
+  double jitter = 0.0;
+  bool ok = false;
+  for (int attempt = 0; attempt < 4 && !ok; attempt++) {
+    ok = true;
+    for (int r = 0; r < q && ok; r++) {
+      for (int c = 0; c <= r; c++) {
+        double s;
+        if (r == 0)
+          s = v0;
+        else if (c == 0)
+          s = cross[i * p + (r - 1)];
+        else
+          s = s_cpp[(r - 1) * p + (c - 1)];
+        if (r == c) s += jitter;
+        for (int k = 0; k < c; k++) s -= L[tri(r, k) * 64] * L[tri(c, k) * 64];
+        if (r == c) {
+          if (!(s > 0.0)) {
+            ok = false;
+            break;
+          }
+          L[tri(r, r) * 64] = sqrt(s);
+        } else {
+          L[tri(r, c) * 64] = s / L[tri(c, c) * 64];
+        }
+      }
+    }
+    if (!ok) jitter = 1e-8 * pow(10.0, (double)attempt);
+  }
+  if (!ok) {
+    scores[i] = NAN;  // not PSD even with jitter 1e-6 (gpytorch raises NotPSDError)
+    return;
+  }
+  const double m0 = mean[i];
+  const double inv_tau = 1.0 / TAU_RELU;
+  double sum = 0.0;  // sum_s exp(fatmax_s - ref), streaming log-sum-exp
+  double ref = -INFINITY;
+  for (int s = 0; s < S; s++) {
+    const double* zs = z + (int64_t)s * q;
+    // li_j = log_fatplus(sign * y_j - best_f), y = m + L z
+    double li[QMAX];
+    double mx = -INFINITY;
+#pragma unroll 1
+    for (int r = 0; r < q; r++) {
+      double y = (r == 0) ? m0 : s_mp[r - 1];
+      for (int c = 0; c <= r; c++) y = fma(L[tri(r, c) * 64], zs[c], y);
+      const double tt = (sign * y - best_f) * inv_tau;
+      const double v = log(TAU_RELU) + log(bbh_fatplus_core(tt));
+      li[r] = v;
+      mx = fmax(mx, v);
+    }
+    // fatmax over the q' points: mx + tau log sum_j (2 / (2 + (mx - li_j)/tau))^2
+    double acc = 0.0;
+#pragma unroll 1
+    for (int r = 0; r < q; r++) {
+      const double u = 2.0 / (2.0 + (mx - li[r]) / TAU_MAX);
+      acc = fma(u, u, acc);
+    }
+    const double fm = mx + TAU_MAX * log(acc);
+    if (fm > ref) {
+      sum = sum * exp(ref - fm) + 1.0;
+      ref = fm;
+    } else {
+      sum += exp(fm - ref);
+    }
+  }
+  scores[i] = ref + log(sum) - log((double)S);
+}
+
+// ---- first-index argmax -----------------------------------------------------------------------
+__device__ __forceinline__ void amax_combine(double& v, int64_t& i, double ov, int64_t oi) {
+  // NaN never wins; ties -> lower index
+  const bool better = (ov > v) || (ov == v && oi < i) || (i < 0 && oi >= 0);
+  if (oi >= 0 && better) {
+    v = ov;
+    i = oi;
+  }
+}
+
+__global__ __launch_bounds__(256) void bbh_argmax_stage1(const double* __restrict__ scores, int64_t N,
+                                                         double* __restrict__ pv, int64_t* __restrict__ pi) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  double v = -INFINITY;
+  int64_t idx = -1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    const double x = scores[i];
+    if (x == x) amax_combine(v, idx, x, i);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_down(v, o, 64);
+    const int64_t oi = __shfl_down(idx, o, 64);
+    amax_combine(v, idx, ov, oi);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) amax_combine(v, idx, sv[w], si[w]);
+    pv[blockIdx.x] = v;
+    pi[blockIdx.x] = idx;
+  }
+}
+
+__global__ __launch_bounds__(256) void bbh_argmax_stage2(const double* __restrict__ pv, const int64_t* __restrict__ pi,
+                                                         int nblocks, double* __restrict__ outv,
+                                                         int64_t* __restrict__ outi) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  double v = -INFINITY;
+  int64_t idx = -1;
+  for (int b = threadIdx.x; b < nblocks; b += 256) amax_combine(v, idx, pv[b], pi[b]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_down(v, o, 64);
+    const int64_t oi = __shfl_down(idx, o, 64);
+    amax_combine(v, idx, ov, oi);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) amax_combine(v, idx, sv[w], si[w]);
+    *outv = v;
+    *outi = idx;
+  }
+}
+
+__global__ void bbh_mask_one_kernel(double* scores, const int64_t* idx) {
+  if (*idx >= 0) scores[*idx] = -INFINITY;
+}
+
+#define ARGMAX_BLOCKS 1024
+
+static int bbh_ensure_red(bbh_handle* h) {
+  if (!h->d_red) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_red, sizeof(double) * (ARGMAX_BLOCKS + 64)));
+  if (!h->d_redi) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_redi, sizeof(int64_t) * (ARGMAX_BLOCKS + 64)));
+  return 0;
+}
+
+static int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
+  const size_t bytes = sizeof(double) * count;
+  if (bytes > h->z_bytes) {
+    if (h->d_z) hipFree(h->d_z);
+    h->d_z = nullptr;
+    h->z_bytes = 0;
+    BBH_HIP_TRY(h, hipMalloc((void**)&h->d_z, bytes));
+    h->z_bytes = bytes;
+  }
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_z, z_host, bytes, hipMemcpyHostToDevice, h->stream));
+  // the host buffer may be released by the caller right after return
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N,
+                             const double* z_host, int64_t S, double best_f, double sign, const uint8_t* alive_dev,
+                             double* scores_dev) {
+  if (!h) return -1;
+  if (!mean_dev || !var_dev || !z_host || !scores_dev || N < 0 || S < 1 || S > 8192) {
+    h->err = "bbh_qlogei_q1: bad arguments (1 <= S <= 8192)";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_upload_z(h, z_host, (size_t)S);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bbh_qlogei_q1_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), sizeof(double) * S, h->stream,
+                     mean_dev, var_dev, N, h->d_z, (int)S, best_f, sign, alive_dev, scores_dev);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const double* var_dev,
+                                  const double* cross_dev, int64_t N, const double* z_host, int64_t S, double best_f,
+                                  double sign, const uint8_t* alive_dev, double* scores_dev) {
+  if (!h) return -1;
+  const int p = h->p;
+  if (!mean_dev || !var_dev || !cross_dev || !z_host || !scores_dev || N < 0 || S < 1 || p < 1) {
+    h->err = "bbh_qlogei_pending: bad arguments / no pending points set";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  // device buffer: z [S, 1+p] followed by the cached pending posterior mean_p [p], cov_pp [p,p]
+  const std::vector<double>& mp = h->pend_mean;
+  const std::vector<double>& cpp = h->pend_cov;
+  int rc;
+  std::vector<double> buf((size_t)S * (p + 1) + p + (size_t)p * p);
+  memcpy(buf.data(), z_host, sizeof(double) * S * (p + 1));
+  memcpy(buf.data() + S * (p + 1), mp.data(), sizeof(double) * p);
+  memcpy(buf.data() + S * (p + 1) + p, cpp.data(), sizeof(double) * p * p);
+  rc = bbh_upload_z(h, buf.data(), buf.size());
+  if (rc) return rc;
+  const double* dz = h->d_z;
+  hipLaunchKernelGGL(bbh_qlogei_pending_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, mean_dev,
+                     var_dev, cross_dev, N, p, dz + S * (p + 1), dz + S * (p + 1) + p, dz, (int)S, best_f, sign,
+                     alive_dev, scores_dev);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,
+                          int64_t* best_idx_host) {
+  if (!h) return -1;
+  if (!scores_dev || N < 1 || !best_val_host || !best_idx_host) {
+    h->err = "bbh_argmax: bad arguments";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_ensure_red(h);
+  if (rc) return rc;
+  int nblocks = (int)((N + 255) / 256);
+  if (nblocks > ARGMAX_BLOCKS) nblocks = ARGMAX_BLOCKS;
+  hipLaunchKernelGGL(bbh_argmax_stage1, dim3(nblocks), dim3(256), 0, h->stream, scores_dev, N, h->d_red, h->d_redi);
+  hipLaunchKernelGGL(bbh_argmax_stage2, dim3(1), dim3(256), 0, h->stream, h->d_red, h->d_redi, nblocks,
+                     h->d_red + ARGMAX_BLOCKS, h->d_redi + ARGMAX_BLOCKS);
+  BBH_HIP_TRY(h, hipMemcpyAsync(best_val_host, h->d_red + ARGMAX_BLOCKS, sizeof(double), hipMemcpyDeviceToHost,
+                                h->stream));
+  BBH_HIP_TRY(h, hipMemcpyAsync(best_idx_host, h->d_redi + ARGMAX_BLOCKS, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                h->stream));
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
+                        int64_t* idx_host) {
+  if (!h) return -1;
+  if (!scores_dev || N < 1 || k < 1 || k > N || !vals_host || !idx_host) {
+    h->err = "bbh_topk: bad arguments";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_ensure_red(h);
+  if (rc) return rc;
+  rc = bbh_ensure_ws(h, sizeof(double) * (size_t)N);
+  if (rc) return rc;
+  double* tmp = h->d_ws;
+  BBH_HIP_TRY(h, hipMemcpyAsync(tmp, scores_dev, sizeof(double) * N, hipMemcpyDeviceToDevice, h->stream));
+  int nblocks = (int)((N + 255) / 256);
+  if (nblocks > ARGMAX_BLOCKS) nblocks = ARGMAX_BLOCKS;
+  std::vector<double> v(k);
+  std::vector<int64_t> ix(k);
+  for (int64_t j = 0; j < k; j++) {
+    hipLaunchKernelGGL(bbh_argmax_stage1, dim3(nblocks), dim3(256), 0, h->stream, tmp, N, h->d_red, h->d_redi);
+    hipLaunchKernelGGL(bbh_argmax_stage2, dim3(1), dim3(256), 0, h->stream, h->d_red, h->d_redi, nblocks,
+                       h->d_red + ARGMAX_BLOCKS, h->d_redi + ARGMAX_BLOCKS);
+    BBH_HIP_TRY(h, hipMemcpyAsync(&v[j], h->d_red + ARGMAX_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    BBH_HIP_TRY(h, hipMemcpyAsync(&ix[j], h->d_redi + ARGMAX_BLOCKS, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(bbh_mask_one_kernel, dim3(1), dim3(1), 0, h->stream, tmp, h->d_redi + ARGMAX_BLOCKS);
+  }
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int64_t j = 0; j < k; j++) {
+    vals_host[j] = v[j];
+    idx_host[j] = ix[j];
+  }
+  return 0;
+}

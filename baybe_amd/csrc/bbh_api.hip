@@ -1,0 +1,194 @@
+// C-ABI entry points that are not tied to one kernel family: lifecycle, posterior dispatch,
+// MFMA layout self-test, instrumentation.  See include/baybe_hip.h for the contract.
+#include <math.h>
+#include <string.h>
+
+#include "bbh_common.h"
+
+static const char* kNoHandle = "bbh: null handle";
+
+extern "C" int bbh_version(void) { return 100; }
+
+extern "C" int bbh_create(int device_id, bbh_handle** out) {
+  if (!out) return -1;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return -10;  // no HIP device: fail loudly
+  if (device_id < 0 || device_id >= count) return -11;
+  if (hipSetDevice(device_id) != hipSuccess) return -12;
+  bbh_handle* h = new bbh_handle();
+  h->device = device_id;
+  *out = h;
+  return 0;
+}
+
+extern "C" int bbh_destroy(bbh_handle* h) {
+  if (!h) return -1;
+  hipSetDevice(h->device);
+  if (h->stream)
+    hipStreamSynchronize(h->stream);
+  else
+    hipDeviceSynchronize();
+  for (auto& pr : h->pending_events) {
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  bbh_free_model_public(h);
+  if (h->d_ws) hipFree(h->d_ws);
+  if (h->d_z) hipFree(h->d_z);
+  if (h->d_red) hipFree(h->d_red);
+  if (h->d_redi) hipFree(h->d_redi);
+  delete h;
+  return 0;
+}
+
+extern "C" const char* bbh_last_error(bbh_handle* h) { return h ? h->err.c_str() : kNoHandle; }
+
+extern "C" int bbh_set_stream(bbh_handle* h, void* hip_stream) {
+  if (!h) return -1;
+  h->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+// ---- MFMA fragment-layout self-test ---------------------------------------------------------
+// C = A B with asymmetric integer-valued A (16x8) and B (8x16): catches row/col swaps and the
+// f32-style C mapping (which misplaces 3 of every 4 rows on the f64 instruction).
+__global__ void bbh_selftest_kernel(const double* A, const double* B, double* C) {
+  const int l = threadIdx.x;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int ks = 0; ks < 2; ks++) {
+    const double a = A[(l & 15) * 8 + 4 * ks + (l >> 4)];
+    const double b = B[(4 * ks + (l >> 4)) * 16 + (l & 15)];
+    acc = mfma_f64(a, b, acc);
+  }
+  for (int r = 0; r < 4; r++) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+extern "C" int bbh_selftest(bbh_handle* h) {
+  if (!h) return -1;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  double hA[16 * 8], hB[8 * 16], hC[256], ref[256];
+  for (int i = 0; i < 16; i++)
+    for (int k = 0; k < 8; k++) hA[i * 8 + k] = (double)(3 * i + 7 * k + 1) - 0.5 * (double)(i * k);
+  for (int k = 0; k < 8; k++)
+    for (int j = 0; j < 16; j++) hB[k * 16 + j] = (double)(5 * k - 2 * j) + 0.25 * (double)(k * j + j);
+  for (int i = 0; i < 16; i++)
+    for (int j = 0; j < 16; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 8; k++) s += hA[i * 8 + k] * hB[k * 16 + j];
+      ref[i * 16 + j] = s;
+    }
+  int rc = bbh_ensure_ws(h, sizeof(double) * 1024);
+  if (rc) return rc;
+  double* dA = h->d_ws;
+  double* dB = dA + 128;
+  double* dC = dB + 128;
+  BBH_HIP_TRY(h, hipMemcpyAsync(dA, hA, sizeof(hA), hipMemcpyHostToDevice, h->stream));
+  BBH_HIP_TRY(h, hipMemcpyAsync(dB, hB, sizeof(hB), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(bbh_selftest_kernel, dim3(1), dim3(64), 0, h->stream, dA, dB, dC);
+  BBH_HIP_TRY(h, hipMemcpyAsync(hC, dC, sizeof(hC), hipMemcpyDeviceToHost, h->stream));
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int e = 0; e < 256; e++)
+    if (fabs(hC[e] - ref[e]) > 1e-9 * (1.0 + fabs(ref[e]))) {
+      h->err = "bbh_selftest: v_mfma_f64_16x16x4_f64 fragment layout mismatch at element " + std::to_string(e);
+      return -20;
+    }
+  return 0;
+}
+
+// ---- posterior ------------------------------------------------------------------------------
+static int check_post_args(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx) {
+  if (!h->factorized) {
+    h->err = "posterior requested before bbh_factorize";
+    return -1;
+  }
+  if (N < 0 || (N > 0 && !X_dev) || ldx < h->desc.d) {
+    h->err = "posterior: bad arguments (need ldx >= d)";
+    return -1;
+  }
+  if (h->dn > 126) {
+    h->err = "fused posterior supports at most 126 numerical columns";
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" int bbh_posterior(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev,
+                             double* var_dev) {
+  if (!h) return -1;
+  int rc = check_post_args(h, X_dev, N, ldx);
+  if (rc) return rc;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  return bbh_launch_fused(h, X_dev, N, ldx, mean_dev, var_dev, nullptr, true);
+}
+
+extern "C" int bbh_posterior_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev,
+                                     double* var_dev) {
+  if (!h) return -1;
+  int rc = check_post_args(h, X_dev, N, ldx);
+  if (rc) return rc;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  return bbh_launch_unfused(h, X_dev, N, ldx, mean_dev, var_dev);
+}
+
+extern "C" int bbh_cross_cov(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* cross_dev) {
+  if (!h) return -1;
+  int rc = check_post_args(h, X_dev, N, ldx);
+  if (rc) return rc;
+  if (h->p < 1 || !cross_dev) {
+    h->err = "bbh_cross_cov: no pending points set";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  return bbh_launch_fused(h, X_dev, N, ldx, nullptr, nullptr, cross_dev, false);
+}
+
+extern "C" int bbh_train_posterior_mean(bbh_handle* h, double* mean_host) {
+  if (!h) return -1;
+  if (!h->factorized || !mean_host) {
+    h->err = "bbh_train_posterior_mean: model not factorised";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  const int64_t n = h->n, d = h->desc.d;
+  int rc = bbh_ensure_ws(h, sizeof(double) * (size_t)(n * d + n));
+  if (rc) return rc;
+  double* dX = h->d_ws;
+  double* dm = dX + n * d;
+  BBH_HIP_TRY(h, hipMemcpyAsync(dX, h->xraw_host.data(), sizeof(double) * n * d, hipMemcpyHostToDevice, h->stream));
+  // pending columns do not affect column 0 (the mean), but keep the call side-effect free
+  rc = bbh_launch_fused(h, dX, n, d, dm, nullptr, nullptr, false);
+  if (rc) return rc;
+  BBH_HIP_TRY(h, hipMemcpyAsync(mean_host, dm, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- instrumentation ------------------------------------------------------------------------
+extern "C" int bbh_timing_enable(bbh_handle* h, int enable) {
+  if (!h) return -1;
+  h->timing = enable != 0;
+  return 0;
+}
+
+extern "C" int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset) {
+  if (!h) return -1;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  for (auto& pr : h->pending_events) {
+    BBH_HIP_TRY(h, hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    BBH_HIP_TRY(h, hipEventElapsedTime(&ms, pr.first, pr.second));
+    h->fused_ms += (double)ms;
+    h->fused_launches += 1;
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  h->pending_events.clear();
+  if (fused_ms_total) *fused_ms_total = h->fused_ms;
+  if (fused_launches) *fused_launches = h->fused_launches;
+  if (reset) {
+    h->fused_ms = 0.0;
+    h->fused_launches = 0;
+  }
+  return 0;
+}

@@ -1,0 +1,147 @@
+// Internal declarations shared by the translation units of libbaybe_hip.so.
+// gfx950 only: 64-lane wavefronts and the fp64 MFMA v_mfma_f64_16x16x4_f64 are assumed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/baybe_hip.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define BBH_WAVE 64
+#define BBH_TB 16          // training points per MFMA block (M/N of the 16x16x4 tile)
+#define BBH_PAD 64         // n is padded to a multiple of this (GEMM tile edge)
+#define BBH_MEANCOLS 16    // columns of the mean/cross operand: [alpha | -beta_1 .. -beta_15]
+#define BBH_SQRT3 1.7320508075688772
+#define BBH_SQRT5 2.23606797749979
+
+// ---- fragment layout of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md §3) ----------
+//   A (16x4): lane l holds A[l & 15][l >> 4]
+//   B (4x16): lane l holds B[l >> 4][l & 15]
+//   C/D (16x16): lane l, reg r holds C[(l >> 4) + 4 r][l & 15]
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+#define BBH_HIP_TRY(h, expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+      return -2;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+struct bbh_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- model description ----
+  bbh_model_desc desc{};
+  bool have_model = false;
+  bool factorized = false;
+  int64_t n = 0;      // training points
+  int64_t np = 0;     // padded to BBH_PAD
+  int64_t nb = 0;     // np / 16
+  int dn = 0;         // numerical columns
+  int kd = 0;         // k-steps of the augmented distance GEMM: ceil((dn+2)/4)
+  int T = 1;          // tasks
+  std::vector<int> numcol;        // numerical column -> comp-rep column
+  std::vector<double> lo, hi;     // per numerical column
+  double ybar = 0.0, ysd = 1.0;
+  std::vector<double> theta;      // last factorised theta
+  std::vector<double> ystd_host;  // [n]
+  std::vector<double> xn_host;    // [n, dn] normalised numerical columns
+  std::vector<int> task_host;     // [n]
+  std::vector<double> xcenter;    // [dn] column means of xn (centring as gpytorch)
+
+  // ---- device state (all fp64 unless noted) ----
+  double* d_xnT = nullptr;     // [dn, np]  normalised training inputs, transposed
+  int* d_task = nullptr;       // [np]      task ids (0 for padding)
+  double* d_ystd = nullptr;    // [np]
+  double* d_theta = nullptr;   // [theta_len]
+  double* d_K = nullptr;       // [np, np]  K + s2 I  -> L (lower, in place)
+  double* d_X = nullptr;       // [np, np]  L^-1
+  double* d_M = nullptr;       // [np, np]  (K + s2 I)^-1
+  double* d_Q = nullptr;       // [np, np]  scratch (LOO: M diag(u) M; Msc)
+  double* d_Q2 = nullptr;      // [np, np]  scratch
+  double* d_D = nullptr;       // [np/64, 64, 64] inverses of the diagonal Cholesky blocks
+  double* d_tmp = nullptr;     // [np/64, 64, 64] trtri scratch
+  double* d_r = nullptr;       // [np] y~ - c
+  double* d_t = nullptr;       // [np] scratch vector
+  double* d_alpha = nullptr;   // [np]
+  double* d_u = nullptr;       // [np] LOO u
+  double* d_w = nullptr;       // [np] LOO w
+  double* d_q = nullptr;       // [np] LOO M w
+  double* d_partial = nullptr; // [np, nslots] gradient partials
+  double* d_out = nullptr;     // [1 + theta_len] value + gradient
+  int* d_info = nullptr;       // Cholesky failure flag
+  // fused-posterior operands (built by bbh_factorize / bbh_pending_set)
+  double* d_trainfrag = nullptr;  // [nb_ext, kd, 64] augmented training fragments (A of the distance GEMM)
+  double* d_rfrag = nullptr;      // packed L^-T fragments (B of the variance GEMM)
+  double* d_meanB = nullptr;      // [nb_ext*4, 64] fragments of [alpha | -beta] (B of the mean/cross GEMM)
+  double* d_sclofs = nullptr;     // [2, dn] per-column scale/offset for candidates
+  int* d_numcol = nullptr;        // [dn]
+  double* d_tasktbl = nullptr;    // [T, T] outputscale * B (or [1] = outputscale)
+  int* d_taskext = nullptr;       // [np_ext] task id per (training | pending) point
+  int64_t rfrag_elems = 0;
+  int64_t* d_pass_off = nullptr;  // [npass] element offsets of the passes in d_rfrag
+  int* d_pass_w = nullptr;        // [npass] pass widths (16-column blocks)
+  int npass = 0;
+  int jbw = 16;                   // j-blocks per pass of the fused kernel
+  int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
+  // pending state
+  int p = 0;
+  std::vector<double> pend_host;  // [p, d]
+  std::vector<double> pend_mean;  // [p]    posterior mean of the pending points (target scale)
+  std::vector<double> pend_cov;   // [p, p] posterior covariance of the pending points
+  std::vector<double> xraw_host;  // [n, d] raw training rows (for bbh_train_posterior_mean)
+  double* d_beta = nullptr;       // [np, 16] columns: alpha, beta_1..beta_p (dense, for packing)
+  // generic workspaces
+  double* d_ws = nullptr;
+  size_t ws_bytes = 0;
+  double* d_z = nullptr;
+  size_t z_bytes = 0;
+  double* d_red = nullptr;        // argmax partials
+  int64_t* d_redi = nullptr;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double fused_ms = 0.0;
+  int64_t fused_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+};
+
+inline int64_t bbh_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- linalg (bbh_linalg.hip) ------------------------------------------------------------
+// C[M,N] = alpha * op(A) op(B) + beta * C, fp64 MFMA, M,N multiples of 64, K multiple of 16.
+// transA: A stored [K,M]; transB: B stored [N,K].  Batched over `batch` with element strides.
+void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+              const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb,
+              int64_t strideB, double beta, double* C, int64_t ldc, int64_t strideC, int batch);
+// In-place blocked Cholesky of the np x np matrix K (lower), with X = L^-1; info!=0 on failure.
+void bbh_potrf_trtri(bbh_handle* h);
+void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,
+                const double* x, double* y);   // y = A x   (row-major A)
+void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,
+                  const double* x, double* y); // y = A^T x
+
+// ---- model (bbh_model.hip) --------------------------------------------------------------
+int bbh_upload_theta(bbh_handle* h, const double* theta_host);
+void bbh_launch_gram(bbh_handle* h, double jitter);
+
+// ---- fused posterior (bbh_panel.hip) ----------------------------------------------------
+int bbh_pack_operands(bbh_handle* h);   // trainfrag, rfrag, meanB, tables (after factorize / pending_set)
+int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev,
+                     double* var_dev, double* cross_dev, bool with_var);
+int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev,
+                       double* var_dev);
+
+int bbh_ensure_ws(bbh_handle* h, size_t bytes);
+void bbh_free_model_public(bbh_handle* h);

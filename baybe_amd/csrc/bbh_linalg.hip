@@ -1,0 +1,224 @@
+// Dense fp64 linear algebra for the GP fit / factorisation (n <= a few thousand):
+//   * bbh_gemm         — LDS-tiled GEMM on v_mfma_f64_16x16x4_f64 (64x64x16 tiles, 4 waves)
+//   * bbh_potrf_trtri  — blocked right-looking Cholesky (64-wide panels) + blocked inverse
+//                        of the triangular factor, both built from bbh_gemm and one
+//                        single-workgroup 64x64 kernel
+//   * matvecs
+// These replace what linear_operator/LAPACK do under gpytorch's ExactMarginalLogLikelihood
+// (reference call site baybe/surrogates/gaussian_process/core.py:340-341).  All matrices are
+// padded to multiples of 64 with an identity block, so no kernel needs edge handling.
+#include "bbh_common.h"
+
+#define GBK 16
+#define GLD 80  // LDS row pitch (doubles): 160 dwords == 32 mod 64 -> the two k-rows a
+                // 32-lane ds_read_b64 group touches land on disjoint bank halves
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void bbh_gemm_kernel(int64_t K, double alpha, const double* A,
+                                                       int64_t lda, int64_t sA, const double* B,
+                                                       int64_t ldb, int64_t sB, double beta, double* C,
+                                                       int64_t ldc, int64_t sC) {
+  __shared__ double As[GBK * GLD];
+  __shared__ double Bs[GBK * GLD];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  for (int64_t k0 = 0; k0 < K; k0 += GBK) {
+    // ---- stage the A tile as As[k][m] ----
+    if (!TA) {  // A stored [M][K]: 4 consecutive k per thread, transposing store
+      const int m = t >> 2, k4 = (t & 3) * 4;
+      const d4 v = *(const d4*)(A + (m0 + m) * lda + k0 + k4);
+#pragma unroll
+      for (int i = 0; i < 4; i++) As[(k4 + i) * GLD + m] = v[i];
+    } else {  // A stored [K][M]: 4 consecutive m per thread
+      const int k = t >> 4, m4 = (t & 15) * 4;
+      const d4 v = *(const d4*)(A + (k0 + k) * lda + m0 + m4);
+#pragma unroll
+      for (int i = 0; i < 4; i++) As[k * GLD + m4 + i] = v[i];
+    }
+    // ---- stage the B tile as Bs[k][n] ----
+    if (!TB) {  // B stored [K][N]
+      const int k = t >> 4, n4 = (t & 15) * 4;
+      const d4 v = *(const d4*)(B + (k0 + k) * ldb + n0 + n4);
+#pragma unroll
+      for (int i = 0; i < 4; i++) Bs[k * GLD + n4 + i] = v[i];
+    } else {  // B stored [N][K]
+      const int n = t >> 2, k4 = (t & 3) * 4;
+      const d4 v = *(const d4*)(B + (n0 + n) * ldb + k0 + k4);
+#pragma unroll
+      for (int i = 0; i < 4; i++) Bs[(k4 + i) * GLD + n] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GBK / 4; kk++) {
+      const int krow = (kk * 4 + (l >> 4)) * GLD;
+      const double a0 = As[krow + wm * 32 + (l & 15)];
+      const double a1 = As[krow + wm * 32 + 16 + (l & 15)];
+      const double b0 = Bs[krow + wn * 32 + (l & 15)];
+      const double b1 = Bs[krow + wn * 32 + 16 + (l & 15)];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+    __syncthreads();  // also orders every global read of this tile before the epilogue (C may alias A)
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + wm * 32 + i * 16 + (l >> 4) + 4 * r;
+        const int64_t col = n0 + wn * 32 + j * 16 + (l & 15);
+        double* c = C + row * ldc + col;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * (*c);
+        *c = v;
+      }
+}
+
+void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+              const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
+              double beta, double* C, int64_t ldc, int64_t strideC, int batch) {
+  if (M <= 0 || N <= 0 || batch <= 0) return;
+  dim3 grid((unsigned)(N / 64), (unsigned)(M / 64), (unsigned)batch), block(256);
+  if (!transA && !transB)
+    hipLaunchKernelGGL((bbh_gemm_kernel<false, false>), grid, block, 0, s, K, alpha, A, lda, strideA, B, ldb,
+                       strideB, beta, C, ldc, strideC);
+  else if (!transA && transB)
+    hipLaunchKernelGGL((bbh_gemm_kernel<false, true>), grid, block, 0, s, K, alpha, A, lda, strideA, B, ldb,
+                       strideB, beta, C, ldc, strideC);
+  else if (transA && !transB)
+    hipLaunchKernelGGL((bbh_gemm_kernel<true, false>), grid, block, 0, s, K, alpha, A, lda, strideA, B, ldb,
+                       strideB, beta, C, ldc, strideC);
+  else
+    hipLaunchKernelGGL((bbh_gemm_kernel<true, true>), grid, block, 0, s, K, alpha, A, lda, strideA, B, ldb,
+                       strideB, beta, C, ldc, strideC);
+}
+
+// ---- 64x64 diagonal block: Cholesky factor and its inverse, one workgroup ----------------
+// In: the (already updated) diagonal block J of A.  Out: L_JJ in place (upper part zeroed),
+// its inverse into D[J] and into the diagonal block of X.  info := 64 J + j + 1 at the first
+// non-positive pivot (the factor then contains NaNs; the host retries with jitter).
+__global__ __launch_bounds__(256) void bbh_potrf_diag_kernel(double* A, int64_t lda, int64_t J, double* D,
+                                                             double* X, int64_t ldx, int* info) {
+  __shared__ double a[64][65];
+  __shared__ double x[64][65];
+  const int t = threadIdx.x;
+  double* Ajj = A + (J * 64) * lda + J * 64;
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    a[i][j] = Ajj[(int64_t)i * lda + j];
+    x[i][j] = 0.0;
+  }
+  __syncthreads();
+  const int i = t & 63, ks = t >> 6;
+  for (int j = 0; j < 64; j++) {
+    const double djj = a[j][j];
+    if (t == 0 && !(djj > 0.0)) atomicCAS(info, 0, (int)(J * 64 + j + 1));
+    const double s = sqrt(djj);
+    __syncthreads();
+    if (t < 64) {
+      if (i == j)
+        a[j][j] = s;
+      else if (i > j)
+        a[i][j] = a[i][j] / s;
+    }
+    __syncthreads();
+    if (i > j) {
+      const double lij = a[i][j];
+      for (int k = j + 1 + ks; k <= i; k += 4) a[i][k] -= lij * a[k][j];
+    }
+    __syncthreads();
+  }
+  // inverse of the lower-triangular block: thread c solves column c by forward substitution
+  if (t < 64) {
+    const int c = t;
+    for (int r = 0; r < 64; r++) {
+      double acc = (r == c) ? 1.0 : 0.0;
+      for (int k = 0; k < r; k++) acc -= a[r][k] * x[k][c];  // x[k][c] == 0 for k < c
+      x[r][c] = (r >= c) ? acc / a[r][r] : 0.0;
+    }
+  }
+  __syncthreads();
+  double* Xjj = X + (J * 64) * ldx + J * 64;
+  double* Dj = D + J * 4096;
+  for (int e = t; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ajj[(int64_t)r * lda + c] = (c <= r) ? a[r][c] : 0.0;
+    const double xv = x[r][c];
+    Dj[e] = xv;
+    Xjj[(int64_t)r * ldx + c] = xv;
+  }
+}
+
+void bbh_potrf_trtri(bbh_handle* h) {
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, nbk = np / 64;
+  hipMemsetAsync(h->d_X, 0, sizeof(double) * np * np, s);
+  hipMemsetAsync(h->d_info, 0, sizeof(int), s);
+  double* A = h->d_K;
+  for (int64_t J = 0; J < nbk; J++) {
+    hipLaunchKernelGGL(bbh_potrf_diag_kernel, dim3(1), dim3(256), 0, s, A, np, J, h->d_D, h->d_X, np, h->d_info);
+    const int64_t rem = nbk - J - 1;
+    if (rem > 0) {
+      double* A21 = A + ((J + 1) * 64) * np + J * 64;
+      double* A22 = A + ((J + 1) * 64) * np + (J + 1) * 64;
+      // panel: A21 <- A21 L_JJ^-T   (in place; each workgroup owns its 64 rows)
+      bbh_gemm(s, false, true, rem * 64, 64, 64, 1.0, A21, np, 0, h->d_D + J * 4096, 64, 0, 0.0, A21, np, 0, 1);
+      // trailing update: A22 <- A22 - A21 A21^T
+      bbh_gemm(s, false, true, rem * 64, rem * 64, 64, -1.0, A21, np, 0, A21, np, 0, 1.0, A22, np, 0, 1);
+    }
+  }
+  // X = L^-1, block sub-diagonal by block sub-diagonal:
+  //   X[z+o][z] = -D[z+o] * sum_{K=z}^{z+o-1} L[z+o][K] X[K][z]
+  for (int64_t o = 1; o < nbk; o++) {
+    const int batch = (int)(nbk - o);
+    const int64_t diag_stride = 64 * np + 64;
+    bbh_gemm(s, false, false, 64, 64, 64 * o, 1.0, A + (o * 64) * np, np, diag_stride, h->d_X, np, diag_stride, 0.0,
+             h->d_tmp, 64, 4096, batch);
+    bbh_gemm(s, false, false, 64, 64, 64, -1.0, h->d_D + o * 4096, 64, 4096, h->d_tmp, 64, 4096, 0.0,
+             h->d_X + (o * 64) * np, np, diag_stride, batch);
+  }
+}
+
+// ---- matvecs -----------------------------------------------------------------------------
+__global__ void bbh_matvec_kernel(const double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+                                  const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < cols; c += 64) s += A[row * lda + c] * x[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) y[row] = s;
+}
+
+__global__ void bbh_matvec_t_kernel(const double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+                                    const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0;
+  for (int64_t r = 0; r < rows; r++) s += A[r * lda + c] * x[r];
+  y[c] = s;
+}
+
+void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols, const double* x,
+                double* y) {
+  hipLaunchKernelGGL(bbh_matvec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, A, lda, rows, cols, x, y);
+}
+void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols, const double* x,
+                  double* y) {
+  hipLaunchKernelGGL(bbh_matvec_t_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, A, lda, rows, cols,
+                     x, y);
+}

@@ -1,0 +1,484 @@
+// GP model state, Gram assembly, fit objective (value + analytic gradient) and factorisation.
+//
+// Follows (see oracle/gp_oracle.py for the maths and the reference citations):
+//   model assembly          baybe/surrogates/gaussian_process/core.py:272-341
+//   kernel / priors         baybe/surrogates/gaussian_process/presets/baybe.py:56-144
+//   ICM task covariance     baybe/surrogates/gaussian_process/components/kernel.py:298-337
+//   MLL / LOO criterion     baybe/surrogates/gaussian_process/components/fit_criterion.py:31-41
+#include <math.h>
+#include <string.h>
+
+#include "bbh_common.h"
+
+// ---- stationary kernels as functions of the scaled squared distance -----------------------
+__device__ __forceinline__ double bbh_kfun(int kind, double r2) {
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
+  return exp(-r);
+}
+// g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3
+__device__ __forceinline__ double bbh_gfun(int kind, double r2) {
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (5.0 / 3.0) * (1.0 + BBH_SQRT5 * r) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return 3.0 * exp(-BBH_SQRT3 * r);
+  return r > 0.0 ? exp(-r) / r : 0.0;
+}
+
+// theta layout: [noise, mean, outputscale, ls[dn], B[T*T]]
+#define TH_NOISE 0
+#define TH_MEAN 1
+#define TH_OS 2
+#define TH_LS 3
+
+int bbh_ensure_ws(bbh_handle* h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return 0;
+  if (h->d_ws) hipFree(h->d_ws);
+  h->d_ws = nullptr;
+  h->ws_bytes = 0;
+  BBH_HIP_TRY(h, hipMalloc((void**)&h->d_ws, bytes));
+  h->ws_bytes = bytes;
+  return 0;
+}
+
+int bbh_upload_theta(bbh_handle* h, const double* theta_host) {
+  const int64_t len = bbh_theta_len(h);
+  for (int64_t i = 0; i < len; i++)
+    if (!(theta_host[i] == theta_host[i])) {
+      h->err = "theta contains NaN";
+      return -3;
+    }
+  h->theta.assign(theta_host, theta_host + len);
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_theta, theta_host, sizeof(double) * len, hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+// K[a][b] = scale * k(r_ab) + (s2 + jitter) [a==b]; identity on the padding.
+__global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict__ xnT, const int* __restrict__ task,
+                                                       const double* __restrict__ theta, int n, int np, int dn,
+                                                       int kind, int use_os, int T, double jitter,
+                                                       double* __restrict__ K) {
+  extern __shared__ double s_invls[];
+  for (int j = threadIdx.x; j < dn; j += blockDim.x) s_invls[j] = 1.0 / theta[TH_LS + j];
+  __syncthreads();
+  const int a = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= np) return;
+  if (a >= n || b >= n) {
+    K[(int64_t)a * np + b] = (a == b) ? 1.0 : 0.0;
+    return;
+  }
+  double r2 = 0.0;
+  for (int j = 0; j < dn; j++) {
+    const double df = (xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + b]) * s_invls[j];
+    r2 += df * df;
+  }
+  double k = bbh_kfun(kind, r2);
+  if (use_os) k *= theta[TH_OS];
+  if (T > 1) k *= theta[TH_LS + dn + task[a] * T + task[b]];
+  if (a == b) k += theta[TH_NOISE] + jitter;
+  K[(int64_t)a * np + b] = k;
+}
+
+void bbh_launch_gram(bbh_handle* h, double jitter) {
+  dim3 grid((unsigned)((h->np + 255) / 256), (unsigned)h->np), block(256);
+  hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn, h->stream, h->d_xnT, h->d_task, h->d_theta,
+                     (int)h->n, (int)h->np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T, jitter,
+                     h->d_K);
+}
+
+__global__ void bbh_resid_kernel(const double* __restrict__ ystd, const double* __restrict__ theta, int n, int np,
+                                 double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) r[i] = (i < n) ? ystd[i] - theta[TH_MEAN] : 0.0;
+}
+
+// LOO helper vectors: d = diag(M), u = 0.5/d + 0.5 alpha^2/d^2, w = alpha/d (0 on padding)
+__global__ void bbh_loo_vec_kernel(const double* __restrict__ M, const double* __restrict__ alpha, int n, int np,
+                                   double* __restrict__ u, double* __restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  if (i >= n) {
+    u[i] = 0.0;
+    w[i] = 0.0;
+    return;
+  }
+  const double d = M[(int64_t)i * np + i], a = alpha[i];
+  u[i] = 0.5 / d + 0.5 * a * a / (d * d);
+  w[i] = a / d;
+}
+
+// Msc[a][b] = M[a][b] * u[b]
+__global__ void bbh_colscale_kernel(const double* __restrict__ M, const double* __restrict__ u, int np,
+                                    double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)np * np) out[e] = M[e] * u[e % np];
+}
+
+__device__ __forceinline__ double bbh_block_sum_256(double v, double* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  return r;
+}
+
+// out[0] = data-term value, out[1 + TH_MEAN] = d/dc   (single workgroup)
+__global__ __launch_bounds__(256) void bbh_value_kernel(const double* __restrict__ L, const double* __restrict__ M,
+                                                        const double* __restrict__ r,
+                                                        const double* __restrict__ alpha,
+                                                        const double* __restrict__ q, int n, int np, int criterion,
+                                                        double* __restrict__ out) {
+  __shared__ double sm[4];
+  double v = 0.0, gm = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    if (criterion == BBH_CRITERION_MLL) {
+      v += -0.5 * r[i] * alpha[i] - log(L[(int64_t)i * np + i]);
+      gm += alpha[i];
+    } else {
+      const double d = M[(int64_t)i * np + i];
+      v += 0.5 * log(d) - 0.5 * alpha[i] * alpha[i] / d;
+      gm += q[i];
+    }
+  }
+  v = bbh_block_sum_256(v, sm);
+  gm = bbh_block_sum_256(gm, sm);
+  if (threadIdx.x == 0) {
+    out[0] = v - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    out[1 + TH_MEAN] = gm;
+  }
+}
+
+// Pair kernel: for every ordered pair (a,b), a,b < n:
+//   G_ab  (MLL: 0.5 (alpha_a alpha_b - M_ab);  LOO: -Q_ab + 0.5 (alpha_a q_b + alpha_b q_a))
+// contributes to   d/dl_j       G g(r) scale Delta_j^2 / l_j^3
+//                  d/dnoise     G [a==b]
+//                  d/doutscale  G k scale_B
+//                  d/dB[ta][tb] G k outputscale
+// One wave-level partial row per (a, b-chunk, wave): partial[row][slot].
+__global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
+    const double* __restrict__ xnT, const int* __restrict__ task, const double* __restrict__ theta,
+    const double* __restrict__ M, const double* __restrict__ Q, const double* __restrict__ alpha,
+    const double* __restrict__ q, int n, int np, int dn, int kind, int use_os, int T, int criterion, int nslots,
+    double* __restrict__ partial) {
+  const int a = blockIdx.x;
+  const int b = blockIdx.y * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool act = (b < n);
+  const int bb = act ? b : a;
+  double G;
+  if (criterion == BBH_CRITERION_MLL)
+    G = 0.5 * (alpha[a] * alpha[bb] - M[(int64_t)a * np + bb]);
+  else
+    G = -Q[(int64_t)a * np + bb] + 0.5 * (alpha[a] * q[bb] + alpha[bb] * q[a]);
+  if (!act) G = 0.0;
+  double r2 = 0.0;
+  for (int j = 0; j < dn; j++) {
+    const double df = (xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb]) / theta[TH_LS + j];
+    r2 += df * df;
+  }
+  const double os = use_os ? theta[TH_OS] : 1.0;
+  const int ta = (T > 1) ? task[a] : 0, tb = (T > 1) ? task[bb] : 0;
+  const double Bab = (T > 1) ? theta[TH_LS + dn + ta * T + tb] : 1.0;
+  const double kb = bbh_kfun(kind, r2);
+  const double Gg = G * bbh_gfun(kind, r2) * os * Bab;
+  double* prow = partial + ((int64_t)(a * gridDim.y + blockIdx.y) * 4 + wave) * nslots;
+  // slot layout = gradient layout of theta: [noise, mean(unused), outputscale, ls.., B..]
+  {
+    double v = (a == bb) ? G : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) prow[TH_NOISE] = v;
+  }
+  {
+    double v = use_os ? G * kb * Bab : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) {
+      prow[TH_OS] = v;
+      prow[TH_MEAN] = 0.0;
+    }
+  }
+  for (int j = 0; j < dn; j++) {
+    const double l = theta[TH_LS + j];
+    const double df = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
+    double v = Gg * df * df / (l * l * l);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) prow[TH_LS + j] = v;
+  }
+  if (T > 1) {
+    const double gk = G * kb * os;
+    for (int c = 0; c < T * T; c++) {
+      double v = (c == ta * T + tb) ? gk : 0.0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) prow[TH_LS + dn + c] = v;
+    }
+  }
+}
+
+// out[1 + slot] = sum over partial rows (fixed order -> deterministic); mean slot is skipped
+__global__ __launch_bounds__(256) void bbh_grad_reduce_kernel(const double* __restrict__ partial, int64_t rows,
+                                                              int nslots, double* __restrict__ out) {
+  __shared__ double sm[4];
+  const int slot = blockIdx.x;
+  double v = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) v += partial[r * nslots + slot];
+  v = bbh_block_sum_256(v, sm);
+  if (threadIdx.x == 0 && slot != TH_MEAN) out[1 + slot] = v;
+}
+
+// -----------------------------------------------------------------------------------------
+extern "C" int64_t bbh_theta_len(bbh_handle* h) {
+  if (!h || !h->have_model) return -1;
+  return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0);
+}
+
+static void bbh_free_model(bbh_handle* h) {
+  void* ptrs[] = {h->d_xnT,   h->d_task,    h->d_ystd,      h->d_theta, h->d_K,     h->d_X,       h->d_M,
+                  h->d_Q,     h->d_Q2,      h->d_D,         h->d_tmp,   h->d_r,     h->d_t,       h->d_alpha,
+                  h->d_u,     h->d_w,       h->d_q,         h->d_partial, h->d_out, h->d_info,    h->d_trainfrag,
+                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  h->d_xnT = h->d_ystd = h->d_theta = h->d_K = h->d_X = h->d_M = h->d_Q = h->d_Q2 = h->d_D = h->d_tmp = nullptr;
+  h->d_r = h->d_t = h->d_alpha = h->d_u = h->d_w = h->d_q = h->d_partial = h->d_out = nullptr;
+  h->d_trainfrag = h->d_rfrag = h->d_meanB = h->d_sclofs = h->d_tasktbl = h->d_beta = nullptr;
+  h->d_task = h->d_info = h->d_numcol = h->d_taskext = h->d_pass_w = nullptr;
+  h->d_pass_off = nullptr;
+  h->rfrag_elems = 0;
+  h->have_model = false;
+  h->factorized = false;
+}
+
+void bbh_free_model_public(bbh_handle* h) { bbh_free_model(h); }
+
+extern "C" int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t n, const double* X_train_host,
+                             const double* y_train_host, const double* lo_host, const double* hi_host) {
+  if (!h) return -1;
+  if (!desc || n < 1 || !X_train_host || !y_train_host || !lo_host || !hi_host) {
+    h->err = "bbh_set_model: bad arguments";
+    return -1;
+  }
+  if (desc->kernel_kind < 0 || desc->kernel_kind > 3 || desc->d < 1 || desc->n_tasks < 1 ||
+      (desc->n_tasks > 1 && (desc->task_col < 0 || desc->task_col >= desc->d)) ||
+      (desc->criterion != BBH_CRITERION_MLL && desc->criterion != BBH_CRITERION_LOO)) {
+    h->err = "bbh_set_model: invalid model description";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  bbh_free_model(h);
+  h->desc = *desc;
+  h->n = n;
+  h->np = bbh_round_up(n, BBH_PAD);
+  h->nb = h->np / BBH_TB;
+  h->T = desc->n_tasks;
+  const int d = desc->d;
+  const int tc = (desc->n_tasks > 1 || desc->task_col >= 0) ? desc->task_col : -1;
+  h->numcol.clear();
+  h->lo.clear();
+  h->hi.clear();
+  for (int c = 0; c < d; c++)
+    if (c != tc) {
+      h->numcol.push_back(c);
+      h->lo.push_back(lo_host[c]);
+      h->hi.push_back(hi_host[c]);
+      if (!(hi_host[c] > lo_host[c])) {
+        h->err = "bbh_set_model: scaling bounds need hi > lo for every numerical column";
+        return -1;
+      }
+    }
+  h->dn = (int)h->numcol.size();
+  if (h->dn < 1) {
+    h->err = "bbh_set_model: no numerical column";
+    return -1;
+  }
+  h->kd = (h->dn + 2 + 3) / 4;
+  // Standardize(m=1): Bessel-corrected std, < 1e-8 (or undefined) -> 1
+  double ybar = 0.0;
+  for (int64_t i = 0; i < n; i++) ybar += y_train_host[i];
+  ybar /= (double)n;
+  double ss = 0.0;
+  for (int64_t i = 0; i < n; i++) ss += (y_train_host[i] - ybar) * (y_train_host[i] - ybar);
+  double sd = (n > 1) ? sqrt(ss / (double)(n - 1)) : NAN;
+  if (!(sd >= 1e-8)) sd = 1.0;
+  h->ybar = ybar;
+  h->ysd = sd;
+  h->ystd_host.resize(n);
+  for (int64_t i = 0; i < n; i++) h->ystd_host[i] = (y_train_host[i] - ybar) / sd;
+  // Normalize numerical columns; keep the task ids
+  h->xn_host.assign((size_t)n * h->dn, 0.0);
+  h->task_host.assign(n, 0);
+  h->xcenter.assign(h->dn, 0.0);
+  for (int64_t i = 0; i < n; i++) {
+    for (int j = 0; j < h->dn; j++) {
+      const double v = (X_train_host[i * d + h->numcol[j]] - h->lo[j]) / (h->hi[j] - h->lo[j]);
+      h->xn_host[(size_t)i * h->dn + j] = v;
+      h->xcenter[j] += v;
+    }
+    if (tc >= 0) {
+      const int t = (int)X_train_host[i * d + tc];
+      if (t < 0 || t >= h->T) {
+        h->err = "bbh_set_model: task id out of range";
+        return -1;
+      }
+      h->task_host[i] = t;
+    }
+  }
+  for (int j = 0; j < h->dn; j++) h->xcenter[j] /= (double)n;
+
+  const int64_t np = h->np;
+  const int64_t tl = 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0);
+  std::vector<double> xnT((size_t)h->dn * np, 0.0), ypad(np, 0.0);
+  std::vector<int> tpad(np, 0);
+  for (int64_t i = 0; i < n; i++) {
+    for (int j = 0; j < h->dn; j++) xnT[(size_t)j * np + i] = h->xn_host[(size_t)i * h->dn + j];
+    ypad[i] = h->ystd_host[i];
+    tpad[i] = h->task_host[i];
+  }
+#define BBH_ALLOC(ptr, count) BBH_HIP_TRY(h, hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)))
+  BBH_ALLOC(h->d_xnT, h->dn * np);
+  BBH_ALLOC(h->d_task, np);
+  BBH_ALLOC(h->d_ystd, np);
+  BBH_ALLOC(h->d_theta, tl);
+  BBH_ALLOC(h->d_K, np * np);
+  BBH_ALLOC(h->d_X, np * np);
+  BBH_ALLOC(h->d_M, np * np);
+  BBH_ALLOC(h->d_Q, np * np);
+  BBH_ALLOC(h->d_Q2, np * np);
+  BBH_ALLOC(h->d_D, np * 64);
+  BBH_ALLOC(h->d_tmp, np * 64);
+  BBH_ALLOC(h->d_r, np);
+  BBH_ALLOC(h->d_t, np);
+  BBH_ALLOC(h->d_alpha, np);
+  BBH_ALLOC(h->d_u, np);
+  BBH_ALLOC(h->d_w, np);
+  BBH_ALLOC(h->d_q, np);
+  const int64_t nchunks = (n + 255) / 256;
+  BBH_ALLOC(h->d_partial, n * nchunks * 4 * tl);
+  BBH_ALLOC(h->d_out, 1 + tl);
+  BBH_ALLOC(h->d_info, 1);
+  BBH_ALLOC(h->d_beta, np * BBH_MEANCOLS);
+  BBH_HIP_TRY(h, hipMemcpy(h->d_xnT, xnT.data(), sizeof(double) * xnT.size(), hipMemcpyHostToDevice));
+  BBH_HIP_TRY(h, hipMemcpy(h->d_task, tpad.data(), sizeof(int) * np, hipMemcpyHostToDevice));
+  BBH_HIP_TRY(h, hipMemcpy(h->d_ystd, ypad.data(), sizeof(double) * np, hipMemcpyHostToDevice));
+  h->xraw_host.assign(X_train_host, X_train_host + n * d);
+  h->p = 0;
+  h->pend_host.clear();
+  h->have_model = true;
+  h->factorized = false;
+  return 0;
+}
+
+extern "C" int bbh_get_standardization(bbh_handle* h, double* ybar, double* ysd) {
+  if (!h || !h->have_model) return -1;
+  if (ybar) *ybar = h->ybar;
+  if (ysd) *ysd = h->ysd;
+  return 0;
+}
+
+// K -> L, X = L^-1, r, alpha.  Returns the Cholesky info flag (0 ok) via *info_out.
+static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
+  hipStream_t s = h->stream;
+  const int64_t np = h->np;
+  bbh_launch_gram(h, jitter);
+  bbh_potrf_trtri(h);
+  hipLaunchKernelGGL(bbh_resid_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, h->d_ystd, h->d_theta,
+                     (int)h->n, (int)np, h->d_r);
+  bbh_matvec(s, h->d_X, np, np, np, h->d_r, h->d_t);        // t = L^-1 r
+  bbh_matvec_t(s, h->d_X, np, np, np, h->d_t, h->d_alpha);  // alpha = L^-T t
+  int info = 0;
+  BBH_HIP_TRY(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  *info_out = info;
+  return 0;
+}
+
+extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, double* value_host, double* grad_host) {
+  if (!h) return -1;
+  if (!h->have_model || !theta_host || !value_host || !grad_host) {
+    h->err = "bbh_fit_value_grad: no model / bad arguments";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_upload_theta(h, theta_host);
+  if (rc) return rc;
+  h->factorized = false;
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, n = h->n;
+  const int64_t tl = bbh_theta_len(h);
+  int info = 0;
+  rc = bbh_chol_and_alpha(h, 0.0, &info);
+  if (rc) return rc;
+  if (info != 0) {
+    *value_host = -INFINITY;
+    for (int64_t i = 0; i < tl; i++) grad_host[i] = 0.0;
+    return 1;
+  }
+  // M = X^T X
+  bbh_gemm(s, true, false, np, np, np, 1.0, h->d_X, np, 0, h->d_X, np, 0, 0.0, h->d_M, np, 0, 1);
+  const int crit = h->desc.criterion;
+  if (crit == BBH_CRITERION_LOO) {
+    hipLaunchKernelGGL(bbh_loo_vec_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, h->d_M, h->d_alpha,
+                       (int)n, (int)np, h->d_u, h->d_w);
+    bbh_matvec(s, h->d_M, np, np, np, h->d_w, h->d_q);  // q = M w
+    hipLaunchKernelGGL(bbh_colscale_kernel, dim3((unsigned)((np * np + 255) / 256)), dim3(256), 0, s, h->d_M, h->d_u,
+                       (int)np, h->d_Q2);
+    bbh_gemm(s, false, false, np, np, np, 1.0, h->d_Q2, np, 0, h->d_M, np, 0, 0.0, h->d_Q, np, 0, 1);
+  }
+  hipMemsetAsync(h->d_out, 0, sizeof(double) * (1 + tl), s);
+  hipLaunchKernelGGL(bbh_value_kernel, dim3(1), dim3(256), 0, s, h->d_K, h->d_M, h->d_r, h->d_alpha, h->d_q, (int)n,
+                     (int)np, crit, h->d_out);
+  const int nchunks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(bbh_grad_pair_kernel, dim3((unsigned)n, (unsigned)nchunks), dim3(256), 0, s, h->d_xnT, h->d_task,
+                     h->d_theta, h->d_M, h->d_Q, h->d_alpha, h->d_q, (int)n, (int)np, h->dn, h->desc.kernel_kind,
+                     h->desc.use_outputscale, h->T, crit, (int)tl, h->d_partial);
+  hipLaunchKernelGGL(bbh_grad_reduce_kernel, dim3((unsigned)tl), dim3(256), 0, s, h->d_partial,
+                     (int64_t)n * nchunks * 4, (int)tl, h->d_out);
+  std::vector<double> out(1 + tl);
+  BBH_HIP_TRY(h, hipMemcpyAsync(out.data(), h->d_out, sizeof(double) * (1 + tl), hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  *value_host = out[0];
+  for (int64_t i = 0; i < tl; i++) grad_host[i] = out[1 + i];
+  return 0;
+}
+
+extern "C" int bbh_factorize(bbh_handle* h, const double* theta_host, double* jitter_used) {
+  if (!h) return -1;
+  if (!h->have_model || !theta_host) {
+    h->err = "bbh_factorize: no model / bad arguments";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_upload_theta(h, theta_host);
+  if (rc) return rc;
+  h->factorized = false;
+  // gpytorch psd_safe_cholesky: plain attempt, then jitter 1e-8 * 10^i, i = 0..2
+  double jitter = 0.0;
+  int info = 0;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    rc = bbh_chol_and_alpha(h, jitter, &info);
+    if (rc) return rc;
+    if (info == 0) break;
+    jitter = 1e-8 * pow(10.0, attempt);
+  }
+  if (info != 0) {
+    h->err = "bbh_factorize: train covariance not positive definite (even with jitter 1e-6)";
+    return -4;
+  }
+  if (jitter_used) *jitter_used = jitter;
+  h->p = 0;
+  h->pend_host.clear();
+  h->factorized = true;
+  rc = bbh_pack_operands(h);
+  if (rc) {
+    h->factorized = false;
+    return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,724 @@
+// Fused GP posterior over a discrete candidate set (the dominant kernel of the path).
+//
+// Replaces, per candidate chunk, what BoTorch does inside
+//   optimize_acqf_discrete -> acqf(chunk) -> model.posterior(chunk)
+// (reference call site baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126; maths
+// SURVEY.md §3.4 / Appendix A7): Normalize, cross-covariance K(X*,X), posterior mean
+// c + k*^T alpha, posterior variance k** - ||L^-1 k*||^2, un-Standardize.
+//
+// One wavefront owns a tile of 16 candidates; everything is expressed in the fragment layout
+// of v_mfma_f64_16x16x4_f64 so that no value ever leaves its lane between stages:
+//
+//   (1) distance GEMM      r2[train, cand] = A_aug[train, :] . B_aug[:, cand]
+//         A_aug = [-2 a_i, |a_i|^2, 1], B_aug = [b_c, 1, |b_c|^2]^T, a/b = centred inputs / l
+//         (M = 16 training points, N = 16 candidates, K = dn + 2 padded to 4).
+//         C layout: lane l, reg r  <->  training point 4 r + (l>>4), candidate l & 15.
+//   (2) kernel function    kv[r] = k(sqrt(r2)) (* outputscale * B[t_c, t_i])  — VALU, in place.
+//         This *is* the A-fragment of the next GEMMs for k-step 4 tb + r:
+//         lane l holds A[cand = l & 15][k = l >> 4].
+//   (3) variance GEMM      V[cand, j] += kv . R[k, j],  R = L^-T (upper triangular, packed in
+//         fragment order), accumulated for a window of W <= 16 column blocks ("pass");
+//         only blocks j >= k are touched.  ||v||^2 is reduced from the accumulators.
+//   (4) mean / cross GEMM  [mean | cross_1..p] += kv . [alpha | -beta_1..-beta_p] in the last pass.
+//
+// Passes of width W keep 8 W accumulator VGPRs (128 for W = 16), i.e. two waves per SIMD, so
+// the VALU work of (2) in one wave overlaps the MFMA work of (3) in the other.  K(X*,X) is
+// never materialised; later passes recompute (1)-(2) for the k-blocks they need.
+#include <math.h>
+#include <string.h>
+
+#include "bbh_common.h"
+
+#define BBH_MAX_PASS 64
+
+__device__ __forceinline__ double bbh_kfun_p(int kind, double r2) {
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
+  return exp(-r);
+}
+
+struct FusedArgs {
+  const double* X;
+  int64_t N, ldx;
+  const double* trainfrag;
+  const double* rfrag;
+  const double* meanB;
+  const double* scl;
+  const double* ofs;
+  const int* numcol;
+  const double* tasktbl;
+  const int* taskext;
+  double* mean;
+  double* var;
+  double* cross;
+  const int64_t* pass_off;  // [npass] element offset of each pass in rfrag
+  const int* pass_w;        // [npass] window width in 16-column blocks
+  int npass;
+  int kind, dn, kd, nb, nb_ext, task_col, T, p, with_var;
+  double ybar, ysd, mean_const, prior_scale;
+};
+
+struct WaveCtx {
+  const double* tf;     // trainfrag + lane
+  const double* candl;  // this wave's candidate fragments in LDS, + lane
+  const double* mb;     // meanB + lane
+  const double* tbl;
+  const int* taskext;
+  int kd, kind, T, tc, q;
+};
+
+// KIND >= 0: compile-time kernel kind (branch-free fast path); KIND < 0: runtime c.kind.
+template <bool HAS_TBL, int KIND>
+__device__ __forceinline__ void compute_kv(const WaveCtx& c, int tb, double (&kv)[4]) {
+  d4 da = {0.0, 0.0, 0.0, 0.0}, db = {0.0, 0.0, 0.0, 0.0};
+  const double* tf = c.tf + (int64_t)tb * c.kd * 64;
+  int k = 0;
+  for (; k + 3 < c.kd; k += 4) {  // loads first, then the MFMA chain (two independent accumulators)
+    const double t0 = tf[k * 64], t1 = tf[(k + 1) * 64], t2 = tf[(k + 2) * 64], t3 = tf[(k + 3) * 64];
+    const double c0 = c.candl[k * 64], c1 = c.candl[(k + 1) * 64], c2 = c.candl[(k + 2) * 64],
+                 c3 = c.candl[(k + 3) * 64];
+    da = mfma_f64(t0, c0, da);
+    db = mfma_f64(t1, c1, db);
+    da = mfma_f64(t2, c2, da);
+    db = mfma_f64(t3, c3, db);
+  }
+  for (; k < c.kd; k++) da = mfma_f64(tf[k * 64], c.candl[k * 64], da);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const double r2 = fmax(da[r] + db[r], 0.0);
+    double v;
+    if (KIND == BBH_KERNEL_MATERN52) {
+      const double rr = sqrt(r2);
+      v = (1.0 + BBH_SQRT5 * rr + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * rr);
+    } else {
+      v = bbh_kfun_p(c.kind, r2);
+    }
+    if (HAS_TBL) v *= c.tbl[c.tc * c.T + c.taskext[16 * tb + 4 * r + c.q]];
+    kv[r] = v;
+  }
+}
+
+// Triangular region of a pass, k-block j0 + TT, as a compile-time recursion over TT (a plain
+// `#pragma unroll` over tt exceeds the unroll threshold and would demote acc[] to scratch).
+template <int W, int D, int TT, bool HAS_TBL, bool DO_MEAN, int KIND>
+__device__ __forceinline__ void diag_steps(const WaveCtx& c, const double* rf, int j0, d4 (&acc)[W], double (&ring)[D],
+                                           d4& accm) {
+  if constexpr (TT < W) {
+    constexpr int TOTAL = 2 * W * (W + 1);
+    constexpr int BASE = 4 * (TT * W - (TT * (TT - 1)) / 2);  // fragments consumed before this k-block
+    constexpr int CNT = W - TT;
+    double kv[4];
+    compute_kv<HAS_TBL, KIND>(c, j0 + TT, kv);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int jj = 0; jj < CNT; jj++) {
+        const int i = BASE + r * CNT + jj;
+        acc[TT + jj] = mfma_f64(kv[r], ring[i % D], acc[TT + jj]);
+        if (i + D < TOTAL) ring[i % D] = rf[(i + D) * 64];
+        if (i % D == D - 1) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at D
+      }
+    if (DO_MEAN) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * (j0 + TT) + r) * 64], accm);
+    }
+    diag_steps<W, D, TT + 1, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);
+  }
+}
+
+// One pass over the column-block window [j0, j0 + W): accumulates ||v||^2 contributions into ss
+// and (DO_MEAN) the mean/cross columns into accm.
+//
+// The R fragments of a pass are stored in exactly the order the MFMAs consume them (k-block tb,
+// k-step r, column block jj), so the operand stream is one linear walk.  It is software-pipelined
+// through a register ring of D fragments: fragment i + D is requested right after MFMA i has
+// consumed ring slot i % D (all indices are compile-time constants; 4 W and the triangular total
+// 2 W (W + 1) are multiples of D).  The first D fragments of a k-block are thus already in flight
+// while its kernel values are computed.
+template <int W, int D, bool HAS_TBL, bool DO_MEAN, int KIND>
+__device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, int j0, double (&ss)[4], d4& accm) {
+  static_assert((4 * W) % D == 0 && (2 * W * (W + 1)) % D == 0, "ring depth must divide the stream");
+  d4 acc[W];
+#pragma unroll
+  for (int jj = 0; jj < W; jj++) acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
+  double ring[D];
+#pragma unroll
+  for (int i = 0; i < D; i++) ring[i] = rf[i * 64];
+  // rectangular region: every column block of the window is active
+  for (int tb = 0; tb < j0; tb++) {
+    double kv[4];
+    compute_kv<HAS_TBL, KIND>(c, tb, kv);
+#pragma unroll
+    for (int i = 0; i < 4 * W; i++) {
+      acc[i % W] = mfma_f64(kv[i / W], ring[i % D], acc[i % W]);
+      ring[i % D] = rf[(i + D) * 64];
+      if (i % D == D - 1) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at D
+    }
+    rf += 4 * W * 64;
+    if (DO_MEAN) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
+    }
+  }
+  // triangular region: k-block j0 + tt only reaches column blocks jj >= tt
+  diag_steps<W, D, 0, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);
+#pragma unroll
+  for (int jj = 0; jj < W; jj++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) ss[r] = fma(acc[jj][r], acc[jj][r], ss[r]);
+}
+
+template <bool HAS_TBL, int KIND>
+__global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double s_cand[];  // [4 waves][kd][64]
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cnd = l & 15, q = l >> 4;
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+  if (tile0 >= a.N) return;  // whole wave out of range (no workgroup barrier is used below)
+  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
+  const double* xr = a.X + row * a.ldx;
+  double* candw = s_cand + (int64_t)w * a.kd * 64;
+
+  // ---- candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2] -------------------
+  double nbsum = 0.0;
+  for (int k = 0; k < a.kd; k++) {
+    const int dim = 4 * k + q;
+    double v = 0.0;
+    if (dim < a.dn) {
+      v = fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
+      nbsum = fma(v, v, nbsum);
+    }
+    candw[k * 64 + l] = v;
+  }
+  nbsum += __shfl_xor(nbsum, 16, 64);
+  nbsum += __shfl_xor(nbsum, 32, 64);
+  {
+    const int k1 = a.dn >> 2, q1 = a.dn & 3;  // slot dn: 1.0
+    if (q == q1) candw[k1 * 64 + l] = 1.0;
+    const int k2 = (a.dn + 1) >> 2, q2 = (a.dn + 1) & 3;  // slot dn + 1: |b|^2
+    if (q == q2) candw[k2 * 64 + l] = nbsum;
+  }
+  int tc = 0;
+  if (HAS_TBL && a.task_col >= 0) {
+    tc = (int)xr[a.task_col];
+    tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+  }
+
+  WaveCtx c;
+  c.tf = a.trainfrag + l;
+  c.candl = candw + l;
+  c.mb = a.meanB + l;
+  c.tbl = a.tasktbl;
+  c.taskext = a.taskext;
+  c.kd = a.kd;
+  c.kind = a.kind;
+  c.T = a.T;
+  c.tc = tc;
+  c.q = q;
+
+  double ss[4] = {0.0, 0.0, 0.0, 0.0};
+  d4 accm = {0.0, 0.0, 0.0, 0.0};
+  double kv[4];
+
+  if (a.with_var) {
+    int j0 = 0;
+    for (int ps = 0; ps < a.npass; ps++) {
+      const int W = a.pass_w[ps];
+      const double* rf = a.rfrag + a.pass_off[ps] + l;
+      const bool last = (ps == a.npass - 1);
+      if (!last) {
+        pass_body<16, 8, HAS_TBL, false, KIND>(c, rf, j0, ss, accm);
+      } else {
+        switch (W) {
+          case 4: pass_body<4, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
+          case 8: pass_body<8, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
+          case 12: pass_body<12, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
+          default: pass_body<16, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
+        }
+      }
+      j0 += W;
+    }
+    // pending block(s): mean/cross columns only
+    for (int tb = a.nb; tb < a.nb_ext; tb++) {
+      compute_kv<HAS_TBL, KIND>(c, tb, kv);
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
+    }
+  } else {
+    for (int tb = 0; tb < a.nb_ext; tb++) {
+      compute_kv<HAS_TBL, KIND>(c, tb, kv);
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
+    }
+  }
+
+  // ---- epilogue: lane (q, cnd), reg r  <->  candidate q + 4 r, column cnd -------------------
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double s = ss[r];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    ss[r] = s;
+  }
+  const double s2 = a.ysd * a.ysd;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = q + 4 * r;  // candidate within the tile
+    const int tcm = __shfl(tc, m, 64);
+    const int64_t gi = tile0 + m;
+    if (gi < a.N) {
+      if (cnd == 0) {
+        if (a.mean) a.mean[gi] = a.ybar + a.ysd * (a.mean_const + accm[r]);
+        if (a.with_var && a.var) {
+          double pv = a.prior_scale;
+          if (HAS_TBL) pv = a.tasktbl[tcm * a.T + tcm];
+          a.var[gi] = s2 * (pv - ss[r]);
+        }
+      } else if (cnd <= a.p && a.cross) {
+        a.cross[gi * a.p + (cnd - 1)] = s2 * accm[r];
+      }
+    }
+  }
+}
+
+// ---- operand packing ------------------------------------------------------------------------
+// R fragments of one pass: for tb in [0, j1), r in 0..3, jb in [max(j0, tb), j1):
+//   lane l <- R[k = 16 tb + 4 r + (l>>4)][j = 16 jb + (l&15)] = X[j][k]   (X = L^-1, lower)
+__global__ void bbh_pack_rfrag_kernel(const double* __restrict__ X, int64_t np, int j0, int W, double* __restrict__ out) {
+  const int tb = blockIdx.x, r = blockIdx.y, l = threadIdx.x;
+  const int j1 = j0 + W;
+  const int lo = tb > j0 ? tb : j0;
+  const int cnt = j1 - lo;
+  // fragments before this tb within the pass
+  int64_t off;
+  if (tb <= j0)
+    off = (int64_t)4 * W * tb;
+  else
+    off = (int64_t)4 * (W * (int64_t)j0 + (int64_t)(tb - j0) * j1 - ((int64_t)(j0 + tb - 1) * (tb - j0)) / 2);
+  off += (int64_t)r * cnt;
+  const int64_t k = 16 * (int64_t)tb + 4 * r + (l >> 4);
+  for (int jb = lo; jb < j1; jb++) {
+    const int64_t j = 16 * (int64_t)jb + (l & 15);
+    out[(off + (jb - lo)) * 64 + l] = (k <= j) ? X[j * np + k] : 0.0;
+  }
+}
+
+// Bm[i][0] = alpha[i] (i < np), everything else zero
+__global__ void bbh_init_meanB_kernel(const double* __restrict__ alpha, int64_t np, int64_t rows, double* __restrict__ Bm) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * 16) return;
+  const int64_t i = e >> 4;
+  const int c = (int)(e & 15);
+  Bm[e] = (c == 0 && i < np) ? alpha[i] : 0.0;
+}
+
+// Bm[i][1 + j] = -betaT[j][i] (i < np);  Bm[np + j][1 + j] = 1
+__global__ void bbh_set_beta_kernel(const double* __restrict__ betaT, int64_t ldb, int64_t np, int p, double* __restrict__ Bm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np + 16) return;
+  for (int j = 0; j < p; j++) {
+    double v;
+    if (i < np)
+      v = -betaT[(int64_t)j * ldb + i];
+    else
+      v = (i - np == j) ? 1.0 : 0.0;
+    Bm[i * 16 + 1 + j] = v;
+  }
+}
+
+static double host_kfun(int kind, double r2) {
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
+  return exp(-r);
+}
+
+// Host-side layout of the augmented training fragments for blocks [tb0, tb1):
+//   frag[tb][k][l] = Aaug[16 tb + (l & 15)][4 k + (l >> 4)]
+// pts: normalised numerical coordinates [cnt, dn] of the real points in this range (row 0 is
+// point index 16 tb0); anything beyond cnt is padding (huge distance -> kernel value 0).
+static void host_pack_trainfrag(const bbh_handle* h, const double* pts, int64_t cnt, int64_t tb0, int64_t tb1,
+                                std::vector<double>& out) {
+  const int dn = h->dn, kd = h->kd;
+  const double* ls = h->theta.data() + 3;
+  out.assign((size_t)(tb1 - tb0) * kd * 64, 0.0);
+  std::vector<double> a(dn);
+  for (int64_t tb = tb0; tb < tb1; tb++)
+    for (int c16 = 0; c16 < 16; c16++) {
+      const int64_t i = (tb - tb0) * 16 + c16;
+      const bool real = i < cnt;
+      double na = 0.0;
+      if (real)
+        for (int j = 0; j < dn; j++) {
+          a[j] = (pts[i * dn + j] - h->xcenter[j]) / ls[j];
+          na += a[j] * a[j];
+        }
+      for (int k = 0; k < kd; k++)
+        for (int qq = 0; qq < 4; qq++) {
+          const int dim = 4 * k + qq;
+          double v = 0.0;
+          if (real) {
+            if (dim < dn)
+              v = -2.0 * a[dim];
+            else if (dim == dn)
+              v = na;
+            else if (dim == dn + 1)
+              v = 1.0;
+          } else if (dim == dn) {
+            v = 1e8;
+          }
+          out[((size_t)(tb - tb0) * kd + k) * 64 + qq * 16 + c16] = v;
+        }
+    }
+}
+
+int bbh_pack_operands(bbh_handle* h) {
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, nb = h->nb;
+  const int dn = h->dn, kd = h->kd, T = h->T;
+  const double* th = h->theta.data();
+  // ---- pass decomposition: full 16-block windows first, the remainder last ----
+  std::vector<int> widths;
+  {
+    int64_t left = nb;
+    while (left >= 16) {
+      widths.push_back(16);
+      left -= 16;
+    }
+    if (left > 0) widths.push_back((int)left);
+  }
+  if ((int)widths.size() > BBH_MAX_PASS) {
+    h->err = "n_train too large for the fused kernel (max 16384)";
+    return -5;
+  }
+  // ---- sizes & allocation ----
+  int64_t total_frags = 0;
+  std::vector<int64_t> pass_off(widths.size());
+  {
+    int j0 = 0;
+    for (size_t ps = 0; ps < widths.size(); ps++) {
+      pass_off[ps] = total_frags * 64;
+      const int W = widths[ps], j1 = j0 + W;
+      total_frags += (int64_t)4 * W * j0;                       // rectangular part
+      for (int tb = j0; tb < j1; tb++) total_frags += 4 * (j1 - tb);  // triangular part
+      j0 = j1;
+    }
+  }
+  if (!h->d_pass_off) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_pass_off, sizeof(int64_t) * BBH_MAX_PASS));
+  if (!h->d_pass_w) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_pass_w, sizeof(int) * BBH_MAX_PASS));
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_pass_off, pass_off.data(), sizeof(int64_t) * pass_off.size(), hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_pass_w, widths.data(), sizeof(int) * widths.size(), hipMemcpyHostToDevice, s));
+  h->npass = (int)widths.size();
+  if (!h->d_rfrag || h->rfrag_elems != total_frags * 64) {
+    if (h->d_rfrag) hipFree(h->d_rfrag);
+    h->d_rfrag = nullptr;
+    BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rfrag, sizeof(double) * total_frags * 64));
+    h->rfrag_elems = total_frags * 64;
+  }
+  if (!h->d_trainfrag) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_trainfrag, sizeof(double) * (nb + 1) * kd * 64));
+  if (!h->d_meanB) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_meanB, sizeof(double) * (np + 16) * 16));
+  if (!h->d_sclofs) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_sclofs, sizeof(double) * 2 * dn));
+  if (!h->d_numcol) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_numcol, sizeof(int) * dn));
+  if (!h->d_tasktbl) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_tasktbl, sizeof(double) * T * T));
+  if (!h->d_taskext) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_taskext, sizeof(int) * (np + 16)));
+  // ---- R fragments from X = L^-1 ----
+  {
+    int j0 = 0;
+    for (size_t ps = 0; ps < widths.size(); ps++) {
+      const int W = widths[ps];
+      hipLaunchKernelGGL(bbh_pack_rfrag_kernel, dim3((unsigned)(j0 + W), 4), dim3(64), 0, s, h->d_X, np, j0, W,
+                         h->d_rfrag + pass_off[ps]);
+      j0 += W;
+    }
+  }
+  // ---- training fragments (+ one all-padding block reserved for pending points) ----
+  std::vector<double> tf;
+  host_pack_trainfrag(h, h->xn_host.data(), h->n, 0, nb + 1, tf);
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag, tf.data(), sizeof(double) * tf.size(), hipMemcpyHostToDevice, s));
+  // ---- candidate-side scale/offset, column map, task table ----
+  std::vector<double> so(2 * dn);
+  for (int j = 0; j < dn; j++) {
+    const double rng = h->hi[j] - h->lo[j];
+    so[j] = 1.0 / (rng * th[3 + j]);
+    so[dn + j] = -(h->lo[j] / rng + h->xcenter[j]) / th[3 + j];
+  }
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_sclofs, so.data(), sizeof(double) * 2 * dn, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_numcol, h->numcol.data(), sizeof(int) * dn, hipMemcpyHostToDevice, s));
+  const double os = h->desc.use_outputscale ? th[2] : 1.0;
+  std::vector<double> tbl((size_t)T * T, os);
+  if (T > 1)
+    for (int i = 0; i < T * T; i++) tbl[i] = os * th[3 + dn + i];
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_tasktbl, tbl.data(), sizeof(double) * T * T, hipMemcpyHostToDevice, s));
+  std::vector<int> te(np + 16, 0);
+  for (int64_t i = 0; i < h->n; i++) te[i] = h->task_host[i];
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_taskext, te.data(), sizeof(int) * (np + 16), hipMemcpyHostToDevice, s));
+  // ---- mean operand ----
+  hipLaunchKernelGGL(bbh_init_meanB_kernel, dim3((unsigned)(((np + 16) * 16 + 255) / 256)), dim3(256), 0, s, h->d_alpha,
+                     np, np + 16, h->d_meanB);
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));  // host staging vectors go out of scope
+  h->nb_ext = nb;
+  h->p = 0;
+  return 0;
+}
+
+int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
+                     double* cross_dev, bool with_var) {
+  if (N <= 0) return 0;
+  FusedArgs a;
+  a.X = X_dev;
+  a.N = N;
+  a.ldx = ldx;
+  a.trainfrag = h->d_trainfrag;
+  a.rfrag = h->d_rfrag;
+  a.meanB = h->d_meanB;
+  a.scl = h->d_sclofs;
+  a.ofs = h->d_sclofs + h->dn;
+  a.numcol = h->d_numcol;
+  a.tasktbl = h->d_tasktbl;
+  a.taskext = h->d_taskext;
+  a.mean = mean_dev;
+  a.var = var_dev;
+  a.cross = cross_dev;
+  a.pass_off = h->d_pass_off;
+  a.pass_w = h->d_pass_w;
+  a.npass = h->npass;
+  a.kind = h->desc.kernel_kind;
+  a.dn = h->dn;
+  a.kd = h->kd;
+  a.nb = (int)h->nb;
+  a.nb_ext = (int)h->nb_ext;
+  a.task_col = h->desc.task_col;
+  a.T = h->T;
+  a.p = h->p;
+  a.with_var = with_var ? 1 : 0;
+  a.ybar = h->ybar;
+  a.ysd = h->ysd;
+  a.mean_const = h->theta[1];
+  a.prior_scale = h->desc.use_outputscale ? h->theta[2] : 1.0;
+  const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
+  const size_t lds = sizeof(double) * 4 * h->kd * 64;
+  dim3 grid((unsigned)((N + 63) / 64)), block(256);
+  const bool timed = h->timing && with_var;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, h->stream);
+  }
+  const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
+  if (has_tbl && m52)
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a);
+  else if (has_tbl)
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, -1>), grid, block, lds, h->stream, a);
+  else if (m52)
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a);
+  else
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, -1>), grid, block, lds, h->stream, a);
+  if (timed) {
+    hipEventRecord(e1, h->stream);
+    h->pending_events.emplace_back(e0, e1);
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---- unfused verification path ------------------------------------------------------------------
+// K(X*, X) materialised with direct-difference distances, then V = K* L^-T through bbh_gemm.
+__global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict__ X, int64_t Nc, int64_t ldx,
+                                                        const double* __restrict__ xnT, const int* __restrict__ task,
+                                                        const double* __restrict__ theta, const int* __restrict__ numcol,
+                                                        const double* __restrict__ lo, const double* __restrict__ hi,
+                                                        int n, int64_t np, int dn, int kind, int use_os, int T,
+                                                        int task_col, double* __restrict__ Kst) {
+  const int64_t cand = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= np) return;
+  double v = 0.0;
+  if (cand < Nc && i < n) {
+    const double* xr = X + cand * ldx;
+    double r2 = 0.0;
+    for (int j = 0; j < dn; j++) {
+      const double xc = (xr[numcol[j]] - lo[j]) / (hi[j] - lo[j]);
+      const double df = (xc - xnT[(int64_t)j * np + i]) / theta[3 + j];
+      r2 += df * df;
+    }
+    v = bbh_kfun_p(kind, r2);
+    if (use_os) v *= theta[2];
+    if (T > 1) {
+      int tcand = (int)xr[task_col];
+      tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
+      v *= theta[3 + dn + tcand * T + task[i]];
+    }
+  }
+  Kst[cand * np + i] = v;
+}
+
+__global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __restrict__ Kst, const double* __restrict__ V,
+                                                            const double* __restrict__ alpha,
+                                                            const double* __restrict__ X, int64_t ldx, int64_t Nc,
+                                                            int64_t np, const double* __restrict__ theta, int dn,
+                                                            int use_os, int T, int task_col, double ybar, double ysd,
+                                                            double* __restrict__ mean, double* __restrict__ var) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cand = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cand >= Nc) return;
+  double sm = 0.0, sv = 0.0;
+  for (int64_t i = lane; i < np; i += 64) {
+    sm = fma(Kst[cand * np + i], alpha[i], sm);
+    const double v = V[cand * np + i];
+    sv = fma(v, v, sv);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sm += __shfl_down(sm, o, 64);
+    sv += __shfl_down(sv, o, 64);
+  }
+  if (lane == 0) {
+    double pv = use_os ? theta[2] : 1.0;
+    if (T > 1) {
+      int tcand = (int)X[cand * ldx + task_col];
+      tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
+      pv *= theta[3 + dn + tcand * T + tcand];
+    }
+    if (mean) mean[cand] = ybar + ysd * (theta[1] + sm);
+    if (var) var[cand] = ysd * ysd * (pv - sv);
+  }
+}
+
+// Kst [Ncpad, np] (rows >= Nc zero) and, if V != nullptr, V = Kst L^-T, for one candidate chunk.
+static int bbh_unfused_chunk(bbh_handle* h, const double* X_dev, int64_t Nc, int64_t ldx, double* Kst, double* V,
+                             const double* d_lo, const double* d_hi) {
+  const int64_t np = h->np;
+  const int64_t Ncpad = bbh_round_up(Nc, 64);
+  dim3 grid((unsigned)((np + 255) / 256), (unsigned)Ncpad), block(256);
+  hipLaunchKernelGGL(bbh_kstar_kernel, grid, block, 0, h->stream, X_dev, Nc, ldx, h->d_xnT, h->d_task, h->d_theta,
+                     h->d_numcol, d_lo, d_hi, (int)h->n, np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T,
+                     h->desc.task_col, Kst);
+  if (V) bbh_gemm(h->stream, false, true, Ncpad, np, np, 1.0, Kst, np, 0, h->d_X, np, 0, 0.0, V, np, 0, 1);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev) {
+  const int64_t np = h->np;
+  const int64_t chunk = 16384;
+  const size_t need = sizeof(double) * (2 * (size_t)chunk * np + 2 * h->dn);
+  int rc = bbh_ensure_ws(h, need);
+  if (rc) return rc;
+  double* Kst = h->d_ws;
+  double* V = Kst + chunk * np;
+  double* d_lo = V + chunk * np;
+  double* d_hi = d_lo + h->dn;
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, h->stream));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, h->stream));
+  for (int64_t s0 = 0; s0 < N; s0 += chunk) {
+    const int64_t Nc = (N - s0 < chunk) ? N - s0 : chunk;
+    rc = bbh_unfused_chunk(h, X_dev + s0 * ldx, Nc, ldx, Kst, V, d_lo, d_hi);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bbh_rowreduce_kernel, dim3((unsigned)((Nc + 3) / 4)), dim3(256), 0, h->stream, Kst, V, h->d_alpha,
+                       X_dev + s0 * ldx, ldx, Nc, np, h->d_theta, h->dn, h->desc.use_outputscale, h->T, h->desc.task_col,
+                       h->ybar, h->ysd, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr);
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// ---- pending points ---------------------------------------------------------------------------
+extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t p, double* mean_p_host,
+                               double* cov_pp_host) {
+  if (!h) return -1;
+  if (!h->factorized) {
+    h->err = "bbh_pending_set: model not factorised";
+    return -1;
+  }
+  if (p < 0 || p > BBH_MAX_PENDING || (p > 0 && !Xpend_host)) {
+    h->err = "bbh_pending_set: 0 <= p <= 15 pending points supported";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, nb = h->nb;
+  const int d = h->desc.d, dn = h->dn, T = h->T;
+  h->pend_host.assign(Xpend_host, Xpend_host + p * d);
+  // reset mean operand to [alpha | 0] and the pending fragment block to padding
+  hipLaunchKernelGGL(bbh_init_meanB_kernel, dim3((unsigned)(((np + 16) * 16 + 255) / 256)), dim3(256), 0, s, h->d_alpha,
+                     np, np + 16, h->d_meanB);
+  std::vector<double> pn((size_t)p * dn);
+  std::vector<int> pt(p, 0);
+  for (int64_t j = 0; j < p; j++) {
+    for (int c = 0; c < dn; c++)
+      pn[j * dn + c] = (Xpend_host[j * d + h->numcol[c]] - h->lo[c]) / (h->hi[c] - h->lo[c]);
+    if (h->desc.task_col >= 0 && T > 1) {
+      int t = (int)Xpend_host[j * d + h->desc.task_col];
+      pt[j] = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    }
+  }
+  std::vector<double> tf;
+  host_pack_trainfrag(h, pn.data(), p, nb, nb + 1, tf);
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag + nb * h->kd * 64, tf.data(), sizeof(double) * tf.size(),
+                                hipMemcpyHostToDevice, s));
+  std::vector<int> te(16, 0);
+  for (int64_t j = 0; j < p; j++) te[j] = pt[j];
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_taskext + np, te.data(), sizeof(int) * 16, hipMemcpyHostToDevice, s));
+  h->p = (int)p;
+  h->nb_ext = nb + (p > 0 ? 1 : 0);
+  h->pend_mean.clear();
+  h->pend_cov.clear();
+  if (p == 0) {
+    BBH_HIP_TRY(h, hipStreamSynchronize(s));
+    return 0;
+  }
+  // workspace: raw pending rows [64, d], Kst [64, np], Tm [64, np], betaT [64, np], lo/hi
+  const size_t need = sizeof(double) * (64 * (size_t)d + 3 * 64 * (size_t)np + 2 * dn);
+  int rc = bbh_ensure_ws(h, need);
+  if (rc) return rc;
+  double* d_xp = h->d_ws;
+  double* Kst = d_xp + 64 * d;
+  double* Tm = Kst + 64 * np;
+  double* betaT = Tm + 64 * np;
+  double* d_lo = betaT + 64 * np;
+  double* d_hi = d_lo + dn;
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_xp, Xpend_host, sizeof(double) * p * d, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * dn, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * dn, hipMemcpyHostToDevice, s));
+  rc = bbh_unfused_chunk(h, d_xp, p, d, Kst, Tm, d_lo, d_hi);  // Tm[j] = (L^-1 k_Pj)^T
+  if (rc) return rc;
+  bbh_gemm(s, false, false, 64, np, np, 1.0, Tm, np, 0, h->d_X, np, 0, 0.0, betaT, np, 0, 1);  // beta_j^T = t_j^T L^-1
+  hipLaunchKernelGGL(bbh_set_beta_kernel, dim3((unsigned)((np + 16 + 255) / 256)), dim3(256), 0, s, betaT, np, np, (int)p,
+                     h->d_meanB);
+  // pending posterior (host, O(p^2 n)): mean_P = ybar + ysd (c + K_P alpha), cov_PP = ysd^2 (K_PP - Tm Tm^T)
+  std::vector<double> hK((size_t)p * np), hT((size_t)p * np), hal(np);
+  BBH_HIP_TRY(h, hipMemcpyAsync(hK.data(), Kst, sizeof(double) * p * np, hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(hT.data(), Tm, sizeof(double) * p * np, hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(hal.data(), h->d_alpha, sizeof(double) * np, hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  const double* th = h->theta.data();
+  const double os = h->desc.use_outputscale ? th[2] : 1.0;
+  h->pend_mean.assign(p, 0.0);
+  h->pend_cov.assign((size_t)p * p, 0.0);
+  for (int64_t i = 0; i < p; i++) {
+    double m = 0.0;
+    for (int64_t k = 0; k < np; k++) m += hK[i * np + k] * hal[k];
+    h->pend_mean[i] = h->ybar + h->ysd * (th[1] + m);
+    for (int64_t j = 0; j < p; j++) {
+      double r2 = 0.0;
+      for (int c = 0; c < dn; c++) {
+        const double df = (pn[i * dn + c] - pn[j * dn + c]) / th[3 + c];
+        r2 += df * df;
+      }
+      double kpp = os * host_kfun(h->desc.kernel_kind, r2);
+      if (T > 1) kpp *= th[3 + dn + pt[i] * T + pt[j]];
+      double dot = 0.0;
+      for (int64_t k = 0; k < np; k++) dot += hT[i * np + k] * hT[j * np + k];
+      h->pend_cov[i * p + j] = h->ysd * h->ysd * (kpp - dot);
+    }
+  }
+  if (mean_p_host) memcpy(mean_p_host, h->pend_mean.data(), sizeof(double) * p);
+  if (cov_pp_host) memcpy(cov_pp_host, h->pend_cov.data(), sizeof(double) * p * p);
+  return 0;
+}

@@ -1,0 +1,381 @@
+"""Host driver of the HIP GP engine: one handle = one single-output GP on one MI355X.
+
+Mirrors, step by step, what BayBE triggers inside BoTorch on the recommend() path
+(SURVEY.md §3.2-3.4): fit_gpytorch_mll -> posterior -> qLogEI -> optimize_acqf_discrete.
+PyTorch-ROCm tensors are used purely as device containers (``data_ptr()``); all arithmetic
+happens in libbaybe_hip through the C-ABI of ``include/baybe_hip.h``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+from scipy import optimize as sopt
+
+from baybe_amd import _lib
+from baybe_amd._lib import HipError, HipUnavailableError
+from baybe_amd.gp_spec import (
+    GPParams,
+    GPSpec,
+    initial_params,
+    objective_from_data_term,
+    pack_raw,
+    raw_bounds,
+    theta_from_params,
+    unpack_raw,
+)
+
+MAX_PENDING = _lib.MAX_PENDING
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def sobol_normal_base_samples(S: int, q: int, seed: int) -> np.ndarray:
+    """Base samples of botorch's SobolQMCNormalSampler: scrambled Sobol (torch's engine, the same
+    one BoTorch uses) -> v = 0.5 + (1 - eps)(u - 0.5) -> sqrt(2) erfinv(2 v - 1).  [S, q] fp64."""
+    import torch
+
+    eng = torch.quasirandom.SobolEngine(dimension=q, scramble=True, seed=int(seed))
+    u = eng.draw(S, dtype=torch.float64)
+    v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
+    return (torch.erfinv(2 * v - 1) * math.sqrt(2)).numpy().copy()
+
+
+def draw_sampler_seed() -> int:
+    """MCSampler seed when none is given: ``torch.randint(0, 1000000, (1,))`` from torch's global
+    RNG at the first acquisition evaluation (so ``active_settings.random_seed`` governs it)."""
+    import torch
+
+    return int(torch.randint(0, 1000000, (1,)).item())
+
+
+@dataclass
+class FitInfo:
+    params: GPParams
+    fun: float
+    nit: int
+    nfev: int
+    status: int
+    message: str
+
+
+@dataclass
+class GreedyResult:
+    indices: list  # candidate positions, in selection order
+    values: list  # acquisition value of each greedy step
+
+
+class ModelFittingError(RuntimeError):
+    """Hyper-parameter fit / factorisation failed (mirrors baybe.exceptions.ModelFittingError)."""
+
+
+class HipGP:
+    """A GP surrogate living on one HIP device."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.bbh_create(int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise HipUnavailableError(
+                f"bbh_create(device={device}) failed with {rc}: no usable HIP device. "
+                "This path has no CPU fallback."
+            )
+        self.device = int(device)
+        self.spec: GPSpec | None = None
+        self.params: GPParams | None = None
+        self.n = 0
+        self.ybar = 0.0
+        self.ysd = 1.0
+        self.jitter = 0.0
+
+    # ---- plumbing -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bbh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            msg = self._lib.bbh_last_error(self._h)
+            raise HipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        return rc
+
+    def _torch(self):
+        import torch
+
+        return torch
+
+    def _dev(self):
+        return self._torch().device("cuda", self.device)
+
+    def use_current_torch_stream(self):
+        """Enqueue on torch's current stream of this device (containers and kernels then share
+        one queue; the default is the legacy null stream, which torch's default stream is)."""
+        torch = self._torch()
+        self._check(
+            self._lib.bbh_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+            "bbh_set_stream",
+        )
+
+    def selftest(self):
+        self._check(self._lib.bbh_selftest(self._h), "bbh_selftest")
+
+    # ---- model ----------------------------------------------------------------------------
+    def set_model(self, spec: GPSpec, X_train: np.ndarray, y_train: np.ndarray):
+        X = np.ascontiguousarray(X_train, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y_train, dtype=np.float64).reshape(-1))
+        if X.ndim != 2 or X.shape[1] != spec.d or X.shape[0] != y.shape[0]:
+            raise ValueError("X_train must be [n, d] and y_train [n]")
+        desc = _lib.ModelDesc(
+            _lib.KERNEL_KINDS[spec.kernel],
+            spec.d,
+            -1 if spec.task_idx is None else int(spec.task_idx),
+            int(spec.n_tasks),
+            1 if spec.use_outputscale else 0,
+            _lib.CRITERIA[spec.criterion],
+        )
+        lo = np.ascontiguousarray(spec.lo, dtype=np.float64)
+        hi = np.ascontiguousarray(spec.hi, dtype=np.float64)
+        if lo.shape[0] != spec.d or hi.shape[0] != spec.d:
+            raise ValueError("spec.lo / spec.hi must have one entry per comp-rep column")
+        self._check(
+            self._lib.bbh_set_model(self._h, C.byref(desc), X.shape[0], _dp(X), _dp(y), _dp(lo), _dp(hi)),
+            "bbh_set_model",
+        )
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.bbh_get_standardization(self._h, C.byref(a), C.byref(b)), "bbh_get_standardization")
+        self.spec, self.n, self.ybar, self.ysd = spec, X.shape[0], a.value, b.value
+        self.params = None
+        self._X_train = X
+
+    def data_term(self, params: GPParams):
+        """Device data term (MLL or LOO) and its gradient in theta layout; (None, None) if the
+        train covariance is not positive definite."""
+        theta = theta_from_params(self.spec, params)
+        val = C.c_double()
+        grad = np.zeros_like(theta)
+        rc = self._check(self._lib.bbh_fit_value_grad(self._h, _dp(theta), C.byref(val), _dp(grad)), "bbh_fit_value_grad")
+        if rc == 1:
+            return None, None
+        return val.value, grad
+
+    def fit(self, p0: GPParams | None = None, maxiter: int = 15000, max_attempts: int = 1) -> FitInfo:
+        """scipy L-BFGS-B over the raw parameters with scipy's defaults, as
+        ``botorch.fit.fit_gpytorch_mll`` does (call site gaussian_process/core.py:340-341);
+        every objective evaluation is one ``bbh_fit_value_grad`` on the device."""
+        spec = self.spec
+        p0 = p0 or initial_params(spec)
+        x0 = pack_raw(spec, p0)
+        n = self.n
+
+        def fun(raw):
+            p = unpack_raw(spec, raw)
+            val, g = self.data_term(p)
+            if val is None:
+                return float("inf"), np.zeros_like(raw)
+            return objective_from_data_term(spec, raw, n, val, g)
+
+        res = sopt.minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=raw_bounds(spec), options={"maxiter": maxiter})
+        if not np.all(np.isfinite(res.x)) or not np.isfinite(res.fun):
+            raise ModelFittingError(f"GP hyper-parameter fit failed: {res.message}")
+        params = unpack_raw(spec, res.x)
+        self.factorize(params)
+        return FitInfo(params, float(res.fun), int(res.nit), int(res.nfev), int(res.status), str(res.message))
+
+    def factorize(self, params: GPParams):
+        theta = theta_from_params(self.spec, params)
+        jit = C.c_double()
+        try:
+            self._check(self._lib.bbh_factorize(self._h, _dp(theta), C.byref(jit)), "bbh_factorize")
+        except HipError as ex:
+            raise ModelFittingError(str(ex)) from ex
+        self.params = params
+        self.jitter = jit.value
+
+    # ---- posterior ------------------------------------------------------------------------
+    def _as_dev(self, X):
+        torch = self._torch()
+        if isinstance(X, np.ndarray):
+            X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64))
+        if X.dtype != torch.float64:
+            X = X.to(torch.float64)
+        X = X.to(self._dev())
+        if X.dim() != 2 or X.shape[1] < self.spec.d:
+            raise ValueError("candidates must be [N, d]")
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        return X
+
+    def posterior(self, X, unfused: bool = False):
+        """Marginal posterior (mean, var) of N candidates as device tensors [N] (fp64)."""
+        torch = self._torch()
+        X = self._as_dev(X)
+        N = X.shape[0]
+        mean = torch.empty(N, dtype=torch.float64, device=X.device)
+        var = torch.empty(N, dtype=torch.float64, device=X.device)
+        fn = self._lib.bbh_posterior_unfused if unfused else self._lib.bbh_posterior
+        self._check(fn(self._h, X.data_ptr(), N, X.stride(0), mean.data_ptr(), var.data_ptr()), "bbh_posterior")
+        return mean, var
+
+    def train_posterior_mean(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.bbh_train_posterior_mean(self._h, _dp(out)), "bbh_train_posterior_mean")
+        return out
+
+    def best_f(self, sign: float = 1.0) -> float:
+        """max_i objective(posterior mean at x_i)  (baybe/acquisition/_builder.py:141-161,256-265)."""
+        return float((sign * self.train_posterior_mean()).max())
+
+    # ---- qLogEI ---------------------------------------------------------------------------
+    def qlogei(self, mean, var, z: np.ndarray, best_f: float, sign: float = 1.0, alive=None):
+        torch = self._torch()
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1)
+        N = mean.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=mean.device)
+        self._check(
+            self._lib.bbh_qlogei_q1(
+                self._h, mean.data_ptr(), var.data_ptr(), N, _dp(z), z.shape[0], float(best_f), float(sign),
+                alive.data_ptr() if alive is not None else None, scores.data_ptr(),
+            ),
+            "bbh_qlogei_q1",
+        )
+        return scores
+
+    def set_pending(self, X_pending: np.ndarray | None):
+        """Pending points = base pending + greedy picks (candidate first, then pending)."""
+        if X_pending is None or len(X_pending) == 0:
+            self._check(self._lib.bbh_pending_set(self._h, None, 0, None, None), "bbh_pending_set")
+            return None, None
+        P = np.ascontiguousarray(X_pending, dtype=np.float64)
+        p = P.shape[0]
+        if p > MAX_PENDING:
+            raise ValueError(f"at most {MAX_PENDING} pending points are supported by the HIP path")
+        mp = np.empty(p)
+        cpp = np.empty((p, p))
+        self._check(self._lib.bbh_pending_set(self._h, _dp(P), p, _dp(mp), _dp(cpp)), "bbh_pending_set")
+        self._p = p
+        return mp, cpp
+
+    def cross_cov(self, X):
+        torch = self._torch()
+        X = self._as_dev(X)
+        N = X.shape[0]
+        cross = torch.empty((N, self._p), dtype=torch.float64, device=X.device)
+        self._check(self._lib.bbh_cross_cov(self._h, X.data_ptr(), N, X.stride(0), cross.data_ptr()), "bbh_cross_cov")
+        return cross
+
+    def qlogei_pending(self, mean, var, cross, z: np.ndarray, best_f: float, sign: float = 1.0, alive=None):
+        torch = self._torch()
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        S = z.shape[0]
+        N = mean.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=mean.device)
+        self._check(
+            self._lib.bbh_qlogei_pending(
+                self._h, mean.data_ptr(), var.data_ptr(), cross.data_ptr(), N, _dp(z), S, float(best_f), float(sign),
+                alive.data_ptr() if alive is not None else None, scores.data_ptr(),
+            ),
+            "bbh_qlogei_pending",
+        )
+        return scores
+
+    # ---- selection ------------------------------------------------------------------------
+    def argmax(self, scores):
+        v, i = C.c_double(), C.c_int64()
+        self._check(self._lib.bbh_argmax(self._h, scores.data_ptr(), scores.shape[0], C.byref(v), C.byref(i)), "bbh_argmax")
+        return v.value, i.value
+
+    def topk(self, scores, k: int):
+        vals = np.empty(k)
+        idx = np.empty(k, dtype=np.int64)
+        self._check(
+            self._lib.bbh_topk(self._h, scores.data_ptr(), scores.shape[0], k, _dp(vals), idx.ctypes.data_as(_lib.c_int64_p)),
+            "bbh_topk",
+        )
+        return vals, idx
+
+    # ---- instrumentation ------------------------------------------------------------------
+    def timing(self, enable: bool):
+        self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")
+
+    def timing_read(self, reset: bool = True):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._lib.bbh_timing_read(self._h, C.byref(ms), C.byref(cnt), 1 if reset else 0), "bbh_timing_read")
+        return ms.value, cnt.value
+
+    # ---- optimize_acqf_discrete with qLogEI -----------------------------------------------
+    def greedy_qlogei(
+        self,
+        X,
+        q: int,
+        S: int = 512,
+        seed: int | None = None,
+        sign: float = 1.0,
+        X_pending: np.ndarray | None = None,
+        best_f: float | None = None,
+        z_by_q: dict | None = None,
+        shard=None,
+    ) -> GreedyResult:
+        """Sequential greedy of ``optimize_acqf_discrete(acqf, q, choices, unique=True)``.
+
+        Step 0 runs the fused posterior over all candidates and caches (mean, var); every later
+        step only needs the cross-covariances with the points picked so far (mean-only pass).
+        ``shard`` (a ``baybe_amd.distributed.RowShard``) makes every selection a global one: the
+        local winner is all-gathered (score, global index, row) and the global first-index argmax
+        wins on every rank.
+        """
+        torch = self._torch()
+        X = self._as_dev(X)
+        N = X.shape[0]
+        d = self.spec.d
+        if seed is None and z_by_q is None:
+            seed = draw_sampler_seed()
+        if best_f is None:
+            best_f = self.best_f(sign)
+        base = np.zeros((0, d)) if X_pending is None or len(X_pending) == 0 else np.atleast_2d(np.asarray(X_pending, dtype=np.float64))
+        alive = torch.ones(N, dtype=torch.uint8, device=X.device)
+        mean, var = self.posterior(X)
+        chosen_rows: list[np.ndarray] = []
+        indices, values = [], []
+
+        def get_z(qp: int) -> np.ndarray:
+            return z_by_q[qp] if z_by_q is not None else sobol_normal_base_samples(S, qp, seed)
+
+        for _step in range(q):
+            pend = np.vstack([base] + chosen_rows) if chosen_rows else base
+            p = pend.shape[0]
+            z = get_z(1 + p)
+            if p == 0:
+                self.set_pending(None)
+                scores = self.qlogei(mean, var, z[:, 0], best_f, sign, alive)
+            else:
+                self.set_pending(pend)
+                cross = self.cross_cov(X)
+                scores = self.qlogei_pending(mean, var, cross, z, best_f, sign, alive)
+            val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
+            if shard is not None:
+                val, gidx, row = shard.global_argmax(val, idx, X)
+                if shard.owns(gidx):
+                    alive[shard.to_local(gidx)] = 0
+                idx = gidx
+            else:
+                row = X[idx, :d].cpu().numpy()
+                alive[idx] = 0
+            indices.append(int(idx))
+            values.append(float(val))
+            chosen_rows.append(np.asarray(row, dtype=np.float64).reshape(1, d))
+        self.set_pending(None if base.shape[0] == 0 else base)
+        return GreedyResult(indices, values)

@@ -1,0 +1,219 @@
+"""Model specification and hyper-parameter bookkeeping of the HIP GP surrogate.
+
+Host-side, O(d) scalar work only: which kernel / priors / constraints BayBE's component
+factories select (``baybe/surrogates/gaussian_process/presets/baybe.py:56-144,203-281``), the
+raw <-> natural parameter transforms of gpytorch constraints, and the prior terms of the fit
+objective.  All O(n^2)/O(n^3) arithmetic is in libbaybe_hip (``bbh_fit_value_grad``).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+from scipy.special import gammaln
+
+MIN_INFERRED_NOISE_LEVEL = 1e-4  # botorch.models.utils.gpytorch_modules (presets/baybe.py:129)
+
+
+def softplus(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > 20.0, x, np.log1p(np.exp(np.minimum(x, 20.0))))
+
+
+def inv_softplus(y):
+    y = np.asarray(y, dtype=np.float64)
+    return np.where(y > 20.0, y, np.log(np.expm1(np.minimum(y, 20.0))))
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))
+
+
+@dataclass
+class GPSpec:
+    """Architecture, priors and constraints of one single-output GP."""
+
+    d: int
+    lo: np.ndarray  # [d] scaling bounds of every comp-rep column
+    hi: np.ndarray
+    kernel: str = "matern52"
+    task_idx: int | None = None
+    n_tasks: int = 1
+    use_outputscale: bool = False
+    ls_constraint: str = "box"  # "box" (GreaterThan(lower, transform=None)) | "softplus" (Positive())
+    ls_lower: float = 2.5e-2
+    ls_prior: tuple | None = None  # ("gamma", concentration, rate) | ("lognormal", mu, sigma)
+    ls_init: float | None = None
+    noise_lower: float = MIN_INFERRED_NOISE_LEVEL
+    noise_prior: tuple | None = None
+    noise_init: float | None = None
+    outputscale_prior: tuple | None = None
+    criterion: str = "mll"
+
+    @property
+    def dn(self) -> int:
+        return self.d - (1 if self.task_idx is not None else 0)
+
+    @property
+    def num_idx(self) -> np.ndarray:
+        return np.array([i for i in range(self.d) if i != self.task_idx], dtype=np.int64)
+
+    @classmethod
+    def baybe_default(cls, d: int, lo, hi, task_idx: int | None = None, n_tasks: int = 1, kernel: str = "matern52"):
+        """The BAYBE preset: Matérn-5/2 ARD without outputscale, dimension-scaled Gamma priors,
+        MLL for one task and LOO pseudo-likelihood otherwise (presets/baybe.py:56-144, 269-281)."""
+        dn = d - (1 if task_idx is not None else 0)
+        conc = 3.0
+        rate = (conc - 1.0) / math.exp(math.sqrt(2.0) - 3.0) / math.sqrt(dn)
+        nconc = 2.0
+        nrate = (nconc - 1.0) / math.exp(-4.0 - 1.0**2)
+        return cls(
+            d=d,
+            lo=np.asarray(lo, dtype=np.float64).copy(),
+            hi=np.asarray(hi, dtype=np.float64).copy(),
+            kernel=kernel,
+            task_idx=task_idx,
+            n_tasks=n_tasks,
+            ls_prior=("gamma", conc, rate),
+            ls_init=(conc - 1.0) / rate,
+            noise_prior=("gamma", nconc, nrate),
+            noise_init=(nconc - 1.0) / nrate,
+            criterion="mll" if n_tasks == 1 else "loo",
+        )
+
+
+@dataclass
+class GPParams:
+    """Natural hyper-parameters (normalised inputs, standardised targets)."""
+
+    lengthscale: np.ndarray
+    noise: float
+    mean: float = 0.0
+    outputscale: float = 1.0
+    task_W: np.ndarray | None = None
+    task_v: np.ndarray | None = None
+
+    def task_B(self):
+        if self.task_W is None:
+            return None
+        return self.task_W @ self.task_W.T + np.diag(self.task_v)
+
+
+def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
+    """Prior modes for the default preset (presets/baybe.py:100-105, 134-142), softplus(0) for
+    Positive()-constrained parameters.  Task factors start deterministically (W = 1/sqrt(T),
+    v = softplus(0)); gpytorch's random start is not reproduced (parity notes)."""
+    ls0 = spec.ls_init if spec.ls_init is not None else float(softplus(0.0))
+    nz0 = spec.noise_init if spec.noise_init is not None else 1e-2
+    p = GPParams(
+        lengthscale=np.full(spec.dn, ls0),
+        noise=nz0,
+        mean=0.0,
+        outputscale=float(softplus(0.0)) if spec.use_outputscale else 1.0,
+    )
+    if spec.n_tasks > 1:
+        T = spec.n_tasks
+        p.task_W = np.full((T, T), task_init / math.sqrt(T))
+        p.task_v = np.full(T, float(softplus(0.0)))
+    return p
+
+
+# ---- natural parameters <-> the device theta vector [noise, mean, outputscale, ls.., B..] ------
+def theta_from_params(spec: GPSpec, p: GPParams) -> np.ndarray:
+    parts = [np.array([p.noise, p.mean, p.outputscale]), np.asarray(p.lengthscale, dtype=np.float64)]
+    if spec.n_tasks > 1:
+        parts.append(p.task_B().reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
+
+
+# ---- raw optimiser vector (order of mll.named_parameters(): noise, mean, kernel parameters) ----
+def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
+    parts = [np.array([p.noise]), np.array([p.mean])]
+    if spec.use_outputscale:
+        parts.append(inv_softplus(np.array([p.outputscale])))
+    parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
+    if spec.n_tasks > 1:
+        parts.append(inv_softplus(p.task_W).reshape(-1))
+        parts.append(inv_softplus(p.task_v))
+    return np.concatenate(parts).astype(np.float64)
+
+
+def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
+    raw = np.asarray(raw, dtype=np.float64)
+    i = 0
+    noise = float(raw[i]); i += 1
+    mean = float(raw[i]); i += 1
+    os_ = 1.0
+    if spec.use_outputscale:
+        os_ = float(softplus(raw[i])); i += 1
+    ls_raw = raw[i : i + spec.dn]; i += spec.dn
+    ls = ls_raw.copy() if spec.ls_constraint == "box" else softplus(ls_raw)
+    W = v = None
+    if spec.n_tasks > 1:
+        T = spec.n_tasks
+        W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
+        v = softplus(raw[i : i + T]); i += T
+    return GPParams(ls, noise, mean, os_, W, v)
+
+
+def raw_bounds(spec: GPSpec):
+    """Only constraints with ``transform=None`` become L-BFGS-B bounds (botorch fit)."""
+    b = [(spec.noise_lower, None), (None, None)]
+    if spec.use_outputscale:
+        b.append((None, None))
+    b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
+    if spec.n_tasks > 1:
+        b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
+    return b
+
+
+def _prior_logp_and_grad(prior, x):
+    x = np.asarray(x, dtype=np.float64)
+    if prior is None:
+        return 0.0, np.zeros_like(x)
+    kind = prior[0]
+    if kind == "gamma":
+        _, c, r = prior
+        lp = c * math.log(r) + (c - 1.0) * np.log(x) - r * x - gammaln(c)
+        return float(lp.sum()), (c - 1.0) / x - r
+    if kind == "lognormal":
+        _, mu, sd = prior
+        lx = np.log(x)
+        lp = -lx - math.log(sd) - 0.5 * math.log(2 * math.pi) - 0.5 * ((lx - mu) / sd) ** 2
+        return float(lp.sum()), (-1.0 - (lx - mu) / sd**2) / x
+    raise ValueError(f"unknown prior kind {kind!r}")
+
+
+def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float, grad_theta: np.ndarray):
+    """-(data term + log priors)/n and its gradient w.r.t. the raw vector, given the device's
+    data term ``value`` and its gradient in theta layout (gpytorch: add priors, divide by n)."""
+    p = unpack_raw(spec, raw)
+    dn = spec.dn
+    g_noise, g_mean, g_os = grad_theta[0], grad_theta[1], grad_theta[2]
+    g_ls = grad_theta[3 : 3 + dn]
+    lp_ls, glp_ls = _prior_logp_and_grad(spec.ls_prior, p.lengthscale)
+    lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.array([p.noise]))
+    lp_os, glp_os = 0.0, np.zeros(1)
+    if spec.use_outputscale:
+        lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
+    total = value + lp_ls + lp_nz + lp_os
+    g = [np.array([g_noise + glp_nz[0]]), np.array([g_mean])]
+    i = 2
+    if spec.use_outputscale:
+        g.append(np.array([(g_os + glp_os[0]) * float(sigmoid(raw[i]))]))
+        i += 1
+    gl = g_ls + glp_ls
+    if spec.ls_constraint != "box":
+        gl = gl * sigmoid(raw[i : i + dn])
+    g.append(gl)
+    i += dn
+    if spec.n_tasks > 1:
+        T = spec.n_tasks
+        S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)
+        gW = (S + S.T) @ p.task_W
+        g.append((gW * sigmoid(raw[i : i + T * T]).reshape(T, T)).reshape(-1))
+        i += T * T
+        g.append(np.diag(S) * sigmoid(raw[i : i + T]))
+    return -total / n, -np.concatenate(g) / n

@@ -1,0 +1,164 @@
+/*
+ * baybe_hip.h — C-ABI of libbaybe_hip.so, the MI355X (gfx950) implementation of
+ * BayBE's GP-surrogate recommend() hot path.
+ *
+ * The reference (emdgroup/baybe) is pure Python; it has no FFI of its own.  Each
+ * entry point below replaces the *third-party call* BayBE makes at the cited
+ * line (botorch / gpytorch, CPU), so that a ctypes stub at that call site is
+ * the whole integration:
+ *
+ *   bbh_set_model            botorch.models.SingleTaskGP(...)            baybe/surrogates/gaussian_process/core.py:331-339
+ *                            Normalize / Standardize                     baybe/surrogates/gaussian_process/core.py:301-306
+ *   bbh_fit_value_grad       one closure call of fit_gpytorch_mll        baybe/surrogates/gaussian_process/core.py:340-341
+ *                            (ExactMLL / LOO-PL value + gradient)        baybe/surrogates/gaussian_process/components/fit_criterion.py:31-41
+ *   bbh_factorize            prediction-strategy caches (L, alpha, L^-T) baybe/surrogates/gaussian_process/core.py:268-269 (first posterior call)
+ *   bbh_posterior            model.posterior(X) for N q=1 t-batches      baybe/surrogates/base.py:249-272, 308-384
+ *   bbh_train_posterior_mean posterior mean at the training inputs       baybe/acquisition/_builder.py:141-161 (best_f, 256-265)
+ *   bbh_qlogei_q1            qLogExpectedImprovement.forward, q'=1       baybe/acquisition/acqfs.py:219-223; baybe/acquisition/base.py:112-159
+ *   bbh_pending_set /        set_X_pending + joint q'-batch posterior    baybe/acquisition/_builder.py:326-334
+ *   bbh_cross_cov /
+ *   bbh_qlogei_pending       qLogEI forward with pending points
+ *   bbh_argmax               the argmax of optimize_acqf_discrete        baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126
+ *
+ * Conventions
+ *  - extern "C"; every function returns 0 on success, <0 on error;
+ *    bbh_last_error(h) returns a message owned by the library (valid until the
+ *    next call on that handle).
+ *  - "_dev" arguments are DEVICE pointers (row-major, contiguous, fp64 unless
+ *    noted) owned by the caller (e.g. torch.Tensor.data_ptr() of a ROCm tensor
+ *    used purely as a container).  "_host" arguments are HOST pointers; they are
+ *    O(n*d) model data or O(S*q) base samples and are copied by the call.
+ *  - All work is enqueued on the handle's stream (bbh_set_stream; default: the
+ *    legacy null stream).  Calls that return host data synchronise that stream.
+ *  - One handle = one single-output GP on one device.  Not thread-safe per
+ *    handle; distinct handles are independent.
+ *  - No CPU fallback exists: without a HIP device bbh_create fails.
+ */
+#ifndef BAYBE_HIP_H
+#define BAYBE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbh_handle bbh_handle;
+
+enum bbh_kernel_kind {
+  BBH_KERNEL_MATERN12 = 0,
+  BBH_KERNEL_MATERN32 = 1,
+  BBH_KERNEL_MATERN52 = 2, /* BayBE default: presets/baybe.py:100-107 */
+  BBH_KERNEL_RBF = 3
+};
+
+enum bbh_criterion {
+  BBH_CRITERION_MLL = 0, /* gpytorch.ExactMarginalLogLikelihood   (1 task)  */
+  BBH_CRITERION_LOO = 1  /* gpytorch.mlls.LeaveOneOutPseudoLikelihood (>1)  */
+};
+
+/* Architecture of the GP (what BayBE's component factories decide). */
+typedef struct bbh_model_desc {
+  int32_t kernel_kind;     /* enum bbh_kernel_kind                                   */
+  int32_t d;               /* comp-rep columns, incl. the task column if any          */
+  int32_t task_col;        /* column index of the INT-coded task parameter, -1 = none */
+  int32_t n_tasks;         /* 1 = single task                                         */
+  int32_t use_outputscale; /* 1 = ScaleKernel wrapper (user kernels)                   */
+  int32_t criterion;       /* enum bbh_criterion                                      */
+} bbh_model_desc;
+
+/*
+ * Natural hyper-parameter vector "theta" (doubles), length bbh_theta_len(h):
+ *   [0]            noise variance s2 (standardised target scale)
+ *   [1]            constant mean c
+ *   [2]            outputscale (ignored unless use_outputscale)
+ *   [3 .. 3+dn)    ARD lengthscales of the dn = d - (task_col>=0) numerical columns,
+ *                  in column order (normalised input scale)
+ *   [3+dn .. +T*T) task covariance B[t][t'] row-major (only when n_tasks > 1)
+ * Gradients are returned in the same layout (for B: dL/dB[t][t'], accumulated
+ * over ordered pairs, i.e. the matrix S with dL = sum_tt' S[t][t'] dB[t][t']).
+ * Constraint transforms (softplus) and prior terms are O(d) scalar work and stay
+ * with the host driver (baybe_amd/fit.py).
+ */
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+int bbh_create(int device_id, bbh_handle** out);
+int bbh_destroy(bbh_handle* h);
+const char* bbh_last_error(bbh_handle* h);
+int bbh_set_stream(bbh_handle* h, void* hip_stream);
+/* library/ABI version: major*10000 + minor*100 + patch */
+int bbh_version(void);
+/* device self-test of the fp64 MFMA fragment layout the kernels rely on (0 = ok) */
+int bbh_selftest(bbh_handle* h);
+
+/* ---- model ------------------------------------------------------------------------- */
+/* X_train_host [n,d] raw comp-rep rows; y_train_host [n] raw targets;
+ * lo_host/hi_host [d] scaling bounds of every column (task column ignored).
+ * Normalises the numerical columns, standardises y (Bessel std, <1e-8 -> 1). */
+int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t n,
+                  const double* X_train_host, const double* y_train_host,
+                  const double* lo_host, const double* hi_host);
+int64_t bbh_theta_len(bbh_handle* h);
+/* standardisation constants chosen by bbh_set_model */
+int bbh_get_standardization(bbh_handle* h, double* ybar, double* ysd);
+
+/* Data term of the fit objective and its gradient w.r.t. theta:
+ *   MLL: log N(y~ | c 1, K_theta + s2 I);  LOO: sum_i log N(y~_i | mu_-i, s2_-i).
+ * Returns 1 (and value=-inf) when K_theta + s2 I is not positive definite. */
+int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, double* value_host,
+                       double* grad_host);
+
+/* Build the prediction caches for theta: L = chol(K + s2 I) (jitter 1e-8*10^i on
+ * failure, as gpytorch psd_safe_cholesky), alpha = (K + s2 I)^-1 (y~ - c), the
+ * packed L^-T operand of the variance contraction.  jitter_used may be NULL. */
+int bbh_factorize(bbh_handle* h, const double* theta_host, double* jitter_used);
+
+/* ---- posterior --------------------------------------------------------------------- */
+/* Marginal posterior (original target scale, no observation noise) of N candidates.
+ * X_dev [N, ldx>=d] raw comp-rep rows on the device; mean_dev / var_dev [N]. */
+int bbh_posterior(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
+                  double* mean_dev, double* var_dev);
+/* Same through the unfused verification path (materialised K(X*,X), generic GEMM). */
+int bbh_posterior_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
+                          double* mean_dev, double* var_dev);
+/* Posterior mean at the n training inputs -> host (for best_f). */
+int bbh_train_posterior_mean(bbh_handle* h, double* mean_host);
+
+/* ---- qLogEI ------------------------------------------------------------------------ */
+/* q'=1 scores: scores[i] = logmeanexp_s log_fatplus(sign*(mean_i + sd_i z_s) - best_f; 1e-6).
+ * z_host [S] Sobol-normal base samples; alive_dev [N] uint8 or NULL (0 -> score = -inf). */
+int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N,
+                  const double* z_host, int64_t S, double best_f, double sign,
+                  const uint8_t* alive_dev, double* scores_dev);
+
+/* Pending points (base pending + greedy picks), p <= BBH_MAX_PENDING.  Computes and
+ * caches beta_j = (K+s2I)^-1 k(X, P_j), the pending posterior mean [p] and covariance
+ * [p,p] (returned to the host if the pointers are non-NULL). */
+#define BBH_MAX_PENDING 15
+int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t p, double* mean_p_host,
+                    double* cov_pp_host);
+/* Posterior cross-covariance of every candidate with the pending points: cross_dev [N,p]. */
+int bbh_cross_cov(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* cross_dev);
+/* q' = 1+p scores of the t-batches [x_i ; pending]; z_host [S, 1+p]. */
+int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const double* var_dev,
+                       const double* cross_dev, int64_t N, const double* z_host, int64_t S,
+                       double best_f, double sign, const uint8_t* alive_dev, double* scores_dev);
+
+/* ---- selection --------------------------------------------------------------------- */
+/* First-index argmax of scores_dev [N] (NaN never wins) -> host. */
+int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,
+               int64_t* best_idx_host);
+/* k best scores, descending, ties -> lower index first; -> host arrays [k]. */
+int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
+             int64_t* idx_host);
+
+/* ---- instrumentation --------------------------------------------------------------- */
+/* Duration (ms) and launch count of the fused posterior kernel accumulated since the
+ * last reset, measured with HIP events on the handle's stream when enabled. */
+int bbh_timing_enable(bbh_handle* h, int enable);
+int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYBE_HIP_H */

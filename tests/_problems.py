@@ -1,0 +1,40 @@
+"""Deterministic synthetic workloads: integer grids in [0,1]^d, quadratic+sine
+targets.  The same arrays feed the oracle, the CPU baseline and the HIP path."""
+
+import numpy as np
+
+
+def make_grid(N: int, d: int, seed: int = 0) -> np.ndarray:
+    return np.random.default_rng(seed).integers(0, 11, size=(N, d)) / 10.0
+
+
+def make_problem(N: int, d: int, n: int, seed: int = 0, minimize: bool = False):
+    X = make_grid(N, d, seed)
+    idx = np.random.default_rng(seed + 1).choice(N, n, replace=False)
+    Xt = X[idx]
+    y = -((Xt - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * Xt[:, 0]) + 0.05 * np.random.default_rng(seed + 2).standard_normal(n)
+    if minimize:
+        y = -y
+    return X, Xt, y
+
+
+def make_tl_problem(N: int, dnum: int, n_per_task: int, T: int = 4, seed: int = 0):
+    """Transfer-learning workload: task column last, INT-coded; candidates = active task 0."""
+    rng = np.random.default_rng(seed)
+    Xc = rng.integers(0, 11, size=(N, dnum)) / 10.0
+    X = np.hstack([Xc, np.zeros((N, 1))])
+    rows, ys = [], []
+    for t in range(T):
+        xt = np.random.default_rng(seed + 10 + t).integers(0, 11, size=(n_per_task, dnum)) / 10.0
+        y = -((xt - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * xt[:, 0])
+        y = (1 - 0.1 * t) * y + 0.2 * t + 0.05 * np.random.default_rng(seed + 20 + t).standard_normal(n_per_task)
+        rows.append(np.hstack([xt, np.full((n_per_task, 1), float(t))]))
+        ys.append(y)
+    return X, np.vstack(rows), np.concatenate(ys)
+
+
+def fixed_theta(d: int):
+    """fixed-theta mode: prior modes of the BAYBE preset (l = e^{sqrt2-3} sqrt(d), s2 = e^-5, c = 0)."""
+    import math
+
+    return math.exp(math.sqrt(2.0) - 3.0) * math.sqrt(d), math.exp(-5.0), 0.0
