@@ -1,0 +1,370 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the oracle on seeded inputs and
+against the committed golden fixtures; at BASELINE sizes through size-independent properties.
+
+Tolerances (fp64 everywhere): posterior mean/variance 1e-9 relative here (north_star allows
+1e-5), scores 1e-8 absolute on values of magnitude 1..50, indices identical.
+"""
+
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from _problems import fixed_theta, make_problem, make_tl_problem
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+MEAN_RTOL = 1e-9
+VAR_RTOL = 1e-8
+SCORE_ATOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from baybe_amd import engine
+
+    g = engine.HipGP(0)
+    g.selftest()
+    yield g
+    g.close()
+
+
+def _ospec(spec):
+    from oracle import gp_oracle as go
+
+    return go.GPSpec(
+        d=spec.d, num_idx=spec.num_idx, lo=spec.lo[spec.num_idx], hi=spec.hi[spec.num_idx], kernel=spec.kernel,
+        task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
+        ls_constraint=spec.ls_constraint, ls_lower=spec.ls_lower, ls_prior=spec.ls_prior, ls_init=spec.ls_init,
+        noise_lower=spec.noise_lower, noise_prior=spec.noise_prior, noise_init=spec.noise_init,
+        outputscale_prior=spec.outputscale_prior, criterion=spec.criterion)
+
+
+def _oparams(p):
+    from oracle import gp_oracle as go
+
+    return go.GPParams(np.array(p.lengthscale, dtype=float), p.noise, p.mean, p.outputscale,
+                       None if p.task_W is None else p.task_W.copy(), None if p.task_v is None else p.task_v.copy())
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def test_library_loaded_and_device_present():
+    from baybe_amd import _lib
+
+    assert _lib.is_available()
+
+
+# ---- fit objective -------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel,criterion,tl,n", [
+    ("matern52", "mll", False, 40), ("rbf", "mll", False, 100), ("matern32", "loo", True, 90),
+    ("matern12", "mll", False, 130), ("matern52", "loo", True, 200), ("matern52", "mll", False, 300),
+])
+def test_data_term_value_and_gradient(gp, kernel, criterion, tl, n):
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    d = 5
+    if tl:
+        X, Xt, y = make_tl_problem(500, d, n // 3, T=3, seed=3)
+        spec = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=3, kernel=kernel)
+        spec.use_outputscale = True
+    else:
+        X, Xt, y = make_problem(500, d, n, seed=1)
+        spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), kernel=kernel)
+    spec.criterion = criterion
+    p = gp_spec.initial_params(spec)
+    rng = np.random.default_rng(5)
+    p.lengthscale = p.lengthscale * (0.7 + 0.6 * rng.random(spec.dn))
+    p.mean = 0.1
+    if tl:
+        p.task_W = 0.3 + rng.random((3, 3))
+        p.outputscale = 1.3
+    gp.set_model(spec, Xt, y)
+    val, g = gp.data_term(p)
+    ospec = _ospec(spec)
+    dt = go.data_term(ospec, _oparams(p), go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+    gref = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls] + ([dt.g_task_B.reshape(-1)] if tl else []))
+    assert math.isclose(val, dt.value, rel_tol=1e-11)
+    assert np.allclose(g, gref, rtol=1e-9, atol=1e-10 * np.abs(gref).max())
+
+
+def test_non_positive_definite_is_reported_not_hidden(gp):
+    from baybe_amd import gp_spec
+
+    X, Xt, y = make_problem(200, 3, 30, seed=2)
+    Xt = np.vstack([Xt, Xt[:5]])  # exact duplicates
+    y = np.concatenate([y, y[:5]])
+    spec = gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3), kernel="rbf")
+    gp.set_model(spec, Xt, y)
+    p = gp_spec.GPParams(np.full(3, 50.0), -1.0, 0.0)  # negative "noise": K - I is not PD
+    val, g = gp.data_term(p)
+    assert val is None and g is None
+
+
+@pytest.mark.parametrize("n,d", [(60, 5), (128, 10)])
+def test_device_fit_reaches_the_oracle_optimum(gp, n, d):
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    X, Xt, y = make_problem(1000, d, n, seed=6)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    gp.set_model(spec, Xt, y)
+    fi = gp.fit()
+    ospec = _ospec(spec)
+    fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+    assert math.isclose(fi.fun, fo.fun, rel_tol=1e-8)
+    assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=1e-4)
+    assert math.isclose(fi.params.noise, fo.params.noise, rel_tol=1e-4)
+
+
+# ---- posterior -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,d,n", [(3000, 5, 40), (3000, 15, 200), (3000, 20, 300), (5000, 20, 512),
+                                   (2000, 3, 20), (1000, 9, 700), (777, 2, 1), (513, 30, 65), (64, 4, 1030)])
+def test_posterior_fused_and_unfused_match_oracle(gp, N, d, n):
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    X, Xt, y = make_problem(max(N, n + 1), d, n, seed=2)
+    X = X[:N]
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    p = gp_spec.GPParams(np.full(d, ls) * (0.8 + 0.4 * np.random.default_rng(7).random(d)), nz, 0.05)
+    gp.set_model(spec, Xt, y)
+    gp.factorize(p)
+    om = go.GPModel(_ospec(spec), _oparams(p), Xt, y)
+    mo, vo = om.posterior(X)
+    for unfused in (False, True):
+        m, v = gp.posterior(X, unfused=unfused)
+        assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12)
+        assert np.allclose(_np(v), vo, rtol=VAR_RTOL)
+    assert np.allclose(gp.train_posterior_mean(), om.posterior(Xt)[0], rtol=MEAN_RTOL, atol=1e-12)
+    assert math.isclose(gp.best_f(-1.0), go.best_f_from_model(om, -1.0), rel_tol=1e-9, abs_tol=1e-12)
+
+
+def test_posterior_scaling_bounds_and_strided_input(gp):
+    """Normalize uses the search-space bounds (not the candidate range) and honours ldx > d."""
+    import torch
+
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    rng = np.random.default_rng(3)
+    d, n, N = 4, 50, 1000
+    lo, hi = np.array([-2.0, 10.0, 0.0, 100.0]), np.array([3.0, 20.0, 0.5, 400.0])
+    X = lo + (hi - lo) * rng.random((N, d))
+    Xt = lo + (hi - lo) * rng.random((n, d))
+    y = np.sin(Xt[:, 0]) + 0.01 * Xt[:, 3]
+    spec = gp_spec.GPSpec.baybe_default(d, lo, hi)
+    gp.set_model(spec, Xt, y)
+    p = gp_spec.GPParams(np.array([0.3, 0.5, 0.7, 0.4]), 1e-3, -0.2)
+    gp.factorize(p)
+    om = go.GPModel(_ospec(spec), _oparams(p), Xt, y)
+    mo, vo = om.posterior(X)
+    wide = torch.zeros((N, d + 3), dtype=torch.float64, device="cuda")
+    wide[:, :d] = torch.from_numpy(X).cuda()
+    m, v = gp.posterior(wide)
+    assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL)
+
+
+def test_multitask_icm_posterior_and_loo(gp):
+    from baybe_amd import gp_spec
+
+    g = np.load(GOLD / "tl_4tasks.npz")
+    T = int(g["T"])
+    d = g["X"].shape[1]
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=T)
+    p = gp_spec.GPParams(g["ls"], float(g["noise"]), float(g["mean_const"]), 1.0, g["task_W"], g["task_v"])
+    gp.set_model(spec, g["Xt"], g["y"])
+    val, grad = gp.data_term(p)
+    assert math.isclose(val, float(g["dt_value"]), rel_tol=1e-10)
+    assert np.allclose(grad, g["dt_grad"], rtol=1e-8, atol=1e-9 * np.abs(g["dt_grad"]).max())
+    gp.factorize(p)
+    for unfused in (False, True):
+        m, v = gp.posterior(g["X"], unfused=unfused)
+        assert np.allclose(_np(m), g["post_mean"], rtol=MEAN_RTOL, atol=1e-12)
+        assert np.allclose(_np(v), g["post_var"], rtol=VAR_RTOL)
+
+
+# ---- golden fixtures -----------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cfg1_plumbing", "small_matern52_max", "small_matern52_min", "small_rbf",
+                                  "small_matern32", "small_matern12", "mid_320"])
+def test_golden_fixture(gp, name):
+    import torch
+
+    from baybe_amd import gp_spec
+
+    g = np.load(GOLD / f"{name}.npz")
+    d = g["X"].shape[1]
+    sign = float(g["sign"])
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), kernel=str(g["kernel"]))
+    gp.set_model(spec, g["Xt"], g["y"])
+    val, grad = gp.data_term(gp_spec.initial_params(spec))
+    assert math.isclose(val, float(g["dt_value"]), rel_tol=1e-10)
+    assert np.allclose(grad, g["dt_grad"], rtol=1e-8, atol=1e-9 * np.abs(g["dt_grad"]).max())
+    gp.factorize(gp_spec.GPParams(g["ls"], float(g["noise"]), float(g["mean_const"])))
+    m, v = gp.posterior(g["X"])
+    assert np.allclose(_np(m), g["post_mean"], rtol=MEAN_RTOL, atol=1e-12)
+    assert np.allclose(_np(v), g["post_var"], rtol=VAR_RTOL)
+    bf = gp.best_f(sign)
+    assert math.isclose(bf, float(g["best_f"]), rel_tol=1e-9, abs_tol=1e-12)
+    s = gp.qlogei(m, v, g["z1"], float(g["best_f"]), sign)
+    assert np.allclose(_np(s), g["scores"], rtol=0, atol=SCORE_ATOL)
+    assert gp.argmax(s)[1] == int(np.argmax(g["scores"]))
+    k = 8
+    assert gp.topk(s, k)[1].tolist() == np.argsort(-g["scores"], kind="stable")[:k].tolist()
+    if name != "mid_320":
+        r = gp.greedy_qlogei(g["X"], int(g["q"]), seed=4321, sign=sign, X_pending=g["pend"], best_f=float(g["best_f"]))
+        assert r.indices == g["greedy_idx"].tolist()
+        assert np.allclose(r.values, g["greedy_val"], rtol=0, atol=SCORE_ATOL)
+
+
+def test_cfg1_fit_on_device_reproduces_oracle_fit(gp):
+    from baybe_amd import gp_spec
+
+    g = np.load(GOLD / "cfg1_plumbing.npz")
+    spec = gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
+    gp.set_model(spec, g["Xt"], g["y"])
+    fi = gp.fit()
+    assert np.allclose(fi.params.lengthscale, g["ls"], rtol=1e-4)
+    assert math.isclose(fi.params.noise, float(g["noise"]), rel_tol=1e-4)
+    r = gp.greedy_qlogei(g["X"], int(g["q"]), seed=4321, X_pending=g["pend"])
+    assert r.indices == g["greedy_idx"].tolist()
+
+
+# ---- acquisition edge cases ----------------------------------------------------------------------
+def test_qlogei_edge_cases(gp):
+    import torch
+
+    from oracle import gp_oracle as go
+
+    z = go.sobol_normal_base_samples(512, 1, 3)[:, 0]
+    mu = np.array([0.0, 5.0, -5.0, 1.0, 1.0, 0.3])
+    var = np.array([1.0, 1e-12, 4.0, 0.0, -1e-13, 1e-9])  # zero / negative variance -> jitter rule
+    for sign, bf in ((1.0, 0.9), (-1.0, 0.2)):
+        so = go.qlogei_q1(mu, var, z, bf, sign)
+        s = gp.qlogei(torch.from_numpy(mu).cuda(), torch.from_numpy(var).cuda(), z, bf, sign)
+        assert np.allclose(_np(s), so, rtol=0, atol=1e-9)
+    alive = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.uint8, device="cuda")
+    s = _np(gp.qlogei(torch.from_numpy(mu).cuda(), torch.from_numpy(var).cuda(), z, 0.9, 1.0, alive))
+    assert np.isneginf(s[1]) and np.isneginf(s[4]) and np.isfinite(s[[0, 2, 3, 5]]).all()
+
+
+def test_argmax_ties_nan_and_all_masked(gp):
+    import torch
+
+    s = torch.tensor([1.0, 3.0, float("nan"), 3.0, 2.0], dtype=torch.float64, device="cuda")
+    assert gp.argmax(s) == (3.0, 1)
+    s = torch.full((5000,), -math.inf, dtype=torch.float64, device="cuda")
+    assert gp.argmax(s)[1] == 0
+    big = torch.zeros(300001, dtype=torch.float64, device="cuda")
+    big[[123456, 299999, 70000]] = 7.0
+    assert gp.argmax(big) == (7.0, 70000)
+    v, i = gp.topk(big, 4)
+    assert i.tolist() == [70000, 123456, 299999, 0]
+
+
+@pytest.mark.parametrize("N,d,n,q,minimize", [(2000, 5, 40, 4, False), (3000, 8, 100, 3, True)])
+def test_greedy_with_pending_matches_oracle(gp, N, d, n, q, minimize):
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    X, Xt, y = make_problem(N, d, n, seed=4, minimize=minimize)
+    sign = -1.0 if minimize else 1.0
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    p = gp_spec.GPParams(np.full(d, ls), nz, 0.0)
+    gp.set_model(spec, Xt, y)
+    gp.factorize(p)
+    om = go.GPModel(_ospec(spec), _oparams(p), Xt, y)
+    ro = go.optimize_acqf_discrete_qlogei(om, X, q, seed=77, sign=sign, X_pending=X[:1])
+    rg = gp.greedy_qlogei(X, q, seed=77, sign=sign, X_pending=X[:1])
+    assert rg.indices == ro.indices
+    assert np.allclose(rg.values, ro.values, rtol=0, atol=SCORE_ATOL)
+    # per-candidate scores with two pending points (candidates distinct from the pending rows)
+    pend = X[[3, 10]]
+    keep = np.ones(600, bool)
+    keep[[3, 10]] = False
+    Xc = X[:600][keep]
+    z = go.sobol_normal_base_samples(512, 3, 5)
+    bf = go.best_f_from_model(om, sign)
+    so = go.qlogei_with_pending(om, Xc, pend, z, bf, sign)
+    mp_, cpp = gp.set_pending(pend)
+    mo_p, co_p = om.posterior_joint(pend)
+    assert np.allclose(mp_, mo_p, rtol=1e-10) and np.allclose(cpp, co_p, rtol=1e-8, atol=1e-14)
+    m, v = gp.posterior(Xc)
+    cr = gp.cross_cov(Xc)
+    sg = _np(gp.qlogei_pending(m, v, cr, z, bf, sign))
+    assert np.allclose(sg, so, rtol=0, atol=SCORE_ATOL)
+    gp.set_pending(None)
+
+
+def test_pending_points_are_not_recommended_again_on_device(gp):
+    from baybe_amd import gp_spec
+
+    X, Xt, y = make_problem(600, 4, 30, seed=7)
+    spec = gp_spec.GPSpec.baybe_default(4, np.zeros(4), np.ones(4))
+    gp.set_model(spec, Xt, y)
+    gp.fit()
+    r1 = gp.greedy_qlogei(X, 3, seed=1337)
+    mask = np.ones(len(X), bool)
+    mask[r1.indices] = False
+    r2 = gp.greedy_qlogei(X[mask], 3, seed=1337, X_pending=X[r1.indices])
+    first = {tuple(np.round(X[i], 3)) for i in r1.indices}
+    second = {tuple(np.round(X[mask][i], 3)) for i in r2.indices}
+    assert not (first & second) and len(set(r1.indices)) == 3
+
+
+# ---- BASELINE sizes: size-independent properties ----------------------------------------------
+@pytest.mark.parametrize("N,d,n", [(100_000, 15, 256), (1_000_000, 20, 512)])
+def test_full_size_properties(gp, N, d, n):
+    """cfg2 / cfg3 of BASELINE.json.  (i) fused == unfused posterior on a 20k slice; (ii) the
+    oracle agrees on a 4k sample and on the global top candidates; (iii) minimise(-y) mirrors
+    maximise(y) exactly (reference tests/integration/test_minimization.py:41-78); (iv) scoring is
+    idempotent and permutation-equivariant."""
+    import torch
+
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    X, Xt, y = make_problem(N, d, n, seed=0)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    p = gp_spec.GPParams(np.full(d, ls), nz, 0.0)
+    gp.set_model(spec, Xt, y)
+    gp.factorize(p)
+    Xd = torch.from_numpy(X).cuda()
+    m, v = gp.posterior(Xd)
+    z = go.sobol_normal_base_samples(512, 1, 1234)[:, 0]
+    bf = gp.best_f()
+    s = gp.qlogei(m, v, z, bf)
+    # (i)
+    m2, v2 = gp.posterior(Xd[:20000], unfused=True)
+    assert torch.allclose(m[:20000], m2, rtol=MEAN_RTOL, atol=1e-12) and torch.allclose(v[:20000], v2, rtol=VAR_RTOL)
+    # (ii)
+    om = go.GPModel(_ospec(spec), _oparams(p), Xt, y)
+    vals, top = gp.topk(s, 10)
+    pick = np.concatenate([np.random.default_rng(1).choice(N, 4000, replace=False), top])
+    mo, vo = om.posterior(X[pick])
+    assert np.allclose(_np(m)[pick], mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v)[pick], vo, rtol=VAR_RTOL)
+    so = go.qlogei_q1(mo, vo, z, go.best_f_from_model(om))
+    assert np.allclose(_np(s)[pick], so, rtol=0, atol=SCORE_ATOL)
+    assert math.isclose(bf, go.best_f_from_model(om), rel_tol=1e-9)
+    # (iv) idempotent, and scoring a permuted candidate set permutes the scores
+    m3, v3 = gp.posterior(Xd)
+    assert torch.equal(m, m3) and torch.equal(v, v3)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(0)).cuda()
+    mp_, vp_ = gp.posterior(Xd[perm].contiguous())
+    assert torch.allclose(mp_, m[perm], rtol=1e-12, atol=1e-13) and torch.allclose(vp_, v[perm], rtol=1e-10)
+    # (iii)
+    gp.set_model(spec, Xt, -y)
+    gp.factorize(p)
+    mn, vn = gp.posterior(Xd)
+    assert torch.allclose(mn, -m, rtol=0, atol=1e-12) and torch.allclose(vn, v, rtol=1e-12)
+    sn = gp.qlogei(mn, vn, -z, gp.best_f(-1.0), -1.0)
+    assert torch.allclose(sn, s, rtol=1e-9, atol=1e-9)
+    assert gp.argmax(sn)[1] == gp.argmax(s)[1]
