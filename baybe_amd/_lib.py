@@ -90,6 +90,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP/HSA runtime: load it FIRST so that libbaybe_hip.so binds to
+    # the same libamdhip64 (same SONAME) instead of pulling a second runtime from /opt/rocm into
+    # the process (two HSA runtimes in one process leave torch with "No HIP GPUs are available").
+    import torch  # noqa: F401
+
     path = library_path()
     if not path.exists():
         raise HipUnavailableError(

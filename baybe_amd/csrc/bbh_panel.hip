@@ -66,7 +66,7 @@ struct WaveCtx {
   const double* mb;     // meanB + lane
   const double* tbl;
   const int* taskext;
-  int kd, kind, T, tc, q;
+  int kd, kind, T, tc, q, l, dn;
 };
 
 // KIND >= 0: compile-time kernel kind (branch-free fast path); KIND < 0: runtime c.kind.
@@ -92,6 +92,20 @@ __device__ __forceinline__ void compute_kv(const WaveCtx& c, int tb, double (&kv
     if (KIND == BBH_KERNEL_MATERN52) {
       const double rr = sqrt(r2);
       v = (1.0 + BBH_SQRT5 * rr + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * rr);
+    } else if (c.kind == BBH_KERNEL_MATERN12) {
+      // exp(-r) is not smooth at r = 0: the |a|^2 + |b|^2 - 2ab form loses ~sqrt(eps) there, so
+      // this (rare) kernel recomputes the distance from direct differences of the same operands
+      // (a_i = -0.5 * A_aug, b_c from LDS) — exact zeros for coinciding points.
+      const double* tfb = tf - c.l;
+      const double* cb = c.candl - c.l;
+      const int il = c.q + 4 * r, cl = c.l & 15;
+      double d2 = 0.0;
+      for (int dim = 0; dim < c.dn; dim++) {
+        const int o = (dim >> 2) * 64 + (dim & 3) * 16;
+        const double df = cb[o + cl] + 0.5 * tfb[o + il];
+        d2 = fma(df, df, d2);
+      }
+      v = (r2 > 1e7) ? 0.0 : exp(-sqrt(d2));  // r2 > 1e7 marks padding (A_aug norm slot = 1e8)
     } else {
       v = bbh_kfun_p(c.kind, r2);
     }
@@ -217,6 +231,8 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
   c.T = a.T;
   c.tc = tc;
   c.q = q;
+  c.l = l;
+  c.dn = a.dn;
 
   double ss[4] = {0.0, 0.0, 0.0, 0.0};
   d4 accm = {0.0, 0.0, 0.0, 0.0};

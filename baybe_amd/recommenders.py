@@ -1,0 +1,241 @@
+"""Host-side mirror of ``BotorchRecommender`` for purely discrete search spaces, on the HIP path.
+
+Same call structure as the reference:
+``recommend`` (``pure/bayesian/base.py:130-197``) -> fit the surrogate and set up the acquisition
+(``_setup_botorch_acqf``, ``base.py:87-111``; best_f / X_pending semantics of
+``acquisition/_builder.py:195-334``) -> ``_recommend_with_discrete_parts``
+(``pure/base.py:248-310``) -> ``_recommend_discrete`` (``botorch/core.py:155-184``) ->
+``recommend_discrete_without_subsets`` (``botorch/discrete.py:78-142``), whose
+``optimize_acqf_discrete`` call is replaced by ``HipGP.greedy_qlogei``.
+
+Differences that are deliberate: the comp-rep rows of the
+candidates are taken positionally from ``subspace_discrete.comp_rep`` (no re-encoding of N rows,
+no float-key merge), so exactly ``batch_size`` index labels are returned even if the search
+space contains duplicate rows.
+"""
+
+from __future__ import annotations
+
+from typing import ClassVar
+
+import numpy as np
+import pandas as pd
+from attrs import define, field
+from attrs.validators import ge, instance_of
+
+from baybe_amd import _lib
+from baybe_amd.acquisition import convert_acqf, qLogExpectedImprovement
+from baybe_amd.engine import draw_sampler_seed, sobol_normal_base_samples
+from baybe_amd.exceptions import (
+    IncompatibilityError,
+    IncompatibleAcquisitionFunctionError,
+    NotEnoughPointsLeftError,
+)
+from baybe_amd.surrogates import HipCompositeSurrogate, HipGaussianProcessSurrogate
+
+
+def _autoreplicate(surrogate):
+    """``pure/bayesian/base.py:35-39``: single-output surrogates are replicated lazily per target."""
+    return surrogate
+
+
+@define(kw_only=True, slots=False)
+class HipBotorchRecommender:
+    """Bayesian recommender scoring the full discrete candidate set on an MI355X."""
+
+    compatibility: ClassVar[str] = "DISCRETE"
+    supports_discrete_subset_generating_constraints: ClassVar[bool] = True
+
+    _surrogate_model = field(alias="surrogate_model", factory=HipGaussianProcessSurrogate, converter=_autoreplicate)
+    acquisition_function = field(default=None, converter=convert_acqf)
+    max_n_subsets: int = field(default=10, validator=[instance_of(int), ge(1)])
+    shard = field(default=None, eq=False, repr=False)
+    """Optional ``baybe_amd.distributed.RowShard``: this process scores only its row range and
+    joins one all-gather per selection step (multi-GPU)."""
+
+    _objective = field(default=None, init=False, eq=False, repr=False)
+    _best_f = field(default=None, init=False, eq=False, repr=False)
+    _pending_comp = field(default=None, init=False, eq=False, repr=False)
+    _cand_cache = field(default=None, init=False, eq=False, repr=False)
+
+    @classmethod
+    def is_available(cls) -> bool:
+        return _lib.is_available()
+
+    # ---- BayesianRecommender surface -----------------------------------------------------------
+    def _get_acquisition_function(self, objective):
+        if self.acquisition_function is None:
+            if len(objective.targets) > 1:
+                raise IncompatibleAcquisitionFunctionError(
+                    "Multi-target (Pareto) objectives need qLogNEHVI, which the HIP path does not score yet."
+                )
+            return qLogExpectedImprovement()
+        return self.acquisition_function
+
+    def get_surrogate(self, searchspace, objective, measurements):
+        self._surrogate_model.fit(searchspace, objective, measurements)
+        return self._surrogate_model
+
+    def _setup_acqf(self, searchspace, objective, measurements, pending_experiments=None):
+        """Native counterpart of ``_setup_botorch_acqf``: fit (cached), best_f, pending rows."""
+        self._objective = objective
+        acqf = self._get_acquisition_function(objective)
+        if len(objective.targets) > 1 and not acqf.supports_multi_output:
+            raise IncompatibleAcquisitionFunctionError(
+                f"You attempted to use a single-output acquisition function in a "
+                f"{len(objective.targets)}-target multi-output context."
+            )
+        if pending_experiments is not None and not acqf.supports_pending_experiments:
+            raise IncompatibleAcquisitionFunctionError(
+                f"The chosen acquisition function of type '{type(acqf).__name__}' does not support pending experiments."
+            )
+        surrogate = self.get_surrogate(searchspace, objective, measurements)
+        self._best_f = surrogate.engine.best_f(surrogate.sign)  # _builder.py:141-161, 256-265
+        self._pending_comp = None
+        if pending_experiments is not None and len(pending_experiments):
+            pend = searchspace.transform(pending_experiments, allow_extra=True)  # _builder.py:326-334
+            self._pending_comp = np.ascontiguousarray(pend.to_numpy(dtype=np.float64))
+        return surrogate, acqf
+
+    def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None) -> pd.DataFrame:
+        if objective is None:
+            raise NotImplementedError(
+                "Recommenders of type 'BayesianRecommender' require that an objective is specified."
+            )
+        if measurements is None or measurements.empty:
+            raise NotImplementedError("Recommenders of type 'BayesianRecommender' do not support empty training data.")
+        cont = getattr(searchspace, "continuous", None)
+        if cont is not None and not getattr(cont, "is_empty", True):
+            raise IncompatibilityError(
+                "HipBotorchRecommender handles purely discrete search spaces; use BotorchRecommender for "
+                "continuous / hybrid spaces."
+            )
+        self._setup_acqf(searchspace, objective, measurements, pending_experiments)
+        return self._recommend_with_discrete_parts(searchspace, batch_size)
+
+    def _recommend_with_discrete_parts(self, searchspace, batch_size) -> pd.DataFrame:
+        candidates_exp, _ = searchspace.discrete.get_candidates()
+        if len(candidates_exp) < batch_size:
+            raise NotEnoughPointsLeftError(
+                f"Using the current settings, there are fewer than {batch_size} possible data points left to recommend."
+            )
+        idxs = self._recommend_discrete(searchspace.discrete, candidates_exp, batch_size)
+        return searchspace.discrete.exp_rep.loc[idxs, :]
+
+    # ---- discrete optimisation -----------------------------------------------------------------
+    def _candidates_on_device(self, subspace_discrete, candidates_exp):
+        """Comp-rep rows of the candidates as a device-resident fp64 matrix, cached per
+        (comp_rep object, index) so repeated recommend() calls do not re-upload N x d doubles."""
+        import torch
+
+        comp_rep = subspace_discrete.comp_rep
+        key = (id(comp_rep), len(candidates_exp), hash(candidates_exp.index.values[:: max(1, len(candidates_exp) // 64)].tobytes()))
+        if self._cand_cache is not None and self._cand_cache[0] == key:
+            return self._cand_cache[1]
+        rows = comp_rep.loc[candidates_exp.index]
+        X = torch.from_numpy(np.ascontiguousarray(rows.to_numpy(dtype=np.float64)))
+        if self.shard is not None:
+            X = X[self.shard.start : self.shard.stop]
+        Xd = X.to(torch.device("cuda", self._engine.device))
+        self._cand_cache = (key, Xd)
+        return Xd
+
+    @property
+    def _engine(self):
+        model = self._surrogate_model
+        return model.engine
+
+    def _recommend_discrete(self, subspace_discrete, candidates_exp: pd.DataFrame, batch_size: int) -> pd.Index:
+        assert self._objective is not None
+        acqf = self._get_acquisition_function(self._objective)
+        if batch_size > 1 and not acqf.supports_batching:
+            raise IncompatibleAcquisitionFunctionError(
+                f"The '{self.__class__.__name__}' only works with Monte Carlo acquisition functions for batch sizes > 1."
+            )
+        n_sub = getattr(subspace_discrete, "n_subsets", 0)
+        if n_sub > 0:
+            return self._recommend_discrete_with_subsets(subspace_discrete, candidates_exp, batch_size)
+        return self._recommend_discrete_without_subsets(subspace_discrete, candidates_exp, batch_size)
+
+    def _recommend_discrete_without_subsets(self, subspace_discrete, candidates_exp, batch_size, return_values=False):
+        surrogate = self._surrogate_model
+        acqf = self._get_acquisition_function(self._objective)
+        Xd = self._candidates_on_device(subspace_discrete, candidates_exp)
+        res = surrogate.engine.greedy_qlogei(
+            Xd, batch_size, S=acqf.n_mc_samples, seed=draw_sampler_seed(), sign=surrogate.sign,
+            X_pending=self._pending_comp, best_f=self._best_f, shard=self.shard,
+        )
+        idxs = candidates_exp.index[np.asarray(res.indices, dtype=np.int64)]
+        return (idxs, res) if return_values else idxs
+
+    def _recommend_discrete_with_subsets(self, subspace_discrete, candidates_exp, batch_size) -> pd.Index:
+        """``recommend_discrete_with_subsets`` (botorch/discrete.py:21-75): one greedy run per
+        batch-constraint subset, the batch with the highest joint acquisition value wins."""
+        if subspace_discrete.n_subsets <= self.max_n_subsets:
+            masks = subspace_discrete.subset_masks(candidates_exp, min_candidates=batch_size)
+        else:
+            masks = subspace_discrete.sample_subset_masks(candidates_exp, self.max_n_subsets, min_candidates=batch_size)
+        best = None
+        for mask in masks:
+            subset = candidates_exp.loc[mask]
+            self._cand_cache = None
+            idxs = self._recommend_discrete_without_subsets(subspace_discrete, subset, batch_size)
+            comp = subspace_discrete.comp_rep.loc[idxs].to_numpy(dtype=np.float64)
+            val = self._joint_value(comp)
+            if best is None or val > best[1]:
+                best = (idxs, val)
+        self._cand_cache = None
+        if best is None:
+            from baybe_amd.exceptions import IncompatibilityError as _E
+
+            raise _E("No feasible subset with enough candidates was found.")
+        return best[0]
+
+    # ---- read-backs (Campaign.acquisition_values / joint_acquisition_value) ---------------------
+    def _joint_value(self, comp: np.ndarray) -> float:
+        """qLogEI of one q-batch (candidate = first row, the others enter as pending rows)."""
+        surrogate = self._surrogate_model
+        eng = surrogate.engine
+        acqf = self._get_acquisition_function(self._objective)
+        base = self._pending_comp if self._pending_comp is not None else np.zeros((0, comp.shape[1]))
+        pend = np.vstack([comp[1:], base])
+        seed = draw_sampler_seed()
+        mean, var = eng.posterior(comp[:1])
+        if len(pend) == 0:
+            z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]
+            s = eng.qlogei(mean, var, z, self._best_f, surrogate.sign)
+        else:
+            eng.set_pending(pend)
+            cross = eng.cross_cov(comp[:1])
+            z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(pend), seed)
+            s = eng.qlogei_pending(mean, var, cross, z, self._best_f, surrogate.sign)
+            eng.set_pending(None)
+        return float(s.cpu().numpy()[0])
+
+    def acquisition_values(self, candidates: pd.DataFrame, searchspace, objective, measurements,
+                           pending_experiments=None, acquisition_function=None) -> pd.Series:
+        """``BayesianRecommender.acquisition_values`` (base.py:199-238): one value per candidate."""
+        if acquisition_function is not None:
+            convert_acqf(acquisition_function)
+        surrogate, acqf = self._setup_acqf(searchspace, objective, measurements, pending_experiments)
+        eng = surrogate.engine
+        comp = np.ascontiguousarray(searchspace.transform(candidates, allow_extra=True).to_numpy(dtype=np.float64))
+        mean, var = eng.posterior(comp)
+        seed = draw_sampler_seed()
+        if self._pending_comp is None:
+            z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]
+            s = eng.qlogei(mean, var, z, self._best_f, surrogate.sign)
+        else:
+            eng.set_pending(self._pending_comp)
+            cross = eng.cross_cov(comp)
+            z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(self._pending_comp), seed)
+            s = eng.qlogei_pending(mean, var, cross, z, self._best_f, surrogate.sign)
+            eng.set_pending(None)
+        return pd.Series(s.cpu().numpy(), index=candidates.index)
+
+    def joint_acquisition_value(self, candidates: pd.DataFrame, searchspace, objective, measurements,
+                                pending_experiments=None, acquisition_function=None) -> float:
+        """``BayesianRecommender.joint_acquisition_value`` (base.py:240-269)."""
+        self._setup_acqf(searchspace, objective, measurements, pending_experiments)
+        comp = np.ascontiguousarray(searchspace.transform(candidates, allow_extra=True).to_numpy(dtype=np.float64))
+        return self._joint_value(comp)

@@ -39,7 +39,7 @@ int main() {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 20000;
-  for (int wg_per_cu = 1; wg_per_cu <= 2; wg_per_cu++) {
+  for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int blocks = 256 * wg_per_cu;
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(e0);

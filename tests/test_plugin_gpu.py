@@ -1,0 +1,182 @@
+"""Drop-in tests of the plug-in surface (HipBotorchRecommender / HipGaussianProcessSurrogate)
+through BayBE-shaped objects, against the oracle.  Mirrors the reference's own hot-path tests:
+tests/test_campaign.py:330-366,401-416 (posterior_stats / acquisition_values shape),
+tests/test_surrogate.py:34-48 (fit caching), tests/test_pending_experiments.py:100-128,
+tests/integration/test_minimization.py:41-78."""
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from _baybe_shim import (
+    Campaign,
+    NumericalDiscreteParameter,
+    NumericalTarget,
+    SearchSpace,
+    SingleTargetObjective,
+    TaskParameter,
+)
+
+pytestmark = pytest.mark.gpu
+
+
+def _space3():
+    vals = np.arange(10) / 9.0
+    return SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(3)])
+
+
+def _measure(exp, rng, minimize=False):
+    X = exp[["x0", "x1", "x2"]].to_numpy(dtype=float)
+    y = -((X - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * X[:, 0]) + 0.05 * rng.standard_normal(len(X))
+    out = exp.copy()
+    out["yield"] = -y if minimize else y
+    return out
+
+
+def _oracle_greedy(space, meas, cand_exp, q, seed, sign=1.0, pending=None):
+    from oracle import gp_oracle as go
+
+    d = 3
+    spec = go.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    Xt = space.transform(meas).to_numpy(dtype=float)
+    m = go.fit_gp(spec, Xt, meas["yield"].to_numpy(dtype=float))
+    Xc = space.transform(cand_exp).to_numpy(dtype=float)
+    pend = None if pending is None else space.transform(pending).to_numpy(dtype=float)
+    r = go.optimize_acqf_discrete_qlogei(m, Xc, q, seed=seed, sign=sign, X_pending=pend)
+    return cand_exp.index[r.indices], m
+
+
+@pytest.mark.parametrize("minimize", [False, True])
+def test_campaign_recommend_is_a_drop_in(minimize):
+    """BASELINE configs[0]: 3 discrete parameters (1000 candidates), n_train = 20, batch 3."""
+    import torch
+
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    rng = np.random.default_rng(0)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 20, replace=False)], rng, minimize)
+    rec = HipBotorchRecommender()
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield", minimize=minimize)), rec)
+    camp.add_measurements(meas)
+    torch.manual_seed(1337)
+    seed = int(torch.randint(0, 1000000, (1,)).item())  # what the recommender will draw
+    torch.manual_seed(1337)
+    got = camp.recommend(3)
+    assert list(got.columns) == ["x0", "x1", "x2"] and len(got) == 3
+    cand = exp.loc[~camp._meta["measured"]]
+    ref_idx, _ = _oracle_greedy(space, meas, cand, 3, seed, -1.0 if minimize else 1.0)
+    assert got.index.tolist() == ref_idx.tolist()
+    assert camp._meta.loc[got.index, "recommended"].all()
+    # second batch: the first one is excluded; with it passed as pending there is no overlap
+    torch.manual_seed(7)
+    got2 = camp.recommend(3, pending_experiments=got)
+    assert not set(got.index) & set(got2.index)
+
+
+def test_fit_is_cached_for_unchanged_measurements():
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    rng = np.random.default_rng(1)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 15, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    rec = HipBotorchRecommender()
+    rec.recommend(1, space, obj, meas)
+    eng = rec._surrogate_model.engine
+    calls = {"n": 0}
+    orig = eng.fit
+
+    def counting_fit(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    eng.fit = counting_fit
+    rec.recommend(1, space, obj, meas)
+    assert calls["n"] == 0
+    meas2 = pd.concat([meas, _measure(exp.iloc[[3]], rng)], ignore_index=True)
+    rec.recommend(1, space, obj, meas2)
+    assert calls["n"] == 1
+
+
+def test_error_behaviour_matches_the_reference():
+    from baybe_amd.exceptions import IncompatibleAcquisitionFunctionError, NotEnoughPointsLeftError
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    rng = np.random.default_rng(2)
+    space = SearchSpace.from_product([NumericalDiscreteParameter("x0", [0, 0.5, 1]), NumericalDiscreteParameter("x1", [0, 1]),
+                                      NumericalDiscreteParameter("x2", [0, 1])])
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[:5], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    rec = HipBotorchRecommender()
+    with pytest.raises(NotImplementedError):
+        rec.recommend(1, space, None, meas)
+    with pytest.raises(NotImplementedError):
+        rec.recommend(1, space, obj, pd.DataFrame())
+    with pytest.raises(NotEnoughPointsLeftError):
+        rec.recommend(len(exp) + 1, space, obj, meas)
+    with pytest.raises(IncompatibleAcquisitionFunctionError):
+        HipBotorchRecommender(acquisition_function="UCB")
+
+
+def test_posterior_stats_and_acquisition_values_readbacks():
+    import torch
+
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from oracle import gp_oracle as go
+
+    rng = np.random.default_rng(3)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 25, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    rec = HipBotorchRecommender()
+    sur = rec.get_surrogate(space, obj, meas)
+    cand = exp.iloc[:200]
+    stats = sur.posterior_stats(cand, stats=("mean", "std", "var", 0.9))
+    assert list(stats.columns) == ["yield_mean", "yield_std", "yield_var", "yield_Q_0.9"]
+    assert stats.index.equals(cand.index) and not stats.isna().any().any()
+    _, m = _oracle_greedy(space, meas, cand, 1, 0)
+    mo, vo = m.posterior(space.transform(cand).to_numpy(dtype=float))
+    assert np.allclose(stats["yield_mean"], mo, rtol=1e-6, atol=1e-9)
+    assert np.allclose(stats["yield_var"], vo, rtol=1e-5)
+    with pytest.raises(ValueError):
+        sur.posterior_stats(cand, stats=(1.5,))
+    torch.manual_seed(11)
+    seed = int(torch.randint(0, 1000000, (1,)).item())
+    torch.manual_seed(11)
+    acq = rec.acquisition_values(cand, space, obj, meas)
+    assert isinstance(acq, pd.Series) and acq.index.equals(cand.index)
+    z = go.sobol_normal_base_samples(512, 1, seed)[:, 0]
+    ref = go.qlogei_q1(mo, vo, z, go.best_f_from_model(m), 1.0)
+    assert np.allclose(acq.to_numpy(), ref, rtol=0, atol=1e-5)
+    joint = rec.joint_acquisition_value(cand.iloc[:3], space, obj, meas)
+    assert np.isfinite(joint)
+
+
+def test_transfer_learning_campaign_recommends():
+    """tests/test_transfer_learning.py:62-68: a TaskParameter search space recommends without
+    error; candidates are the active task's rows only."""
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    rng = np.random.default_rng(4)
+    vals = np.arange(6) / 5.0
+    params = [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals), NumericalDiscreteParameter("x2", vals),
+              TaskParameter("task", ["A", "B", "C"], active_values=["A"])]
+    space = SearchSpace.from_product(params)
+    exp = space.discrete.exp_rep
+    rows = []
+    for t, shift in (("A", 0.0), ("B", 0.2), ("C", -0.1)):
+        sub = exp.iloc[rng.choice(len(exp), 12, replace=False)].copy()
+        sub["task"] = t
+        m = _measure(sub, rng)
+        m["yield"] += shift
+        rows.append(m)
+    meas = pd.concat(rows, ignore_index=True)
+    rec = HipBotorchRecommender()
+    got = rec.recommend(2, space, SingleTargetObjective(NumericalTarget("yield")), meas)
+    assert len(got) == 2 and (got["task"] == "A").all()
+    assert rec._surrogate_model.engine.spec.criterion == "loo"
