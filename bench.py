@@ -151,13 +151,20 @@ def main():
     flops_per_cand = n * n + 2 * n * d + 16 * n + 16 * S
     avg_ms = fused_ms / max(fused_launches, 1)
     achieved = rows_local * flops_per_cand / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    traffic = None
+    try:  # PMC-derived HBM bytes per launch for this exact workload (collected offline, profiles/)
+        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        traffic = tj["workloads"].get(f"{rows_local}x{d}_n{n}", {}).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        traffic = None
     roofline = {
         "bound": "mfma",
         "achieved": achieved,
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; algorithmic = %d)" % (rows_local * (8 * d + 16)),
         "kernel": "bbh_fused_posterior_kernel",
         "avg_launch_ms": avg_ms,
         "launches": fused_launches,
