@@ -51,6 +51,9 @@ class RowShard:
     def _all_gather(self, payload):
         import torch
 
+        backend = self._dist.get_backend(self.group)
+        if backend == "gloo" and payload.is_cuda:  # CPU tests / single-GPU dry runs: stage through the host
+            payload = payload.cpu()
         out = torch.empty((self.world, payload.numel()), dtype=payload.dtype, device=payload.device)
         self._dist.all_gather_into_tensor(out, payload.reshape(1, -1).contiguous(), group=self.group)
         return out

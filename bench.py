@@ -71,12 +71,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    # BENCH_SINGLE_DEVICE=1: dry run of the N > 1 code path on ONE GPU (all ranks on cuda:0, gloo
+    # instead of RCCL) — used to test the sharded path where only one device is available.
+    single_dev = os.environ.get("BENCH_SINGLE_DEVICE", "0") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if single_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from baybe_amd import engine, gp_spec
     from baybe_amd.distributed import RowShard, shard_bounds
@@ -140,7 +148,7 @@ def main():
     fused_ms, fused_launches = gp.timing_read(reset=True)
     gp.timing(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_dev else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
