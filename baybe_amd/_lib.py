@@ -41,6 +41,7 @@ class ModelDesc(C.Structure):
 KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15
+MAX_OBJECTIVES = 4
 
 # name -> (restype, argtypes); every symbol include/baybe_hip.h declares
 SIGNATURES = {
@@ -54,12 +55,20 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.POINTER(ModelDesc), C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p],
     ),
+    "bbh_set_model_ex": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(ModelDesc), C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
+         C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_double],
+    ),
     "bbh_theta_len": (C.c_int64, [C.c_void_p]),
     "bbh_get_standardization": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "bbh_fit_value_grad": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "bbh_factorize": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "bbh_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "bbh_posterior_unfused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bbh_posterior_joint": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    "bbh_set_mean_columns": (C.c_int, [C.c_void_p, c_double_p, C.c_int64]),
+    "bbh_posterior_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "bbh_train_posterior_mean": (C.c_int, [C.c_void_p, c_double_p]),
     "bbh_qlogei_q1": (
         C.c_int,
@@ -72,6 +81,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double,
          C.c_double, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_qlognehvi": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
+         C.c_int64, c_int64_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p],
     ),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),

@@ -350,3 +350,137 @@ extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int6
   }
   return 0;
 }
+
+// =================================================================================================
+// qLogNEHVI (q' = 1): per MC sample, log-sum over the cells of that sample's box decomposition of
+//   sum_o fatmin( log_fatplus(f_o - lo_o; tau_relu), loglen_o; tau_max ),  then logmeanexp over samples.
+// One thread per candidate; the cell data is uniform across the wave (scalar / broadcast loads).
+// =================================================================================================
+struct NehviArgs {
+  const double* tmat[BBH_MAX_OBJECTIVES];
+  const double* var[BBH_MAX_OBJECTIVES];
+  double sign[BBH_MAX_OBJECTIVES];
+  int m;
+  int64_t N;
+  int S;
+  const double* zx;        // [S, m]
+  const int64_t* cell_off; // [S + 1]
+  const double* cell_lo;   // [ncells, m]
+  const double* cell_ll;   // [ncells, m]
+  const uint8_t* alive;
+  double* scores;
+};
+
+__device__ __forceinline__ double bbh_fatmin2(double a, double b) {
+  // min(a,b) - tau log(1 + (alpha / (alpha + |a-b|/tau))^alpha), alpha = 2, tau = 1e-2
+  const double mn = fmin(a, b);
+  double diff = fabs(a - b);
+  if (!(diff == diff)) diff = INFINITY;  // (-inf) - (-inf)
+  const double u = 2.0 / (2.0 + diff * (1.0 / TAU_MAX));
+  return mn - TAU_MAX * log1p(u * u);
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void bbh_qlognehvi_kernel(const NehviArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N) return;
+  if (a.alive && !a.alive[i]) {
+    a.scores[i] = -INFINITY;
+    return;
+  }
+  double sd[M], sg[M];
+  const double* trow[M];
+#pragma unroll
+  for (int o = 0; o < M; o++) {
+    sd[o] = bbh_safe_sd(a.var[o][i]);
+    sg[o] = a.sign[o];
+    trow[o] = a.tmat[o] + i * (int64_t)a.S;
+  }
+  const double inv_tau = 1.0 / TAU_RELU;
+  const double log_tau = log(TAU_RELU);
+  double sref = -INFINITY, ssum = 0.0;  // streaming log-sum-exp over MC samples
+  for (int s = 0; s < a.S; s++) {
+    double f[M];
+#pragma unroll
+    for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s]);
+    double cref = -INFINITY, csum = 0.0;  // streaming log-sum-exp over the cells of this sample
+    const int64_t c0 = a.cell_off[s], c1 = a.cell_off[s + 1];
+    for (int64_t c = c0; c < c1; c++) {
+      double la = 0.0;
+#pragma unroll
+      for (int o = 0; o < M; o++) {
+        const double t = (f[o] - a.cell_lo[c * M + o]) * inv_tau;
+        const double li = log_tau + log(bbh_fatplus_core(t));
+        la += bbh_fatmin2(li, a.cell_ll[c * M + o]);
+      }
+      if (la > cref) {
+        csum = csum * exp(cref - la) + 1.0;
+        cref = la;
+      } else if (la > -INFINITY) {
+        csum += exp(la - cref);
+      }
+    }
+    const double v = (cref > -INFINITY) ? cref + log(csum) : -INFINITY;
+    if (v > sref) {
+      ssum = ssum * exp(sref - v) + 1.0;
+      sref = v;
+    } else if (v > -INFINITY) {
+      ssum += exp(v - sref);
+    }
+  }
+  a.scores[i] = (sref > -INFINITY) ? sref + log(ssum) - log((double)a.S) : -INFINITY;
+}
+
+extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                             const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                             const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
+                             const uint8_t* alive_dev, double* scores_dev) {
+  if (!h) return -1;
+  if (m < 1 || m > BBH_MAX_OBJECTIVES || N < 0 || S < 1 || !tmat_dev || !var_dev || !sign_host || !zx_host ||
+      !cell_off_host || !scores_dev) {
+    h->err = "bbh_qlognehvi: bad arguments (1 <= m <= 4)";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  const int64_t ncells = cell_off_host[S];
+  if (ncells < 0 || (ncells > 0 && (!cell_lo_host || !cell_loglen_host))) {
+    h->err = "bbh_qlognehvi: inconsistent cell arrays";
+    return -1;
+  }
+  // one upload: zx [S*m] | cell_lo [ncells*m] | cell_ll [ncells*m] | cell_off [S+1] (int64, 8-byte slots)
+  const size_t nd = (size_t)S * m + 2 * (size_t)ncells * m;
+  std::vector<double> buf(nd + (size_t)S + 1);
+  memcpy(buf.data(), zx_host, sizeof(double) * S * m);
+  if (ncells > 0) {
+    memcpy(buf.data() + S * m, cell_lo_host, sizeof(double) * ncells * m);
+    memcpy(buf.data() + S * m + ncells * m, cell_loglen_host, sizeof(double) * ncells * m);
+  }
+  memcpy(buf.data() + nd, cell_off_host, sizeof(int64_t) * (S + 1));
+  int rc = bbh_upload_z(h, buf.data(), buf.size());
+  if (rc) return rc;
+  NehviArgs a;
+  for (int o = 0; o < BBH_MAX_OBJECTIVES; o++) {
+    a.tmat[o] = o < m ? tmat_dev[o] : nullptr;
+    a.var[o] = o < m ? var_dev[o] : nullptr;
+    a.sign[o] = o < m ? sign_host[o] : 1.0;
+  }
+  a.m = m;
+  a.N = N;
+  a.S = (int)S;
+  a.zx = h->d_z;
+  a.cell_lo = h->d_z + S * m;
+  a.cell_ll = h->d_z + S * m + ncells * m;
+  a.cell_off = (const int64_t*)(h->d_z + nd);
+  a.alive = alive_dev;
+  a.scores = scores_dev;
+  dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  switch (m) {
+    case 1: hipLaunchKernelGGL(bbh_qlognehvi_kernel<1>, grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL(bbh_qlognehvi_kernel<2>, grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL(bbh_qlognehvi_kernel<3>, grid, block, 0, h->stream, a); break;
+    default: hipLaunchKernelGGL(bbh_qlognehvi_kernel<4>, grid, block, 0, h->stream, a); break;
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}

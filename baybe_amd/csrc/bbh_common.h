@@ -63,6 +63,8 @@ struct bbh_handle {
   // ---- device state (all fp64 unless noted) ----
   double* d_xnT = nullptr;     // [dn, np]  normalised training inputs, transposed
   int* d_task = nullptr;       // [np]      task ids (0 for padding)
+  double* d_nmask = nullptr;   // [np]      noise mask (1 = noisy observation, 0 = latent value / padding)
+  std::vector<double> nmask_host;
   double* d_ystd = nullptr;    // [np]
   double* d_theta = nullptr;   // [theta_len]
   double* d_K = nullptr;       // [np, np]  K + s2 I  -> L (lower, in place)
@@ -102,6 +104,10 @@ struct bbh_handle {
   std::vector<double> pend_cov;   // [p, p] posterior covariance of the pending points
   std::vector<double> xraw_host;  // [n, d] raw training rows (for bbh_train_posterior_mean)
   double* d_beta = nullptr;       // [np, 16] columns: alpha, beta_1..beta_p (dense, for packing)
+  // alternative target columns (qLogNEHVI): alpha columns in fragment order
+  double* d_colfrag = nullptr;    // [S/128, np/4 (+ext), 8, 64]
+  int64_t colfrag_elems = 0;
+  int64_t ncols = 0;              // S (padded to 128 internally)
   // generic workspaces
   double* d_ws = nullptr;
   size_t ws_bytes = 0;

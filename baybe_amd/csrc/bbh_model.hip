@@ -57,6 +57,7 @@ int bbh_upload_theta(bbh_handle* h, const double* theta_host) {
 
 // K[a][b] = scale * k(r_ab) + (s2 + jitter) [a==b]; identity on the padding.
 __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict__ xnT, const int* __restrict__ task,
+                                                       const double* __restrict__ nmask,
                                                        const double* __restrict__ theta, int n, int np, int dn,
                                                        int kind, int use_os, int T, double jitter,
                                                        double* __restrict__ K) {
@@ -78,13 +79,13 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
   double k = bbh_kfun(kind, r2);
   if (use_os) k *= theta[TH_OS];
   if (T > 1) k *= theta[TH_LS + dn + task[a] * T + task[b]];
-  if (a == b) k += theta[TH_NOISE] + jitter;
+  if (a == b) k += theta[TH_NOISE] * nmask[a] + jitter;
   K[(int64_t)a * np + b] = k;
 }
 
 void bbh_launch_gram(bbh_handle* h, double jitter) {
   dim3 grid((unsigned)((h->np + 255) / 256), (unsigned)h->np), block(256);
-  hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn, h->stream, h->d_xnT, h->d_task, h->d_theta,
+  hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn, h->stream, h->d_xnT, h->d_task, h->d_nmask, h->d_theta,
                      (int)h->n, (int)h->np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T, jitter,
                      h->d_K);
 }
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(256) void bbh_value_kernel(const double* __restrict
 //                  d/dB[ta][tb] G k outputscale
 // One wave-level partial row per (a, b-chunk, wave): partial[row][slot].
 __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
-    const double* __restrict__ xnT, const int* __restrict__ task, const double* __restrict__ theta,
-    const double* __restrict__ M, const double* __restrict__ Q, const double* __restrict__ alpha,
+    const double* __restrict__ xnT, const int* __restrict__ task, const double* __restrict__ nmask,
+    const double* __restrict__ theta, const double* __restrict__ M, const double* __restrict__ Q, const double* __restrict__ alpha,
     const double* __restrict__ q, int n, int np, int dn, int kind, int use_os, int T, int criterion, int nslots,
     double* __restrict__ partial) {
   const int a = blockIdx.x;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   double* prow = partial + ((int64_t)(a * gridDim.y + blockIdx.y) * 4 + wave) * nslots;
   // slot layout = gradient layout of theta: [noise, mean(unused), outputscale, ls.., B..]
   {
-    double v = (a == bb) ? G : 0.0;
+    double v = (a == bb) ? G * nmask[a] : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (lane == 0) prow[TH_NOISE] = v;
@@ -243,7 +244,7 @@ static void bbh_free_model(bbh_handle* h) {
   void* ptrs[] = {h->d_xnT,   h->d_task,    h->d_ystd,      h->d_theta, h->d_K,     h->d_X,       h->d_M,
                   h->d_Q,     h->d_Q2,      h->d_D,         h->d_tmp,   h->d_r,     h->d_t,       h->d_alpha,
                   h->d_u,     h->d_w,       h->d_q,         h->d_partial, h->d_out, h->d_info,    h->d_trainfrag,
-                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w};
+                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag};
   for (void* p : ptrs)
     if (p) hipFree(p);
   h->d_xnT = h->d_ystd = h->d_theta = h->d_K = h->d_X = h->d_M = h->d_Q = h->d_Q2 = h->d_D = h->d_tmp = nullptr;
@@ -251,6 +252,10 @@ static void bbh_free_model(bbh_handle* h) {
   h->d_trainfrag = h->d_rfrag = h->d_meanB = h->d_sclofs = h->d_tasktbl = h->d_beta = nullptr;
   h->d_task = h->d_info = h->d_numcol = h->d_taskext = h->d_pass_w = nullptr;
   h->d_pass_off = nullptr;
+  h->d_nmask = nullptr;
+  h->d_colfrag = nullptr;
+  h->colfrag_elems = 0;
+  h->ncols = 0;
   h->rfrag_elems = 0;
   h->have_model = false;
   h->factorized = false;
@@ -260,6 +265,12 @@ void bbh_free_model_public(bbh_handle* h) { bbh_free_model(h); }
 
 extern "C" int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t n, const double* X_train_host,
                              const double* y_train_host, const double* lo_host, const double* hi_host) {
+  return bbh_set_model_ex(h, desc, n, X_train_host, y_train_host, lo_host, hi_host, nullptr, 0, 0.0, 1.0);
+}
+
+extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64_t n, const double* X_train_host,
+                                const double* y_train_host, const double* lo_host, const double* hi_host,
+                                const uint8_t* noise_mask_host, int use_given_std, double ybar_in, double ysd_in) {
   if (!h) return -1;
   if (!desc || n < 1 || !X_train_host || !y_train_host || !lo_host || !hi_host) {
     h->err = "bbh_set_model: bad arguments";
@@ -307,6 +318,14 @@ extern "C" int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t 
   for (int64_t i = 0; i < n; i++) ss += (y_train_host[i] - ybar) * (y_train_host[i] - ybar);
   double sd = (n > 1) ? sqrt(ss / (double)(n - 1)) : NAN;
   if (!(sd >= 1e-8)) sd = 1.0;
+  if (use_given_std) {
+    ybar = ybar_in;
+    sd = ysd_in;
+    if (!(sd > 0.0)) {
+      h->err = "bbh_set_model_ex: ysd must be positive";
+      return -1;
+    }
+  }
   h->ybar = ybar;
   h->ysd = sd;
   h->ystd_host.resize(n);
@@ -336,6 +355,8 @@ extern "C" int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t 
   const int64_t tl = 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0);
   std::vector<double> xnT((size_t)h->dn * np, 0.0), ypad(np, 0.0);
   std::vector<int> tpad(np, 0);
+  h->nmask_host.assign(np, 0.0);
+  for (int64_t i = 0; i < n; i++) h->nmask_host[i] = (noise_mask_host && !noise_mask_host[i]) ? 0.0 : 1.0;
   for (int64_t i = 0; i < n; i++) {
     for (int j = 0; j < h->dn; j++) xnT[(size_t)j * np + i] = h->xn_host[(size_t)i * h->dn + j];
     ypad[i] = h->ystd_host[i];
@@ -344,6 +365,7 @@ extern "C" int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t 
 #define BBH_ALLOC(ptr, count) BBH_HIP_TRY(h, hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)))
   BBH_ALLOC(h->d_xnT, h->dn * np);
   BBH_ALLOC(h->d_task, np);
+  BBH_ALLOC(h->d_nmask, np);
   BBH_ALLOC(h->d_ystd, np);
   BBH_ALLOC(h->d_theta, tl);
   BBH_ALLOC(h->d_K, np * np);
@@ -366,6 +388,7 @@ extern "C" int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t 
   BBH_ALLOC(h->d_beta, np * BBH_MEANCOLS);
   BBH_HIP_TRY(h, hipMemcpy(h->d_xnT, xnT.data(), sizeof(double) * xnT.size(), hipMemcpyHostToDevice));
   BBH_HIP_TRY(h, hipMemcpy(h->d_task, tpad.data(), sizeof(int) * np, hipMemcpyHostToDevice));
+  BBH_HIP_TRY(h, hipMemcpy(h->d_nmask, h->nmask_host.data(), sizeof(double) * np, hipMemcpyHostToDevice));
   BBH_HIP_TRY(h, hipMemcpy(h->d_ystd, ypad.data(), sizeof(double) * np, hipMemcpyHostToDevice));
   h->xraw_host.assign(X_train_host, X_train_host + n * d);
   h->p = 0;
@@ -436,7 +459,7 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
                      (int)np, crit, h->d_out);
   const int nchunks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bbh_grad_pair_kernel, dim3((unsigned)n, (unsigned)nchunks), dim3(256), 0, s, h->d_xnT, h->d_task,
-                     h->d_theta, h->d_M, h->d_Q, h->d_alpha, h->d_q, (int)n, (int)np, h->dn, h->desc.kernel_kind,
+                     h->d_nmask, h->d_theta, h->d_M, h->d_Q, h->d_alpha, h->d_q, (int)n, (int)np, h->dn, h->desc.kernel_kind,
                      h->desc.use_outputscale, h->T, crit, (int)tl, h->d_partial);
   hipLaunchKernelGGL(bbh_grad_reduce_kernel, dim3((unsigned)tl), dim3(256), 0, s, h->d_partial,
                      (int64_t)n * nchunks * 4, (int)tl, h->d_out);

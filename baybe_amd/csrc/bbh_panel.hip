@@ -738,3 +738,289 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
   if (cov_pp_host) memcpy(cov_pp_host, h->pend_cov.data(), sizeof(double) * p * p);
   return 0;
 }
+
+// =================================================================================================
+// qLogNEHVI support: conditional means under S alternative target columns, joint posterior.
+// =================================================================================================
+
+// Mean-only variant of the fused kernel with 128 output columns (8 column blocks) per launch:
+//   tmat[cand][col0 + c] = ybar + ysd * (mean_const + sum_k K*[cand][k] * Acol[k][col0 + c])
+// colfrag layout: [group][k-step][column block (8)][64 lanes], lane l <- Acol[4 ks + (l>>4)][128 g + 16 cb + (l&15)].
+template <bool HAS_TBL, int KIND>
+__global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedArgs a, const double* __restrict__ colfrag,
+                                                                   int64_t col0, int64_t ldt, double* __restrict__ tmat) {
+  extern __shared__ __attribute__((aligned(16))) double s_cand[];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cnd = l & 15, q = l >> 4;
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+  if (tile0 >= a.N) return;
+  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
+  const double* xr = a.X + row * a.ldx;
+  double* candw = s_cand + (int64_t)w * a.kd * 64;
+  double nbsum = 0.0;
+  for (int k = 0; k < a.kd; k++) {
+    const int dim = 4 * k + q;
+    double v = 0.0;
+    if (dim < a.dn) {
+      v = fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
+      nbsum = fma(v, v, nbsum);
+    }
+    candw[k * 64 + l] = v;
+  }
+  nbsum += __shfl_xor(nbsum, 16, 64);
+  nbsum += __shfl_xor(nbsum, 32, 64);
+  {
+    const int k1 = a.dn >> 2, q1 = a.dn & 3;
+    if (q == q1) candw[k1 * 64 + l] = 1.0;
+    const int k2 = (a.dn + 1) >> 2, q2 = (a.dn + 1) & 3;
+    if (q == q2) candw[k2 * 64 + l] = nbsum;
+  }
+  int tc = 0;
+  if (HAS_TBL && a.task_col >= 0) {
+    tc = (int)xr[a.task_col];
+    tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+  }
+  WaveCtx c;
+  c.tf = a.trainfrag + l;
+  c.candl = candw + l;
+  c.mb = a.meanB + l;
+  c.tbl = a.tasktbl;
+  c.taskext = a.taskext;
+  c.kd = a.kd;
+  c.kind = a.kind;
+  c.T = a.T;
+  c.tc = tc;
+  c.q = q;
+  c.l = l;
+  c.dn = a.dn;
+  d4 acc[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; cb++) acc[cb] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* cf = colfrag + l;
+  double kv[4];
+  for (int tb = 0; tb < a.nb; tb++) {
+    double bq[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int cb = 0; cb < 8; cb++) bq[r][cb] = cf[((int64_t)(4 * tb + r) * 8 + cb) * 64];
+    compute_kv<HAS_TBL, KIND>(c, tb, kv);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int cb = 0; cb < 8; cb++) acc[cb] = mfma_f64(kv[r], bq[r][cb], acc[cb]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int64_t gi = tile0 + q + 4 * r;
+    if (gi < a.N) {
+#pragma unroll
+      for (int cb = 0; cb < 8; cb++)
+        tmat[gi * ldt + col0 + 16 * cb + cnd] = a.ybar + a.ysd * (a.mean_const + acc[cb][r]);
+    }
+  }
+}
+
+// colfrag <- alpha columns A [np, spad] (row-major)
+__global__ void bbh_pack_colfrag_kernel(const double* __restrict__ A, int64_t spad, int64_t nks, double* __restrict__ out) {
+  const int64_t g = blockIdx.z, ks = blockIdx.x, cb = blockIdx.y;
+  const int l = threadIdx.x;
+  out[((g * nks + ks) * 8 + cb) * 64 + l] = A[(4 * ks + (l >> 4)) * spad + 128 * g + 16 * cb + (l & 15)];
+}
+
+// Yc[i][s] = (Y[i][s] - ybar) / ysd - c for real rows and columns, 0 on the padding
+__global__ void bbh_prep_columns_kernel(const double* __restrict__ Y, int64_t n, int64_t S, int64_t np, int64_t spad,
+                                        double ybar, double ysd, double c, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np * spad) return;
+  const int64_t i = e / spad, s = e % spad;
+  out[e] = (i < n && s < S) ? (Y[i * S + s] - ybar) / ysd - c : 0.0;
+}
+
+extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t S) {
+  if (!h) return -1;
+  if (!h->factorized || !Y_host || S < 1 || S > 8192) {
+    h->err = "bbh_set_mean_columns: model not factorised / bad arguments (1 <= S <= 8192)";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, n = h->n;
+  const int64_t spad = bbh_round_up(S, 128);
+  const size_t need = sizeof(double) * ((size_t)n * S + 3 * (size_t)np * spad);
+  int rc = bbh_ensure_ws(h, need);
+  if (rc) return rc;
+  double* dY = h->d_ws;
+  double* Yc = dY + n * S;
+  double* T1 = Yc + np * spad;
+  double* A = T1 + np * spad;
+  BBH_HIP_TRY(h, hipMemcpyAsync(dY, Y_host, sizeof(double) * n * S, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bbh_prep_columns_kernel, dim3((unsigned)((np * spad + 255) / 256)), dim3(256), 0, s, dY, n, S, np, spad,
+                     h->ybar, h->ysd, h->theta[1], Yc);
+  bbh_gemm(s, false, false, np, spad, np, 1.0, h->d_X, np, 0, Yc, spad, 0, 0.0, T1, spad, 0, 1);  // L^-1 Yc
+  bbh_gemm(s, true, false, np, spad, np, 1.0, h->d_X, np, 0, T1, spad, 0, 0.0, A, spad, 0, 1);    // L^-T (.)
+  const int64_t nks = np / 4, groups = spad / 128;
+  const int64_t elems = groups * nks * 8 * 64;
+  if (!h->d_colfrag || h->colfrag_elems < elems) {
+    if (h->d_colfrag) hipFree(h->d_colfrag);
+    h->d_colfrag = nullptr;
+    BBH_HIP_TRY(h, hipMalloc((void**)&h->d_colfrag, sizeof(double) * elems));
+    h->colfrag_elems = elems;
+  }
+  hipLaunchKernelGGL(bbh_pack_colfrag_kernel, dim3((unsigned)nks, 8, (unsigned)groups), dim3(64), 0, s, A, spad, nks,
+                     h->d_colfrag);
+  BBH_HIP_TRY(h, hipGetLastError());
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));  // the workspace may be reused by the next call
+  h->ncols = S;
+  return 0;
+}
+
+static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev, int64_t N, int64_t ldx) {
+  a.X = X_dev;
+  a.N = N;
+  a.ldx = ldx;
+  a.trainfrag = h->d_trainfrag;
+  a.rfrag = h->d_rfrag;
+  a.meanB = h->d_meanB;
+  a.scl = h->d_sclofs;
+  a.ofs = h->d_sclofs + h->dn;
+  a.numcol = h->d_numcol;
+  a.tasktbl = h->d_tasktbl;
+  a.taskext = h->d_taskext;
+  a.mean = nullptr;
+  a.var = nullptr;
+  a.cross = nullptr;
+  a.pass_off = h->d_pass_off;
+  a.pass_w = h->d_pass_w;
+  a.npass = h->npass;
+  a.kind = h->desc.kernel_kind;
+  a.dn = h->dn;
+  a.kd = h->kd;
+  a.nb = (int)h->nb;
+  a.nb_ext = (int)h->nb;
+  a.task_col = h->desc.task_col;
+  a.T = h->T;
+  a.p = 0;
+  a.with_var = 0;
+  a.ybar = h->ybar;
+  a.ysd = h->ysd;
+  a.mean_const = h->theta[1];
+  a.prior_scale = h->desc.use_outputscale ? h->theta[2] : 1.0;
+}
+
+extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
+  if (!h) return -1;
+  if (!h->factorized || h->ncols < 1 || !h->d_colfrag || !tmat_dev || N < 0 || (N > 0 && !X_dev) || ldx < h->desc.d) {
+    h->err = "bbh_posterior_columns: call bbh_set_mean_columns first / bad arguments";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  FusedArgs a;
+  bbh_fill_fused_args(h, a, X_dev, N, ldx);
+  const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
+  const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
+  const size_t lds = sizeof(double) * 4 * h->kd * 64;
+  dim3 grid((unsigned)((N + 63) / 64)), block(256);
+  const int64_t S = h->ncols, spad = bbh_round_up(S, 128), groups = spad / 128;
+  const int64_t nks = h->np / 4;
+  // the last group may be partially padded: write it through a bounce buffer only if S % 128 != 0
+  double* bounce = nullptr;
+  if (S % 128 != 0) {
+    int rc = bbh_ensure_ws(h, sizeof(double) * (size_t)N * 128);
+    if (rc) return rc;
+    bounce = h->d_ws;
+  }
+  for (int64_t g = 0; g < groups; g++) {
+    const double* cf = h->d_colfrag + g * nks * 8 * 64;
+    const bool partial = (g == groups - 1) && bounce;
+    double* out = partial ? bounce : tmat_dev;
+    const int64_t col0 = partial ? 0 : 128 * g;
+    const int64_t ldt = partial ? 128 : S;
+    if (has_tbl && m52)
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<true, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+    else if (has_tbl)
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<true, -1>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+    else if (m52)
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<false, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+    else
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<false, -1>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+    if (partial) {
+      const int64_t w = S - 128 * g;
+      BBH_HIP_TRY(h, hipMemcpy2DAsync(tmat_dev + 128 * g, sizeof(double) * S, bounce, sizeof(double) * 128,
+                                      sizeof(double) * w, N, hipMemcpyDeviceToDevice, h->stream));
+    }
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// prior covariance among q points given as raw rows (normalised on the fly), direct differences
+__global__ __launch_bounds__(256) void bbh_kqq_kernel(const double* __restrict__ Xq, int64_t q, int64_t qpad, int64_t ldx,
+                                                      const double* __restrict__ theta, const int* __restrict__ numcol,
+                                                      const double* __restrict__ lo, const double* __restrict__ hi, int dn,
+                                                      int kind, int use_os, int T, int task_col, double* __restrict__ Kqq) {
+  const int64_t a = blockIdx.y;
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= qpad) return;
+  double v = 0.0;
+  if (a < q && b < q) {
+    double r2 = 0.0;
+    for (int j = 0; j < dn; j++) {
+      const double rng = hi[j] - lo[j];
+      const double df = ((Xq[a * ldx + numcol[j]] - lo[j]) / rng - (Xq[b * ldx + numcol[j]] - lo[j]) / rng) / theta[3 + j];
+      r2 += df * df;
+    }
+    v = bbh_kfun_p(kind, r2);
+    if (use_os) v *= theta[2];
+    if (T > 1) {
+      int ta = (int)Xq[a * ldx + task_col], tb = (int)Xq[b * ldx + task_col];
+      ta = ta < 0 ? 0 : (ta >= T ? T - 1 : ta);
+      tb = tb < 0 ? 0 : (tb >= T ? T - 1 : tb);
+      v *= theta[3 + dn + ta * T + tb];
+    }
+  }
+  Kqq[a * qpad + b] = v;
+}
+
+extern "C" int bbh_posterior_joint(bbh_handle* h, const double* Xq_host, int64_t q, double* mean_host, double* cov_host) {
+  if (!h) return -1;
+  if (!h->factorized || !Xq_host || q < 1 || q > 4096 || !mean_host || !cov_host) {
+    h->err = "bbh_posterior_joint: model not factorised / bad arguments (1 <= q <= 4096)";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, d = h->desc.d, dn = h->dn;
+  const int64_t qpad = bbh_round_up(q, 64);
+  const size_t need = sizeof(double) * ((size_t)qpad * d + 2 * (size_t)qpad * np + (size_t)qpad * qpad + qpad + 2 * dn);
+  int rc = bbh_ensure_ws(h, need);
+  if (rc) return rc;
+  double* dX = h->d_ws;
+  double* Kst = dX + qpad * d;
+  double* Tm = Kst + qpad * np;
+  double* Kqq = Tm + qpad * np;
+  double* dm = Kqq + qpad * qpad;
+  double* d_lo = dm + qpad;
+  double* d_hi = d_lo + dn;
+  BBH_HIP_TRY(h, hipMemcpyAsync(dX, Xq_host, sizeof(double) * q * d, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * dn, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * dn, hipMemcpyHostToDevice, s));
+  rc = bbh_unfused_chunk(h, dX, q, d, Kst, Tm, d_lo, d_hi);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bbh_kqq_kernel, dim3((unsigned)((qpad + 255) / 256), (unsigned)qpad), dim3(256), 0, s, dX, q, qpad, d,
+                     h->d_theta, h->d_numcol, d_lo, d_hi, (int)dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T,
+                     h->desc.task_col, Kqq);
+  bbh_gemm(s, false, true, qpad, qpad, np, -1.0, Tm, np, 0, Tm, np, 0, 1.0, Kqq, qpad, 0, 1);  // Kqq - Tm Tm^T
+  bbh_matvec(s, Kst, np, qpad, np, h->d_alpha, dm);
+  std::vector<double> hc((size_t)qpad * qpad), hm(qpad);
+  BBH_HIP_TRY(h, hipMemcpyAsync(hc.data(), Kqq, sizeof(double) * qpad * qpad, hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(hm.data(), dm, sizeof(double) * qpad, hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  const double s2 = h->ysd * h->ysd;
+  for (int64_t i = 0; i < q; i++) {
+    mean_host[i] = h->ybar + h->ysd * (h->theta[1] + hm[i]);
+    for (int64_t j = 0; j < q; j++) cov_host[i * q + j] = s2 * 0.5 * (hc[i * qpad + j] + hc[j * qpad + i]);
+  }
+  return 0;
+}

@@ -134,7 +134,10 @@ class HipGP:
         self._check(self._lib.bbh_selftest(self._h), "bbh_selftest")
 
     # ---- model ----------------------------------------------------------------------------
-    def set_model(self, spec: GPSpec, X_train: np.ndarray, y_train: np.ndarray):
+    def set_model(self, spec: GPSpec, X_train: np.ndarray, y_train: np.ndarray, noise_mask: np.ndarray | None = None,
+                  standardization: tuple | None = None):
+        """``noise_mask`` [n] (0 = noise-free latent value) and ``standardization`` = (ybar, ysd) are
+        used by the qLogNEHVI machinery (model conditioned on sampled baseline values)."""
         X = np.ascontiguousarray(X_train, dtype=np.float64)
         y = np.ascontiguousarray(np.asarray(y_train, dtype=np.float64).reshape(-1))
         if X.ndim != 2 or X.shape[1] != spec.d or X.shape[0] != y.shape[0]:
@@ -151,15 +154,22 @@ class HipGP:
         hi = np.ascontiguousarray(spec.hi, dtype=np.float64)
         if lo.shape[0] != spec.d or hi.shape[0] != spec.d:
             raise ValueError("spec.lo / spec.hi must have one entry per comp-rep column")
+        mask_p = None
+        if noise_mask is not None:
+            mask = np.ascontiguousarray(noise_mask, dtype=np.uint8)
+            mask_p = mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        given, yb, ys = (1, float(standardization[0]), float(standardization[1])) if standardization else (0, 0.0, 1.0)
         self._check(
-            self._lib.bbh_set_model(self._h, C.byref(desc), X.shape[0], _dp(X), _dp(y), _dp(lo), _dp(hi)),
-            "bbh_set_model",
+            self._lib.bbh_set_model_ex(self._h, C.byref(desc), X.shape[0], _dp(X), _dp(y), _dp(lo), _dp(hi), mask_p,
+                                       given, yb, ys),
+            "bbh_set_model_ex",
         )
         a, b = C.c_double(), C.c_double()
         self._check(self._lib.bbh_get_standardization(self._h, C.byref(a), C.byref(b)), "bbh_get_standardization")
         self.spec, self.n, self.ybar, self.ysd = spec, X.shape[0], a.value, b.value
         self.params = None
         self._X_train = X
+        self._y_train = y
 
     def data_term(self, params: GPParams):
         """Device data term (MLL or LOO) and its gradient in theta layout; (None, None) if the
@@ -229,6 +239,31 @@ class HipGP:
         fn = self._lib.bbh_posterior_unfused if unfused else self._lib.bbh_posterior
         self._check(fn(self._h, X.data_ptr(), N, X.stride(0), mean.data_ptr(), var.data_ptr()), "bbh_posterior")
         return mean, var
+
+    def posterior_joint(self, Xq: np.ndarray):
+        """Joint posterior (mean [q], cov [q,q]) of a small point set (host arrays)."""
+        Xq = np.ascontiguousarray(np.atleast_2d(Xq), dtype=np.float64)
+        q = Xq.shape[0]
+        mean, cov = np.empty(q), np.empty((q, q))
+        self._check(self._lib.bbh_posterior_joint(self._h, _dp(Xq), q, _dp(mean), _dp(cov)), "bbh_posterior_joint")
+        return mean, cov
+
+    def set_mean_columns(self, Y: np.ndarray):
+        """Alternative target columns Y [n, S] (original scale) for ``posterior_columns``."""
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        if Y.ndim != 2 or Y.shape[0] != self.n:
+            raise ValueError("Y must be [n, S]")
+        self._ncols = Y.shape[1]
+        self._check(self._lib.bbh_set_mean_columns(self._h, _dp(Y), Y.shape[1]), "bbh_set_mean_columns")
+
+    def posterior_columns(self, X):
+        """[N, S] posterior means of the candidates under each target column."""
+        torch = self._torch()
+        X = self._as_dev(X)
+        N = X.shape[0]
+        tmat = torch.empty((N, self._ncols), dtype=torch.float64, device=X.device)
+        self._check(self._lib.bbh_posterior_columns(self._h, X.data_ptr(), N, X.stride(0), tmat.data_ptr()), "bbh_posterior_columns")
+        return tmat
 
     def train_posterior_mean(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.float64)

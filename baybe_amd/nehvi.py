@@ -1,0 +1,191 @@
+"""qLogNoisyExpectedHypervolumeImprovement on the HIP path (BayBE's default for ParetoObjective,
+``baybe/acquisition/acqfs.py:477-484``; arguments per ``baybe/acquisition/_builder.py:301-324``).
+
+Structure.  BoTorch draws f(x) *jointly* with the baseline values f(X_b) through a
+cached Cholesky root, per MC sample s and per (independent) output o.  That joint draw is the
+posterior of a GP whose training set is extended by the baseline points as noise-free observations
+of the sampled values F_b,s:
+
+    f_o(x)_s = E[f_o(x) | D_o, f_o(X_b) = F_b,s] + sd[f_o(x) | D_o, f_o(X_b)] * z_x,s,o
+
+so the per-candidate work is exactly the fused posterior kernel on an *extended model*
+(``bbh_set_model_ex`` with a noise mask): one variance pass, and the S conditional means as a
+contraction of the same cross-covariance with S target columns (``bbh_posterior_columns``).
+Host set-up per selection step (O(n_b^3 + S n_b^2), as in BoTorch): joint posterior of the baseline
+(device), its Cholesky factor and the sampled values, baseline pruning, and the per-sample box
+decomposition.  The per-candidate scoring over cells runs in ``bbh_qlognehvi``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from baybe_amd import _lib
+from baybe_amd.box_decomposition import pack_cells, pareto_mask
+from baybe_amd.engine import GreedyResult, HipGP, _dp, draw_sampler_seed, sobol_normal_base_samples
+
+PRUNE_SAMPLES = 2048  # prune_inferior_points_multi_objective(num_samples=2048)
+
+
+def compute_ref_point(array, maximize=None, factor: float = 0.1) -> np.ndarray:
+    """``_ExpectedHypervolumeImprovement.compute_ref_point`` (acqfs.py:369-426)."""
+    array = np.asarray(array, dtype=np.float64)
+    if array.ndim != 2:
+        raise ValueError("The specified data array must have exactly two dimensions.")
+    mx = np.where(np.ones(array.shape[1], bool) if maximize is None else np.asarray(maximize), 1.0, -1.0)
+    a = array * mx[None, :]
+    lo, hi = a.min(axis=0), a.max(axis=0)
+    return (lo - factor * (hi - lo)) * mx
+
+
+def _chol_with_jitter(A: np.ndarray) -> np.ndarray:
+    """psd_safe_cholesky: plain attempt, then jitter 1e-8 * 10^i."""
+    jit = 0.0
+    for attempt in range(4):
+        try:
+            return np.linalg.cholesky(A + jit * np.eye(A.shape[0]))
+        except np.linalg.LinAlgError:
+            jit = 1e-8 * 10**attempt
+    raise np.linalg.LinAlgError("baseline posterior covariance is not positive definite")
+
+
+@dataclass
+class _Output:
+    engine: HipGP  # fitted model of this target
+    ext: HipGP  # the same model conditioned on sampled baseline values
+    sign: float
+
+
+class HipNEHVI:
+    """qLogNEHVI scorer over m independent HIP GPs (q = 1 t-batches, pending points cached into the
+    baseline exactly as BoTorch's ``cache_pending=True``)."""
+
+    def __init__(self, engines, signs, X_baseline, ref_point, n_mc_samples: int = 128, prune_baseline: bool = True,
+                 device: int = 0):
+        if not 1 <= len(engines) <= _lib.MAX_OBJECTIVES:
+            raise ValueError(f"1..{_lib.MAX_OBJECTIVES} objectives are supported")
+        self.m = len(engines)
+        self.outputs = [_Output(e, HipGP(device), float(s)) for e, s in zip(engines, signs)]
+        self.signs = np.asarray(signs, dtype=np.float64)
+        self.X_baseline = np.ascontiguousarray(np.atleast_2d(X_baseline), dtype=np.float64)
+        self.ref = np.asarray(ref_point, dtype=np.float64)
+        self.S = int(n_mc_samples)
+        self.prune = bool(prune_baseline)
+        self._lib = _lib.load_library()
+        self._prepared = False
+        self._pruned = None
+
+    # ---- set-up ----------------------------------------------------------------------------------
+    def _baseline_posteriors(self, Xb):
+        mus, Ls = [], []
+        for out in self.outputs:
+            mu, cov = out.engine.posterior_joint(Xb)
+            mus.append(mu)
+            Ls.append(_chol_with_jitter(cov))
+        return mus, Ls
+
+    def prune_points(self, Xb: np.ndarray, seed: int) -> np.ndarray:
+        """Keep baseline points that are Pareto-optimal and above the reference point in at least one
+        of 2048 joint posterior samples (``prune_inferior_points_multi_objective``)."""
+        nb = len(Xb)
+        z = sobol_normal_base_samples(PRUNE_SAMPLES, nb * self.m, seed).reshape(PRUNE_SAMPLES, nb, self.m)
+        mus, Ls = self._baseline_posteriors(Xb)
+        obj = np.empty((PRUNE_SAMPLES, nb, self.m))
+        for o in range(self.m):
+            obj[:, :, o] = (mus[o][None, :] + z[:, :, o] @ Ls[o].T) * self.signs[o]
+        keep = np.zeros(nb, bool)
+        for s in range(PRUNE_SAMPLES):
+            keep |= pareto_mask(obj[s]) & (obj[s] > self.ref).all(1)
+        idx = np.nonzero(keep)[0]
+        return Xb[idx] if len(idx) else Xb[:0]
+
+    def prepare(self, seed: int, extra_baseline: np.ndarray | None = None, prune_seed: int | None = None):
+        """Sample the baseline, decompose, and condition the per-output models (one selection step)."""
+        if self._pruned is None:  # pruning happens once, when the acquisition function is built
+            Xb0 = self.X_baseline
+            if self.prune and len(Xb0):
+                Xb0 = self.prune_points(Xb0, draw_sampler_seed() if prune_seed is None else prune_seed)
+            self._pruned = Xb0
+        Xb = self._pruned
+        if extra_baseline is not None and len(extra_baseline):
+            Xb = np.vstack([Xb, np.atleast_2d(extra_baseline)])  # cache_pending: picks join the baseline
+        nb = len(Xb)
+        z = sobol_normal_base_samples(self.S, (nb + 1) * self.m, seed).reshape(self.S, nb + 1, self.m)
+        self.zx = np.ascontiguousarray(z[:, nb, :])  # [S, m] base samples of the candidate
+        Fb = np.empty((self.S, nb, self.m))
+        if nb:
+            mus, Ls = self._baseline_posteriors(Xb)
+            for o in range(self.m):
+                Fb[:, :, o] = mus[o][None, :] + z[:, :nb, o] @ Ls[o].T
+        self.cell_off, self.cell_lo, self.cell_ll = pack_cells(Fb * self.signs[None, None, :], self.ref)
+        for o, out in enumerate(self.outputs):
+            eng = out.engine
+            Xt, yt = eng._X_train, eng._y_train
+            X_ext = np.vstack([Xt, Xb]) if nb else Xt
+            y_ext = np.concatenate([yt, mus[o]]) if nb else yt
+            mask = np.concatenate([np.ones(len(yt), np.uint8), np.zeros(nb, np.uint8)])
+            out.ext.set_model(eng.spec, X_ext, y_ext, noise_mask=mask, standardization=(eng.ybar, eng.ysd))
+            out.ext.factorize(eng.params)
+            Y = np.empty((len(y_ext), self.S))
+            Y[: len(yt), :] = yt[:, None]
+            if nb:
+                Y[len(yt):, :] = Fb[:, :, o].T
+            out.ext.set_mean_columns(Y)
+        self.X_b_current = Xb
+        self._prepared = True
+
+    # ---- scoring ---------------------------------------------------------------------------------
+    def score(self, X_dev, alive=None):
+        import torch
+
+        assert self._prepared, "call prepare() first"
+        tmats, vars_ = [], []
+        for out in self.outputs:
+            _, var = out.ext.posterior(X_dev)
+            tmats.append(out.ext.posterior_columns(X_dev))
+            vars_.append(var)
+        N = X_dev.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=X_dev.device)
+        tp = (C.c_void_p * self.m)(*[t.data_ptr() for t in tmats])
+        vp = (C.c_void_p * self.m)(*[v.data_ptr() for v in vars_])
+        h = self.outputs[0].ext
+        sg = np.ascontiguousarray(self.signs)
+        zx = np.ascontiguousarray(self.zx)
+        off = np.ascontiguousarray(self.cell_off, dtype=np.int64)
+        rc = self._lib.bbh_qlognehvi(
+            h._h, self.m, N, tp, vp, _dp(sg), _dp(zx), self.S, off.ctypes.data_as(_lib.c_int64_p),
+            _dp(self.cell_lo) if len(self.cell_lo) else None, _dp(self.cell_ll) if len(self.cell_ll) else None,
+            alive.data_ptr() if alive is not None else None, scores.data_ptr(),
+        )
+        h._check(rc, "bbh_qlognehvi")
+        torch.cuda.synchronize(X_dev.device)  # tmats / vars_ must outlive the kernel
+        return scores
+
+    def greedy(self, X_dev, q: int, seed: int | None = None, prune_seed: int | None = None,
+               X_pending: np.ndarray | None = None) -> GreedyResult:
+        """Sequential greedy of optimize_acqf_discrete: pending points and each pick join the
+        baseline (``cache_pending=True``)."""
+        import torch
+
+        X_dev = self.outputs[0].engine._as_dev(X_dev)
+        d = self.outputs[0].engine.spec.d
+        if seed is None:
+            seed = draw_sampler_seed()
+        alive = torch.ones(X_dev.shape[0], dtype=torch.uint8, device=X_dev.device)
+        picks: list[np.ndarray] = []
+        if X_pending is not None and len(X_pending):
+            picks.append(np.atleast_2d(np.asarray(X_pending, dtype=np.float64)))
+        indices, values = [], []
+        for _ in range(q):
+            self.prepare(seed, np.vstack(picks) if picks else None, prune_seed)
+            scores = self.score(X_dev, alive)
+            val, idx = self.outputs[0].ext.argmax(scores)
+            indices.append(int(idx))
+            values.append(float(val))
+            alive[idx] = 0
+            picks.append(X_dev[idx, :d].cpu().numpy().reshape(1, d))
+        return GreedyResult(indices, values)

@@ -24,7 +24,7 @@ from attrs import define, field
 from attrs.validators import ge, instance_of
 
 from baybe_amd import _lib
-from baybe_amd.acquisition import convert_acqf, qLogExpectedImprovement
+from baybe_amd.acquisition import convert_acqf, qLogExpectedImprovement, qLogNoisyExpectedHypervolumeImprovement
 from baybe_amd.engine import draw_sampler_seed, sobol_normal_base_samples
 from baybe_amd.exceptions import (
     IncompatibilityError,
@@ -57,6 +57,7 @@ class HipBotorchRecommender:
     _best_f = field(default=None, init=False, eq=False, repr=False)
     _pending_comp = field(default=None, init=False, eq=False, repr=False)
     _cand_cache = field(default=None, init=False, eq=False, repr=False)
+    _nehvi = field(default=None, init=False, eq=False, repr=False)
 
     @classmethod
     def is_available(cls) -> bool:
@@ -64,15 +65,13 @@ class HipBotorchRecommender:
 
     # ---- BayesianRecommender surface -----------------------------------------------------------
     def _get_acquisition_function(self, objective):
-        if self.acquisition_function is None:
-            if len(objective.targets) > 1:
-                raise IncompatibleAcquisitionFunctionError(
-                    "Multi-target (Pareto) objectives need qLogNEHVI, which the HIP path does not score yet."
-                )
-            return qLogExpectedImprovement()
+        if self.acquisition_function is None:  # pure/bayesian/base.py:70-74
+            return qLogNoisyExpectedHypervolumeImprovement() if len(objective.targets) > 1 else qLogExpectedImprovement()
         return self.acquisition_function
 
     def get_surrogate(self, searchspace, objective, measurements):
+        if len(objective.targets) > 1 and not self._surrogate_model.supports_multi_output:
+            self._surrogate_model = self._surrogate_model.replicate()  # pure/bayesian/base.py:35-39
         self._surrogate_model.fit(searchspace, objective, measurements)
         return self._surrogate_model
 
@@ -90,11 +89,36 @@ class HipBotorchRecommender:
                 f"The chosen acquisition function of type '{type(acqf).__name__}' does not support pending experiments."
             )
         surrogate = self.get_surrogate(searchspace, objective, measurements)
-        self._best_f = surrogate.engine.best_f(surrogate.sign)  # _builder.py:141-161, 256-265
         self._pending_comp = None
         if pending_experiments is not None and len(pending_experiments):
             pend = searchspace.transform(pending_experiments, allow_extra=True)  # _builder.py:326-334
             self._pending_comp = np.ascontiguousarray(pend.to_numpy(dtype=np.float64))
+        self._nehvi = None
+        if len(objective.targets) > 1:
+            if self.shard is not None:
+                raise IncompatibilityError("Row sharding of qLogNEHVI is not available yet.")
+            from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+
+            models = surrogate.models
+            signs = np.array([m.sign for m in models])
+            names = [t.name for t in objective.targets]
+            ref = acqf.reference_point
+            if not isinstance(ref, tuple):  # _builder.py:301-317: from completely measured rows
+                complete = measurements[names].dropna()
+                if complete.empty:
+                    raise ValueError(
+                        "For calculating a default reference point, at least one configuration must have a "
+                        "measured value for all targets. Set 'reference_point' explicitly."
+                    )
+                kw = {} if ref is None else {"factor": ref}
+                ref = compute_ref_point(complete.to_numpy(dtype=np.float64) * signs[None, :], **kw)
+            X_base = np.ascontiguousarray(searchspace.transform(measurements, allow_extra=True).to_numpy(dtype=np.float64))
+            self._nehvi = HipNEHVI([m.engine for m in models], signs, X_base, np.asarray(ref, dtype=np.float64),
+                                   n_mc_samples=acqf.n_mc_samples, prune_baseline=acqf.prune_baseline,
+                                   device=models[0].engine.device)
+            self._best_f = None
+        else:
+            self._best_f = surrogate.engine.best_f(surrogate.sign)  # _builder.py:141-161, 256-265
         return surrogate, acqf
 
     def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None) -> pd.DataFrame:
@@ -143,7 +167,7 @@ class HipBotorchRecommender:
     @property
     def _engine(self):
         model = self._surrogate_model
-        return model.engine
+        return model.models[0].engine if isinstance(model, HipCompositeSurrogate) else model.engine
 
     def _recommend_discrete(self, subspace_discrete, candidates_exp: pd.DataFrame, batch_size: int) -> pd.Index:
         assert self._objective is not None
@@ -161,6 +185,10 @@ class HipBotorchRecommender:
         surrogate = self._surrogate_model
         acqf = self._get_acquisition_function(self._objective)
         Xd = self._candidates_on_device(subspace_discrete, candidates_exp)
+        if self._nehvi is not None:
+            res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp)
+            idxs = candidates_exp.index[np.asarray(res.indices, dtype=np.int64)]
+            return (idxs, res) if return_values else idxs
         res = surrogate.engine.greedy_qlogei(
             Xd, batch_size, S=acqf.n_mc_samples, seed=draw_sampler_seed(), sign=surrogate.sign,
             X_pending=self._pending_comp, best_f=self._best_f, shard=self.shard,
@@ -194,6 +222,11 @@ class HipBotorchRecommender:
     # ---- read-backs (Campaign.acquisition_values / joint_acquisition_value) ---------------------
     def _joint_value(self, comp: np.ndarray) -> float:
         """qLogEI of one q-batch (candidate = first row, the others enter as pending rows)."""
+        if self._nehvi is not None:
+            # incremental NEHVI: the batch value is the value of its last point given the others
+            self._nehvi.prepare(draw_sampler_seed(), np.vstack([comp[:-1]] + ([self._pending_comp] if self._pending_comp is not None else [])) if len(comp) > 1 or self._pending_comp is not None else None)
+            sc = self._nehvi.score(self._nehvi.outputs[0].engine._as_dev(comp[-1:]))
+            return float(sc.cpu().numpy()[0])
         surrogate = self._surrogate_model
         eng = surrogate.engine
         acqf = self._get_acquisition_function(self._objective)
@@ -218,8 +251,12 @@ class HipBotorchRecommender:
         if acquisition_function is not None:
             convert_acqf(acquisition_function)
         surrogate, acqf = self._setup_acqf(searchspace, objective, measurements, pending_experiments)
-        eng = surrogate.engine
         comp = np.ascontiguousarray(searchspace.transform(candidates, allow_extra=True).to_numpy(dtype=np.float64))
+        if self._nehvi is not None:
+            self._nehvi.prepare(draw_sampler_seed(), self._pending_comp)
+            sc = self._nehvi.score(self._nehvi.outputs[0].engine._as_dev(comp))
+            return pd.Series(sc.cpu().numpy(), index=candidates.index)
+        eng = surrogate.engine
         mean, var = eng.posterior(comp)
         seed = draw_sampler_seed()
         if self._pending_comp is None:

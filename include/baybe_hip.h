@@ -19,6 +19,11 @@
  *   bbh_cross_cov /
  *   bbh_qlogei_pending       qLogEI forward with pending points
  *   bbh_argmax               the argmax of optimize_acqf_discrete        baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126
+ *   bbh_set_model_ex /       ModelListGP member conditioned on sampled   baybe/surrogates/composite.py:125-134;
+ *   bbh_posterior_joint /    baseline values (joint draw of f(X) with    baybe/acquisition/_builder.py:319-324 (X_baseline)
+ *   bbh_set_mean_columns /   f(X_baseline), cached Cholesky root)
+ *   bbh_posterior_columns
+ *   bbh_qlognehvi            qLogNoisyExpectedHypervolumeImprovement     baybe/acquisition/acqfs.py:477-484
  *
  * Conventions
  *  - extern "C"; every function returns 0 on success, <0 on error;
@@ -98,6 +103,12 @@ int bbh_selftest(bbh_handle* h);
 int bbh_set_model(bbh_handle* h, const bbh_model_desc* desc, int64_t n,
                   const double* X_train_host, const double* y_train_host,
                   const double* lo_host, const double* hi_host);
+/* Same, with (a) an optional per-point noise mask [n] (0 = noise-free observation: the point is a
+ * latent function value, as the sampled baseline values of qLogNEHVI are) and (b) an optional fixed
+ * standardisation (use_given_std != 0: ybar/ysd are taken as given instead of computed from y). */
+int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64_t n, const double* X_train_host,
+                     const double* y_train_host, const double* lo_host, const double* hi_host,
+                     const uint8_t* noise_mask_host, int use_given_std, double ybar, double ysd);
 int64_t bbh_theta_len(bbh_handle* h);
 /* standardisation constants chosen by bbh_set_model */
 int bbh_get_standardization(bbh_handle* h, double* ybar, double* ysd);
@@ -121,6 +132,16 @@ int bbh_posterior(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
 /* Same through the unfused verification path (materialised K(X*,X), generic GEMM). */
 int bbh_posterior_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
                           double* mean_dev, double* var_dev);
+/* Joint posterior (original scale, no observation noise) of q <= 4096 points given on the host:
+ * mean_host [q], cov_host [q,q]. */
+int bbh_posterior_joint(bbh_handle* h, const double* Xq_host, int64_t q, double* mean_host, double* cov_host);
+/* Alternative target columns for the mean contraction: Y_host [n, S] (original target scale, point
+ * major).  Computes alpha_s = (K + s2 M)^-1 (y~_s - c) for every column on the device.  With the
+ * extended model of bbh_set_model_ex this yields, per MC sample s, the posterior mean of f(x)
+ * conditioned on the sampled baseline values. */
+int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t S);
+/* tmat_dev [N, S]: posterior mean of every candidate under each target column (original scale). */
+int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev);
 /* Posterior mean at the n training inputs -> host (for best_f). */
 int bbh_train_posterior_mean(bbh_handle* h, double* mean_host);
 
@@ -143,6 +164,19 @@ int bbh_cross_cov(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, do
 int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const double* var_dev,
                        const double* cross_dev, int64_t N, const double* z_host, int64_t S,
                        double best_f, double sign, const uint8_t* alive_dev, double* scores_dev);
+
+/* ---- qLogNEHVI ---------------------------------------------------------------------- */
+#define BBH_MAX_OBJECTIVES 4
+/* q'=1 scores over m <= 4 independent outputs.  Per output o: tmat_dev[o] [N,S] conditional means
+ * per MC sample (bbh_posterior_columns of the extended model), var_dev[o] [N] conditional variance;
+ * sample f_o(x)_s = tmat[o][i][s] + sqrt(var[o][i]) zx_host[s*m+o], oriented by sign_host[o].
+ * Cells of sample s: cell_off_host[s] .. cell_off_host[s+1] (prefix offsets, [S+1]); cell c stores
+ * cell_lo_host[c*m+o] (lower bound) and cell_loglen_host[c*m+o] = log(min(upper,1e10) - lower).
+ * score = logmeanexp_s logsumexp_c sum_o fatmin(log_fatplus(f_o - lo; 1e-6), loglen; 1e-2). */
+int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                  const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                  const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
+                  const uint8_t* alive_dev, double* scores_dev);
 
 /* ---- selection --------------------------------------------------------------------- */
 /* First-index argmax of scores_dev [N] (NaN never wins) -> host. */

@@ -138,6 +138,17 @@ class SingleTargetObjective:
         return (self._target,)
 
 
+class ParetoObjective:
+    is_multi_output = True
+
+    def __init__(self, targets):
+        self._targets = tuple(targets)
+
+    @property
+    def targets(self):
+        return self._targets
+
+
 class Campaign:
     """recommend() plumbing of baybe/campaign.py:495-642 for discrete spaces (default flags:
     recommended, measured and pending rows are excluded from the candidates)."""

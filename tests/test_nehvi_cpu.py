@@ -1,0 +1,103 @@
+"""qLogNEHVI oracle pins (CPU): the box decomposition tiles the non-dominated region exactly (checked
+against an independent slicing hypervolume), the product-side decomposition equals the oracle's, the
+smoothed log-HVI tends to log(HVI), and the reference point rule matches BayBE's doctest."""
+
+import math
+
+import numpy as np
+import pytest
+
+from baybe_amd import box_decomposition as bd
+from baybe_amd.nehvi import compute_ref_point
+from oracle import gp_oracle as go
+from oracle import nehvi_oracle as no
+
+
+def test_compute_ref_point_doctest_values():
+    """baybe/acquisition/acqfs.py:385-392 (doctest of compute_ref_point)."""
+    assert np.allclose(compute_ref_point([[0, 10], [2, 20]], [True, True], 0.1), [-0.2, 9.0])
+    assert np.allclose(compute_ref_point([[0, 10], [2, 20]], [True, False], 0.2), [-0.4, 22.0])
+    assert np.allclose(no.compute_ref_point([[0, 10], [2, 20]], [True, False], 0.2), [-0.4, 22.0])
+    with pytest.raises(ValueError):
+        compute_ref_point([1.0, 2.0])
+
+
+@pytest.mark.parametrize("m", [2, 3, 4])
+def test_cells_tile_the_nondominated_region(m):
+    rng = np.random.default_rng(m)
+    for trial in range(25):
+        n = int(rng.integers(0, 12))
+        Y = rng.random((n, m))
+        ref = np.full(m, -0.1 if trial % 2 else 0.2)
+        lows, ups = no.nondominated_cells(Y, ref)
+        for _ in range(15):
+            y = rng.random(m) * 1.3
+            expect = no.exact_hvi(y, Y, ref) if (y > ref).all() else 0.0
+            assert math.isclose(no.hvi_from_cells(y, lows, ups), expect, rel_tol=1e-10, abs_tol=1e-13)
+        pts = rng.random((1500, m)) * 1.5 - 0.2
+        P = no.pareto_front(Y) if n else np.zeros((0, m))
+        nondom = np.array([(p >= ref).all() and not (P >= p).all(1).any() for p in pts])
+        inside = ((pts[:, None, :] >= lows[None]) & (pts[:, None, :] < ups[None])).all(2).sum(1) if len(lows) else np.zeros(len(pts), int)
+        assert inside.max(initial=0) <= 1 and np.array_equal(inside.astype(bool), nondom)
+        lo2, up2 = bd.nondominated_cells(Y, ref)
+        assert len(lo2) == len(lows)
+        if len(lows):
+            A, B = np.hstack([lows, ups]), np.hstack([lo2, up2])
+            assert np.array_equal(A[np.lexsort(A.T)], B[np.lexsort(B.T)])
+
+
+def test_smoothed_log_hvi_approaches_log_hvi():
+    rng = np.random.default_rng(0)
+    Y = rng.random((8, 3))
+    ref = np.zeros(3)
+    lows, ups = no.nondominated_cells(Y, ref)
+    for _ in range(20):
+        y = 0.3 + rng.random(3)
+        hvi = no.exact_hvi(y, Y, ref)
+        if hvi > 1e-3:
+            assert abs(no.log_hvi_smoothed(y, lows, ups) - math.log(hvi)) < 0.2
+    # a dominated point has (almost) no improvement: very negative value, but finite (fat tails)
+    dom = Y.min(0) * 0.5 + 0.01
+    v = no.log_hvi_smoothed(dom, lows, ups)
+    assert np.isfinite(v) and v < -20
+
+
+def test_pack_cells_layout():
+    rng = np.random.default_rng(1)
+    obj = rng.random((5, 6, 2))
+    off, lo, ll = bd.pack_cells(obj, np.zeros(2))
+    assert off[0] == 0 and off[-1] == len(lo) == len(ll)
+    for s in range(5):
+        l2, u2 = bd.nondominated_cells(obj[s], np.zeros(2))
+        assert off[s + 1] - off[s] == len(l2)
+        assert np.array_equal(lo[off[s]:off[s + 1]], l2)
+        assert np.allclose(ll[off[s]:off[s + 1]], np.log(np.minimum(u2, 1e10) - l2))
+
+
+def test_joint_sampling_equals_conditioning_on_sampled_baseline():
+    """The identity the HIP path uses: drawing f(x) jointly with f(X_b) through the (n_b+1)
+    Cholesky factor == posterior of the GP extended by noise-free observations F_b,s at X_b."""
+    from _problems import make_problem
+    from scipy import linalg as sla
+
+    X, Xt, y = make_problem(300, 3, 15, seed=3)
+    spec = go.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
+    model = go.fit_gp(spec, Xt, y)
+    Xb = Xt[:6]
+    z = no.sobol_normal_base_samples_nd(16, len(Xb) + 1, 1, 5)
+    orc = no.NEHVIOracle([model], [1.0], Xb, np.array([-10.0]), z)
+    x = X[7]
+    f_joint = orc.candidate_samples(x)[:, 0]
+    # conditioning form, in the standardised/normalised space of the model
+    p = model.params
+    Xe = np.vstack([model.Xn, go.normalize_inputs(spec, Xb)])
+    Ke = go.cross_cov(spec, p, Xe, Xe)
+    Ke[: len(Xt), : len(Xt)] += p.noise * np.eye(len(Xt))
+    L = sla.cholesky(Ke, lower=True)
+    kx = go.cross_cov(spec, p, go.normalize_inputs(spec, x[None, :]), Xe)[0]
+    v = sla.solve_triangular(L, kx, lower=True)
+    var = model.ysd**2 * (1.0 - v @ v)
+    for s in range(16):
+        ye = np.concatenate([model.ystd, (orc.Fb[s, :, 0] - model.ybar) / model.ysd]) - p.mean
+        mean_s = model.ybar + model.ysd * (p.mean + kx @ sla.cho_solve((L, True), ye))
+        assert math.isclose(mean_s + math.sqrt(var) * z[s, -1, 0], f_joint[s], rel_tol=1e-6, abs_tol=1e-8)
