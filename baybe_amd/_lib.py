@@ -87,6 +87,7 @@ SIGNATURES = {
         [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
          C.c_int64, c_int64_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p],
     ),
+    "bbh_pareto_frequency": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
     "bbh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -484,3 +484,66 @@ extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* 
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
 }
+
+// ---- Pareto frequency of the baseline points over MC samples (pruning) ---------------------------
+template <int M>
+__global__ __launch_bounds__(256) void bbh_pareto_freq_kernel(const double* __restrict__ obj, int n, const double* __restrict__ ref,
+                                                              unsigned long long* __restrict__ counts) {
+  extern __shared__ double s_obj[];  // [n, M] of this sample
+  const double* src = obj + (int64_t)blockIdx.x * n * M;
+  for (int e = threadIdx.x; e < n * M; e += blockDim.x) s_obj[e] = src[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double yi[M];
+    bool above = true;
+#pragma unroll
+    for (int o = 0; o < M; o++) {
+      yi[o] = s_obj[i * M + o];
+      above = above && (yi[o] > ref[o]);
+    }
+    bool dominated = false;
+    for (int j = 0; j < n && !dominated; j++) {
+      bool ge = true, gt = false;
+#pragma unroll
+      for (int o = 0; o < M; o++) {
+        const double yj = s_obj[j * M + o];
+        ge = ge && (yj >= yi[o]);
+        gt = gt || (yj > yi[o]);
+      }
+      dominated = ge && gt;
+    }
+    if (above && !dominated) atomicAdd(&counts[i], 1ULL);
+  }
+}
+
+extern "C" int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64_t S, int64_t n, int32_t m,
+                                    const double* ref_host, int64_t* counts_host) {
+  if (!h) return -1;
+  if (!obj_host || !ref_host || !counts_host || S < 1 || n < 1 || n > 8192 / (m > 0 ? m : 1) || m < 1 ||
+      m > BBH_MAX_OBJECTIVES) {
+    h->err = "bbh_pareto_frequency: bad arguments (n * m <= 8192, 1 <= m <= 4)";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  const size_t nobj = (size_t)S * n * m;
+  int rc = bbh_ensure_ws(h, sizeof(double) * (nobj + m + n));
+  if (rc) return rc;
+  double* d_obj = h->d_ws;
+  double* d_ref = d_obj + nobj;
+  unsigned long long* d_cnt = (unsigned long long*)(d_ref + m);
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_obj, obj_host, sizeof(double) * nobj, hipMemcpyHostToDevice, h->stream));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_ref, ref_host, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+  BBH_HIP_TRY(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * n, h->stream));
+  const size_t lds = sizeof(double) * n * m;
+  dim3 grid((unsigned)S), block(256);
+  switch (m) {
+    case 1: hipLaunchKernelGGL(bbh_pareto_freq_kernel<1>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
+    case 2: hipLaunchKernelGGL(bbh_pareto_freq_kernel<2>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
+    case 3: hipLaunchKernelGGL(bbh_pareto_freq_kernel<3>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
+    default: hipLaunchKernelGGL(bbh_pareto_freq_kernel<4>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  BBH_HIP_TRY(h, hipMemcpyAsync(counts_host, d_cnt, sizeof(int64_t) * n, hipMemcpyDeviceToHost, h->stream));
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}

@@ -97,10 +97,16 @@ class HipNEHVI:
         obj = np.empty((PRUNE_SAMPLES, nb, self.m))
         for o in range(self.m):
             obj[:, :, o] = (mus[o][None, :] + z[:, :, o] @ Ls[o].T) * self.signs[o]
-        keep = np.zeros(nb, bool)
-        for s in range(PRUNE_SAMPLES):
-            keep |= pareto_mask(obj[s]) & (obj[s] > self.ref).all(1)
-        idx = np.nonzero(keep)[0]
+        counts = np.zeros(nb, dtype=np.int64)
+        obj = np.ascontiguousarray(obj)
+        ref = np.ascontiguousarray(self.ref, dtype=np.float64)
+        eng = self.outputs[0].engine
+        eng._check(
+            self._lib.bbh_pareto_frequency(eng._h, _dp(obj), PRUNE_SAMPLES, nb, self.m, _dp(ref),
+                                           counts.ctypes.data_as(_lib.c_int64_p)),
+            "bbh_pareto_frequency",
+        )
+        idx = np.nonzero(counts > 0)[0]
         return Xb[idx] if len(idx) else Xb[:0]
 
     def prepare(self, seed: int, extra_baseline: np.ndarray | None = None, prune_seed: int | None = None):

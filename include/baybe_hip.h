@@ -178,6 +178,12 @@ int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat
                   const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
                   const uint8_t* alive_dev, double* scores_dev);
 
+/* Baseline pruning support (prune_inferior_points_multi_objective): obj_host [S, n, m] oriented
+ * objective samples; counts_host[i] = number of samples in which point i is non-dominated and above
+ * ref_host [m] in every objective. */
+int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64_t S, int64_t n, int32_t m,
+                         const double* ref_host, int64_t* counts_host);
+
 /* ---- selection --------------------------------------------------------------------- */
 /* First-index argmax of scores_dev [N] (NaN never wins) -> host. */
 int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,
