@@ -75,6 +75,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double, C.c_double,
          C.c_void_p, C.c_void_p],
     ),
+    "bbh_score_qlogei": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, C.c_int64, C.c_double, C.c_double, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "bbh_pending_set": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "bbh_cross_cov": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "bbh_qlogei_pending": (

@@ -317,38 +317,134 @@ extern "C" int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, do
   return 0;
 }
 
+// ---- single-pass top-k -----------------------------------------------------------------------------
+// stage 1: each workgroup owns a chunk of <= TOPK_CHUNK scores in LDS and extracts its k best by k
+// rounds of workgroup-argmax + mask; stage 2: one workgroup merges the (blocks x k) survivors.
+#define TOPK_CHUNK 4096
+#define TOPK_MAXK 64
+
+__device__ __forceinline__ void bbh_wg_argmax(double& v, int64_t& idx, double* sv, int64_t* si) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_down(v, o, 64);
+    const int64_t oi = __shfl_down(idx, o, 64);
+    amax_combine(v, idx, ov, oi);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = v;
+    si[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  v = sv[0];
+  idx = si[0];
+  for (int w = 1; w < 4; w++) amax_combine(v, idx, sv[w], si[w]);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bbh_topk_stage1(const double* __restrict__ scores, int64_t N, int k,
+                                                       double* __restrict__ pv, int64_t* __restrict__ pi) {
+  __shared__ double s_val[TOPK_CHUNK];
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  const int64_t base = (int64_t)blockIdx.x * TOPK_CHUNK;
+  const int cnt = (int)((N - base < TOPK_CHUNK) ? N - base : TOPK_CHUNK);
+  for (int e = threadIdx.x; e < TOPK_CHUNK; e += 256) s_val[e] = (e < cnt) ? scores[base + e] : NAN;
+  __syncthreads();
+  for (int j = 0; j < k; j++) {
+    double v = -INFINITY;
+    int64_t idx = -1;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+      const double x = s_val[e];
+      if (x == x) amax_combine(v, idx, x, base + e);
+    }
+    bbh_wg_argmax(v, idx, sv, si);
+    if (threadIdx.x == 0) {
+      pv[(int64_t)blockIdx.x * k + j] = v;
+      pi[(int64_t)blockIdx.x * k + j] = idx;
+      if (idx >= 0) s_val[idx - base] = NAN;  // taken
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bbh_topk_stage2(double* __restrict__ pv, const int64_t* __restrict__ pi, int64_t cnt,
+                                                       int k, double* __restrict__ outv, int64_t* __restrict__ outi) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  __shared__ int64_t s_pos;
+  for (int j = 0; j < k; j++) {
+    double v = -INFINITY;
+    int64_t idx = -1, pos = -1;
+    for (int64_t e = threadIdx.x; e < cnt; e += 256) {
+      const double x = pv[e];
+      const int64_t gi = pi[e];
+      if (gi >= 0 && x == x) {
+        const int64_t before = idx;
+        amax_combine(v, idx, x, gi);
+        if (idx != before) pos = e;
+      }
+    }
+    double bv = v;
+    int64_t bi = idx;
+    bbh_wg_argmax(bv, bi, sv, si);
+    if (idx == bi && bi >= 0 && pos >= 0) s_pos = pos;  // unique owner: global indices are distinct
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      outv[j] = bv;
+      outi[j] = bi;
+      if (bi >= 0) pv[s_pos] = NAN;
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
                         int64_t* idx_host) {
   if (!h) return -1;
-  if (!scores_dev || N < 1 || k < 1 || k > N || !vals_host || !idx_host) {
-    h->err = "bbh_topk: bad arguments";
+  if (!scores_dev || N < 1 || k < 1 || k > N || k > TOPK_MAXK || !vals_host || !idx_host) {
+    h->err = "bbh_topk: bad arguments (1 <= k <= min(N, 64))";
     return -1;
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
-  int rc = bbh_ensure_red(h);
+  const int64_t blocks = (N + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  const size_t need = (sizeof(double) + sizeof(int64_t)) * (size_t)(blocks * k + k);
+  int rc = bbh_ensure_ws(h, need);
   if (rc) return rc;
-  rc = bbh_ensure_ws(h, sizeof(double) * (size_t)N);
-  if (rc) return rc;
-  double* tmp = h->d_ws;
-  BBH_HIP_TRY(h, hipMemcpyAsync(tmp, scores_dev, sizeof(double) * N, hipMemcpyDeviceToDevice, h->stream));
-  int nblocks = (int)((N + 255) / 256);
-  if (nblocks > ARGMAX_BLOCKS) nblocks = ARGMAX_BLOCKS;
-  std::vector<double> v(k);
-  std::vector<int64_t> ix(k);
-  for (int64_t j = 0; j < k; j++) {
-    hipLaunchKernelGGL(bbh_argmax_stage1, dim3(nblocks), dim3(256), 0, h->stream, tmp, N, h->d_red, h->d_redi);
-    hipLaunchKernelGGL(bbh_argmax_stage2, dim3(1), dim3(256), 0, h->stream, h->d_red, h->d_redi, nblocks,
-                       h->d_red + ARGMAX_BLOCKS, h->d_redi + ARGMAX_BLOCKS);
-    BBH_HIP_TRY(h, hipMemcpyAsync(&v[j], h->d_red + ARGMAX_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    BBH_HIP_TRY(h, hipMemcpyAsync(&ix[j], h->d_redi + ARGMAX_BLOCKS, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    hipLaunchKernelGGL(bbh_mask_one_kernel, dim3(1), dim3(1), 0, h->stream, tmp, h->d_redi + ARGMAX_BLOCKS);
-  }
+  double* pv = h->d_ws;
+  double* outv = pv + blocks * k;
+  int64_t* pi = (int64_t*)(outv + k);
+  int64_t* outi = pi + blocks * k;
+  hipLaunchKernelGGL(bbh_topk_stage1, dim3((unsigned)blocks), dim3(256), 0, h->stream, scores_dev, N, (int)k, pv, pi);
+  hipLaunchKernelGGL(bbh_topk_stage2, dim3(1), dim3(256), 0, h->stream, pv, pi, blocks * k, (int)k, outv, outi);
+  BBH_HIP_TRY(h, hipGetLastError());
+  BBH_HIP_TRY(h, hipMemcpyAsync(vals_host, outv, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
+  BBH_HIP_TRY(h, hipMemcpyAsync(idx_host, outi, sizeof(int64_t) * k, hipMemcpyDeviceToHost, h->stream));
   BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
-  for (int64_t j = 0; j < k; j++) {
-    vals_host[j] = v[j];
-    idx_host[j] = ix[j];
-  }
   return 0;
+}
+
+extern "C" int bbh_score_qlogei(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, const double* z_host,
+                                int64_t S, double best_f, double sign, const uint8_t* alive_dev, double* mean_dev,
+                                double* var_dev, double* scores_dev) {
+  if (!h) return -1;
+  if (!h->factorized || N < 0 || (N > 0 && !X_dev) || ldx < h->desc.d || !z_host || S < 1 || S > 4096 || !scores_dev) {
+    h->err = "bbh_score_qlogei: model not factorised / bad arguments (1 <= S <= 4096)";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_upload_z(h, z_host, (size_t)S);
+  if (rc) return rc;
+  h->fuse_qz = h->d_z;
+  h->fuse_S = (int)S;
+  h->fuse_best_f = best_f;
+  h->fuse_sign = sign;
+  h->fuse_alive = alive_dev;
+  h->fuse_scores = scores_dev;
+  rc = bbh_launch_fused(h, X_dev, N, ldx, mean_dev, var_dev, nullptr, true);
+  h->fuse_qz = nullptr;
+  h->fuse_scores = nullptr;
+  return rc;
 }
 
 // =================================================================================================

@@ -108,6 +108,12 @@ struct bbh_handle {
   double* d_colfrag = nullptr;    // [S/128, np/4 (+ext), 8, 64]
   int64_t colfrag_elems = 0;
   int64_t ncols = 0;              // S (padded to 128 internally)
+  // fused qLogEI epilogue request (valid during one bbh_score_qlogei call)
+  const double* fuse_qz = nullptr;
+  int fuse_S = 0;
+  double fuse_best_f = 0.0, fuse_sign = 1.0;
+  const uint8_t* fuse_alive = nullptr;
+  double* fuse_scores = nullptr;
   // generic workspaces
   double* d_ws = nullptr;
   size_t ws_bytes = 0;

@@ -58,6 +58,12 @@ struct FusedArgs {
   int npass;
   int kind, dn, kd, nb, nb_ext, task_col, T, p, with_var;
   double ybar, ysd, mean_const, prior_scale;
+  // fused qLogEI epilogue (q' = 1): disabled when qz == nullptr
+  const double* qz;
+  int qS;
+  double q_best_f, q_sign;
+  const uint8_t* q_alive;
+  double* q_scores;
 };
 
 struct WaveCtx {
@@ -186,10 +192,15 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
 
 template <bool HAS_TBL, int KIND>
 __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const FusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double s_cand[];  // [4 waves][kd][64]
+  extern __shared__ __attribute__((aligned(16))) double s_cand[];  // [4 waves][kd][64] (+ z[qS])
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cnd = l & 15, q = l >> 4;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+  double* s_z = s_cand + 4 * (int64_t)a.kd * 64;
+  if (a.qz) {  // the only workgroup barrier, before any wave may leave
+    for (int s = threadIdx.x; s < a.qS; s += 256) s_z[s] = a.qz[s];
+    __syncthreads();
+  }
   if (tile0 >= a.N) return;  // whole wave out of range (no workgroup barrier is used below)
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
@@ -281,22 +292,66 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     ss[r] = s;
   }
   const double s2 = a.ysd * a.ysd;
+  double mval[4], vval[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int m = q + 4 * r;  // candidate within the tile
     const int tcm = __shfl(tc, m, 64);
     const int64_t gi = tile0 + m;
+    double pv = a.prior_scale;
+    if (HAS_TBL) pv = a.tasktbl[tcm * a.T + tcm];
+    mval[r] = a.ybar + a.ysd * (a.mean_const + accm[r]);  // meaningful in the cnd == 0 lanes
+    vval[r] = s2 * (pv - ss[r]);
     if (gi < a.N) {
       if (cnd == 0) {
-        if (a.mean) a.mean[gi] = a.ybar + a.ysd * (a.mean_const + accm[r]);
-        if (a.with_var && a.var) {
-          double pv = a.prior_scale;
-          if (HAS_TBL) pv = a.tasktbl[tcm * a.T + tcm];
-          a.var[gi] = s2 * (pv - ss[r]);
-        }
+        if (a.mean) a.mean[gi] = mval[r];
+        if (a.with_var && a.var) a.var[gi] = vval[r];
       } else if (cnd <= a.p && a.cross) {
         a.cross[gi * a.p + (cnd - 1)] = s2 * accm[r];
       }
+    }
+  }
+  // ---- fused qLogEI (q' = 1): lane (q, cnd) evaluates samples s = q, q+4, ... of candidate cnd ---
+  if (a.qz && a.with_var) {
+    double mu = 0.0, vr = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {  // candidate cnd = q' + 4 r' lives in lane 16 q', register r'
+      const double tm = __shfl(mval[r], (cnd & 3) * 16, 64);
+      const double tv = __shfl(vval[r], (cnd & 3) * 16, 64);
+      if ((cnd >> 2) == r) {
+        mu = tm;
+        vr = tv;
+      }
+    }
+    if (!(vr > 0.0)) {  // 1x1 psd_safe_cholesky jitter rule
+      vr += 1e-8;
+      if (!(vr > 0.0)) {
+        vr += 1e-7;
+        if (!(vr > 0.0)) vr += 1e-6;
+      }
+    }
+    const double inv_tau = 1e6;  // 1 / tau_relu
+    const double ca = (a.q_sign * mu - a.q_best_f) * inv_tau;
+    const double cb = a.q_sign * sqrt(fmax(vr, 0.0)) * inv_tau;
+    double sum = 0.0;
+    for (int s = q; s < a.qS; s += 4) {
+      const double t = fma(cb, s_z[s], ca);
+      double sp;
+      if (t > 20.0)
+        sp = t;
+      else if (t < -750.0)
+        sp = 0.0;
+      else
+        sp = log1p(exp(t));
+      sum += sp + 0.1 / fma(t, t, 1.0);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const int64_t gi = tile0 + cnd;
+    if (q == 0 && gi < a.N) {
+      double sc = log(1e-6) + log(sum) - log((double)a.qS);
+      if (a.q_alive && !a.q_alive[gi]) sc = -INFINITY;
+      a.q_scores[gi] = sc;
     }
   }
 }
@@ -516,8 +571,22 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   a.ysd = h->ysd;
   a.mean_const = h->theta[1];
   a.prior_scale = h->desc.use_outputscale ? h->theta[2] : 1.0;
+  a.qz = nullptr;
+  a.qS = 0;
+  a.q_best_f = 0.0;
+  a.q_sign = 1.0;
+  a.q_alive = nullptr;
+  a.q_scores = nullptr;
+  if (h->fuse_qz && with_var) {  // set by bbh_score_qlogei for this launch only
+    a.qz = h->fuse_qz;
+    a.qS = h->fuse_S;
+    a.q_best_f = h->fuse_best_f;
+    a.q_sign = h->fuse_sign;
+    a.q_alive = h->fuse_alive;
+    a.q_scores = h->fuse_scores;
+  }
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
-  const size_t lds = sizeof(double) * 4 * h->kd * 64;
+  const size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0));
   dim3 grid((unsigned)((N + 63) / 64)), block(256);
   const bool timed = h->timing && with_var;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -906,6 +975,12 @@ static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev
   a.ysd = h->ysd;
   a.mean_const = h->theta[1];
   a.prior_scale = h->desc.use_outputscale ? h->theta[2] : 1.0;
+  a.qz = nullptr;
+  a.qS = 0;
+  a.q_best_f = 0.0;
+  a.q_sign = 1.0;
+  a.q_alive = nullptr;
+  a.q_scores = nullptr;
 }
 
 extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {

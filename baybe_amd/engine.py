@@ -289,6 +289,27 @@ class HipGP:
         )
         return scores
 
+    def score_qlogei(self, X, z: np.ndarray, best_f: float, sign: float = 1.0, alive=None, want_posterior: bool = True):
+        """Fused scoring pass: posterior + q'=1 qLogEI in one kernel.  Returns (scores, mean, var);
+        mean/var are None unless ``want_posterior``."""
+        torch = self._torch()
+        X = self._as_dev(X)
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1)
+        N = X.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=X.device)
+        mean = torch.empty(N, dtype=torch.float64, device=X.device) if want_posterior else None
+        var = torch.empty(N, dtype=torch.float64, device=X.device) if want_posterior else None
+        self._check(
+            self._lib.bbh_score_qlogei(
+                self._h, X.data_ptr(), N, X.stride(0), _dp(z), z.shape[0], float(best_f), float(sign),
+                alive.data_ptr() if alive is not None else None,
+                mean.data_ptr() if mean is not None else None, var.data_ptr() if var is not None else None,
+                scores.data_ptr(),
+            ),
+            "bbh_score_qlogei",
+        )
+        return scores, mean, var
+
     def set_pending(self, X_pending: np.ndarray | None):
         """Pending points = base pending + greedy picks (candidate first, then pending)."""
         if X_pending is None or len(X_pending) == 0:
@@ -382,7 +403,7 @@ class HipGP:
             best_f = self.best_f(sign)
         base = np.zeros((0, d)) if X_pending is None or len(X_pending) == 0 else np.atleast_2d(np.asarray(X_pending, dtype=np.float64))
         alive = torch.ones(N, dtype=torch.uint8, device=X.device)
-        mean, var = self.posterior(X)
+        mean = var = None
         chosen_rows: list[np.ndarray] = []
         indices, values = [], []
 
@@ -395,8 +416,13 @@ class HipGP:
             z = get_z(1 + p)
             if p == 0:
                 self.set_pending(None)
-                scores = self.qlogei(mean, var, z[:, 0], best_f, sign, alive)
+                if mean is None:  # first step: fused posterior + qLogEI, (mean, var) cached for later steps
+                    scores, mean, var = self.score_qlogei(X, z[:, 0], best_f, sign, alive, want_posterior=q > 1)
+                else:
+                    scores = self.qlogei(mean, var, z[:, 0], best_f, sign, alive)
             else:
+                if mean is None:
+                    mean, var = self.posterior(X)
                 self.set_pending(pend)
                 cross = self.cross_cov(X)
                 scores = self.qlogei_pending(mean, var, cross, z, best_f, sign, alive)

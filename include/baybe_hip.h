@@ -152,6 +152,12 @@ int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double* var_dev, 
                   const double* z_host, int64_t S, double best_f, double sign,
                   const uint8_t* alive_dev, double* scores_dev);
 
+/* Fused scoring pass (the hot call of optimize_acqf_discrete's first greedy step): posterior AND
+ * q'=1 qLogEI in one kernel.  mean_dev / var_dev may be NULL (scores only). */
+int bbh_score_qlogei(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, const double* z_host,
+                     int64_t S, double best_f, double sign, const uint8_t* alive_dev, double* mean_dev,
+                     double* var_dev, double* scores_dev);
+
 /* Pending points (base pending + greedy picks), p <= BBH_MAX_PENDING.  Computes and
  * caches beta_j = (K+s2I)^-1 k(X, P_j), the pending posterior mean [p] and covariance
  * [p,p] (returned to the host if the pointers are non-NULL). */

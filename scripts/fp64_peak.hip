@@ -5,11 +5,18 @@
 #include <stdio.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+__device__ long long g_clk[4];
+
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_k(double* out, int iters) {
+__global__ __launch_bounds__(256) void mfma_k(double* out, int iters, double scale = 1.0) {
+  long long c0 = 0, w0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    c0 = clock64();        // shader clock (s_memtime)
+    w0 = wall_clock64();   // constant-rate counter
+  }
   d4 acc[NACC];
   for (int i = 0; i < NACC; i++) acc[i] = (d4){0, 0, 0, 0};
-  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+  double a = scale * threadIdx.x * 1e-3, b = scale * (1.0 + threadIdx.x * 1e-4);
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
@@ -17,6 +24,10 @@ __global__ __launch_bounds__(256) void mfma_k(double* out, int iters) {
   double s = 0;
   for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk[0] = clock64() - c0;
+    g_clk[1] = wall_clock64() - w0;
+  }
 }
 
 __global__ __launch_bounds__(256) void valu_k(double* out, int iters) {
@@ -60,6 +71,28 @@ int main() {
       hipEventElapsedTime(&ms, e0, e1);
       const double flops = (double)blocks * 4 * iters * 8 * 2048.0;
       if (rep) printf("mfma_f64_16x16x4 NACC=8 blocks=%d: %.3f ms  %.2f TFLOP/s\n", blocks, ms, flops / ms / 1e9);
+    }
+  }
+  // zero operands: same instruction stream, far less switching power -> shows whether the rate above
+  // is bounded by the matrix pipe (64 cycles / instruction) or by the power-limited clock (DVFS)
+  for (int rep = 0; rep < 2; rep++) {
+    const int blocks = 512;
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(mfma_k<8>, dim3(blocks), dim3(256), 0, 0, d, iters, 0.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 8 * 2048.0;
+    if (rep) printf("mfma_f64_16x16x4 NACC=8 blocks=%d ZERO operands: %.3f ms  %.2f TFLOP/s\n", blocks, ms, flops / ms / 1e9);
+    if (rep) {
+      long long hc[4];
+      hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc));
+      int wrate = 0;
+      hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0);
+      const double wall_s = (double)hc[1] / ((double)wrate * 1e3);
+      printf("  block 0: %lld shader cycles over %.3f ms wall (wall clock %d kHz) -> %.0f MHz shader clock; %.1f cycles per MFMA per wave\n",
+             hc[0], wall_s * 1e3, wrate, hc[0] / wall_s / 1e6, (double)hc[0] / (iters * 8.0));
     }
   }
   for (int wpc = 1; wpc <= 4; wpc *= 2) {

@@ -214,6 +214,11 @@ def test_golden_fixture(gp, name):
     assert math.isclose(bf, float(g["best_f"]), rel_tol=1e-9, abs_tol=1e-12)
     s = gp.qlogei(m, v, g["z1"], float(g["best_f"]), sign)
     assert np.allclose(_np(s), g["scores"], rtol=0, atol=SCORE_ATOL)
+    sf, mf, vf = gp.score_qlogei(g["X"], g["z1"], float(g["best_f"]), sign)  # fused posterior + qLogEI
+    assert np.allclose(_np(sf), g["scores"], rtol=0, atol=SCORE_ATOL)
+    assert torch.equal(mf, m) and torch.equal(vf, v)
+    sf2, none_m, _ = gp.score_qlogei(g["X"], g["z1"], float(g["best_f"]), sign, want_posterior=False)
+    assert none_m is None and torch.equal(sf2, sf)
     assert gp.argmax(s)[1] == int(np.argmax(g["scores"]))
     k = 8
     assert gp.topk(s, k)[1].tolist() == np.argsort(-g["scores"], kind="stable")[:k].tolist()
@@ -266,6 +271,16 @@ def test_argmax_ties_nan_and_all_masked(gp):
     assert gp.argmax(big) == (7.0, 70000)
     v, i = gp.topk(big, 4)
     assert i.tolist() == [70000, 123456, 299999, 0]
+    rng = np.random.default_rng(0)
+    for N, k in ((1, 1), (5, 5), (4097, 64), (100_000, 17), (1_000_000, 8)):
+        x = rng.integers(0, 50, size=N).astype(np.float64)  # many ties
+        x[rng.integers(0, N, size=max(1, N // 100))] = np.nan
+        xs = np.where(np.isnan(x), -np.inf, x)
+        order = np.argsort(-xs, kind="stable")[:k]
+        valid = int((~np.isnan(x)).sum())
+        v, i = gp.topk(torch.from_numpy(x).cuda(), k)
+        kk = min(k, valid)
+        assert i[:kk].tolist() == order[:kk].tolist() and np.array_equal(v[:kk], xs[order[:kk]])
 
 
 @pytest.mark.parametrize("N,d,n,q,minimize", [(2000, 5, 40, 4, False), (3000, 8, 100, 3, True)])
