@@ -416,10 +416,9 @@ class HipGP:
             z = get_z(1 + p)
             if p == 0:
                 self.set_pending(None)
-                if mean is None:  # first step: fused posterior + qLogEI, (mean, var) cached for later steps
-                    scores, mean, var = self.score_qlogei(X, z[:, 0], best_f, sign, alive, want_posterior=q > 1)
-                else:
-                    scores = self.qlogei(mean, var, z[:, 0], best_f, sign, alive)
+                if mean is None:  # first step: posterior of every candidate, cached for the later steps
+                    mean, var = self.posterior(X)
+                scores = self.qlogei(mean, var, z[:, 0], best_f, sign, alive)
             else:
                 if mean is None:
                     mean, var = self.posterior(X)

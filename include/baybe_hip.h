@@ -83,7 +83,7 @@ typedef struct bbh_model_desc {
  * Gradients are returned in the same layout (for B: dL/dB[t][t'], accumulated
  * over ordered pairs, i.e. the matrix S with dL = sum_tt' S[t][t'] dB[t][t']).
  * Constraint transforms (softplus) and prior terms are O(d) scalar work and stay
- * with the host driver (baybe_amd/fit.py).
+ * with the host driver (baybe_amd/gp_spec.py, baybe_amd/engine.py).
  */
 
 /* ---- lifecycle --------------------------------------------------------------------- */
