@@ -42,6 +42,8 @@ KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15
 MAX_OBJECTIVES = 4
+ACQ_KINDS = {"qLogEI": 0, "qEI": 1, "qPI": 2, "qSR": 3, "qUCB": 4, "qPSTD": 5,
+             "PM": 10, "PSTD": 11, "UCB": 12, "EI": 13, "LogEI": 14, "PI": 15}
 
 # name -> (restype, argtypes); every symbol include/baybe_hip.h declares
 SIGNATURES = {
@@ -91,6 +93,21 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
          C.c_int64, c_int64_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_mc_acq_q1": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double, C.c_double,
+         C.c_double, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_mc_acq_pending": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double,
+         C.c_double, C.c_double, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_analytic_acq": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int32,
+         C.c_void_p, C.c_void_p],
     ),
     "bbh_pareto_frequency": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),

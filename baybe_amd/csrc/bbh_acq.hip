@@ -643,3 +643,232 @@ extern "C" int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64
   BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
   return 0;
 }
+
+// =================================================================================================
+// Other acquisition functions of baybe/acquisition/acqfs.py:161-290 on the same (mean, var, cross)
+// inputs.  MC family (BoTorch SampleReducingMCAcquisitionFunction): mean_s max_j u(obj_sj);
+// analytic family: closed forms in (mu~, sigma), sigma^2 clamped at 1e-12 as BoTorch does.
+// =================================================================================================
+__device__ __forceinline__ double bbh_mc_utility(int kind, double obj, double m, double best_f, double cu) {
+  switch (kind) {
+    case BBH_ACQ_QEI: return fmax(obj - best_f, 0.0);
+    case BBH_ACQ_QPI: return 1.0 / (1.0 + exp(-(obj - best_f) * 1e3));
+    case BBH_ACQ_QSR: return obj;
+    case BBH_ACQ_QUCB: return m + cu * fabs(obj - m);
+    default: return cu * fabs(obj - m);  // QPSTD
+  }
+}
+
+__global__ __launch_bounds__(256) void bbh_mc_q1_kernel(int kind, const double* __restrict__ mean, const double* __restrict__ var,
+                                                        int64_t N, const double* __restrict__ z, int S, double zbar,
+                                                        double best_f, double sign, double cu,
+                                                        const uint8_t* __restrict__ alive, double* __restrict__ scores) {
+  extern __shared__ double s_z[];
+  for (int s = threadIdx.x; s < S; s += blockDim.x) s_z[s] = z[s];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  const double a = sign * mean[i], b = sign * bbh_safe_sd(var[i]);
+  const double m = fma(b, zbar, a);
+  double sum = 0.0;
+  for (int s = 0; s < S; s++) sum += bbh_mc_utility(kind, fma(b, s_z[s], a), m, best_f, cu);
+  scores[i] = sum / (double)S;
+}
+
+__global__ __launch_bounds__(64) void bbh_mc_pending_kernel(int kind, const double* __restrict__ mean, const double* __restrict__ var,
+                                                            const double* __restrict__ cross, int64_t N, int p,
+                                                            const double* __restrict__ mean_p, const double* __restrict__ cov_pp,
+                                                            const double* __restrict__ z, const double* __restrict__ zbar, int S,
+                                                            double best_f, double sign, double cu,
+                                                            const uint8_t* __restrict__ alive, double* __restrict__ scores) {
+  __shared__ double s_L[QTRI * 64];
+  __shared__ double s_mp[QMAX];
+  __shared__ double s_cpp[QMAX * QMAX];
+  const int t = threadIdx.x;
+  const int q = p + 1;
+  for (int e = t; e < p; e += 64) s_mp[e] = mean_p[e];
+  for (int e = t; e < p * p; e += 64) s_cpp[e] = cov_pp[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 64 + t;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  double* L = s_L + t;
+  const double v0 = var[i];
+  double jitter = 0.0;
+  bool ok = false;
+  for (int attempt = 0; attempt < 4 && !ok; attempt++) {
+    ok = true;
+    for (int r = 0; r < q && ok; r++) {
+      for (int c = 0; c <= r; c++) {
+        double s = (r == 0) ? v0 : (c == 0 ? cross[i * p + (r - 1)] : s_cpp[(r - 1) * p + (c - 1)]);
+        if (r == c) s += jitter;
+        for (int k = 0; k < c; k++) s -= L[tri(r, k) * 64] * L[tri(c, k) * 64];
+        if (r == c) {
+          if (!(s > 0.0)) {
+            ok = false;
+            break;
+          }
+          L[tri(r, r) * 64] = sqrt(s);
+        } else {
+          L[tri(r, c) * 64] = s / L[tri(c, c) * 64];
+        }
+      }
+    }
+    if (!ok) jitter = 1e-8 * pow(10.0, (double)attempt);
+  }
+  if (!ok) {
+    scores[i] = NAN;
+    return;
+  }
+  const double m0 = mean[i];
+  double mbar[QMAX];  // per-point sample means of the objective
+#pragma unroll 1
+  for (int r = 0; r < q; r++) {
+    double y = (r == 0) ? m0 : s_mp[r - 1];
+    for (int c = 0; c <= r; c++) y = fma(L[tri(r, c) * 64], zbar[c], y);
+    mbar[r] = sign * y;
+  }
+  double sum = 0.0;
+  for (int s = 0; s < S; s++) {
+    const double* zs = z + (int64_t)s * q;
+    double mx = -INFINITY;
+#pragma unroll 1
+    for (int r = 0; r < q; r++) {
+      double y = (r == 0) ? m0 : s_mp[r - 1];
+      for (int c = 0; c <= r; c++) y = fma(L[tri(r, c) * 64], zs[c], y);
+      mx = fmax(mx, bbh_mc_utility(kind, sign * y, mbar[r], best_f, cu));
+    }
+    sum += mx;
+  }
+  scores[i] = sum / (double)S;
+}
+
+__device__ __forceinline__ double bbh_log_h(double u) {
+  // log(phi(u) + u Phi(u)), asymptotic branch for u < -1 (BoTorch _log_ei_helper)
+  const double inv_sqrt2 = 0.7071067811865476, half_log_2pi = 0.9189385332046727;
+  if (u > -1.0) {
+    const double phi = exp(-0.5 * u * u - half_log_2pi), Phi = 0.5 * erfc(-u * inv_sqrt2);
+    return log(phi + u * Phi);
+  }
+  const double au = fabs(u);
+  const double logphi = -0.5 * u * u - half_log_2pi;
+  if (u > -1e6) return logphi + log1p(-au * erfcx(au * inv_sqrt2) * 1.2533141373155003);
+  return logphi - 2.0 * log(au);
+}
+
+__global__ void bbh_analytic_kernel(int kind, const double* __restrict__ mean, const double* __restrict__ var, int64_t N,
+                                    double best_f, double sign, double beta, int maximize,
+                                    const uint8_t* __restrict__ alive, double* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  const double mt = sign * mean[i];
+  const double v = var[i];
+  double out;
+  if (kind == BBH_ACQ_PM) {
+    out = mt;
+  } else if (kind == BBH_ACQ_PSTD) {
+    const double sd = sqrt(fmax(v, 0.0));
+    out = maximize ? sd : -sd;
+  } else {
+    const double sd = sqrt(fmax(v, 1e-12));
+    const double u = (mt - best_f) / sd;
+    if (kind == BBH_ACQ_UCB)
+      out = mt + sqrt(beta) * sd;
+    else if (kind == BBH_ACQ_EI)
+      out = sd * (exp(-0.5 * u * u - 0.9189385332046727) + u * 0.5 * erfc(-u * 0.7071067811865476));
+    else if (kind == BBH_ACQ_PI)
+      out = 0.5 * erfc(-u * 0.7071067811865476);
+    else
+      out = log(sd) + bbh_log_h(u);  // LogEI
+  }
+  scores[i] = out;
+}
+
+static double bbh_mc_cu(int kind, double beta) {
+  if (kind == BBH_ACQ_QUCB) return sqrt(beta * 3.141592653589793 / 2.0);
+  if (kind == BBH_ACQ_QPSTD) return sqrt(3.141592653589793 / 2.0);
+  return 0.0;
+}
+
+extern "C" int bbh_mc_acq_q1(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev, int64_t N,
+                             const double* z_host, int64_t S, double best_f, double sign, double beta,
+                             const uint8_t* alive_dev, double* scores_dev) {
+  if (!h) return -1;
+  if (kind == BBH_ACQ_QLOGEI) return bbh_qlogei_q1(h, mean_dev, var_dev, N, z_host, S, best_f, sign, alive_dev, scores_dev);
+  if (kind < BBH_ACQ_QEI || kind > BBH_ACQ_QPSTD || !mean_dev || !var_dev || !z_host || !scores_dev || N < 0 || S < 1 ||
+      S > 8192) {
+    h->err = "bbh_mc_acq_q1: bad arguments";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  double zbar = 0.0;
+  for (int64_t s = 0; s < S; s++) zbar += z_host[s];
+  zbar /= (double)S;
+  int rc = bbh_upload_z(h, z_host, (size_t)S);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bbh_mc_q1_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), sizeof(double) * S, h->stream, kind,
+                     mean_dev, var_dev, N, h->d_z, (int)S, zbar, best_f, sign, bbh_mc_cu(kind, beta), alive_dev, scores_dev);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int bbh_mc_acq_pending(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev,
+                                  const double* cross_dev, int64_t N, const double* z_host, int64_t S, double best_f,
+                                  double sign, double beta, const uint8_t* alive_dev, double* scores_dev) {
+  if (!h) return -1;
+  if (kind == BBH_ACQ_QLOGEI)
+    return bbh_qlogei_pending(h, mean_dev, var_dev, cross_dev, N, z_host, S, best_f, sign, alive_dev, scores_dev);
+  const int p = h->p;
+  if (kind < BBH_ACQ_QEI || kind > BBH_ACQ_QPSTD || !mean_dev || !var_dev || !cross_dev || !z_host || !scores_dev ||
+      N < 0 || S < 1 || p < 1) {
+    h->err = "bbh_mc_acq_pending: bad arguments / no pending points set";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  const int q = p + 1;
+  std::vector<double> buf((size_t)S * q + q + p + (size_t)p * p, 0.0);
+  memcpy(buf.data(), z_host, sizeof(double) * S * q);
+  double* zb = buf.data() + S * q;
+  for (int64_t s = 0; s < S; s++)
+    for (int c = 0; c < q; c++) zb[c] += z_host[s * q + c];
+  for (int c = 0; c < q; c++) zb[c] /= (double)S;
+  memcpy(zb + q, h->pend_mean.data(), sizeof(double) * p);
+  memcpy(zb + q + p, h->pend_cov.data(), sizeof(double) * p * p);
+  int rc = bbh_upload_z(h, buf.data(), buf.size());
+  if (rc) return rc;
+  const double* dz = h->d_z;
+  hipLaunchKernelGGL(bbh_mc_pending_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, kind, mean_dev, var_dev,
+                     cross_dev, N, p, dz + S * q + q, dz + S * q + q + p, dz, dz + S * q, (int)S, best_f, sign,
+                     bbh_mc_cu(kind, beta), alive_dev, scores_dev);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int bbh_analytic_acq(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev, int64_t N,
+                                double best_f, double sign, double beta, int32_t maximize, const uint8_t* alive_dev,
+                                double* scores_dev) {
+  if (!h) return -1;
+  if (kind < BBH_ACQ_PM || kind > BBH_ACQ_PI || !mean_dev || !var_dev || !scores_dev || N < 0) {
+    h->err = "bbh_analytic_acq: bad arguments";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(bbh_analytic_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, kind, mean_dev, var_dev,
+                     N, best_f, sign, beta, (int)maximize, alive_dev, scores_dev);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}

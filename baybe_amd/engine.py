@@ -289,6 +289,39 @@ class HipGP:
         )
         return scores
 
+    def mc_acq(self, kind: str, mean, var, z: np.ndarray, best_f: float = 0.0, sign: float = 1.0, beta: float = 0.2,
+               alive=None, cross=None):
+        """MC acquisition values (qLogEI, qEI, qPI, qSR, qUCB, qPSTD) of N t-batches [x_i ; pending]."""
+        torch = self._torch()
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        N = mean.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=mean.device)
+        k = _lib.ACQ_KINDS[kind]
+        al = alive.data_ptr() if alive is not None else None
+        if cross is None:
+            z = z.reshape(-1)
+            rc = self._lib.bbh_mc_acq_q1(self._h, k, mean.data_ptr(), var.data_ptr(), N, _dp(z), z.shape[0], float(best_f),
+                                         float(sign), float(beta), al, scores.data_ptr())
+        else:
+            rc = self._lib.bbh_mc_acq_pending(self._h, k, mean.data_ptr(), var.data_ptr(), cross.data_ptr(), N, _dp(z),
+                                              z.shape[0], float(best_f), float(sign), float(beta), al, scores.data_ptr())
+        self._check(rc, "bbh_mc_acq")
+        return scores
+
+    def analytic_acq(self, kind: str, mean, var, best_f: float = 0.0, sign: float = 1.0, beta: float = 0.2,
+                     maximize: bool = True, alive=None):
+        """Analytic acquisition values (PM, PSTD, UCB, EI, LogEI, PI) of N single candidates."""
+        torch = self._torch()
+        N = mean.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=mean.device)
+        self._check(
+            self._lib.bbh_analytic_acq(self._h, _lib.ACQ_KINDS[kind], mean.data_ptr(), var.data_ptr(), N, float(best_f),
+                                       float(sign), float(beta), 1 if maximize else 0,
+                                       alive.data_ptr() if alive is not None else None, scores.data_ptr()),
+            "bbh_analytic_acq",
+        )
+        return scores
+
     def score_qlogei(self, X, z: np.ndarray, best_f: float, sign: float = 1.0, alive=None, want_posterior: bool = True):
         """Fused scoring pass: posterior + q'=1 qLogEI in one kernel.  Returns (scores, mean, var);
         mean/var are None unless ``want_posterior``."""
@@ -384,6 +417,8 @@ class HipGP:
         best_f: float | None = None,
         z_by_q: dict | None = None,
         shard=None,
+        kind: str = "qLogEI",
+        beta: float = 0.2,
     ) -> GreedyResult:
         """Sequential greedy of ``optimize_acqf_discrete(acqf, q, choices, unique=True)``.
 
@@ -418,13 +453,13 @@ class HipGP:
                 self.set_pending(None)
                 if mean is None:  # first step: posterior of every candidate, cached for the later steps
                     mean, var = self.posterior(X)
-                scores = self.qlogei(mean, var, z[:, 0], best_f, sign, alive)
+                scores = self.mc_acq(kind, mean, var, z[:, 0], best_f, sign, beta, alive)
             else:
                 if mean is None:
                     mean, var = self.posterior(X)
                 self.set_pending(pend)
                 cross = self.cross_cov(X)
-                scores = self.qlogei_pending(mean, var, cross, z, best_f, sign, alive)
+                scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
             val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
             if shard is not None:
                 val, gidx, row = shard.global_argmax(val, idx, X)

@@ -189,10 +189,22 @@ class HipBotorchRecommender:
             res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp)
             idxs = candidates_exp.index[np.asarray(res.indices, dtype=np.int64)]
             return (idxs, res) if return_values else idxs
-        res = surrogate.engine.greedy_qlogei(
-            Xd, batch_size, S=acqf.n_mc_samples, seed=draw_sampler_seed(), sign=surrogate.sign,
-            X_pending=self._pending_comp, best_f=self._best_f, shard=self.shard,
-        )
+        if acqf.is_analytic:  # q = 1 by construction (supports_batching is False)
+            eng = surrogate.engine
+            mean, var = eng.posterior(Xd)
+            scores = self._analytic_scores(eng, acqf, mean, var, surrogate.sign)
+            val, idx = eng.argmax(scores)
+            if self.shard is not None:
+                val, idx, _ = self.shard.global_argmax(val, idx, Xd)
+            from baybe_amd.engine import GreedyResult
+
+            res = GreedyResult([int(idx)], [float(val)])
+        else:
+            res = surrogate.engine.greedy_qlogei(
+                Xd, batch_size, S=acqf.n_mc_samples, seed=draw_sampler_seed(), sign=surrogate.sign,
+                X_pending=self._pending_comp, best_f=self._best_f, shard=self.shard, kind=acqf.kind,
+                beta=getattr(acqf, "beta", 0.2),
+            )
         idxs = candidates_exp.index[np.asarray(res.indices, dtype=np.int64)]
         return (idxs, res) if return_values else idxs
 
@@ -219,6 +231,10 @@ class HipBotorchRecommender:
             raise _E("No feasible subset with enough candidates was found.")
         return best[0]
 
+    def _analytic_scores(self, eng, acqf, mean, var, sign):
+        return eng.analytic_acq(acqf.kind, mean, var, self._best_f, sign, getattr(acqf, "beta", 0.2),
+                                getattr(acqf, "maximize", True))
+
     # ---- read-backs (Campaign.acquisition_values / joint_acquisition_value) ---------------------
     def _joint_value(self, comp: np.ndarray) -> float:
         """qLogEI of one q-batch (candidate = first row, the others enter as pending rows)."""
@@ -234,14 +250,19 @@ class HipBotorchRecommender:
         pend = np.vstack([comp[1:], base])
         seed = draw_sampler_seed()
         mean, var = eng.posterior(comp[:1])
+        if acqf.is_analytic:
+            if len(pend):
+                raise IncompatibleAcquisitionFunctionError("Analytic acquisition functions score single points only.")
+            return float(self._analytic_scores(eng, acqf, mean, var, surrogate.sign).cpu().numpy()[0])
+        beta = getattr(acqf, "beta", 0.2)
         if len(pend) == 0:
             z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]
-            s = eng.qlogei(mean, var, z, self._best_f, surrogate.sign)
+            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta)
         else:
             eng.set_pending(pend)
             cross = eng.cross_cov(comp[:1])
             z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(pend), seed)
-            s = eng.qlogei_pending(mean, var, cross, z, self._best_f, surrogate.sign)
+            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta, cross=cross)
             eng.set_pending(None)
         return float(s.cpu().numpy()[0])
 
@@ -258,15 +279,19 @@ class HipBotorchRecommender:
             return pd.Series(sc.cpu().numpy(), index=candidates.index)
         eng = surrogate.engine
         mean, var = eng.posterior(comp)
+        if acqf.is_analytic:
+            s = self._analytic_scores(eng, acqf, mean, var, surrogate.sign)
+            return pd.Series(s.cpu().numpy(), index=candidates.index)
         seed = draw_sampler_seed()
+        beta = getattr(acqf, "beta", 0.2)
         if self._pending_comp is None:
             z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]
-            s = eng.qlogei(mean, var, z, self._best_f, surrogate.sign)
+            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta)
         else:
             eng.set_pending(self._pending_comp)
             cross = eng.cross_cov(comp)
             z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(self._pending_comp), seed)
-            s = eng.qlogei_pending(mean, var, cross, z, self._best_f, surrogate.sign)
+            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta, cross=cross)
             eng.set_pending(None)
         return pd.Series(s.cpu().numpy(), index=candidates.index)
 

@@ -171,6 +171,23 @@ int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const double* var_
                        const double* cross_dev, int64_t N, const double* z_host, int64_t S,
                        double best_f, double sign, const uint8_t* alive_dev, double* scores_dev);
 
+/* ---- the other acquisition functions of acqfs.py:161-290 on the same inputs ----------- */
+enum bbh_acq_kind {
+  BBH_ACQ_QLOGEI = 0, BBH_ACQ_QEI = 1, BBH_ACQ_QPI = 2, BBH_ACQ_QSR = 3, BBH_ACQ_QUCB = 4, BBH_ACQ_QPSTD = 5,
+  BBH_ACQ_PM = 10, BBH_ACQ_PSTD = 11, BBH_ACQ_UCB = 12, BBH_ACQ_EI = 13, BBH_ACQ_LOGEI = 14, BBH_ACQ_PI = 15
+};
+/* MC family, q'=1 and q'=1+p (mean_s max_j u(obj_sj); qPI tau = 1e-3; qUCB/qPSTD use the sample mean). */
+int bbh_mc_acq_q1(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev, int64_t N,
+                  const double* z_host, int64_t S, double best_f, double sign, double beta,
+                  const uint8_t* alive_dev, double* scores_dev);
+int bbh_mc_acq_pending(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev,
+                       const double* cross_dev, int64_t N, const double* z_host, int64_t S, double best_f,
+                       double sign, double beta, const uint8_t* alive_dev, double* scores_dev);
+/* Analytic family (q = 1): PM, PSTD(+-), UCB(beta), EI, LogEI, PI; sigma^2 clamped at 1e-12. */
+int bbh_analytic_acq(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev, int64_t N,
+                     double best_f, double sign, double beta, int32_t maximize, const uint8_t* alive_dev,
+                     double* scores_dev);
+
 /* ---- qLogNEHVI ---------------------------------------------------------------------- */
 #define BBH_MAX_OBJECTIVES 4
 /* q'=1 scores over m <= 4 independent outputs.  Per output o: tmat_dev[o] [N,S] conditional means

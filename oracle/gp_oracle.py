@@ -744,3 +744,90 @@ def topk_first_index(scores: np.ndarray, k: int) -> np.ndarray:
     """k best q=1 scores, descending, ties -> lower index first (stable)."""
     order = np.argsort(-scores, kind="stable")
     return order[:k]
+
+
+# --------------------------------------------------------------------------------------
+# other acquisition functions of baybe/acquisition/acqfs.py:161-290 (SURVEY.md §8f-2)
+# --------------------------------------------------------------------------------------
+# MC family (BoTorch SampleReducingMCAcquisitionFunction [UPSTREAM]): value = mean_s max_j u(obj_sj)
+#   qEI:   u = relu(obj - best_f)                      qSR:  u = obj
+#   qPI:   u = sigmoid((obj - best_f) / tau), tau=1e-3  qUCB: u = m + sqrt(beta pi / 2) |obj - m|, m = mean_s obj
+#   qPSTD: u = sqrt(pi / 2) |obj - m|
+# analytic family (q = 1; u = (mu~ - best_f) / sigma with mu~ = sign * mu):
+#   PM: mu~   PSTD: +-sigma   UCB: mu~ + sqrt(beta) sigma   EI: sigma (phi(u) + u Phi(u))   PI: Phi(u)
+#   LogEI: log(sigma) + log(phi(u) + u Phi(u)) evaluated with the asymptotic branch for u < -1
+MC_KINDS = ("qLogEI", "qEI", "qPI", "qSR", "qUCB", "qPSTD")
+ANALYTIC_KINDS = ("PM", "PSTD", "UCB", "EI", "LogEI", "PI")
+TAU_PI = 1e-3  # [UPSTREAM] qProbabilityOfImprovement tau
+
+
+def _mc_utility(kind: str, obj: np.ndarray, best_f: float, beta: float) -> np.ndarray:
+    """obj [S, ...] -> per-sample utilities of the same shape."""
+    if kind == "qEI":
+        return np.maximum(obj - best_f, 0.0)
+    if kind == "qPI":
+        return 1.0 / (1.0 + np.exp(-(obj - best_f) / TAU_PI))
+    if kind == "qSR":
+        return obj
+    m = obj.mean(axis=0, keepdims=True)
+    if kind == "qUCB":
+        return m + math.sqrt(beta * math.pi / 2.0) * np.abs(obj - m)
+    if kind == "qPSTD":
+        return math.sqrt(math.pi / 2.0) * np.abs(obj - m)
+    raise ValueError(kind)
+
+
+def mc_acq_q1(kind: str, mu, var, z, best_f: float = 0.0, sign: float = 1.0, beta: float = 0.2) -> np.ndarray:
+    if kind == "qLogEI":
+        return qlogei_q1(mu, var, z, best_f, sign)
+    sd = _safe_sqrt_var(var)
+    obj = sign * (mu[None, :] + sd[None, :] * z.reshape(-1, 1))
+    return _mc_utility(kind, obj, best_f, beta).mean(axis=0)
+
+
+def mc_acq_joint(kind: str, mean, cov, z, best_f: float = 0.0, sign: float = 1.0, beta: float = 0.2) -> float:
+    if kind == "qLogEI":
+        return qlogei_joint(mean, cov, z, best_f, sign)
+    samples = mean[None, :] + z @ _safe_cholesky(cov).T
+    return float(_mc_utility(kind, sign * samples, best_f, beta).max(axis=-1).mean())
+
+
+def _log_h(u: np.ndarray) -> np.ndarray:
+    """log(phi(u) + u Phi(u)), stable for very negative u (BoTorch _log_ei_helper [UPSTREAM])."""
+    from scipy.special import erfcx, log_ndtr  # noqa: F401
+    from scipy.stats import norm
+
+    u = np.asarray(u, dtype=np.float64)
+    out = np.empty_like(u)
+    hi = u > -1.0
+    out[hi] = np.log(norm.pdf(u[hi]) + u[hi] * norm.cdf(u[hi]))
+    lo = ~hi
+    ul = u[lo]
+    logphi = -0.5 * ul * ul - 0.5 * math.log(2 * math.pi)
+    w = np.abs(ul) * erfcx(np.abs(ul) / math.sqrt(2.0)) * math.sqrt(math.pi / 2.0)  # |u| Phi(u) / phi(u) < 1
+    with np.errstate(divide="ignore"):
+        tail = np.where(ul > -1e6, np.log1p(-w), -2.0 * np.log(np.abs(ul)))
+    out[lo] = logphi + tail
+    return out
+
+
+def analytic_acq(kind: str, mu, var, best_f: float = 0.0, sign: float = 1.0, beta: float = 0.2, maximize: bool = True):
+    from scipy.stats import norm
+
+    mu = np.asarray(mu, dtype=np.float64)
+    sd = np.sqrt(np.maximum(np.asarray(var, dtype=np.float64), 1e-12 if kind in ("EI", "LogEI", "PI", "UCB") else 0.0))
+    mt = sign * mu
+    if kind == "PM":
+        return mt
+    if kind == "PSTD":
+        return sd if maximize else -sd
+    if kind == "UCB":
+        return mt + math.sqrt(beta) * sd
+    u = (mt - best_f) / sd
+    if kind == "EI":
+        return sd * (norm.pdf(u) + u * norm.cdf(u))
+    if kind == "PI":
+        return norm.cdf(u)
+    if kind == "LogEI":
+        return np.log(sd) + _log_h(u)
+    raise ValueError(kind)
