@@ -419,11 +419,13 @@ class HipGP:
         shard=None,
         kind: str = "qLogEI",
         beta: float = 0.2,
+        alive=None,
     ) -> GreedyResult:
         """Sequential greedy of ``optimize_acqf_discrete(acqf, q, choices, unique=True)``.
 
         Step 0 runs the fused posterior over all candidates and caches (mean, var); every later
         step only needs the cross-covariances with the points picked so far (mean-only pass).
+        ``alive`` (uint8 device tensor) restricts the candidates to a subset of the resident rows.
         ``shard`` (a ``baybe_amd.distributed.RowShard``) makes every selection a global one: the
         local winner is all-gathered (score, global index, row) and the global first-index argmax
         wins on every rank.
@@ -437,7 +439,7 @@ class HipGP:
         if best_f is None:
             best_f = self.best_f(sign)
         base = np.zeros((0, d)) if X_pending is None or len(X_pending) == 0 else np.atleast_2d(np.asarray(X_pending, dtype=np.float64))
-        alive = torch.ones(N, dtype=torch.uint8, device=X.device)
+        alive = torch.ones(N, dtype=torch.uint8, device=X.device) if alive is None else alive.clone()
         mean = var = None
         chosen_rows: list[np.ndarray] = []
         indices, values = [], []

@@ -172,7 +172,7 @@ class HipNEHVI:
         return scores
 
     def greedy(self, X_dev, q: int, seed: int | None = None, prune_seed: int | None = None,
-               X_pending: np.ndarray | None = None) -> GreedyResult:
+               X_pending: np.ndarray | None = None, alive=None) -> GreedyResult:
         """Sequential greedy of optimize_acqf_discrete: pending points and each pick join the
         baseline (``cache_pending=True``)."""
         import torch
@@ -181,7 +181,7 @@ class HipNEHVI:
         d = self.outputs[0].engine.spec.d
         if seed is None:
             seed = draw_sampler_seed()
-        alive = torch.ones(X_dev.shape[0], dtype=torch.uint8, device=X_dev.device)
+        alive = torch.ones(X_dev.shape[0], dtype=torch.uint8, device=X_dev.device) if alive is None else alive.clone()
         picks: list[np.ndarray] = []
         if X_pending is not None and len(X_pending):
             picks.append(np.atleast_2d(np.asarray(X_pending, dtype=np.float64)))

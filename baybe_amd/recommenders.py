@@ -148,21 +148,39 @@ class HipBotorchRecommender:
 
     # ---- discrete optimisation -----------------------------------------------------------------
     def _candidates_on_device(self, subspace_discrete, candidates_exp):
-        """Comp-rep rows of the candidates as a device-resident fp64 matrix, cached per
-        (comp_rep object, index) so repeated recommend() calls do not re-upload N x d doubles."""
+        """(X_dev, alive, labels): the *whole* comp rep of the discrete subspace as a device-resident
+        fp64 matrix (uploaded once per search space, cached), plus a uint8 mask of the rows that are
+        candidates in this call (``None`` = all) and the index labels of the resident rows.
+
+        Campaign.recommend shrinks the candidate set by a few rows per iteration
+        (``campaign.py:549-572``); masking instead of re-encoding / re-uploading N x d doubles removes
+        the O(N) pandas work and the PCIe copy from every call after the first.
+        Row order = search-space order, so first-index tie-breaking is unchanged."""
         import torch
 
         comp_rep = subspace_discrete.comp_rep
-        key = (id(comp_rep), len(candidates_exp), hash(candidates_exp.index.values[:: max(1, len(candidates_exp) // 64)].tobytes()))
-        if self._cand_cache is not None and self._cand_cache[0] == key:
-            return self._cand_cache[1]
-        rows = comp_rep.loc[candidates_exp.index]
-        X = torch.from_numpy(np.ascontiguousarray(rows.to_numpy(dtype=np.float64)))
-        if self.shard is not None:
-            X = X[self.shard.start : self.shard.stop]
-        Xd = X.to(torch.device("cuda", self._engine.device))
-        self._cand_cache = (key, Xd)
-        return Xd
+        key = (id(comp_rep), comp_rep.shape)
+        if self._cand_cache is None or self._cand_cache[0] != key:
+            X = torch.from_numpy(np.ascontiguousarray(comp_rep.to_numpy(dtype=np.float64)))
+            if self.shard is not None:
+                if self.shard.N_total != len(comp_rep):
+                    raise ValueError(
+                        f"RowShard was built for {self.shard.N_total} rows but the discrete subspace has {len(comp_rep)}"
+                    )
+                X = X[self.shard.start : self.shard.stop]
+            self._cand_cache = (key, X.to(torch.device("cuda", self._engine.device)), comp_rep.index)
+        _, Xd, labels = self._cand_cache
+        alive = None
+        if len(candidates_exp) != len(labels) or not candidates_exp.index.equals(labels):
+            pos = labels.get_indexer(candidates_exp.index)
+            if (pos < 0).any():
+                raise KeyError("candidates contain rows that are not part of the discrete subspace")
+            mask = np.zeros(len(labels), dtype=np.uint8)
+            mask[pos] = 1
+            if self.shard is not None:
+                mask = mask[self.shard.start : self.shard.stop]
+            alive = torch.from_numpy(mask).to(Xd.device)
+        return Xd, alive, labels
 
     @property
     def _engine(self):
@@ -184,15 +202,15 @@ class HipBotorchRecommender:
     def _recommend_discrete_without_subsets(self, subspace_discrete, candidates_exp, batch_size, return_values=False):
         surrogate = self._surrogate_model
         acqf = self._get_acquisition_function(self._objective)
-        Xd = self._candidates_on_device(subspace_discrete, candidates_exp)
+        Xd, alive, labels = self._candidates_on_device(subspace_discrete, candidates_exp)
         if self._nehvi is not None:
-            res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp)
-            idxs = candidates_exp.index[np.asarray(res.indices, dtype=np.int64)]
+            res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp, alive=alive)
+            idxs = labels[np.asarray(res.indices, dtype=np.int64)]
             return (idxs, res) if return_values else idxs
         if acqf.is_analytic:  # q = 1 by construction (supports_batching is False)
             eng = surrogate.engine
             mean, var = eng.posterior(Xd)
-            scores = self._analytic_scores(eng, acqf, mean, var, surrogate.sign)
+            scores = self._analytic_scores(eng, acqf, mean, var, surrogate.sign, alive)
             val, idx = eng.argmax(scores)
             if self.shard is not None:
                 val, idx, _ = self.shard.global_argmax(val, idx, Xd)
@@ -203,9 +221,9 @@ class HipBotorchRecommender:
             res = surrogate.engine.greedy_qlogei(
                 Xd, batch_size, S=acqf.n_mc_samples, seed=draw_sampler_seed(), sign=surrogate.sign,
                 X_pending=self._pending_comp, best_f=self._best_f, shard=self.shard, kind=acqf.kind,
-                beta=getattr(acqf, "beta", 0.2),
+                beta=getattr(acqf, "beta", 0.2), alive=alive,
             )
-        idxs = candidates_exp.index[np.asarray(res.indices, dtype=np.int64)]
+        idxs = labels[np.asarray(res.indices, dtype=np.int64)]
         return (idxs, res) if return_values else idxs
 
     def _recommend_discrete_with_subsets(self, subspace_discrete, candidates_exp, batch_size) -> pd.Index:
@@ -218,22 +236,20 @@ class HipBotorchRecommender:
         best = None
         for mask in masks:
             subset = candidates_exp.loc[mask]
-            self._cand_cache = None
             idxs = self._recommend_discrete_without_subsets(subspace_discrete, subset, batch_size)
             comp = subspace_discrete.comp_rep.loc[idxs].to_numpy(dtype=np.float64)
             val = self._joint_value(comp)
             if best is None or val > best[1]:
                 best = (idxs, val)
-        self._cand_cache = None
         if best is None:
             from baybe_amd.exceptions import IncompatibilityError as _E
 
             raise _E("No feasible subset with enough candidates was found.")
         return best[0]
 
-    def _analytic_scores(self, eng, acqf, mean, var, sign):
+    def _analytic_scores(self, eng, acqf, mean, var, sign, alive=None):
         return eng.analytic_acq(acqf.kind, mean, var, self._best_f, sign, getattr(acqf, "beta", 0.2),
-                                getattr(acqf, "maximize", True))
+                                getattr(acqf, "maximize", True), alive)
 
     # ---- read-backs (Campaign.acquisition_values / joint_acquisition_value) ---------------------
     def _joint_value(self, comp: np.ndarray) -> float:

@@ -119,7 +119,7 @@ def test_error_behaviour_matches_the_reference():
     with pytest.raises(NotEnoughPointsLeftError):
         rec.recommend(len(exp) + 1, space, obj, meas)
     with pytest.raises(IncompatibleAcquisitionFunctionError):
-        HipBotorchRecommender(acquisition_function="UCB")
+        HipBotorchRecommender(acquisition_function="qKG")  # knowledge gradient: continuous spaces only
 
 
 def test_posterior_stats_and_acquisition_values_readbacks():
