@@ -130,6 +130,11 @@ __device__ __forceinline__ void diag_steps(const WaveCtx& c, const double* rf, i
     constexpr int BASE = 4 * (TT * W - (TT * (TT - 1)) / 2);  // fragments consumed before this k-block
     constexpr int CNT = W - TT;
     double kv[4];
+    double mbv[4];
+    if (DO_MEAN) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * (j0 + TT) + r) * 64];
+    }
     compute_kv<HAS_TBL, KIND>(c, j0 + TT, kv);
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -142,7 +147,7 @@ __device__ __forceinline__ void diag_steps(const WaveCtx& c, const double* rf, i
       }
     if (DO_MEAN) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * (j0 + TT) + r) * 64], accm);
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
     }
     diag_steps<W, D, TT + 1, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);
   }
@@ -169,6 +174,11 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
   // rectangular region: every column block of the window is active
   for (int tb = 0; tb < j0; tb++) {
     double kv[4];
+    double mbv[4];
+    if (DO_MEAN) {  // requested first (oldest in the in-order vmcnt queue): its wait never drains the ring
+#pragma unroll
+      for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * tb + r) * 64];
+    }
     compute_kv<HAS_TBL, KIND>(c, tb, kv);
 #pragma unroll
     for (int i = 0; i < 4 * W; i++) {
@@ -179,7 +189,7 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
     rf += 4 * W * 64;
     if (DO_MEAN) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
     }
   }
   // triangular region: k-block j0 + tt only reaches column blocks jj >= tt
