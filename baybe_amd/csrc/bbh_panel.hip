@@ -136,6 +136,11 @@ __device__ __forceinline__ void diag_steps(const WaveCtx& c, const double* rf, i
       for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * (j0 + TT) + r) * 64];
     }
     compute_kv<HAS_TBL, KIND>(c, j0 + TT, kv);
+    if (DO_MEAN) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -145,10 +150,6 @@ __device__ __forceinline__ void diag_steps(const WaveCtx& c, const double* rf, i
         if (i + D < TOTAL) ring[i % D] = rf[(i + D) * 64];
         if (i % D == D - 1) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at D
       }
-    if (DO_MEAN) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
-    }
     diag_steps<W, D, TT + 1, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);
   }
 }
@@ -180,6 +181,11 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
       for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * tb + r) * 64];
     }
     compute_kv<HAS_TBL, KIND>(c, tb, kv);
+    if (DO_MEAN) {  // before the ring loop, so that mbv is dead while the ring is live
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < 4 * W; i++) {
       acc[i % W] = mfma_f64(kv[i / W], ring[i % D], acc[i % W]);
@@ -187,10 +193,6 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
       if (i % D == D - 1) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at D
     }
     rf += 4 * W * 64;
-    if (DO_MEAN) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
-    }
   }
   // triangular region: k-block j0 + tt only reaches column blocks jj >= tt
   diag_steps<W, D, 0, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);

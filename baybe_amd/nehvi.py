@@ -172,9 +172,11 @@ class HipNEHVI:
         return scores
 
     def greedy(self, X_dev, q: int, seed: int | None = None, prune_seed: int | None = None,
-               X_pending: np.ndarray | None = None, alive=None) -> GreedyResult:
+               X_pending: np.ndarray | None = None, alive=None, shard=None) -> GreedyResult:
         """Sequential greedy of optimize_acqf_discrete: pending points and each pick join the
-        baseline (``cache_pending=True``)."""
+        baseline (``cache_pending=True``).  With ``shard`` (``RowShard``) every rank scores its rows
+        and one all-gather per step makes the pick global; the set-up is replicated (all ranks must
+        use the same seeds, i.e. the same torch RNG state, as for the single-target path)."""
         import torch
 
         X_dev = self.outputs[0].engine._as_dev(X_dev)
@@ -189,9 +191,16 @@ class HipNEHVI:
         for _ in range(q):
             self.prepare(seed, np.vstack(picks) if picks else None, prune_seed)
             scores = self.score(X_dev, alive)
-            val, idx = self.outputs[0].ext.argmax(scores)
+            val, idx = self.outputs[0].ext.argmax(scores) if X_dev.shape[0] else (-math.inf, -1)
+            if shard is not None:
+                val, gidx, row = shard.global_argmax(val, idx, X_dev)
+                if shard.owns(gidx):
+                    alive[shard.to_local(gidx)] = 0
+                idx = gidx
+            else:
+                row = X_dev[idx, :d].cpu().numpy()
+                alive[idx] = 0
             indices.append(int(idx))
             values.append(float(val))
-            alive[idx] = 0
-            picks.append(X_dev[idx, :d].cpu().numpy().reshape(1, d))
+            picks.append(np.asarray(row, dtype=np.float64).reshape(1, d))
         return GreedyResult(indices, values)

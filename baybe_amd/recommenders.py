@@ -95,8 +95,6 @@ class HipBotorchRecommender:
             self._pending_comp = np.ascontiguousarray(pend.to_numpy(dtype=np.float64))
         self._nehvi = None
         if len(objective.targets) > 1:
-            if self.shard is not None:
-                raise IncompatibilityError("Row sharding of qLogNEHVI is not available yet.")
             from baybe_amd.nehvi import HipNEHVI, compute_ref_point
 
             models = surrogate.models
@@ -204,7 +202,7 @@ class HipBotorchRecommender:
         acqf = self._get_acquisition_function(self._objective)
         Xd, alive, labels = self._candidates_on_device(subspace_discrete, candidates_exp)
         if self._nehvi is not None:
-            res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp, alive=alive)
+            res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp, alive=alive, shard=self.shard)
             idxs = labels[np.asarray(res.indices, dtype=np.int64)]
             return (idxs, res) if return_values else idxs
         if acqf.is_analytic:  # q = 1 by construction (supports_batching is False)

@@ -87,6 +87,63 @@ def test_two_rank_sharded_greedy_equals_single_process():
     assert ti == ri.tolist() and np.allclose(tv, rv, rtol=0, atol=1e-12)
 
 
+def _nehvi_setup(N, d, n):
+    from baybe_amd import engine, gp_spec
+
+    X, Xt, y = make_problem(N, d, n, seed=5)
+    Y = np.stack([y, -((Xt - 0.7) ** 2).sum(1)], 1)
+    engines = []
+    for o in range(2):
+        g = engine.HipGP(0)
+        _model(g, d, Xt, Y[:, o])
+        engines.append(g)
+    return X, Xt, Y, engines
+
+
+def _nehvi_worker(rank, world, port, N, d, n, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from baybe_amd.distributed import RowShard
+        from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+
+        X, Xt, Y, engines = _nehvi_setup(N, d, n)
+        sh = RowShard(N, rank, world)
+        hv = HipNEHVI(engines, np.ones(2), Xt, compute_ref_point(Y), n_mc_samples=32)
+        res = hv.greedy(torch.from_numpy(X[sh.start:sh.stop]).cuda(), 2, seed=4, prune_seed=6, shard=sh)
+        if rank == 0:
+            out.put((res.indices, res.values))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_nehvi_equals_single_process():
+    import torch
+    import torch.multiprocessing as mp
+
+    from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+
+    N, d, n, world = 5001, 4, 30, 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nehvi_worker, args=(r, world, port, N, d, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    idx, vals = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    X, Xt, Y, engines = _nehvi_setup(N, d, n)
+    hv = HipNEHVI(engines, np.ones(2), Xt, compute_ref_point(Y), n_mc_samples=32)
+    ref = hv.greedy(torch.from_numpy(X).cuda(), 2, seed=4, prune_seed=6)
+    assert idx == ref.indices and np.allclose(vals, ref.values, rtol=0, atol=1e-12)
+
+
 def test_campaign_iterations_loop():
     """recommend -> measure -> add, several rounds; nothing is recommended twice, the candidate cache
     follows the shrinking candidate set, batch sizes vary."""
