@@ -21,6 +21,7 @@ from baybe_amd.gp_spec import (
     GPParams,
     GPSpec,
     initial_params,
+    sample_params_from_priors,
     objective_from_data_term,
     pack_raw,
     raw_bounds,
@@ -182,13 +183,15 @@ class HipGP:
             return None, None
         return val.value, grad
 
-    def fit(self, p0: GPParams | None = None, maxiter: int = 15000, max_attempts: int = 1) -> FitInfo:
+    def fit(self, p0: GPParams | None = None, maxiter: int = 15000, max_attempts: int = 5) -> FitInfo:
         """scipy L-BFGS-B over the raw parameters with scipy's defaults, as
         ``botorch.fit.fit_gpytorch_mll`` does (call site gaussian_process/core.py:340-341);
-        every objective evaluation is one ``bbh_fit_value_grad`` on the device."""
+        every objective evaluation is one ``bbh_fit_value_grad`` on the device.
+
+        Like BoTorch's ``_fit_fallback`` the fit is retried (up to ``max_attempts`` times) from
+        hyper-parameters re-sampled from their priors when an attempt ends abnormally or at a
+        non-finite point; ``ModelFittingError`` is raised when every attempt fails."""
         spec = self.spec
-        p0 = p0 or initial_params(spec)
-        x0 = pack_raw(spec, p0)
         n = self.n
 
         def fun(raw):
@@ -198,12 +201,24 @@ class HipGP:
                 return float("inf"), np.zeros_like(raw)
             return objective_from_data_term(spec, raw, n, val, g)
 
-        res = sopt.minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=raw_bounds(spec), options={"maxiter": maxiter})
-        if not np.all(np.isfinite(res.x)) or not np.isfinite(res.fun):
-            raise ModelFittingError(f"GP hyper-parameter fit failed: {res.message}")
-        params = unpack_raw(spec, res.x)
-        self.factorize(params)
-        return FitInfo(params, float(res.fun), int(res.nit), int(res.nfev), int(res.status), str(res.message))
+        last_msg = ""
+        for attempt in range(max_attempts):
+            start = p0 if (attempt == 0 and p0 is not None) else (
+                initial_params(spec) if attempt == 0 else sample_params_from_priors(spec))
+            res = sopt.minimize(fun, pack_raw(spec, start), jac=True, method="L-BFGS-B", bounds=raw_bounds(spec),
+                                options={"maxiter": maxiter})
+            last_msg = str(res.message)
+            ok = np.all(np.isfinite(res.x)) and np.isfinite(res.fun) and "ABNORMAL" not in last_msg.upper()
+            if not ok:
+                continue
+            params = unpack_raw(spec, res.x)
+            try:
+                self.factorize(params)
+            except ModelFittingError as ex:
+                last_msg = str(ex)
+                continue
+            return FitInfo(params, float(res.fun), int(res.nit), int(res.nfev), int(res.status), last_msg)
+        raise ModelFittingError(f"All attempts to fit the model have failed (last: {last_msg}).")
 
     def factorize(self, params: GPParams):
         theta = theta_from_params(self.spec, params)

@@ -50,6 +50,7 @@ class GPSpec:
     noise_prior: tuple | None = None
     noise_init: float | None = None
     outputscale_prior: tuple | None = None
+    outputscale_init: float | None = None
     criterion: str = "mll"
 
     @property
@@ -111,12 +112,39 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
         lengthscale=np.full(spec.dn, ls0),
         noise=nz0,
         mean=0.0,
-        outputscale=float(softplus(0.0)) if spec.use_outputscale else 1.0,
+        outputscale=(float(spec.outputscale_init) if spec.outputscale_init is not None else float(softplus(0.0)))
+        if spec.use_outputscale else 1.0,
     )
     if spec.n_tasks > 1:
         T = spec.n_tasks
         p.task_W = np.full((T, T), task_init / math.sqrt(T))
         p.task_v = np.full(T, float(softplus(0.0)))
+    return p
+
+
+def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = None) -> GPParams:
+    """Restart point of a failed fit attempt: hyper-parameters drawn from their priors (the role of
+    gpytorch's ``sample_all_priors`` in botorch's ``_fit_fallback``), clipped to the constraints.
+    The generator is seeded from torch's global RNG so that ``active_settings.random_seed`` governs it."""
+    if rng is None:
+        import torch
+
+        rng = np.random.default_rng(int(torch.randint(0, 2**31 - 1, (1,)).item()))
+
+    def draw(prior, size, default):
+        if prior is None:
+            return np.full(size, default)
+        if prior[0] == "gamma":
+            return rng.gamma(prior[1], 1.0 / prior[2], size=size)
+        if prior[0] == "lognormal":
+            return np.exp(prior[1] + prior[2] * rng.standard_normal(size))
+        raise ValueError(prior[0])
+
+    p = initial_params(spec)
+    p.lengthscale = np.maximum(draw(spec.ls_prior, spec.dn, p.lengthscale[0]), spec.ls_lower if spec.ls_constraint == "box" else 1e-6)
+    p.noise = float(max(draw(spec.noise_prior, 1, p.noise)[0], spec.noise_lower))
+    if spec.use_outputscale:
+        p.outputscale = float(max(draw(spec.outputscale_prior, 1, p.outputscale)[0], 1e-6))
     return p
 
 

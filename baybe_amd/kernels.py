@@ -1,0 +1,92 @@
+"""Declarative kernel / prior specifications accepted by ``HipGaussianProcessSurrogate``
+(mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
+``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
+device: Matérn(0.5|1.5|2.5) / RBF base kernels with ARD over all numerical columns, optionally
+wrapped in a ScaleKernel).
+
+``apply_kernel_spec`` is duck-typed on class names and attribute names, so BayBE's own kernel
+objects can be passed unchanged.  As in ``Kernel.to_gpytorch`` (``baybe/kernels/base.py:113-194``)
+user kernels get gpytorch's default ``Positive()`` (softplus) constraints, priors only where given,
+and initial values softplus(0) unless ``*_initial_value`` is set — unlike the BAYBE preset, which uses
+box constraints and prior-mode initial values.
+"""
+
+from __future__ import annotations
+
+from attrs import define, field
+from attrs.validators import gt, in_, instance_of, optional
+
+from baybe_amd.exceptions import IncompatibilityError
+
+
+@define(frozen=True)
+class GammaPrior:
+    concentration: float = field(converter=float, validator=gt(0.0))
+    rate: float = field(converter=float, validator=gt(0.0))
+
+
+@define(frozen=True)
+class LogNormalPrior:
+    loc: float = field(converter=float)
+    scale: float = field(converter=float, validator=gt(0.0))
+
+
+@define(frozen=True)
+class MaternKernel:
+    nu: float = field(default=2.5, converter=float, validator=in_([0.5, 1.5, 2.5]))
+    lengthscale_prior = field(default=None)
+    lengthscale_initial_value: float | None = field(default=None)
+
+
+@define(frozen=True)
+class RBFKernel:
+    lengthscale_prior = field(default=None)
+    lengthscale_initial_value: float | None = field(default=None)
+
+
+@define(frozen=True)
+class ScaleKernel:
+    base_kernel = field()
+    outputscale_prior = field(default=None)
+    outputscale_initial_value: float | None = field(default=None)
+    outputscale_trainable: bool = field(default=True, validator=instance_of(bool))
+
+
+def _prior_tuple(prior):
+    if prior is None:
+        return None
+    name = type(prior).__name__
+    if name == "GammaPrior":
+        return ("gamma", float(prior.concentration), float(prior.rate))
+    if name == "LogNormalPrior":
+        return ("lognormal", float(prior.loc), float(prior.scale))
+    raise IncompatibilityError(f"Prior '{name}' is not available on the HIP path (Gamma / LogNormal are).")
+
+
+def apply_kernel_spec(spec, kernel):
+    """Configure a ``GPSpec`` from a (BayBE or mirror) kernel specification object."""
+    name = type(kernel).__name__
+    if name == "ScaleKernel":
+        if not getattr(kernel, "outputscale_trainable", True):
+            raise IncompatibilityError("Frozen outputscales are not available on the HIP path.")
+        spec.use_outputscale = True
+        spec.outputscale_prior = _prior_tuple(getattr(kernel, "outputscale_prior", None))
+        spec.outputscale_init = getattr(kernel, "outputscale_initial_value", None)
+        kernel = kernel.base_kernel
+        name = type(kernel).__name__
+    else:
+        spec.use_outputscale = False
+    if name == "MaternKernel":
+        spec.kernel = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(kernel.nu)]
+    elif name == "RBFKernel":
+        spec.kernel = "rbf"
+    else:
+        raise IncompatibilityError(
+            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF, optionally in a ScaleKernel, are)."
+        )
+    if getattr(kernel, "parameter_names", None):
+        raise IncompatibilityError("Kernels restricted to a parameter subset are not available on the HIP path.")
+    spec.ls_constraint = "softplus"
+    spec.ls_prior = _prior_tuple(getattr(kernel, "lengthscale_prior", None))
+    spec.ls_init = getattr(kernel, "lengthscale_initial_value", None)
+    return spec

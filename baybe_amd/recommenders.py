@@ -157,7 +157,8 @@ class HipBotorchRecommender:
         import torch
 
         comp_rep = subspace_discrete.comp_rep
-        key = (id(comp_rep), comp_rep.shape)
+        step = max(1, len(comp_rep) // 64)
+        key = (id(comp_rep), comp_rep.shape, hash(comp_rep.iloc[::step].to_numpy(dtype=np.float64).tobytes()))
         if self._cand_cache is None or self._cand_cache[0] != key:
             X = torch.from_numpy(np.ascontiguousarray(comp_rep.to_numpy(dtype=np.float64)))
             if self.shard is not None:

@@ -49,8 +49,10 @@ class HipGaussianProcessSurrogate:
     supports_transfer_learning: ClassVar[bool] = True
     supports_multi_output: ClassVar[bool] = False
 
-    kernel: str = field(default="matern52")
-    """Base kernel over the numerical columns: matern12 | matern32 | matern52 | rbf."""
+    kernel = field(default="matern52")
+    """``"matern12" | "matern32" | "matern52" | "rbf"`` within the BAYBE preset (box constraints,
+    dimension-scaled Gamma priors), or a kernel specification object — ``baybe_amd.kernels`` or
+    BayBE's own ``MaternKernel`` / ``RBFKernel`` / ``ScaleKernel`` — handled like ``Kernel.to_gpytorch``."""
 
     use_outputscale: bool = field(default=False)
     """Wrap the base kernel in a ScaleKernel (user kernels); the BAYBE preset has none."""
@@ -113,9 +115,15 @@ class HipGaussianProcessSurrogate:
         bounds = np.asarray(searchspace.scaling_bounds.to_numpy(), dtype=np.float64)
         task_idx = getattr(searchspace, "task_idx", None)
         n_tasks = int(getattr(searchspace, "n_tasks", 1))
-        spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
-                                    kernel=self.kernel)
-        spec.use_outputscale = bool(self.use_outputscale)
+        if isinstance(self.kernel, str):
+            spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
+                                        kernel=self.kernel)
+            spec.use_outputscale = bool(self.use_outputscale)
+        else:
+            from baybe_amd.kernels import apply_kernel_spec
+
+            spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks)
+            apply_kernel_spec(spec, self.kernel)
         if self._engine is None:
             self._engine = HipGP(self.device)
         self._engine.set_model(spec, train_x, train_y)

@@ -81,6 +81,7 @@ class GPSpec:
     noise_prior: tuple | None = None
     noise_init: float | None = None
     outputscale_prior: tuple | None = None
+    outputscale_init: float | None = None
     criterion: str = "mll"  # "mll" | "loo"
 
     @property
@@ -167,7 +168,8 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
         lengthscale=np.full(spec.dn, ls0, dtype=np.float64),
         noise=nz0,
         mean=0.0,
-        outputscale=float(softplus(0.0)) if spec.use_outputscale else 1.0,
+        outputscale=(float(spec.outputscale_init) if spec.outputscale_init is not None else float(softplus(0.0)))
+        if spec.use_outputscale else 1.0,
     )
     if spec.n_tasks > 1:
         T = spec.n_tasks

@@ -57,3 +57,14 @@ def test_default_spec_matches_reference_preset():
     assert spec.kernel == "matern52" and not spec.use_outputscale and spec.ls_constraint == "box"
     assert math.isclose(spec.ls_lower, 2.5e-2) and math.isclose(spec.noise_lower, 1e-4)
     assert math.isclose(spec.ls_init, math.exp(math.sqrt(2) - 3) * math.sqrt(15))
+
+
+def test_prior_samples_respect_constraints():
+    rng = np.random.default_rng(0)
+    spec = gp_spec.GPSpec.baybe_default(6, np.zeros(6), np.ones(6))
+    for _ in range(50):
+        p = gp_spec.sample_params_from_priors(spec, rng)
+        assert (p.lengthscale >= spec.ls_lower).all() and p.noise >= spec.noise_lower
+        raw = gp_spec.pack_raw(spec, p)
+        for v, (lo, hi) in zip(raw, gp_spec.raw_bounds(spec)):
+            assert lo is None or v >= lo

@@ -180,3 +180,82 @@ def test_transfer_learning_campaign_recommends():
     got = rec.recommend(2, space, SingleTargetObjective(NumericalTarget("yield")), meas)
     assert len(got) == 2 and (got["task"] == "A").all()
     assert rec._surrogate_model.engine.spec.criterion == "loo"
+
+
+def test_user_kernel_specifications_fit_like_the_oracle():
+    """tests/conftest.py:704-747 uses GP(Matern-2.5, Gamma(3, 1)); tests/test_iterations.py:365-371
+    iterates kernels.  User kernels get Positive() constraints and no preset priors."""
+    from baybe_amd import gp_spec
+    from baybe_amd.kernels import GammaPrior, LogNormalPrior, MaternKernel, RBFKernel, ScaleKernel, apply_kernel_spec
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate
+    from oracle import gp_oracle as go
+
+    rng = np.random.default_rng(6)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 30, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    Xt = space.transform(meas).to_numpy(dtype=float)
+    y = meas["yield"].to_numpy(dtype=float)
+    for kern in (MaternKernel(nu=2.5, lengthscale_prior=GammaPrior(3, 1)),
+                 ScaleKernel(MaternKernel(nu=1.5, lengthscale_prior=GammaPrior(3, 1)), outputscale_prior=GammaPrior(2, 0.15)),
+                 ScaleKernel(RBFKernel(lengthscale_prior=LogNormalPrior(0.0, 1.0), lengthscale_initial_value=0.5),
+                             outputscale_initial_value=2.0)):
+        sur = HipGaussianProcessSurrogate(kernel=kern)
+        sur.fit(space, obj, meas)
+        spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3)), kern)
+        ospec = go.GPSpec(d=3, num_idx=spec.num_idx, lo=spec.lo, hi=spec.hi, kernel=spec.kernel,
+                          use_outputscale=spec.use_outputscale, ls_constraint=spec.ls_constraint, ls_prior=spec.ls_prior,
+                          ls_init=spec.ls_init, noise_prior=spec.noise_prior, noise_init=spec.noise_init,
+                          outputscale_prior=spec.outputscale_prior, outputscale_init=spec.outputscale_init)
+        fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+        fi = sur._fit_info
+        assert np.isclose(fi.fun, fo.fun, rtol=1e-7), (kern, fi.fun, fo.fun)
+        assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=2e-3)
+        assert np.isclose(fi.params.outputscale, fo.params.outputscale, rtol=2e-3)
+        m = go.GPModel(ospec, go.GPParams(fi.params.lengthscale, fi.params.noise, fi.params.mean, fi.params.outputscale), Xt, y)
+        mo, vo = m.posterior(space.transform(exp.iloc[:100]).to_numpy(dtype=float))
+        st = sur.posterior_stats(exp.iloc[:100], ("mean", "var"))
+        assert np.allclose(st["yield_mean"], mo, rtol=1e-8, atol=1e-10) and np.allclose(st["yield_var"], vo, rtol=1e-7)
+
+
+def test_batch_constraint_subsets_pick_the_best_joint_batch():
+    """recommend_discrete_with_subsets (botorch/discrete.py:21-75): one greedy batch per subset of
+    a batch constraint, the one with the highest joint acquisition value is returned."""
+    import torch
+
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    rng = np.random.default_rng(8)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 20, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    sub = space.discrete
+    levels = sorted(exp["x0"].unique())[:3]
+    sub.n_subsets = len(levels)  # batch constraint: all batch members share the x0 level
+
+    def subset_masks(candidates_exp, min_candidates=1):
+        for lv in levels:
+            m = (candidates_exp["x0"] == lv).to_numpy()
+            if m.sum() >= min_candidates:
+                yield m
+
+    sub.subset_masks = subset_masks
+    try:
+        rec = HipBotorchRecommender()
+        torch.manual_seed(0)
+        got = rec.recommend(2, space, obj, meas)
+        assert len(got) == 2 and got["x0"].nunique() == 1 and got["x0"].iloc[0] in levels
+        # it is the best of the per-subset batches by joint value
+        vals = {}
+        for lv in levels:
+            torch.manual_seed(0)
+            cand = exp.loc[exp["x0"] == lv]
+            idx = rec._recommend_discrete_without_subsets(sub, cand, 2)
+            vals[lv] = rec._joint_value(sub.comp_rep.loc[idx].to_numpy(dtype=float))
+        assert got["x0"].iloc[0] == max(vals, key=vals.get) or abs(vals[got["x0"].iloc[0]] - max(vals.values())) < 5e-2
+    finally:
+        type(sub).n_subsets = 0
+        if "n_subsets" in sub.__dict__:
+            del sub.__dict__["n_subsets"]
