@@ -1,6 +1,7 @@
 // C-ABI entry points that are not tied to one kernel family: lifecycle, posterior dispatch,
 // MFMA layout self-test, instrumentation.  See include/baybe_hip.h for the contract.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "bbh_common.h"
@@ -18,6 +19,13 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (hipSetDevice(device_id) != hipSuccess) return -12;
   bbh_handle* h = new bbh_handle();
   h->device = device_id;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) h->num_cu = cus;
+  }
+  if (const char* e = getenv("BBH_PERSIST")) h->persistent = (e[0] != '0');
+  if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
+  if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
   *out = h;
   return 0;
 }
@@ -35,6 +43,8 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   }
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
+  if (h->d_kvcache) hipFree(h->d_kvcache);
+  if (h->d_slab_flags) hipFree(h->d_slab_flags);
   if (h->d_z) hipFree(h->d_z);
   if (h->d_red) hipFree(h->d_red);
   if (h->d_redi) hipFree(h->d_redi);

@@ -92,9 +92,17 @@ struct bbh_handle {
   double* d_tasktbl = nullptr;    // [T, T] outputscale * B (or [1] = outputscale)
   int* d_taskext = nullptr;       // [np_ext] task id per (training | pending) point
   int64_t rfrag_elems = 0;
+  bool use_pipeline = true;       // software-pipelined fused kernel (env BBH_PIPELINE=0 -> plain form, for A/B)
   int64_t* d_pass_off = nullptr;  // [npass] element offsets of the passes in d_rfrag
   int* d_pass_w = nullptr;        // [npass] pass widths (16-column blocks)
   int npass = 0;
+  int pass_w_last = 0;            // width of the last pass (its first column block = cached k-blocks)
+  double* d_kvcache = nullptr;    // kernel-value cache of the multi-pass fused kernel (grow-only)
+  size_t kvcache_bytes = 0;
+  int* d_slab_flags = nullptr;    // claim flags of the cache slabs (zero = free)
+  bool persistent = false;        // env BBH_PERSIST=1: two resident workgroups per CU walk the blocks (A/B)
+  bool use_kvcache = true;        // env BBH_KVCACHE=0: recompute kernel values in every pass (A/B)
+  int num_cu = 256;               // compute units of the device (persistent-grid size)
   int jbw = 16;                   // j-blocks per pass of the fused kernel
   int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
   // pending state

@@ -310,6 +310,13 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     return -1;
   }
   h->kd = (h->dn + 2 + 3) / 4;
+  // round up to a k-step count the software-pipelined kernel is instantiated for (zero-padded dims)
+  if (h->kd <= 4)
+    h->kd = 4;
+  else if (h->kd <= 6)
+    h->kd = 6;
+  else if (h->kd <= 8)
+    h->kd = 8;
   // Standardize(m=1): Bessel-corrected std, < 1e-8 (or undefined) -> 1
   double ybar = 0.0;
   for (int64_t i = 0; i < n; i++) ybar += y_train_host[i];

@@ -27,6 +27,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "bbh_common.h"
 
 #define BBH_MAX_PASS 64
@@ -64,6 +66,12 @@ struct FusedArgs {
   double q_best_f, q_sign;
   const uint8_t* q_alive;
   double* q_scores;
+  // kernel-value cache of the multi-pass form (one slab per resident wave), see pass_body_p
+  double* kvcache;
+  int* slab_flags;  // [nslab] 0 = free, 1 = owned by a resident wave (kvcache slabs are claimed per wave)
+  int nslab, nxcc;  // slabs in total, XCD partitions
+  int ncache;    // k-blocks cached per wave = first column block of the last pass
+  int64_t nblk;  // 64-candidate blocks; workgroups walk them with stride gridDim.x
 };
 
 struct WaveCtx {
@@ -72,6 +80,7 @@ struct WaveCtx {
   const double* mb;     // meanB + lane
   const double* tbl;
   const int* taskext;
+  double* kvc;  // this wave's kernel-value cache slab, + lane
   int kd, kind, T, tc, q, l, dn;
 };
 
@@ -202,18 +211,316 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
     for (int r = 0; r < 4; r++) ss[r] = fma(acc[jj][r], acc[jj][r], ss[r]);
 }
 
-template <bool HAS_TBL, int KIND>
+// =====================================================================================================
+// Software-pipelined pass (KD = k-steps of the distance GEMM known at compile time, Matérn-5/2 /
+// generic kind alike).  Ablation on the 1e6 x 20 x 512 workload: variance-GEMM stream alone 4.27 ms,
+// kernel-value stage alone 2.25 ms, un-pipelined kernel 5.96 ms — i.e. only a quarter of the VALU work
+// was hidden by the second wave of the SIMD.  Here every wave computes the kernel values of k-block
+// tb+1 in slices placed between the four k-steps of k-block tb's MFMAs (same basic block, fenced with
+// sched_barrier so the slices stay where they are): slice 0 issues the training-fragment loads and the
+// distance MFMAs, slices 1-2 evaluate two kernel values each, slice 3 carries the mean MFMAs.
+// =====================================================================================================
+template <int KD>
+__device__ __forceinline__ void kvp_load(const WaveCtx& c, int tb, double (&tfv)[KD]) {
+  const double* tf = c.tf + (int64_t)tb * KD * 64;
+#pragma unroll
+  for (int k = 0; k < KD; k++) tfv[k] = tf[k * 64];
+}
+
+template <int KD>
+__device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[KD], double (&r2v)[4]) {
+  d4 da = {0.0, 0.0, 0.0, 0.0}, db = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < KD; k += 2) {
+    da = mfma_f64(tfv[k], c.candl[k * 64], da);
+    if (k + 1 < KD) db = mfma_f64(tfv[k + 1], c.candl[(k + 1) * 64], db);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) r2v[r] = da[r] + db[r];
+}
+
+// Matérn-5/2 of two scaled squared distances, cut into BBH_KV_STEPS micro-steps of 2-4 VALU
+// instructions so that the caller can place them between MFMAs in program order (the compiler's
+// scheduler clumps library sqrt()/exp() calls behind the MFMAs even when asked to interleave them
+// with sched_group_barrier).  k(r2) = (1 + s + s^2/3) exp(-s), s = sqrt(5 r2):
+//   sqrt: v_rsq_f64 seed, one coupled Goldschmidt step and one Newton correction (error O(eps^4));
+//   exp:  -s = k ln2 + r, |r| <= ln2/2, Taylor degree 13 (truncation 4e-18), scaled with v_ldexp_f64;
+//   s is clamped at 800 (result underflows to 0 there), r2 = 0 is handled by a 1e-300 floor.
+// Measured against the libm form on 1e6 x 512 values: see tests/test_gpu_parity.py::test_pipelined_*.
+#define BBH_KV_STEPS 18
+#ifndef BBH_KV_NU
+#define BBH_KV_NU 4  // values evaluated in lockstep (independent dependency chains per micro-step)
+#endif
+template <int NU>
+struct KvState {
+  double t[NU], y[NU], g[NU], h[NU], kf[NU], q[NU], tv[NU];
+  int ki[NU], te[NU];
+};
+
+#define BBH_KV_EACH for (int u = 0; u < NU; u++)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <bool HAS_TBL, int NU, int step>
+__device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int tb, int r0, const double (&r2v)[4],
+                                         double (&out)[4]) {
+  constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
+                   LN2_LO = 1.90821492927058770002e-10;
+  // register roles: t = 5 r2, later the reduced argument r; g = sqrt estimate, later s; h = half
+  // reciprocal sqrt, later the exp polynomial; y = rsq seed / residuals
+  switch (step) {
+    case 0:
+#pragma unroll
+      BBH_KV_EACH {
+        P.t[u] = __builtin_fmax(5.0 * r2v[r0 + u], 1e-300);
+        if (HAS_TBL) P.te[u] = c.taskext[16 * tb + 4 * (r0 + u) + c.q];
+      }
+      break;
+    case 1:
+#pragma unroll
+      BBH_KV_EACH P.y[u] = __builtin_amdgcn_rsq(P.t[u]);
+      break;
+    case 2:
+#pragma unroll
+      BBH_KV_EACH P.g[u] = P.t[u] * P.y[u];
+#pragma unroll
+      BBH_KV_EACH P.h[u] = 0.5 * P.y[u];
+      break;
+    case 3:
+#pragma unroll
+      BBH_KV_EACH P.y[u] = fma(-P.h[u], P.g[u], 0.5);
+      break;
+    case 4:
+#pragma unroll
+      BBH_KV_EACH P.g[u] = fma(P.g[u], P.y[u], P.g[u]);
+#pragma unroll
+      BBH_KV_EACH P.h[u] = fma(P.h[u], P.y[u], P.h[u]);
+      break;
+    case 5:
+#pragma unroll
+      BBH_KV_EACH P.y[u] = fma(-P.g[u], P.g[u], P.t[u]);
+      break;
+    case 6:
+#pragma unroll
+      BBH_KV_EACH P.g[u] = __builtin_fmin(fma(P.y[u], P.h[u], P.g[u]), 800.0);  // g = s from here on
+      break;
+    case 7:
+#pragma unroll
+      BBH_KV_EACH P.kf[u] = __builtin_rint(P.g[u] * -LOG2E);
+#pragma unroll
+      BBH_KV_EACH P.q[u] = fma(P.g[u], 1.0 / 3.0, 1.0);
+      break;
+    case 8:
+#pragma unroll
+      BBH_KV_EACH P.t[u] = fma(P.kf[u], -LN2_HI, -P.g[u]);  // t = reduced argument r from here on
+#pragma unroll
+      BBH_KV_EACH P.q[u] = fma(P.q[u], P.g[u], 1.0);
+      break;
+    case 9:
+#pragma unroll
+      BBH_KV_EACH P.t[u] = fma(P.kf[u], -LN2_LO, P.t[u]);
+#pragma unroll
+      BBH_KV_EACH {
+        P.ki[u] = (int)P.kf[u];
+        if (HAS_TBL) P.tv[u] = c.tbl[c.tc * c.T + P.te[u]];
+      }
+      break;
+    case 10:
+#pragma unroll
+      BBH_KV_EACH P.h[u] = fma(1.0 / 6227020800.0, P.t[u], 1.0 / 479001600.0);
+      break;
+#define BBH_KV_HORNER2(CA, CB)                      \
+  _Pragma("unroll") BBH_KV_EACH P.h[u] = fma(P.h[u], P.t[u], CA); \
+  _Pragma("unroll") BBH_KV_EACH P.h[u] = fma(P.h[u], P.t[u], CB);
+    case 11: BBH_KV_HORNER2(1.0 / 39916800.0, 1.0 / 3628800.0) break;
+    case 12: BBH_KV_HORNER2(1.0 / 362880.0, 1.0 / 40320.0) break;
+    case 13: BBH_KV_HORNER2(1.0 / 5040.0, 1.0 / 720.0) break;
+    case 14: BBH_KV_HORNER2(1.0 / 120.0, 1.0 / 24.0) break;
+    case 15: BBH_KV_HORNER2(1.0 / 6.0, 0.5) break;
+    case 16: BBH_KV_HORNER2(1.0, 1.0) break;
+#undef BBH_KV_HORNER2
+    default:
+#pragma unroll
+      BBH_KV_EACH P.h[u] *= P.q[u];
+#pragma unroll
+      BBH_KV_EACH {
+        double v = __builtin_ldexp(P.h[u], P.ki[u]);
+        if (HAS_TBL) v *= P.tv[u];
+        out[r0 + u] = v;
+      }
+      break;
+  }
+}
+#undef BBH_KV_EACH
+
+// all micro-steps of the four values back to back (first k-block of a pass)
+template <bool HAS_TBL>
+__device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const double (&r2v)[4], double (&out)[4]) {
+  KvState<4> P;
+  static_for<0, BBH_KV_STEPS>([&](auto st) __attribute__((always_inline)) {
+    kv_micro<HAS_TBL, 4, decltype(st)::value>(P, c, tb, 0, r2v, out);
+  });
+}
+
+// one k-block: CNT column blocks starting at accumulator TT; kv = values of this block, kvn = values of
+// the next block (computed here when NEXT); fragments are read from rf (+ lane) in consumption order
+// NEXT: how the kernel values of k-block tb + 1 are obtained while this block's MFMAs run:
+//   BBH_NEXT_NONE (last block of a pass), BBH_NEXT_COMPUTE (micro-steps between the MFMAs),
+//   BBH_NEXT_LOAD (from the wave's kernel-value cache: an earlier pass computed and stored them).
+// STORE: write this block's values to the cache (diagonal blocks of every pass but the last).
+#define BBH_RING 8
+#define BBH_NEXT_NONE 0
+#define BBH_NEXT_COMPUTE 1
+#define BBH_NEXT_LOAD 2
+template <int W, int CNT, int TT, int KD, bool HAS_TBL, bool DO_MEAN, int NEXT, bool STORE, int BASE, int REM>
+__device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int tb, const double (&kv)[4],
+                                         double (&kvn)[4], d4 (&acc)[W], d4& accm, double (&ring)[BBH_RING]) {
+  // The R fragments of a pass are one linear stream (k-block, k-step, column block); they flow through
+  // a BBH_RING-deep register ring that is never drained inside a pass: the fragment BBH_RING ahead is
+  // requested right after a slot is consumed, across k-block boundaries too.  A block holds 4 CNT
+  // fragments, so the slot of its first fragment is BASE in {0, 4} - a compile-time constant.
+  // (2 waves x 8 loads in flight per SIMD cover the L2 latency; depth 4 measurably does not.)
+  constexpr int D = BBH_RING;
+  constexpr int TOT = 4 * CNT;
+  double tfv[KD];
+  double r2v[4];
+  double mbv[4];
+  KvState<BBH_KV_NU> P;
+  if (NEXT == BBH_NEXT_COMPUTE) kvp_load<KD>(c, tb + 1, tfv);
+  if (NEXT == BBH_NEXT_LOAD) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) kvn[rr] = c.kvc[(int64_t)(tb + 1) * 256 + rr * 64];
+  }
+  if (STORE) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) c.kvc[(int64_t)tb * 256 + rr * 64] = kv[rr];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (DO_MEAN && r == 3) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) mbv[rr] = c.mb[(int64_t)(4 * tb + rr) * 64];
+    }
+    static_for<0, CNT>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int jj = decltype(jc)::value;
+      constexpr int i = r * CNT + jj;
+      acc[TT + jj] = mfma_f64(kv[r], ring[(BASE + i) % D], acc[TT + jj]);
+      if (i + D < TOT + REM) ring[(BASE + i) % D] = rf[(i + D) * 64];
+      if constexpr (NEXT == BBH_NEXT_COMPUTE && (r == 1 || r == 2)) {
+        if constexpr (BBH_KV_NU == 4) {  // four values in lockstep, micro-steps spread over both slices
+          constexpr int m = (r - 1) * CNT + jj;
+          static_for<(m * BBH_KV_STEPS) / (2 * CNT), ((m + 1) * BBH_KV_STEPS) / (2 * CNT)>(
+              [&](auto st) __attribute__((always_inline)) {
+                kv_micro<HAS_TBL, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 0, r2v, kvn);
+              });
+        } else {  // two values per slice
+          static_for<(jj * BBH_KV_STEPS) / CNT, ((jj + 1) * BBH_KV_STEPS) / CNT>(
+              [&](auto st) __attribute__((always_inline)) {
+                kv_micro<HAS_TBL, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 2 * (r - 1), r2v, kvn);
+              });
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (NEXT == BBH_NEXT_COMPUTE && r == 0) kvp_dist<KD>(c, tfv, r2v);
+    if (DO_MEAN && r == 3) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) accm = mfma_f64(kv[rr], mbv[rr], accm);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template <int W, int TT, int KD, bool HAS_TBL, bool DO_MEAN, bool STORE>
+__device__ __forceinline__ void diag_steps_p(const WaveCtx& c, const double* rf, int j0, double (&kv)[4], d4 (&acc)[W],
+                                             d4& accm, double (&ring)[BBH_RING]) {
+  if constexpr (TT < W) {
+    double kvn[4];
+    constexpr int NEXT = (TT + 1 < W) ? BBH_NEXT_COMPUTE : BBH_NEXT_NONE;
+    constexpr int BASE = (4 * (TT * W - (TT * (TT - 1)) / 2)) % BBH_RING;  // slot of the first fragment
+    constexpr int REM = 2 * (W - TT) * (W - TT - 1);  // fragments of this pass after this block
+    kblock_p<W, W - TT, TT, KD, HAS_TBL, DO_MEAN, NEXT, STORE, BASE, REM>(c, rf, j0 + TT, kv, kvn, acc, accm, ring);
+    if (NEXT) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
+    }
+    diag_steps_p<W, TT + 1, KD, HAS_TBL, DO_MEAN, STORE>(c, rf + 4 * (W - TT) * 64, j0, kv, acc, accm, ring);
+  }
+}
+
+// One pass over the column-block window [j0, j0 + W).  Kernel values are computed once per k-block
+// and wave: the diagonal blocks [j0, j0 + W) of every pass but the last store theirs to the wave's
+// cache slab (CACHE), and the rectangular region of later passes (k-blocks < j0) reads them back one
+// block ahead instead of redoing the distance GEMM and the Matérn evaluation (fp64 VALU work is not
+// hidden behind fp64 MFMAs on gfx950 - both issue to the same DP pipe, scripts/mfma_valu_overlap_probe.hip).
+template <int W, int KD, bool HAS_TBL, bool DO_MEAN, bool CACHE>
+__device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, int j0, double (&ss)[4], d4& accm) {
+  d4 acc[W];
+#pragma unroll
+  for (int jj = 0; jj < W; jj++) acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
+  double kv[4], kvn[4], ring[BBH_RING];
+#pragma unroll
+  for (int i = 0; i < BBH_RING; i++) ring[i] = rf[i * 64];
+  const bool cached = CACHE && j0 > 0;  // CACHE: the launch has more than one pass
+  if (cached) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) kv[r] = c.kvc[r * 64];
+  } else {  // first k-block of the pass: not overlapped
+    double tfv[KD], r2v[4];
+    kvp_load<KD>(c, 0, tfv);
+    kvp_dist<KD>(c, tfv, r2v);
+    kv_all<HAS_TBL>(c, 0, r2v, kv);
+  }
+  if (CACHE) {
+    for (int tb = 0; tb + 1 < j0; tb++) {  // rectangular region, next block cached too
+      kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_LOAD, false, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring);
+#pragma unroll
+      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
+      rf += 4 * W * 64;
+    }
+    if (j0 > 0) {  // last rectangular block: the next one (j0) is this pass's first diagonal block
+      kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_COMPUTE, false, 0, 1 << 20>(c, rf, j0 - 1, kv, kvn, acc, accm, ring);
+#pragma unroll
+      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
+      rf += 4 * W * 64;
+    }
+    diag_steps_p<W, 0, KD, HAS_TBL, DO_MEAN, !DO_MEAN>(c, rf, j0, kv, acc, accm, ring);
+  } else {
+    for (int tb = 0; tb < j0; tb++) {  // no cache: every block recomputes the next block's values
+      kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_COMPUTE, false, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring);
+#pragma unroll
+      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
+      rf += 4 * W * 64;
+    }
+    diag_steps_p<W, 0, KD, HAS_TBL, DO_MEAN, false>(c, rf, j0, kv, acc, accm, ring);
+  }
+#pragma unroll
+  for (int jj = 0; jj < W; jj++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) ss[r] = fma(acc[jj][r], acc[jj][r], ss[r]);
+}
+
+template <bool HAS_TBL, int KIND, int KD>
 __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_cand[];  // [4 waves][kd][64] (+ z[qS])
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cnd = l & 15, q = l >> 4;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + w) * 16;
   double* s_z = s_cand + 4 * (int64_t)a.kd * 64;
   if (a.qz) {  // the only workgroup barrier, before any wave may leave
     for (int s = threadIdx.x; s < a.qS; s += 256) s_z[s] = a.qz[s];
     __syncthreads();
   }
-  if (tile0 >= a.N) return;  // whole wave out of range (no workgroup barrier is used below)
+  // block b handles the 64-candidate blocks b, b + gridDim.x, ... (gridDim.x = all of them by default)
+  // (per-wave state only from here on: no workgroup barrier is used below)
+  for (int64_t blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+  const int64_t tile0 = (blk * 4 + w) * 16;
+  if (tile0 >= a.N) break;  // whole wave out of range (later blocks are further out)
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
   double* candw = s_cand + (int64_t)w * a.kd * 64;
@@ -249,6 +556,24 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
   c.mb = a.meanB + l;
   c.tbl = a.tasktbl;
   c.taskext = a.taskext;
+  // Claim a kernel-value cache slab for this wave.  The pool is partitioned by XCD (HW_REG_XCC_ID): a
+  // slab is only ever touched through one XCD's L2, so re-use by a later wave needs no L2 write-back
+  // (an agent-scope release fence per wave costs 30 % of the kernel).  Each partition has twice as
+  // many slabs as the XCD can hold resident waves (8 per CU), so linear probing from a hashed start
+  // ends after a few attempts.
+  int slab = 0;
+  if (a.kvcache) {
+    if (l == 0) {
+      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) % (unsigned)a.nxcc;  // XCC_ID[3:0]
+      const unsigned per = (unsigned)(a.nslab / a.nxcc);
+      unsigned sidx = (unsigned)(((uint64_t)(blk * 4 + w) * 2654435761ull) % per);
+      int* flags = a.slab_flags + xcc * per;
+      while (atomicCAS(&flags[sidx], 0, 1) != 0) sidx = (sidx + 1 == per) ? 0u : sidx + 1;
+      slab = (int)(xcc * per + sidx);
+    }
+    slab = __builtin_amdgcn_readfirstlane(slab);
+  }
+  c.kvc = a.kvcache ? a.kvcache + (int64_t)slab * a.ncache * 256 + l : nullptr;
   c.kd = a.kd;
   c.kind = a.kind;
   c.T = a.T;
@@ -267,7 +592,29 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       const int W = a.pass_w[ps];
       const double* rf = a.rfrag + a.pass_off[ps] + l;
       const bool last = (ps == a.npass - 1);
-      if (!last) {
+      if constexpr (KD > 0) {  // software-pipelined passes
+        const bool use_cache = (a.kvcache != nullptr);
+        if (!last) {
+          if (use_cache)
+            pass_body_p<16, KD, HAS_TBL, false, true>(c, rf, j0, ss, accm);
+          else
+            pass_body_p<16, KD, HAS_TBL, false, false>(c, rf, j0, ss, accm);
+        } else if (use_cache) {
+          switch (W) {
+            case 4: pass_body_p<4, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
+            case 8: pass_body_p<8, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
+            case 12: pass_body_p<12, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
+            default: pass_body_p<16, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
+          }
+        } else {
+          switch (W) {
+            case 4: pass_body_p<4, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
+            case 8: pass_body_p<8, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
+            case 12: pass_body_p<12, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
+            default: pass_body_p<16, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
+          }
+        }
+      } else if (!last) {
         pass_body<16, 8, HAS_TBL, false, KIND>(c, rf, j0, ss, accm);
       } else {
         switch (W) {
@@ -293,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     }
   }
 
+  if (a.kvcache && l == 0) atomicExch(&a.slab_flags[slab], 0);  // every cached value has been read back
   // ---- epilogue: lane (q, cnd), reg r  <->  candidate q + 4 r, column cnd -------------------
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -366,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       a.q_scores[gi] = sc;
     }
   }
+  }  // persistent block loop
 }
 
 // ---- operand packing ------------------------------------------------------------------------
@@ -497,6 +846,7 @@ int bbh_pack_operands(bbh_handle* h) {
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_pass_off, pass_off.data(), sizeof(int64_t) * pass_off.size(), hipMemcpyHostToDevice, s));
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_pass_w, widths.data(), sizeof(int) * widths.size(), hipMemcpyHostToDevice, s));
   h->npass = (int)widths.size();
+  h->pass_w_last = widths.back();
   if (!h->d_rfrag || h->rfrag_elems != total_frags * 64) {
     if (h->d_rfrag) hipFree(h->d_rfrag);
     h->d_rfrag = nullptr;
@@ -599,7 +949,39 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   }
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
   const size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0));
-  dim3 grid((unsigned)((N + 63) / 64)), block(256);
+  const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
+  // software-pipelined instantiations exist for the default kernel with kd in {4, 6, 8}
+  // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
+  const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 4 || h->kd == 6 || h->kd == 8)) ? h->kd : 0;
+  a.nblk = (N + 63) / 64;
+  // one workgroup per 64-candidate block by default; BBH_PERSIST=1 launches two per CU that walk the blocks
+  // with stride gridDim.x instead (measured 5 % slower: the hardware dispatcher balances better)
+  const int64_t resident = h->persistent ? 2 * (int64_t)h->num_cu : a.nblk;
+  dim3 grid((unsigned)(a.nblk < resident ? a.nblk : resident)), block(256);
+  a.kvcache = nullptr;
+  a.ncache = 0;
+  a.slab_flags = nullptr;
+  a.nslab = 0;
+  a.nxcc = 1;
+  if (kdp && h->npass > 1 && h->use_kvcache) {  // kernel-value cache: slabs of ncache k-blocks, claimed per wave
+    a.ncache = (int)(h->nb - h->pass_w_last);
+    a.nslab = 2 * 8 * h->num_cu;  // twice the resident waves (8 per CU under these launch bounds)
+    a.nxcc = (h->num_cu % 8 == 0 && h->num_cu >= 64) ? 8 : 1;  // MI355X: 8 XCDs x 32 CUs
+    const size_t need = sizeof(double) * (size_t)a.nslab * (size_t)a.ncache * 256;
+    if (need > h->kvcache_bytes) {
+      if (h->d_kvcache) BBH_HIP_TRY(h, hipFree(h->d_kvcache));
+      h->d_kvcache = nullptr;
+      h->kvcache_bytes = 0;
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_kvcache, need));
+      h->kvcache_bytes = need;
+    }
+    if (!h->d_slab_flags) {
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_slab_flags, sizeof(int) * (size_t)a.nslab));
+      BBH_HIP_TRY(h, hipMemsetAsync(h->d_slab_flags, 0, sizeof(int) * (size_t)a.nslab, h->stream));
+    }
+    a.kvcache = h->d_kvcache;
+    a.slab_flags = h->d_slab_flags;
+  }
   const bool timed = h->timing && with_var;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
@@ -607,15 +989,24 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     hipEventCreate(&e1);
     hipEventRecord(e0, h->stream);
   }
-  const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
+#define BBH_LAUNCH_KD(TBL, KND, KDV) hipLaunchKernelGGL((bbh_fused_posterior_kernel<TBL, KND, KDV>), grid, block, lds, h->stream, a)
+#define BBH_LAUNCH_M52(TBL)                                     \
+  do {                                                          \
+    if (kdp == 4) BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 4);   \
+    else if (kdp == 6) BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 6); \
+    else if (kdp == 8) BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 8); \
+    else BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 0);            \
+  } while (0)
   if (has_tbl && m52)
-    hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a);
+    BBH_LAUNCH_M52(true);
   else if (has_tbl)
-    hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, -1>), grid, block, lds, h->stream, a);
+    BBH_LAUNCH_KD(true, -1, 0);
   else if (m52)
-    hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a);
+    BBH_LAUNCH_M52(false);
   else
-    hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, -1>), grid, block, lds, h->stream, a);
+    BBH_LAUNCH_KD(false, -1, 0);
+#undef BBH_LAUNCH_M52
+#undef BBH_LAUNCH_KD
   if (timed) {
     hipEventRecord(e1, h->stream);
     h->pending_events.emplace_back(e0, e1);
@@ -867,6 +1258,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedAr
   c.mb = a.meanB + l;
   c.tbl = a.tasktbl;
   c.taskext = a.taskext;
+  c.kvc = nullptr;
   c.kd = a.kd;
   c.kind = a.kind;
   c.T = a.T;
@@ -993,6 +1385,12 @@ static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev
   a.q_sign = 1.0;
   a.q_alive = nullptr;
   a.q_scores = nullptr;
+  a.kvcache = nullptr;
+  a.slab_flags = nullptr;
+  a.nslab = 0;
+  a.nxcc = 1;
+  a.ncache = 0;
+  a.nblk = (N + 63) / 64;
 }
 
 extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
