@@ -100,7 +100,6 @@ struct bbh_handle {
   double* d_kvcache = nullptr;    // kernel-value cache of the multi-pass fused kernel (grow-only)
   size_t kvcache_bytes = 0;
   int* d_slab_flags = nullptr;    // claim flags of the cache slabs (zero = free)
-  bool persistent = false;        // env BBH_PERSIST=1: two resident workgroups per CU walk the blocks (A/B)
   bool use_kvcache = true;        // env BBH_KVCACHE=0: recompute kernel values in every pass (A/B)
   int num_cu = 256;               // compute units of the device (persistent-grid size)
   int jbw = 16;                   // j-blocks per pass of the fused kernel

@@ -71,7 +71,7 @@ struct FusedArgs {
   int* slab_flags;  // [nslab] 0 = free, 1 = owned by a resident wave (kvcache slabs are claimed per wave)
   int nslab, nxcc;  // slabs in total, XCD partitions
   int ncache;    // k-blocks cached per wave = first column block of the last pass
-  int64_t nblk;  // 64-candidate blocks; workgroups walk them with stride gridDim.x
+  int64_t nblk;  // 64-candidate blocks = workgroups
 };
 
 struct WaveCtx {
@@ -373,7 +373,9 @@ __device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const double (&
 //   BBH_NEXT_NONE (last block of a pass), BBH_NEXT_COMPUTE (micro-steps between the MFMAs),
 //   BBH_NEXT_LOAD (from the wave's kernel-value cache: an earlier pass computed and stored them).
 // STORE: write this block's values to the cache (diagonal blocks of every pass but the last).
+#ifndef BBH_RING
 #define BBH_RING 8
+#endif
 #define BBH_NEXT_NONE 0
 #define BBH_NEXT_COMPUTE 1
 #define BBH_NEXT_LOAD 2
@@ -516,11 +518,12 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     for (int s = threadIdx.x; s < a.qS; s += 256) s_z[s] = a.qz[s];
     __syncthreads();
   }
-  // block b handles the 64-candidate blocks b, b + gridDim.x, ... (gridDim.x = all of them by default)
-  // (per-wave state only from here on: no workgroup barrier is used below)
-  for (int64_t blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+  // per-wave state only from here on: no workgroup barrier is used below.  (A persistent variant - two
+  // workgroups per CU walking the candidate blocks - measured 5 % slower than one workgroup per block:
+  // the hardware dispatcher balances the tail better.)
+  const int64_t blk = blockIdx.x;
   const int64_t tile0 = (blk * 4 + w) * 16;
-  if (tile0 >= a.N) break;  // whole wave out of range (later blocks are further out)
+  if (tile0 >= a.N) return;  // whole wave out of range
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
   double* candw = s_cand + (int64_t)w * a.kd * 64;
@@ -714,7 +717,6 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       a.q_scores[gi] = sc;
     }
   }
-  }  // persistent block loop
 }
 
 // ---- operand packing ------------------------------------------------------------------------
@@ -954,10 +956,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
   const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 4 || h->kd == 6 || h->kd == 8)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
-  // one workgroup per 64-candidate block by default; BBH_PERSIST=1 launches two per CU that walk the blocks
-  // with stride gridDim.x instead (measured 5 % slower: the hardware dispatcher balances better)
-  const int64_t resident = h->persistent ? 2 * (int64_t)h->num_cu : a.nblk;
-  dim3 grid((unsigned)(a.nblk < resident ? a.nblk : resident)), block(256);
+  dim3 grid((unsigned)a.nblk), block(256);
   a.kvcache = nullptr;
   a.ncache = 0;
   a.slab_flags = nullptr;
