@@ -243,11 +243,15 @@ __device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[K
 // instructions so that the caller can place them between MFMAs in program order (the compiler's
 // scheduler clumps library sqrt()/exp() calls behind the MFMAs even when asked to interleave them
 // with sched_group_barrier).  k(r2) = (1 + s + s^2/3) exp(-s), s = sqrt(5 r2):
-//   sqrt: v_rsq_f64 seed, one coupled Goldschmidt step and one Newton correction (error O(eps^4));
+//   sqrt: v_rsq_f64 seed and one Newton step (error 1.5 eps^2 = 3e-16; the Goldschmidt + Newton form
+//         with error O(eps^4) is kept behind BBH_KV_SQRT_NR=0 and measured 1 % slower);
 //   exp:  -s = k ln2 + r, |r| <= ln2/2, Taylor degree 13 (truncation 4e-18), scaled with v_ldexp_f64;
 //   s is clamped at 800 (result underflows to 0 there), r2 = 0 is handled by a 1e-300 floor.
-// Measured against the libm form on 1e6 x 512 values: see tests/test_gpu_parity.py::test_pipelined_*.
+// Measured against the libm form on 1e6 x 512 values: tests/test_gpu_parity.py::test_pipelined_kernel_matches_plain_form, scripts/gpu_kv_accuracy.py.
 #define BBH_KV_STEPS 18
+#ifndef BBH_KV_SQRT_NR
+#define BBH_KV_SQRT_NR 1  // 1: one Newton step on the v_rsq_f64 seed (4 VALU); 0: Goldschmidt + Newton (7 VALU)
+#endif
 #ifndef BBH_KV_NU
 #define BBH_KV_NU 4  // values evaluated in lockstep (independent dependency chains per micro-step)
 #endif
@@ -285,6 +289,25 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
 #pragma unroll
       BBH_KV_EACH P.y[u] = __builtin_amdgcn_rsq(P.t[u]);
       break;
+#if BBH_KV_SQRT_NR  // s = u + (u/2)(1 - u y), u = t y: error 1.5 eps^2 with eps = 2^-26 of v_rsq_f64
+    case 2:
+#pragma unroll
+      BBH_KV_EACH P.g[u] = P.t[u] * P.y[u];
+      break;
+    case 3:
+#pragma unroll
+      BBH_KV_EACH P.y[u] = fma(-P.g[u], P.y[u], 1.0);
+      break;
+    case 4:
+#pragma unroll
+      BBH_KV_EACH P.h[u] = 0.5 * P.g[u];
+      break;
+    case 5: break;
+    case 6:
+#pragma unroll
+      BBH_KV_EACH P.g[u] = __builtin_fmin(fma(P.h[u], P.y[u], P.g[u]), 800.0);  // g = s from here on
+      break;
+#else
     case 2:
 #pragma unroll
       BBH_KV_EACH P.g[u] = P.t[u] * P.y[u];
@@ -309,6 +332,7 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
 #pragma unroll
       BBH_KV_EACH P.g[u] = __builtin_fmin(fma(P.y[u], P.h[u], P.g[u]), 800.0);  // g = s from here on
       break;
+#endif
     case 7:
 #pragma unroll
       BBH_KV_EACH P.kf[u] = __builtin_rint(P.g[u] * -LOG2E);

@@ -146,6 +146,40 @@ def test_posterior_fused_and_unfused_match_oracle(gp, N, d, n):
     assert math.isclose(gp.best_f(-1.0), go.best_f_from_model(om, -1.0), rel_tol=1e-9, abs_tol=1e-12)
 
 
+@pytest.mark.parametrize("N,d,n", [(20_000, 20, 600), (30_000, 6, 1100), (4_000, 28, 300)])
+def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
+    """The software-pipelined fused kernel (staged rsq/Taylor Matérn evaluation, kernel-value cache
+    slabs claimed per wave) against the same launch with libm sqrt/exp and no cache; the switches are
+    read when the handle is created.  Enough candidates to keep every CU busy, several passes."""
+    from baybe_amd import engine, gp_spec
+
+    X, Xt, y = make_problem(N, d, n, seed=11)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    p = gp_spec.GPParams(np.full(d, ls), nz, 0.0)
+    out = {}
+    for name, env in (("pipelined", {}), ("no_cache", {"BBH_KVCACHE": "0"}), ("plain", {"BBH_PIPELINE": "0"})):
+        for k in ("BBH_KVCACHE", "BBH_PIPELINE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = engine.HipGP(0)
+        try:
+            g.set_model(spec, Xt, y)
+            g.factorize(p)
+            for _ in range(3):  # slabs are re-claimed on every launch
+                m, v = g.posterior(X)
+            out[name] = (_np(m), _np(v))
+        finally:
+            g.close()
+    scale = float(np.std(y))
+    for name in ("pipelined", "no_cache"):
+        assert np.max(np.abs(out[name][0] - out["plain"][0])) <= 1e-11 * scale
+        assert np.max(np.abs(out[name][1] - out["plain"][1])) <= 1e-11 * scale**2
+    assert np.array_equal(out["pipelined"][0], out["no_cache"][0])  # cached values are the computed ones
+    assert np.array_equal(out["pipelined"][1], out["no_cache"][1])
+
+
 def test_posterior_scaling_bounds_and_strided_input(gp):
     """Normalize uses the search-space bounds (not the candidate range) and honours ldx > d."""
     import torch
