@@ -172,11 +172,14 @@ def main():
         "bound": "mfma",
         "achieved": achieved,
         "peak": FP64_MFMA_PEAK_TFLOPS,
-        "peak_sustained_microbench": 49.0,  # scripts/fp64_peak.hip: 1 MFMA / ~100 cycles / SIMD at 2.39 GHz
+        # scripts/mfma_valu_overlap_probe.hip: a pure v_mfma_f64_16x16x4_f64 stream reaches 77.8 TFLOP/s, and
+        # fp64 VALU work issued next to it adds its time (one shared DP pipe) - the peak is for MFMA + VALU
+        "peak_mfma_stream_microbench": 77.8,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
         "traffic": traffic,
-        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; algorithmic = %d)" % (rows_local * (8 * d + 16)),
+        "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json; algorithmic = %d; "
+                        "4.1e9 of it is the kernel-value cache, Infinity-Cache resident - the kernel is fp64-pipe bound)" % (rows_local * (8 * d + 16)),
         "kernel": "bbh_fused_posterior_kernel",
         "avg_launch_ms": avg_ms,
         "launches": fused_launches,

@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 passes behind profiles/rNN_*: kernel trace + stats, then one PMC pass per counter group
+# (never combined with a trace domain), all on `bench.py --steps 3 --warmup 1 --cpu-budget 0`.
+# Run on the GPU box from the repo root:  bash scripts/profile_bench.sh r01
+# Raw output goes to gpurun_out/prof_<tag>/, the summaries are aggregated by scripts/profile_summarize.py.
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --cpu-budget 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA" \
+           "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo "$grp" | tr ' ' '+')
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- $CMD > "$OUT/pmc_$name.log" 2>&1
+done
+cd "$ROOT" && python scripts/profile_summarize.py "$OUT" "$TAG"
