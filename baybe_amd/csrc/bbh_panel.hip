@@ -21,727 +21,13 @@
 //         only blocks j >= k are touched.  ||v||^2 is reduced from the accumulators.
 //   (4) mean / cross GEMM  [mean | cross_1..p] += kv . [alpha | -beta_1..-beta_p] in the last pass.
 //
-// Passes of width W keep 8 W accumulator VGPRs (128 for W = 16), i.e. two waves per SIMD, so
-// the VALU work of (2) in one wave overlaps the MFMA work of (3) in the other.  K(X*,X) is
-// never materialised; later passes recompute (1)-(2) for the k-blocks they need.
-#include <math.h>
-#include <string.h>
-
-#include <type_traits>
-
-#include "bbh_common.h"
-
-#define BBH_MAX_PASS 64
-
-__device__ __forceinline__ double bbh_kfun_p(int kind, double r2) {
-  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
-  const double r = sqrt(r2);
-  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
-  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
-  return exp(-r);
-}
-
-struct FusedArgs {
-  const double* X;
-  int64_t N, ldx;
-  const double* trainfrag;
-  const double* rfrag;
-  const double* meanB;
-  const double* scl;
-  const double* ofs;
-  const int* numcol;
-  const double* tasktbl;
-  const int* taskext;
-  double* mean;
-  double* var;
-  double* cross;
-  const int64_t* pass_off;  // [npass] element offset of each pass in rfrag
-  const int* pass_w;        // [npass] window width in 16-column blocks
-  int npass;
-  int kind, dn, kd, nb, nb_ext, task_col, T, p, with_var;
-  double ybar, ysd, mean_const, prior_scale;
-  // fused qLogEI epilogue (q' = 1): disabled when qz == nullptr
-  const double* qz;
-  int qS;
-  double q_best_f, q_sign;
-  const uint8_t* q_alive;
-  double* q_scores;
-  // kernel-value cache of the multi-pass form (one slab per resident wave), see pass_body_p
-  double* kvcache;
-  int* slab_flags;  // [nslab] 0 = free, 1 = owned by a resident wave (kvcache slabs are claimed per wave)
-  int nslab, nxcc;  // slabs in total, XCD partitions
-  int ncache;    // k-blocks cached per wave = first column block of the last pass
-  int64_t nblk;  // 64-candidate blocks = workgroups
-};
-
-struct WaveCtx {
-  const double* tf;     // trainfrag + lane
-  const double* candl;  // this wave's candidate fragments in LDS, + lane
-  const double* mb;     // meanB + lane
-  const double* tbl;
-  const int* taskext;
-  double* kvc;  // this wave's kernel-value cache slab, + lane
-  int kd, kind, T, tc, q, l, dn;
-};
-
-// KIND >= 0: compile-time kernel kind (branch-free fast path); KIND < 0: runtime c.kind.
-template <bool HAS_TBL, int KIND>
-__device__ __forceinline__ void compute_kv(const WaveCtx& c, int tb, double (&kv)[4]) {
-  d4 da = {0.0, 0.0, 0.0, 0.0}, db = {0.0, 0.0, 0.0, 0.0};
-  const double* tf = c.tf + (int64_t)tb * c.kd * 64;
-  int k = 0;
-  for (; k + 3 < c.kd; k += 4) {  // loads first, then the MFMA chain (two independent accumulators)
-    const double t0 = tf[k * 64], t1 = tf[(k + 1) * 64], t2 = tf[(k + 2) * 64], t3 = tf[(k + 3) * 64];
-    const double c0 = c.candl[k * 64], c1 = c.candl[(k + 1) * 64], c2 = c.candl[(k + 2) * 64],
-                 c3 = c.candl[(k + 3) * 64];
-    da = mfma_f64(t0, c0, da);
-    db = mfma_f64(t1, c1, db);
-    da = mfma_f64(t2, c2, da);
-    db = mfma_f64(t3, c3, db);
-  }
-  for (; k < c.kd; k++) da = mfma_f64(tf[k * 64], c.candl[k * 64], da);
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const double r2 = fmax(da[r] + db[r], 0.0);
-    double v;
-    if (KIND == BBH_KERNEL_MATERN52) {
-      const double rr = sqrt(r2);
-      v = (1.0 + BBH_SQRT5 * rr + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * rr);
-    } else if (c.kind == BBH_KERNEL_MATERN12) {
-      // exp(-r) is not smooth at r = 0: the |a|^2 + |b|^2 - 2ab form loses ~sqrt(eps) there, so
-      // this (rare) kernel recomputes the distance from direct differences of the same operands
-      // (a_i = -0.5 * A_aug, b_c from LDS) — exact zeros for coinciding points.
-      const double* tfb = tf - c.l;
-      const double* cb = c.candl - c.l;
-      const int il = c.q + 4 * r, cl = c.l & 15;
-      double d2 = 0.0;
-      for (int dim = 0; dim < c.dn; dim++) {
-        const int o = (dim >> 2) * 64 + (dim & 3) * 16;
-        const double df = cb[o + cl] + 0.5 * tfb[o + il];
-        d2 = fma(df, df, d2);
-      }
-      v = (r2 > 1e7) ? 0.0 : exp(-sqrt(d2));  // r2 > 1e7 marks padding (A_aug norm slot = 1e8)
-    } else {
-      v = bbh_kfun_p(c.kind, r2);
-    }
-    if (HAS_TBL) v *= c.tbl[c.tc * c.T + c.taskext[16 * tb + 4 * r + c.q]];
-    kv[r] = v;
-  }
-}
-
-// Triangular region of a pass, k-block j0 + TT, as a compile-time recursion over TT (a plain
-// `#pragma unroll` over tt exceeds the unroll threshold and would demote acc[] to scratch).
-template <int W, int D, int TT, bool HAS_TBL, bool DO_MEAN, int KIND>
-__device__ __forceinline__ void diag_steps(const WaveCtx& c, const double* rf, int j0, d4 (&acc)[W], double (&ring)[D],
-                                           d4& accm) {
-  if constexpr (TT < W) {
-    constexpr int TOTAL = 2 * W * (W + 1);
-    constexpr int BASE = 4 * (TT * W - (TT * (TT - 1)) / 2);  // fragments consumed before this k-block
-    constexpr int CNT = W - TT;
-    double kv[4];
-    double mbv[4];
-    if (DO_MEAN) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * (j0 + TT) + r) * 64];
-    }
-    compute_kv<HAS_TBL, KIND>(c, j0 + TT, kv);
-    if (DO_MEAN) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-      for (int jj = 0; jj < CNT; jj++) {
-        const int i = BASE + r * CNT + jj;
-        acc[TT + jj] = mfma_f64(kv[r], ring[i % D], acc[TT + jj]);
-        if (i + D < TOTAL) ring[i % D] = rf[(i + D) * 64];
-        if (i % D == D - 1) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at D
-      }
-    diag_steps<W, D, TT + 1, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);
-  }
-}
-
-// One pass over the column-block window [j0, j0 + W): accumulates ||v||^2 contributions into ss
-// and (DO_MEAN) the mean/cross columns into accm.
-//
-// The R fragments of a pass are stored in exactly the order the MFMAs consume them (k-block tb,
-// k-step r, column block jj), so the operand stream is one linear walk.  It is software-pipelined
-// through a register ring of D fragments: fragment i + D is requested right after MFMA i has
-// consumed ring slot i % D (all indices are compile-time constants; 4 W and the triangular total
-// 2 W (W + 1) are multiples of D).  The first D fragments of a k-block are thus already in flight
-// while its kernel values are computed.
-template <int W, int D, bool HAS_TBL, bool DO_MEAN, int KIND>
-__device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, int j0, double (&ss)[4], d4& accm) {
-  static_assert((4 * W) % D == 0 && (2 * W * (W + 1)) % D == 0, "ring depth must divide the stream");
-  d4 acc[W];
-#pragma unroll
-  for (int jj = 0; jj < W; jj++) acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
-  double ring[D];
-#pragma unroll
-  for (int i = 0; i < D; i++) ring[i] = rf[i * 64];
-  // rectangular region: every column block of the window is active
-  for (int tb = 0; tb < j0; tb++) {
-    double kv[4];
-    double mbv[4];
-    if (DO_MEAN) {  // requested first (oldest in the in-order vmcnt queue): its wait never drains the ring
-#pragma unroll
-      for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * tb + r) * 64];
-    }
-    compute_kv<HAS_TBL, KIND>(c, tb, kv);
-    if (DO_MEAN) {  // before the ring loop, so that mbv is dead while the ring is live
-#pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4 * W; i++) {
-      acc[i % W] = mfma_f64(kv[i / W], ring[i % D], acc[i % W]);
-      ring[i % D] = rf[(i + D) * 64];
-      if (i % D == D - 1) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at D
-    }
-    rf += 4 * W * 64;
-  }
-  // triangular region: k-block j0 + tt only reaches column blocks jj >= tt
-  diag_steps<W, D, 0, HAS_TBL, DO_MEAN, KIND>(c, rf, j0, acc, ring, accm);
-#pragma unroll
-  for (int jj = 0; jj < W; jj++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) ss[r] = fma(acc[jj][r], acc[jj][r], ss[r]);
-}
-
-// =====================================================================================================
-// Software-pipelined pass (KD = k-steps of the distance GEMM known at compile time, Matérn-5/2 /
-// generic kind alike).  Ablation on the 1e6 x 20 x 512 workload: variance-GEMM stream alone 4.27 ms,
-// kernel-value stage alone 2.25 ms, un-pipelined kernel 5.96 ms — i.e. only a quarter of the VALU work
-// was hidden by the second wave of the SIMD.  Here every wave computes the kernel values of k-block
-// tb+1 in slices placed between the four k-steps of k-block tb's MFMAs (same basic block, fenced with
-// sched_barrier so the slices stay where they are): slice 0 issues the training-fragment loads and the
-// distance MFMAs, slices 1-2 evaluate two kernel values each, slice 3 carries the mean MFMAs.
-// =====================================================================================================
-template <int KD>
-__device__ __forceinline__ void kvp_load(const WaveCtx& c, int tb, double (&tfv)[KD]) {
-  const double* tf = c.tf + (int64_t)tb * KD * 64;
-#pragma unroll
-  for (int k = 0; k < KD; k++) tfv[k] = tf[k * 64];
-}
-
-template <int KD>
-__device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[KD], double (&r2v)[4]) {
-  d4 da = {0.0, 0.0, 0.0, 0.0}, db = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int k = 0; k < KD; k += 2) {
-    da = mfma_f64(tfv[k], c.candl[k * 64], da);
-    if (k + 1 < KD) db = mfma_f64(tfv[k + 1], c.candl[(k + 1) * 64], db);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) r2v[r] = da[r] + db[r];
-}
-
-// Matérn-5/2 of two scaled squared distances, cut into BBH_KV_STEPS micro-steps of 2-4 VALU
-// instructions so that the caller can place them between MFMAs in program order (the compiler's
-// scheduler clumps library sqrt()/exp() calls behind the MFMAs even when asked to interleave them
-// with sched_group_barrier).  k(r2) = (1 + s + s^2/3) exp(-s), s = sqrt(5 r2):
-//   sqrt: v_rsq_f64 seed and one Newton step (error 1.5 eps^2 = 3e-16; the Goldschmidt + Newton form
-//         with error O(eps^4) is kept behind BBH_KV_SQRT_NR=0 and measured 1 % slower);
-//   exp:  -s = k ln2 + r, |r| <= ln2/2, Taylor degree 13 (truncation 4e-18), scaled with v_ldexp_f64;
-//   s is clamped at 800 (result underflows to 0 there), r2 = 0 is handled by a 1e-300 floor.
-// Measured against the libm form on 1e6 x 512 values: tests/test_gpu_parity.py::test_pipelined_kernel_matches_plain_form, scripts/gpu_kv_accuracy.py.
-#define BBH_KV_STEPS 18
-#ifndef BBH_KV_SQRT_NR
-#define BBH_KV_SQRT_NR 1  // 1: one Newton step on the v_rsq_f64 seed (4 VALU); 0: Goldschmidt + Newton (7 VALU)
-#endif
-#ifndef BBH_KV_NU
-#define BBH_KV_NU 4  // values evaluated in lockstep (independent dependency chains per micro-step)
-#endif
-template <int NU>
-struct KvState {
-  double t[NU], y[NU], g[NU], h[NU], kf[NU], q[NU], tv[NU];
-  int ki[NU], te[NU];
-};
-
-#define BBH_KV_EACH for (int u = 0; u < NU; u++)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-template <bool HAS_TBL, int NU, int step>
-__device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int tb, int r0, const double (&r2v)[4],
-                                         double (&out)[4]) {
-  constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
-                   LN2_LO = 1.90821492927058770002e-10;
-  // register roles: t = 5 r2, later the reduced argument r; g = sqrt estimate, later s; h = half
-  // reciprocal sqrt, later the exp polynomial; y = rsq seed / residuals
-  switch (step) {
-    case 0:
-#pragma unroll
-      BBH_KV_EACH {
-        P.t[u] = __builtin_fmax(5.0 * r2v[r0 + u], 1e-300);
-        if (HAS_TBL) P.te[u] = c.taskext[16 * tb + 4 * (r0 + u) + c.q];
-      }
-      break;
-    case 1:
-#pragma unroll
-      BBH_KV_EACH P.y[u] = __builtin_amdgcn_rsq(P.t[u]);
-      break;
-#if BBH_KV_SQRT_NR  // s = u + (u/2)(1 - u y), u = t y: error 1.5 eps^2 with eps = 2^-26 of v_rsq_f64
-    case 2:
-#pragma unroll
-      BBH_KV_EACH P.g[u] = P.t[u] * P.y[u];
-      break;
-    case 3:
-#pragma unroll
-      BBH_KV_EACH P.y[u] = fma(-P.g[u], P.y[u], 1.0);
-      break;
-    case 4:
-#pragma unroll
-      BBH_KV_EACH P.h[u] = 0.5 * P.g[u];
-      break;
-    case 5: break;
-    case 6:
-#pragma unroll
-      BBH_KV_EACH P.g[u] = __builtin_fmin(fma(P.h[u], P.y[u], P.g[u]), 800.0);  // g = s from here on
-      break;
-#else
-    case 2:
-#pragma unroll
-      BBH_KV_EACH P.g[u] = P.t[u] * P.y[u];
-#pragma unroll
-      BBH_KV_EACH P.h[u] = 0.5 * P.y[u];
-      break;
-    case 3:
-#pragma unroll
-      BBH_KV_EACH P.y[u] = fma(-P.h[u], P.g[u], 0.5);
-      break;
-    case 4:
-#pragma unroll
-      BBH_KV_EACH P.g[u] = fma(P.g[u], P.y[u], P.g[u]);
-#pragma unroll
-      BBH_KV_EACH P.h[u] = fma(P.h[u], P.y[u], P.h[u]);
-      break;
-    case 5:
-#pragma unroll
-      BBH_KV_EACH P.y[u] = fma(-P.g[u], P.g[u], P.t[u]);
-      break;
-    case 6:
-#pragma unroll
-      BBH_KV_EACH P.g[u] = __builtin_fmin(fma(P.y[u], P.h[u], P.g[u]), 800.0);  // g = s from here on
-      break;
-#endif
-    case 7:
-#pragma unroll
-      BBH_KV_EACH P.kf[u] = __builtin_rint(P.g[u] * -LOG2E);
-#pragma unroll
-      BBH_KV_EACH P.q[u] = fma(P.g[u], 1.0 / 3.0, 1.0);
-      break;
-    case 8:
-#pragma unroll
-      BBH_KV_EACH P.t[u] = fma(P.kf[u], -LN2_HI, -P.g[u]);  // t = reduced argument r from here on
-#pragma unroll
-      BBH_KV_EACH P.q[u] = fma(P.q[u], P.g[u], 1.0);
-      break;
-    case 9:
-#pragma unroll
-      BBH_KV_EACH P.t[u] = fma(P.kf[u], -LN2_LO, P.t[u]);
-#pragma unroll
-      BBH_KV_EACH {
-        P.ki[u] = (int)P.kf[u];
-        if (HAS_TBL) P.tv[u] = c.tbl[c.tc * c.T + P.te[u]];
-      }
-      break;
-    case 10:
-#pragma unroll
-      BBH_KV_EACH P.h[u] = fma(1.0 / 6227020800.0, P.t[u], 1.0 / 479001600.0);
-      break;
-#define BBH_KV_HORNER2(CA, CB)                      \
-  _Pragma("unroll") BBH_KV_EACH P.h[u] = fma(P.h[u], P.t[u], CA); \
-  _Pragma("unroll") BBH_KV_EACH P.h[u] = fma(P.h[u], P.t[u], CB);
-    case 11: BBH_KV_HORNER2(1.0 / 39916800.0, 1.0 / 3628800.0) break;
-    case 12: BBH_KV_HORNER2(1.0 / 362880.0, 1.0 / 40320.0) break;
-    case 13: BBH_KV_HORNER2(1.0 / 5040.0, 1.0 / 720.0) break;
-    case 14: BBH_KV_HORNER2(1.0 / 120.0, 1.0 / 24.0) break;
-    case 15: BBH_KV_HORNER2(1.0 / 6.0, 0.5) break;
-    case 16: BBH_KV_HORNER2(1.0, 1.0) break;
-#undef BBH_KV_HORNER2
-    default:
-#pragma unroll
-      BBH_KV_EACH P.h[u] *= P.q[u];
-#pragma unroll
-      BBH_KV_EACH {
-        double v = __builtin_ldexp(P.h[u], P.ki[u]);
-        if (HAS_TBL) v *= P.tv[u];
-        out[r0 + u] = v;
-      }
-      break;
-  }
-}
-#undef BBH_KV_EACH
-
-// all micro-steps of the four values back to back (first k-block of a pass)
-template <bool HAS_TBL>
-__device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const double (&r2v)[4], double (&out)[4]) {
-  KvState<4> P;
-  static_for<0, BBH_KV_STEPS>([&](auto st) __attribute__((always_inline)) {
-    kv_micro<HAS_TBL, 4, decltype(st)::value>(P, c, tb, 0, r2v, out);
-  });
-}
-
-// one k-block: CNT column blocks starting at accumulator TT; kv = values of this block, kvn = values of
-// the next block (computed here when NEXT); fragments are read from rf (+ lane) in consumption order
-// NEXT: how the kernel values of k-block tb + 1 are obtained while this block's MFMAs run:
-//   BBH_NEXT_NONE (last block of a pass), BBH_NEXT_COMPUTE (micro-steps between the MFMAs),
-//   BBH_NEXT_LOAD (from the wave's kernel-value cache: an earlier pass computed and stored them).
-// STORE: write this block's values to the cache (diagonal blocks of every pass but the last).
-#ifndef BBH_RING
-#define BBH_RING 8
-#endif
-#define BBH_NEXT_NONE 0
-#define BBH_NEXT_COMPUTE 1
-#define BBH_NEXT_LOAD 2
-template <int W, int CNT, int TT, int KD, bool HAS_TBL, bool DO_MEAN, int NEXT, bool STORE, int BASE, int REM>
-__device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int tb, const double (&kv)[4],
-                                         double (&kvn)[4], d4 (&acc)[W], d4& accm, double (&ring)[BBH_RING]) {
-  // The R fragments of a pass are one linear stream (k-block, k-step, column block); they flow through
-  // a BBH_RING-deep register ring that is never drained inside a pass: the fragment BBH_RING ahead is
-  // requested right after a slot is consumed, across k-block boundaries too.  A block holds 4 CNT
-  // fragments, so the slot of its first fragment is BASE in {0, 4} - a compile-time constant.
-  // (2 waves x 8 loads in flight per SIMD cover the L2 latency; depth 4 measurably does not.)
-  constexpr int D = BBH_RING;
-  constexpr int TOT = 4 * CNT;
-  double tfv[KD];
-  double r2v[4];
-  double mbv[4];
-  KvState<BBH_KV_NU> P;
-  if (NEXT == BBH_NEXT_COMPUTE) kvp_load<KD>(c, tb + 1, tfv);
-  if (NEXT == BBH_NEXT_LOAD) {
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) kvn[rr] = c.kvc[(int64_t)(tb + 1) * 256 + rr * 64];
-  }
-  if (STORE) {
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) c.kvc[(int64_t)tb * 256 + rr * 64] = kv[rr];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
-    constexpr int r = decltype(rc)::value;
-    if (DO_MEAN && r == 3) {
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) mbv[rr] = c.mb[(int64_t)(4 * tb + rr) * 64];
-    }
-    static_for<0, CNT>([&](auto jc) __attribute__((always_inline)) {
-      constexpr int jj = decltype(jc)::value;
-      constexpr int i = r * CNT + jj;
-      acc[TT + jj] = mfma_f64(kv[r], ring[(BASE + i) % D], acc[TT + jj]);
-      if (i + D < TOT + REM) ring[(BASE + i) % D] = rf[(i + D) * 64];
-      if constexpr (NEXT == BBH_NEXT_COMPUTE && (r == 1 || r == 2)) {
-        if constexpr (BBH_KV_NU == 4) {  // four values in lockstep, micro-steps spread over both slices
-          constexpr int m = (r - 1) * CNT + jj;
-          static_for<(m * BBH_KV_STEPS) / (2 * CNT), ((m + 1) * BBH_KV_STEPS) / (2 * CNT)>(
-              [&](auto st) __attribute__((always_inline)) {
-                kv_micro<HAS_TBL, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 0, r2v, kvn);
-              });
-        } else {  // two values per slice
-          static_for<(jj * BBH_KV_STEPS) / CNT, ((jj + 1) * BBH_KV_STEPS) / CNT>(
-              [&](auto st) __attribute__((always_inline)) {
-                kv_micro<HAS_TBL, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 2 * (r - 1), r2v, kvn);
-              });
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if (NEXT == BBH_NEXT_COMPUTE && r == 0) kvp_dist<KD>(c, tfv, r2v);
-    if (DO_MEAN && r == 3) {
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) accm = mfma_f64(kv[rr], mbv[rr], accm);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-template <int W, int TT, int KD, bool HAS_TBL, bool DO_MEAN, bool STORE>
-__device__ __forceinline__ void diag_steps_p(const WaveCtx& c, const double* rf, int j0, double (&kv)[4], d4 (&acc)[W],
-                                             d4& accm, double (&ring)[BBH_RING]) {
-  if constexpr (TT < W) {
-    double kvn[4];
-    constexpr int NEXT = (TT + 1 < W) ? BBH_NEXT_COMPUTE : BBH_NEXT_NONE;
-    constexpr int BASE = (4 * (TT * W - (TT * (TT - 1)) / 2)) % BBH_RING;  // slot of the first fragment
-    constexpr int REM = 2 * (W - TT) * (W - TT - 1);  // fragments of this pass after this block
-    kblock_p<W, W - TT, TT, KD, HAS_TBL, DO_MEAN, NEXT, STORE, BASE, REM>(c, rf, j0 + TT, kv, kvn, acc, accm, ring);
-    if (NEXT) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
-    }
-    diag_steps_p<W, TT + 1, KD, HAS_TBL, DO_MEAN, STORE>(c, rf + 4 * (W - TT) * 64, j0, kv, acc, accm, ring);
-  }
-}
-
-// One pass over the column-block window [j0, j0 + W).  Kernel values are computed once per k-block
-// and wave: the diagonal blocks [j0, j0 + W) of every pass but the last store theirs to the wave's
-// cache slab (CACHE), and the rectangular region of later passes (k-blocks < j0) reads them back one
-// block ahead instead of redoing the distance GEMM and the Matérn evaluation (fp64 VALU work is not
-// hidden behind fp64 MFMAs on gfx950 - both issue to the same DP pipe, scripts/mfma_valu_overlap_probe.hip).
-template <int W, int KD, bool HAS_TBL, bool DO_MEAN, bool CACHE>
-__device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, int j0, double (&ss)[4], d4& accm) {
-  d4 acc[W];
-#pragma unroll
-  for (int jj = 0; jj < W; jj++) acc[jj] = (d4){0.0, 0.0, 0.0, 0.0};
-  double kv[4], kvn[4], ring[BBH_RING];
-#pragma unroll
-  for (int i = 0; i < BBH_RING; i++) ring[i] = rf[i * 64];
-  const bool cached = CACHE && j0 > 0;  // CACHE: the launch has more than one pass
-  if (cached) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) kv[r] = c.kvc[r * 64];
-  } else {  // first k-block of the pass: not overlapped
-    double tfv[KD], r2v[4];
-    kvp_load<KD>(c, 0, tfv);
-    kvp_dist<KD>(c, tfv, r2v);
-    kv_all<HAS_TBL>(c, 0, r2v, kv);
-  }
-  if (CACHE) {
-    for (int tb = 0; tb + 1 < j0; tb++) {  // rectangular region, next block cached too
-      kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_LOAD, false, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring);
-#pragma unroll
-      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
-      rf += 4 * W * 64;
-    }
-    if (j0 > 0) {  // last rectangular block: the next one (j0) is this pass's first diagonal block
-      kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_COMPUTE, false, 0, 1 << 20>(c, rf, j0 - 1, kv, kvn, acc, accm, ring);
-#pragma unroll
-      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
-      rf += 4 * W * 64;
-    }
-    diag_steps_p<W, 0, KD, HAS_TBL, DO_MEAN, !DO_MEAN>(c, rf, j0, kv, acc, accm, ring);
-  } else {
-    for (int tb = 0; tb < j0; tb++) {  // no cache: every block recomputes the next block's values
-      kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_COMPUTE, false, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring);
-#pragma unroll
-      for (int r = 0; r < 4; r++) kv[r] = kvn[r];
-      rf += 4 * W * 64;
-    }
-    diag_steps_p<W, 0, KD, HAS_TBL, DO_MEAN, false>(c, rf, j0, kv, acc, accm, ring);
-  }
-#pragma unroll
-  for (int jj = 0; jj < W; jj++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) ss[r] = fma(acc[jj][r], acc[jj][r], ss[r]);
-}
-
-template <bool HAS_TBL, int KIND, int KD>
-__global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const FusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double s_cand[];  // [4 waves][kd][64] (+ z[qS])
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int cnd = l & 15, q = l >> 4;
-  double* s_z = s_cand + 4 * (int64_t)a.kd * 64;
-  if (a.qz) {  // the only workgroup barrier, before any wave may leave
-    for (int s = threadIdx.x; s < a.qS; s += 256) s_z[s] = a.qz[s];
-    __syncthreads();
-  }
-  // per-wave state only from here on: no workgroup barrier is used below.  (A persistent variant - two
-  // workgroups per CU walking the candidate blocks - measured 5 % slower than one workgroup per block:
-  // the hardware dispatcher balances the tail better.)
-  const int64_t blk = blockIdx.x;
-  const int64_t tile0 = (blk * 4 + w) * 16;
-  if (tile0 >= a.N) return;  // whole wave out of range
-  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
-  const double* xr = a.X + row * a.ldx;
-  double* candw = s_cand + (int64_t)w * a.kd * 64;
-
-  // ---- candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2] -------------------
-  double nbsum = 0.0;
-  for (int k = 0; k < a.kd; k++) {
-    const int dim = 4 * k + q;
-    double v = 0.0;
-    if (dim < a.dn) {
-      v = fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
-      nbsum = fma(v, v, nbsum);
-    }
-    candw[k * 64 + l] = v;
-  }
-  nbsum += __shfl_xor(nbsum, 16, 64);
-  nbsum += __shfl_xor(nbsum, 32, 64);
-  {
-    const int k1 = a.dn >> 2, q1 = a.dn & 3;  // slot dn: 1.0
-    if (q == q1) candw[k1 * 64 + l] = 1.0;
-    const int k2 = (a.dn + 1) >> 2, q2 = (a.dn + 1) & 3;  // slot dn + 1: |b|^2
-    if (q == q2) candw[k2 * 64 + l] = nbsum;
-  }
-  int tc = 0;
-  if (HAS_TBL && a.task_col >= 0) {
-    tc = (int)xr[a.task_col];
-    tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
-  }
-
-  WaveCtx c;
-  c.tf = a.trainfrag + l;
-  c.candl = candw + l;
-  c.mb = a.meanB + l;
-  c.tbl = a.tasktbl;
-  c.taskext = a.taskext;
-  // Claim a kernel-value cache slab for this wave.  The pool is partitioned by XCD (HW_REG_XCC_ID): a
-  // slab is only ever touched through one XCD's L2, so re-use by a later wave needs no L2 write-back
-  // (an agent-scope release fence per wave costs 30 % of the kernel).  Each partition has twice as
-  // many slabs as the XCD can hold resident waves (8 per CU), so linear probing from a hashed start
-  // ends after a few attempts.
-  int slab = 0;
-  if (a.kvcache) {
-    if (l == 0) {
-      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) % (unsigned)a.nxcc;  // XCC_ID[3:0]
-      const unsigned per = (unsigned)(a.nslab / a.nxcc);
-      unsigned sidx = (unsigned)(((uint64_t)(blk * 4 + w) * 2654435761ull) % per);
-      int* flags = a.slab_flags + xcc * per;
-      while (atomicCAS(&flags[sidx], 0, 1) != 0) sidx = (sidx + 1 == per) ? 0u : sidx + 1;
-      slab = (int)(xcc * per + sidx);
-    }
-    slab = __builtin_amdgcn_readfirstlane(slab);
-  }
-  c.kvc = a.kvcache ? a.kvcache + (int64_t)slab * a.ncache * 256 + l : nullptr;
-  c.kd = a.kd;
-  c.kind = a.kind;
-  c.T = a.T;
-  c.tc = tc;
-  c.q = q;
-  c.l = l;
-  c.dn = a.dn;
-
-  double ss[4] = {0.0, 0.0, 0.0, 0.0};
-  d4 accm = {0.0, 0.0, 0.0, 0.0};
-  double kv[4];
-
-  if (a.with_var) {
-    int j0 = 0;
-    for (int ps = 0; ps < a.npass; ps++) {
-      const int W = a.pass_w[ps];
-      const double* rf = a.rfrag + a.pass_off[ps] + l;
-      const bool last = (ps == a.npass - 1);
-      if constexpr (KD > 0) {  // software-pipelined passes
-        const bool use_cache = (a.kvcache != nullptr);
-        if (!last) {
-          if (use_cache)
-            pass_body_p<16, KD, HAS_TBL, false, true>(c, rf, j0, ss, accm);
-          else
-            pass_body_p<16, KD, HAS_TBL, false, false>(c, rf, j0, ss, accm);
-        } else if (use_cache) {
-          switch (W) {
-            case 4: pass_body_p<4, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
-            case 8: pass_body_p<8, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
-            case 12: pass_body_p<12, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
-            default: pass_body_p<16, KD, HAS_TBL, true, true>(c, rf, j0, ss, accm); break;
-          }
-        } else {
-          switch (W) {
-            case 4: pass_body_p<4, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
-            case 8: pass_body_p<8, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
-            case 12: pass_body_p<12, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
-            default: pass_body_p<16, KD, HAS_TBL, true, false>(c, rf, j0, ss, accm); break;
-          }
-        }
-      } else if (!last) {
-        pass_body<16, 8, HAS_TBL, false, KIND>(c, rf, j0, ss, accm);
-      } else {
-        switch (W) {
-          case 4: pass_body<4, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
-          case 8: pass_body<8, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
-          case 12: pass_body<12, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
-          default: pass_body<16, 8, HAS_TBL, true, KIND>(c, rf, j0, ss, accm); break;
-        }
-      }
-      j0 += W;
-    }
-    // pending block(s): mean/cross columns only
-    for (int tb = a.nb; tb < a.nb_ext; tb++) {
-      compute_kv<HAS_TBL, KIND>(c, tb, kv);
-#pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
-    }
-  } else {
-    for (int tb = 0; tb < a.nb_ext; tb++) {
-      compute_kv<HAS_TBL, KIND>(c, tb, kv);
-#pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
-    }
-  }
-
-  if (a.kvcache && l == 0) atomicExch(&a.slab_flags[slab], 0);  // every cached value has been read back
-  // ---- epilogue: lane (q, cnd), reg r  <->  candidate q + 4 r, column cnd -------------------
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    double s = ss[r];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    ss[r] = s;
-  }
-  const double s2 = a.ysd * a.ysd;
-  double mval[4], vval[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int m = q + 4 * r;  // candidate within the tile
-    const int tcm = __shfl(tc, m, 64);
-    const int64_t gi = tile0 + m;
-    double pv = a.prior_scale;
-    if (HAS_TBL) pv = a.tasktbl[tcm * a.T + tcm];
-    mval[r] = a.ybar + a.ysd * (a.mean_const + accm[r]);  // meaningful in the cnd == 0 lanes
-    vval[r] = s2 * (pv - ss[r]);
-    if (gi < a.N) {
-      if (cnd == 0) {
-        if (a.mean) a.mean[gi] = mval[r];
-        if (a.with_var && a.var) a.var[gi] = vval[r];
-      } else if (cnd <= a.p && a.cross) {
-        a.cross[gi * a.p + (cnd - 1)] = s2 * accm[r];
-      }
-    }
-  }
-  // ---- fused qLogEI (q' = 1): lane (q, cnd) evaluates samples s = q, q+4, ... of candidate cnd ---
-  if (a.qz && a.with_var) {
-    double mu = 0.0, vr = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {  // candidate cnd = q' + 4 r' lives in lane 16 q', register r'
-      const double tm = __shfl(mval[r], (cnd & 3) * 16, 64);
-      const double tv = __shfl(vval[r], (cnd & 3) * 16, 64);
-      if ((cnd >> 2) == r) {
-        mu = tm;
-        vr = tv;
-      }
-    }
-    if (!(vr > 0.0)) {  // 1x1 psd_safe_cholesky jitter rule
-      vr += 1e-8;
-      if (!(vr > 0.0)) {
-        vr += 1e-7;
-        if (!(vr > 0.0)) vr += 1e-6;
-      }
-    }
-    const double inv_tau = 1e6;  // 1 / tau_relu
-    const double ca = (a.q_sign * mu - a.q_best_f) * inv_tau;
-    const double cb = a.q_sign * sqrt(fmax(vr, 0.0)) * inv_tau;
-    double sum = 0.0;
-    for (int s = q; s < a.qS; s += 4) {
-      const double t = fma(cb, s_z[s], ca);
-      double sp;
-      if (t > 20.0)
-        sp = t;
-      else if (t < -750.0)
-        sp = 0.0;
-      else
-        sp = log1p(exp(t));
-      sum += sp + 0.1 / fma(t, t, 1.0);
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const int64_t gi = tile0 + cnd;
-    if (q == 0 && gi < a.N) {
-      double sc = log(1e-6) + log(sum) - log((double)a.qS);
-      if (a.q_alive && !a.q_alive[gi]) sc = -INFINITY;
-      a.q_scores[gi] = sc;
-    }
-  }
-}
+// Passes of width W keep 8 W accumulator VGPRs (128 for W = 16), i.e. two waves per SIMD.  fp64 VALU
+// and fp64 MFMA instructions share the SIMD's DP pipe on gfx950 (scripts/mfma_valu_overlap_probe.hip), so
+// stage (2) is not hidden but minimised: software-pipelined micro-steps between the MFMAs, a staged
+// rsq/Taylor Matérn evaluation, and a per-wave cache of kernel values instead of recomputation in later
+// passes.  K(X*,X) is never materialised.  Device code: bbh_fused.h (instantiated per k-step count in
+// bbh_fused_kd{0,4,6,8}.hip); this file holds operand packing, launch logic and the related kernels.
+#include "bbh_fused.h"
 
 // ---- operand packing ------------------------------------------------------------------------
 // R fragments of one pass: for tb in [0, j1), r in 0..3, jb in [max(j0, tb), j1):
@@ -1012,24 +298,14 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     hipEventCreate(&e1);
     hipEventRecord(e0, h->stream);
   }
-#define BBH_LAUNCH_KD(TBL, KND, KDV) hipLaunchKernelGGL((bbh_fused_posterior_kernel<TBL, KND, KDV>), grid, block, lds, h->stream, a)
-#define BBH_LAUNCH_M52(TBL)                                     \
-  do {                                                          \
-    if (kdp == 4) BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 4);   \
-    else if (kdp == 6) BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 6); \
-    else if (kdp == 8) BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 8); \
-    else BBH_LAUNCH_KD(TBL, BBH_KERNEL_MATERN52, 0);            \
-  } while (0)
-  if (has_tbl && m52)
-    BBH_LAUNCH_M52(true);
-  else if (has_tbl)
-    BBH_LAUNCH_KD(true, -1, 0);
-  else if (m52)
-    BBH_LAUNCH_M52(false);
+  if (kdp == 4)
+    bbh_fused_launch_kd4(has_tbl, grid, block, lds, h->stream, a);
+  else if (kdp == 6)
+    bbh_fused_launch_kd6(has_tbl, grid, block, lds, h->stream, a);
+  else if (kdp == 8)
+    bbh_fused_launch_kd8(has_tbl, grid, block, lds, h->stream, a);
   else
-    BBH_LAUNCH_KD(false, -1, 0);
-#undef BBH_LAUNCH_M52
-#undef BBH_LAUNCH_KD
+    bbh_fused_launch_kd0(has_tbl, m52, grid, block, lds, h->stream, a);
   if (timed) {
     hipEventRecord(e1, h->stream);
     h->pending_events.emplace_back(e0, e1);
