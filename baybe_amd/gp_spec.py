@@ -47,6 +47,7 @@ class GPSpec:
     ls_prior: tuple | None = None  # ("gamma", concentration, rate) | ("lognormal", mu, sigma)
     ls_init: float | None = None
     noise_lower: float = MIN_INFERRED_NOISE_LEVEL
+    noise_constraint: str = "box"  # "box" (GreaterThan(lower, transform=None)) | "softplus" (gpytorch default)
     noise_prior: tuple | None = None
     noise_init: float | None = None
     outputscale_prior: tuple | None = None
@@ -83,6 +84,80 @@ class GPSpec:
             noise_init=(nconc - 1.0) / nrate,
             criterion="mll" if n_tasks == 1 else "loo",
         )
+
+
+PRESETS = ("BAYBE", "BOTORCH", "CHEN", "EDBO", "EDBO_SMOOTHED", "HVARFNER")
+
+
+def from_preset(preset: str, d: int, lo, hi, task_idx: int | None = None, n_tasks: int = 1,
+                edbo_encodings: bool = False) -> GPSpec:
+    """The reference's GP presets as data (``GaussianProcessPreset``, presets/core.py:8-27):
+
+    * ``BAYBE`` — ``GPSpec.baybe_default`` (presets/baybe.py);
+    * ``EDBO`` — ScaleKernel(Matérn-5/2), Gamma priors / initial values switched on the effective
+      dimensionality (presets/edbo.py:75-119 kernel, :147-172 likelihood); ``edbo_encodings`` = the search
+      space has a substance parameter with a MORDRED/RDKIT encoding (presets/edbo.py:39-54);
+    * ``EDBO_SMOOTHED`` — the same moments interpolated linearly between d = 8 and d = 75
+      (presets/edbo_smoothed.py:60-72, :118-123);
+    * ``CHEN`` — lengthscale 0.4 sqrt(d) + 4, Gamma(2 l, 2) / Gamma(l, 1) priors (presets/chen.py:43-60),
+      default BayBE likelihood;
+    * ``HVARFNER`` / ``BOTORCH`` (single task) — BoTorch's dimension-scaled defaults: RBF ARD,
+      LogNormal(sqrt 2 + log(d)/2, sqrt 3) lengthscale prior with l >= 0.025 (no transform), noise
+      LogNormal(-4, 1) with sigma^2 >= 1e-4, both started at the prior mode, plain MLL
+      (presets/hvarfner.py:60-71, :118-122; botorch ``get_covar_module_with_dim_scaled_prior``).
+      Their multi-task forms use a per-task mean and a multi-task likelihood and are not on this path.
+
+    Kernels built from BayBE kernel objects use gpytorch's ``Positive()`` (softplus) constraints and the
+    likelihoods of EDBO/EDBO_SMOOTHED gpytorch's default ``GreaterThan(1e-4)`` with a softplus transform.
+    Transfer learning wraps the numerical kernel into the same ICM structure as the BAYBE preset and
+    switches the criterion to LOO (``_enable_transfer_learning`` / ``_MLLForNonTLFitCriterionFactory``)."""
+    name = str(getattr(preset, "value", preset)).upper()
+    if name not in PRESETS:
+        raise ValueError(f"unknown Gaussian process preset {preset!r}; available: {PRESETS}")
+    if name == "BAYBE":
+        return GPSpec.baybe_default(d, lo, hi, task_idx=task_idx, n_tasks=n_tasks)
+    spec = GPSpec.baybe_default(d, lo, hi, task_idx=task_idx, n_tasks=n_tasks)
+    dn = spec.dn
+    if name in ("HVARFNER", "BOTORCH"):
+        if n_tasks > 1:
+            raise NotImplementedError(f"the multi-task form of the {name} preset is not on the HIP path")
+        mu, sd = math.sqrt(2.0) + 0.5 * math.log(dn), math.sqrt(3.0)
+        spec.kernel = "rbf"
+        spec.ls_constraint, spec.ls_lower = "box", 2.5e-2
+        spec.ls_prior, spec.ls_init = ("lognormal", mu, sd), math.exp(mu - sd * sd)
+        spec.noise_prior, spec.noise_init = ("lognormal", -4.0, 1.0), math.exp(-4.0 - 1.0)
+        spec.criterion = "mll"
+        return spec
+    spec.use_outputscale = True
+    spec.ls_constraint = "softplus"
+    if name == "CHEN":
+        ls = 0.4 * math.sqrt(dn) + 4.0
+        spec.ls_prior, spec.ls_init = ("gamma", 2.0 * ls, 2.0), ls
+        spec.outputscale_prior, spec.outputscale_init = ("gamma", 1.0 * ls, 1.0), ls
+        return spec  # likelihood: the BayBE default (LazyGaussianLikelihoodFactory)
+    spec.noise_constraint = "softplus"
+    if name == "EDBO":
+        switching = bool(edbo_encodings) and dn >= 50
+        if dn < 5:
+            lp, l0, op, o0, nprior, n0 = (1.2, 1.1), 0.2, (5.0, 0.5), 8.0, (1.05, 0.5), 0.1
+        elif switching and dn < 100:
+            lp, l0, op, o0, nprior, n0 = (2.0, 0.2), 5.0, (5.0, 0.5), 8.0, (1.5, 0.1), 5.0
+        elif switching:
+            lp, l0, op, o0, nprior, n0 = (2.0, 0.1), 10.0, (2.0, 0.1), 10.0, (1.5, 0.1), 5.0
+        else:
+            lp, l0, op, o0, nprior, n0 = (3.0, 1.0), 2.0, (5.0, 0.2), 20.0, (1.5, 0.1), 5.0
+    else:  # EDBO_SMOOTHED
+        lim = (8, 75)
+        lp = (float(np.interp(dn, lim, [1.2, 2.5])), float(np.interp(dn, lim, [1.1, 0.55])))
+        l0 = float(np.interp(dn, lim, [0.2, 6.0]))
+        op = (float(np.interp(dn, lim, [5.0, 3.5])), float(np.interp(dn, lim, [0.5, 0.15])))
+        o0 = float(np.interp(dn, lim, [8.0, 15.0]))
+        nprior = (float(np.interp(dn, lim, [1.05, 1.5])), float(np.interp(dn, lim, [0.5, 0.1])))
+        n0 = float(np.interp(dn, lim, [0.1, 5.0]))
+    spec.ls_prior, spec.ls_init = ("gamma",) + lp, l0
+    spec.outputscale_prior, spec.outputscale_init = ("gamma",) + op, o0
+    spec.noise_prior, spec.noise_init = ("gamma",) + nprior, n0
+    return spec
 
 
 @dataclass
@@ -158,7 +233,8 @@ def theta_from_params(spec: GPSpec, p: GPParams) -> np.ndarray:
 
 # ---- raw optimiser vector (order of mll.named_parameters(): noise, mean, kernel parameters) ----
 def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
-    parts = [np.array([p.noise]), np.array([p.mean])]
+    nz = np.array([p.noise]) if spec.noise_constraint == "box" else inv_softplus(np.array([p.noise - spec.noise_lower]))
+    parts = [nz, np.array([p.mean])]
     if spec.use_outputscale:
         parts.append(inv_softplus(np.array([p.outputscale])))
     parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
@@ -171,7 +247,8 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
 def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     raw = np.asarray(raw, dtype=np.float64)
     i = 0
-    noise = float(raw[i]); i += 1
+    noise = float(raw[i]) if spec.noise_constraint == "box" else spec.noise_lower + float(softplus(raw[i]))
+    i += 1
     mean = float(raw[i]); i += 1
     os_ = 1.0
     if spec.use_outputscale:
@@ -188,7 +265,7 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
 
 def raw_bounds(spec: GPSpec):
     """Only constraints with ``transform=None`` become L-BFGS-B bounds (botorch fit)."""
-    b = [(spec.noise_lower, None), (None, None)]
+    b = [((spec.noise_lower, None) if spec.noise_constraint == "box" else (None, None)), (None, None)]
     if spec.use_outputscale:
         b.append((None, None))
     b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
@@ -227,7 +304,10 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
     if spec.use_outputscale:
         lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
     total = value + lp_ls + lp_nz + lp_os
-    g = [np.array([g_noise + glp_nz[0]]), np.array([g_mean])]
+    g_nz = g_noise + glp_nz[0]
+    if spec.noise_constraint != "box":
+        g_nz = g_nz * float(sigmoid(raw[0]))
+    g = [np.array([g_nz]), np.array([g_mean])]
     i = 2
     if spec.use_outputscale:
         g.append(np.array([(g_os + glp_os[0]) * float(sigmoid(raw[i]))]))

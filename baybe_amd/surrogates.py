@@ -31,6 +31,17 @@ def _frame_hash(df: pd.DataFrame) -> str:
     return joblib.hash(df)
 
 
+def _has_edbo_encoding(searchspace) -> bool:
+    """Any substance parameter with a MORDRED / RDKIT / RDKIT2DDESCRIPTORS encoding (presets/edbo.py:39-54)."""
+    params = getattr(getattr(searchspace, "discrete", None), "parameters", ()) or ()
+    for prm in params:
+        enc = getattr(prm, "encoding", None)
+        name = str(getattr(enc, "name", enc)).upper() if enc is not None else ""
+        if name in ("MORDRED", "RDKIT", "RDKIT2DDESCRIPTORS") and type(prm).__name__ == "SubstanceParameter":
+            return True
+    return False
+
+
 def _target_sign(target) -> float:
     """+1 maximise / -1 minimise.  Only identity transformations are on the HIP path (row a9)."""
     tr = getattr(target, "transformation", None)
@@ -57,6 +68,10 @@ class HipGaussianProcessSurrogate:
     use_outputscale: bool = field(default=False)
     """Wrap the base kernel in a ScaleKernel (user kernels); the BAYBE preset has none."""
 
+    preset: str = field(default="BAYBE", converter=lambda v: str(getattr(v, "value", v)).upper())
+    """``GaussianProcessPreset`` (presets/core.py:8-27): BAYBE | BOTORCH | CHEN | EDBO | EDBO_SMOOTHED |
+    HVARFNER — prior tables, constraints and initial values as data (``gp_spec.from_preset``)."""
+
     device: int = field(default=0)
     """HIP device ordinal."""
 
@@ -72,6 +87,11 @@ class HipGaussianProcessSurrogate:
     _target_index = field(default=None, eq=False, repr=False)
     """Which target of a multi-target objective this (replicated) model represents (None = the
     single target of a single-target objective)."""
+
+    @classmethod
+    def from_preset(cls, preset, **kwargs):
+        """``GaussianProcessSurrogate.from_preset`` (gaussian_process/core.py:215-246)."""
+        return cls(preset=preset, **kwargs)
 
     @classmethod
     def is_available(cls) -> bool:
@@ -96,6 +116,7 @@ class HipGaussianProcessSurrogate:
             int(getattr(searchspace, "n_tasks", 1)),
             tuple((t.name, bool(getattr(t, "minimize", False))) for t in objective.targets),
             self._target_index,
+            self.preset,
             _frame_hash(measurements),
         )
         if self._engine is not None and mhash == self._measurements_hash:
@@ -115,7 +136,14 @@ class HipGaussianProcessSurrogate:
         bounds = np.asarray(searchspace.scaling_bounds.to_numpy(), dtype=np.float64)
         task_idx = getattr(searchspace, "task_idx", None)
         n_tasks = int(getattr(searchspace, "n_tasks", 1))
-        if isinstance(self.kernel, str):
+        if self.preset != "BAYBE":
+            from baybe_amd.gp_spec import from_preset
+
+            if not isinstance(self.kernel, str) or self.kernel != "matern52" or self.use_outputscale:
+                raise ValueError("a preset fixes the kernel; pass either preset=... or kernel=...")
+            spec = from_preset(self.preset, train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
+                               edbo_encodings=_has_edbo_encoding(searchspace))
+        elif isinstance(self.kernel, str):
             spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
                                         kernel=self.kernel)
             spec.use_outputscale = bool(self.use_outputscale)
@@ -210,7 +238,7 @@ class HipCompositeSurrogate:
         if len(self._models) != m:
             self._models = [
                 HipGaussianProcessSurrogate(kernel=self.template.kernel, use_outputscale=self.template.use_outputscale,
-                                            device=self.template.device, target_index=i)
+                                            preset=self.template.preset, device=self.template.device, target_index=i)
                 for i in range(m)
             ]
         for model in self._models:

@@ -78,6 +78,7 @@ class GPSpec:
     ls_prior: tuple | None = None  # ("gamma", concentration, rate)
     ls_init: float | None = None
     noise_lower: float = MIN_INFERRED_NOISE_LEVEL
+    noise_constraint: str = "box"  # "box": sigma^2 >= lower, no transform | "softplus": lower + softplus(raw)
     noise_prior: tuple | None = None
     noise_init: float | None = None
     outputscale_prior: tuple | None = None
@@ -364,7 +365,10 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
 
 # ---- raw <-> natural packing (order = mll.named_parameters(): noise, mean, kernel) ----
 def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
-    parts = [np.array([p.noise]), np.array([p.mean])]
+    # gpytorch's default noise constraint GreaterThan(1e-4) has a softplus transform (EDBO likelihoods,
+    # presets/edbo.py:170-172); botorch's / BayBE's own likelihoods use transform=None [UPSTREAM A6]
+    nz = np.array([p.noise]) if spec.noise_constraint == "box" else inv_softplus(np.array([p.noise - spec.noise_lower]))
+    parts = [nz, np.array([p.mean])]
     if spec.use_outputscale:
         parts.append(inv_softplus(np.array([p.outputscale])))
     parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
@@ -377,7 +381,8 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
 def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     raw = np.asarray(raw, dtype=np.float64)
     i = 0
-    noise = float(raw[i]); i += 1
+    noise = float(raw[i]) if spec.noise_constraint == "box" else spec.noise_lower + float(softplus(raw[i]))
+    i += 1
     mean = float(raw[i]); i += 1
     os_ = 1.0
     if spec.use_outputscale:
@@ -394,7 +399,8 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
 
 def raw_bounds(spec: GPSpec) -> list[tuple[float | None, float | None]]:
     """L-BFGS-B bounds: only constraints with transform=None become bounds [UPSTREAM A6]."""
-    b: list[tuple[float | None, float | None]] = [(spec.noise_lower, None), (None, None)]
+    b: list[tuple[float | None, float | None]] = [
+        (spec.noise_lower, None) if spec.noise_constraint == "box" else (None, None), (None, None)]
     if spec.use_outputscale:
         b.append((None, None))
     b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
@@ -417,7 +423,10 @@ def fit_objective(spec: GPSpec, raw: np.ndarray, Xn: np.ndarray, ystd: np.ndarra
     if spec.use_outputscale:
         lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
     total = dt.value + lp_ls + lp_nz + lp_os
-    g = [np.array([dt.g_noise + glp_nz[0]]), np.array([dt.g_mean])]
+    g_nz = dt.g_noise + glp_nz[0]
+    if spec.noise_constraint != "box":
+        g_nz = g_nz * float(sigmoid(raw[0]))
+    g = [np.array([g_nz]), np.array([dt.g_mean])]
     i = 2
     if spec.use_outputscale:
         g.append(np.array([(dt.g_outputscale + glp_os[0]) * float(sigmoid(raw[i]))]))

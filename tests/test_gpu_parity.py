@@ -38,8 +38,9 @@ def _ospec(spec):
         d=spec.d, num_idx=spec.num_idx, lo=spec.lo[spec.num_idx], hi=spec.hi[spec.num_idx], kernel=spec.kernel,
         task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
         ls_constraint=spec.ls_constraint, ls_lower=spec.ls_lower, ls_prior=spec.ls_prior, ls_init=spec.ls_init,
-        noise_lower=spec.noise_lower, noise_prior=spec.noise_prior, noise_init=spec.noise_init,
-        outputscale_prior=spec.outputscale_prior, criterion=spec.criterion)
+        noise_lower=spec.noise_lower, noise_constraint=spec.noise_constraint, noise_prior=spec.noise_prior,
+        noise_init=spec.noise_init, outputscale_prior=spec.outputscale_prior, outputscale_init=spec.outputscale_init,
+        criterion=spec.criterion)
 
 
 def _oparams(p):
@@ -120,6 +121,30 @@ def test_device_fit_reaches_the_oracle_optimum(gp, n, d):
     assert math.isclose(fi.fun, fo.fun, rel_tol=1e-8)
     assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=1e-4)
     assert math.isclose(fi.params.noise, fo.params.noise, rel_tol=1e-4)
+
+
+@pytest.mark.parametrize("preset", ["EDBO", "EDBO_SMOOTHED", "CHEN", "HVARFNER"])
+def test_preset_fit_on_device_reaches_the_oracle_optimum(gp, preset):
+    """The reference's other GP presets are data for the same kernels: ScaleKernel +
+    softplus-constrained lengthscales / noise (EDBO family, CHEN), RBF with LogNormal priors (HVARFNER)."""
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    n, d = 50, 6
+    X, Xt, y = make_problem(500, d, n, seed=8)
+    spec = gp_spec.from_preset(preset, d, np.zeros(d), np.ones(d))
+    gp.set_model(spec, Xt, y)
+    fi = gp.fit()
+    ospec = _ospec(spec)
+    fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+    # strong priors make these objectives flat near the optimum: L-BFGS-B may stop a few 1e-7 apart
+    assert math.isclose(fi.fun, fo.fun, rel_tol=1e-6)
+    assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=2e-2)
+    assert math.isclose(fi.params.noise, fo.params.noise, rel_tol=2e-2)
+    assert math.isclose(fi.params.outputscale, fo.params.outputscale, rel_tol=2e-2)
+    m, v = gp.posterior(X)
+    mo, vo = go.GPModel(ospec, _oparams(fi.params), Xt, y).posterior(X)
+    assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL)
 
 
 # ---- posterior -----------------------------------------------------------------------------------

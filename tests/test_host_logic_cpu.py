@@ -1,6 +1,8 @@
 """Host-side fit bookkeeping (baybe_amd/gp_spec.py) against the oracle, using the oracle's data
 term in place of the device call (checker role only)."""
 
+import math
+
 import numpy as np
 import pytest
 
@@ -14,8 +16,9 @@ def _ospec(spec):
         d=spec.d, num_idx=spec.num_idx, lo=spec.lo[spec.num_idx], hi=spec.hi[spec.num_idx], kernel=spec.kernel,
         task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
         ls_constraint=spec.ls_constraint, ls_lower=spec.ls_lower, ls_prior=spec.ls_prior, ls_init=spec.ls_init,
-        noise_lower=spec.noise_lower, noise_prior=spec.noise_prior, noise_init=spec.noise_init,
-        outputscale_prior=spec.outputscale_prior, criterion=spec.criterion)
+        noise_lower=spec.noise_lower, noise_constraint=spec.noise_constraint, noise_prior=spec.noise_prior,
+        noise_init=spec.noise_init, outputscale_prior=spec.outputscale_prior, outputscale_init=spec.outputscale_init,
+        criterion=spec.criterion)
 
 
 @pytest.mark.parametrize("tl", [False, True])
@@ -68,3 +71,71 @@ def test_prior_samples_respect_constraints():
         raw = gp_spec.pack_raw(spec, p)
         for v, (lo, hi) in zip(raw, gp_spec.raw_bounds(spec)):
             assert lo is None or v >= lo
+
+
+# ---- GP presets as data ---------------------------------------------------------
+def test_preset_tables_follow_the_reference():
+    """Spot values of presets/edbo.py:75-119,147-172, edbo_smoothed.py:60-72, chen.py:43-60 and the
+    dimension-scaled BoTorch defaults used by presets/hvarfner.py / botorch.py."""
+    import math
+
+    from baybe_amd import gp_spec
+
+    lo, hi = np.zeros(30), np.ones(30)
+    e3 = gp_spec.from_preset("EDBO", 3, lo[:3], hi[:3])
+    assert e3.use_outputscale and e3.ls_constraint == "softplus" and e3.noise_constraint == "softplus"
+    assert e3.ls_prior == ("gamma", 1.2, 1.1) and e3.ls_init == 0.2
+    assert e3.outputscale_prior == ("gamma", 5.0, 0.5) and e3.outputscale_init == 8.0
+    assert e3.noise_prior == ("gamma", 1.05, 0.5) and e3.noise_init == 0.1
+    e30 = gp_spec.from_preset("EDBO", 30, lo, hi)
+    assert e30.ls_prior == ("gamma", 3.0, 1.0) and e30.outputscale_init == 20.0 and e30.noise_init == 5.0
+    big = gp_spec.from_preset("edbo", 60, np.zeros(60), np.ones(60), edbo_encodings=True)
+    assert big.ls_prior == ("gamma", 2.0, 0.2) and big.ls_init == 5.0
+    huge = gp_spec.from_preset("EDBO", 120, np.zeros(120), np.ones(120), edbo_encodings=True)
+    assert huge.ls_prior == ("gamma", 2.0, 0.1) and huge.outputscale_prior == ("gamma", 2.0, 0.1)
+    sm = gp_spec.from_preset("EDBO_SMOOTHED", 8, lo[:8], hi[:8])
+    assert sm.ls_prior == ("gamma", 1.2, 1.1) and sm.noise_init == pytest.approx(0.1)
+    sm2 = gp_spec.from_preset("EDBO_SMOOTHED", 200, np.zeros(200), np.ones(200))
+    assert sm2.ls_prior == ("gamma", 2.5, 0.55) and sm2.outputscale_init == 15.0
+    mid = gp_spec.from_preset("EDBO_SMOOTHED", 41, np.zeros(41), np.ones(41))
+    assert 1.2 < mid.ls_prior[1] < 2.5 and 0.2 < mid.ls_init < 6.0
+    ch = gp_spec.from_preset("CHEN", 16, lo[:16], hi[:16])
+    assert ch.ls_init == pytest.approx(5.6) and ch.ls_prior == ("gamma", pytest.approx(11.2), 2.0)
+    assert ch.outputscale_prior == ("gamma", pytest.approx(5.6), 1.0) and ch.noise_constraint == "box"
+    hv = gp_spec.from_preset("HVARFNER", 10, lo[:10], hi[:10])
+    assert hv.kernel == "rbf" and not hv.use_outputscale and hv.ls_constraint == "box"
+    assert hv.ls_prior == ("lognormal", pytest.approx(math.sqrt(2) + 0.5 * math.log(10)), pytest.approx(math.sqrt(3)))
+    assert hv.ls_init == pytest.approx(math.exp(math.sqrt(2) + 0.5 * math.log(10) - 3.0))
+    assert hv.noise_init == pytest.approx(math.exp(-5.0)) and hv.criterion == "mll"
+    assert gp_spec.from_preset("BOTORCH", 10, lo[:10], hi[:10]).ls_prior == hv.ls_prior
+    tl = gp_spec.from_preset("CHEN", 5, lo[:5], hi[:5], task_idx=4, n_tasks=3)
+    assert tl.criterion == "loo" and tl.dn == 4
+    with pytest.raises(NotImplementedError):
+        gp_spec.from_preset("HVARFNER", 5, lo[:5], hi[:5], task_idx=4, n_tasks=2)
+    with pytest.raises(ValueError):
+        gp_spec.from_preset("NOPE", 5, lo[:5], hi[:5])
+
+
+@pytest.mark.parametrize("preset", ["EDBO", "EDBO_SMOOTHED", "CHEN", "HVARFNER"])
+def test_preset_raw_parameterisation_round_trip_and_oracle_gradient(preset):
+    """pack/unpack are inverse for every constraint kind, host and oracle agree on the raw vector, and the
+    oracle's objective gradient matches finite differences (softplus noise / outputscale chain rules)."""
+    d, n = 4, 25
+    rng = np.random.default_rng(3)
+    X, y = rng.random((n, d)), rng.standard_normal(n)
+    spec = gp_spec.from_preset(preset, d, np.zeros(d), np.ones(d))
+    p = gp_spec.initial_params(spec)
+    raw = gp_spec.pack_raw(spec, p)
+    q = gp_spec.unpack_raw(spec, raw)
+    assert np.allclose(q.lengthscale, p.lengthscale) and math.isclose(q.noise, p.noise, rel_tol=1e-12)
+    assert math.isclose(q.outputscale, p.outputscale, rel_tol=1e-12)
+    ospec = _ospec(spec)
+    assert np.allclose(go.pack_raw(ospec, go.initial_params(ospec)), raw)
+    Xn, ys = go.normalize_inputs(ospec, X), go.standardize_targets(y)[0]
+    raw = raw + 0.05 * rng.standard_normal(raw.shape)
+    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+    for i in range(len(raw)):
+        e = np.zeros_like(raw)
+        e[i] = 1e-6
+        fd = (go.fit_objective(ospec, raw + e, Xn, ys)[0] - go.fit_objective(ospec, raw - e, Xn, ys)[0]) / 2e-6
+        assert math.isclose(fd, g0[i], rel_tol=2e-5, abs_tol=1e-8)
