@@ -109,6 +109,19 @@ void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int
 // In: the (already updated) diagonal block J of A.  Out: L_JJ in place (upper part zeroed),
 // its inverse into D[J] and into the diagonal block of X.  info := 64 J + j + 1 at the first
 // non-positive pivot (the factor then contains NaNs; the host retries with jitter).
+//
+// The factorisation is latency-bound (one block, 64 dependent pivots), so it runs out of registers
+// in a single wavefront instead of through LDS with three workgroup barriers per column: lane i
+// holds row i of the block (64 doubles); pivot and column entries travel by v_readlane, every index
+// is a compile-time constant (both loops fully unrolled: 2016 readlane pairs + FMAs).  The inverse
+// is a forward substitution per lane (lane c = column c of L^-1) with L read from LDS as broadcasts.
+// 92 us -> 50 us per block; this kernel was 53 % of a fit evaluation at n = 512.
+__device__ __forceinline__ double bbh_readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void bbh_potrf_diag_kernel(double* A, int64_t lda, int64_t J, double* D,
                                                              double* X, int64_t ldx, int* info) {
   __shared__ double a[64][65];
@@ -118,43 +131,59 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag_kernel(double* A, int64_t 
   for (int e = t; e < 4096; e += 256) {
     const int i = e >> 6, j = e & 63;
     a[i][j] = Ajj[(int64_t)i * lda + j];
-    x[i][j] = 0.0;
   }
   __syncthreads();
-  const int i = t & 63, ks = t >> 6;
-  for (int j = 0; j < 64; j++) {
-    const double djj = a[j][j];
-    if (t == 0 && !(djj > 0.0)) atomicCAS(info, 0, (int)(J * 64 + j + 1));
-    const double s = sqrt(djj);
-    __syncthreads();
-    if (t < 64) {
-      if (i == j)
-        a[j][j] = s;
-      else if (i > j)
-        a[i][j] = a[i][j] / s;
+  __shared__ double rdiag[64];
+  if (t < 64) {  // wave 0
+    double row[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) row[k] = a[t][k];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      const double djj = bbh_readlane_f64(row[j], j);  // wave-uniform
+      bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
+      const double sj = sqrt(djj);
+      const double rs = 1.0 / sj;
+      row[j] = (t == j) ? sj : row[j] * rs;  // l_ij for i > j (rows above the pivot are never read)
+      if (t == j) rdiag[j] = rs;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = j + 1; k < 64; k++) {
+        const double lkj = bbh_readlane_f64(row[j], k);
+        row[k] = fma(-row[j], lkj, row[k]);  // meaningful for i >= k
+        // pin the update next to its broadcast: otherwise the compiler sinks the FMAs towards the pivot
+        // that needs row[k] and keeps every broadcast value alive in SGPRs (3000 SGPR spills)
+        asm volatile("" : "+v"(row[k]));
+        if (((k - j) & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    if (i > j) {
-      const double lij = a[i][j];
-      for (int k = j + 1 + ks; k <= i; k += 4) a[i][k] -= lij * a[k][j];
-    }
-    __syncthreads();
+    if (t == 0 && bad) atomicCAS(info, 0, (int)(J * 64 + bad));
+#pragma unroll
+    for (int k = 0; k < 64; k++) a[t][k] = (k <= t) ? row[k] : 0.0;
   }
-  // inverse of the lower-triangular block: thread c solves column c by forward substitution
-  if (t < 64) {
-    const int c = t;
+  __syncthreads();
+  if (t < 64) {  // column t of L^-1 by forward substitution, L broadcast from LDS
+    // (an explicit 16-coefficient prefetch with fences ran slower than the compiler's own schedule:
+    //  82 vs 50 us for the kernel; the next step is a 16 x 16-blocked form on MFMA)
+    double xc[64];
+#pragma unroll
     for (int r = 0; r < 64; r++) {
-      double acc = (r == c) ? 1.0 : 0.0;
-      for (int k = 0; k < r; k++) acc -= a[r][k] * x[k][c];  // x[k][c] == 0 for k < c
-      x[r][c] = (r >= c) ? acc / a[r][r] : 0.0;
+      double acc = (r == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; k++) acc = fma(-a[r][k], xc[k], acc);  // xc[k] == 0 for k < t
+      xc[r] = (r >= t) ? acc * rdiag[r] : 0.0;
     }
+#pragma unroll
+    for (int r = 0; r < 64; r++) x[r][t] = xc[r];
   }
   __syncthreads();
   double* Xjj = X + (J * 64) * ldx + J * 64;
   double* Dj = D + J * 4096;
   for (int e = t; e < 4096; e += 256) {
     const int r = e >> 6, c = e & 63;
-    Ajj[(int64_t)r * lda + c] = (c <= r) ? a[r][c] : 0.0;
+    Ajj[(int64_t)r * lda + c] = a[r][c];
     const double xv = x[r][c];
     Dj[e] = xv;
     Xjj[(int64_t)r * ldx + c] = xv;
@@ -204,13 +233,25 @@ __global__ void bbh_matvec_kernel(const double* __restrict__ A, int64_t lda, int
   if (lane == 0) y[row] = s;
 }
 
-__global__ void bbh_matvec_t_kernel(const double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols,
-                                    const double* __restrict__ x, double* __restrict__ y) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// y = A^T x: 64 columns x 16 row groups per workgroup, partial sums combined in a fixed order through LDS
+// (deterministic).  One thread per column over all rows took 112 us at 512 x 512 - two workgroups.
+__global__ __launch_bounds__(1024) void bbh_matvec_t_kernel(const double* __restrict__ A, int64_t lda, int64_t rows,
+                                                            int64_t cols, const double* __restrict__ x,
+                                                            double* __restrict__ y) {
+  __shared__ double part[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
   double s = 0.0;
-  for (int64_t r = 0; r < rows; r++) s += A[r * lda + c] * x[r];
-  y[c] = s;
+  if (c < cols)
+    for (int64_t r = rg; r < rows; r += 16) s = fma(A[r * lda + c], x[r], s);
+  part[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; g++) tot += part[g][cl];
+    y[c] = tot;
+  }
 }
 
 void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols, const double* x,
@@ -219,6 +260,6 @@ void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64
 }
 void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols, const double* x,
                   double* y) {
-  hipLaunchKernelGGL(bbh_matvec_t_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, A, lda, rows, cols,
+  hipLaunchKernelGGL(bbh_matvec_t_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, s, A, lda, rows, cols,
                      x, y);
 }
