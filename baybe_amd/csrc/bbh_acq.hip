@@ -22,7 +22,14 @@ __device__ __forceinline__ double bbh_fatplus_core(double t) {
     sp = 0.0;
   else
     sp = log1p(exp(t));
-  return sp + 0.1 / fma(t, t, 1.0);
+  // 0.1 / (1 + t^2) without the IEEE division sequence (div_scale / div_fmas / div_fixup, ~15 VALU
+  // of the ~22 per sample): v_rcp_f64 seed (2^-26) and two Newton steps; 1 + t^2 is in [1, 1e40) for
+  // every reachable t, so no scaling is needed.  Relative error <= 2 ulp.
+  const double d = fma(t, t, 1.0);
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  return fma(0.1, y, sp);
 }
 
 // 1x1 psd_safe_cholesky: v <= 0 (or NaN) -> add jitter 1e-8, 1e-7, 1e-6

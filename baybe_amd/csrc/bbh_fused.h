@@ -692,7 +692,11 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
         sp = 0.0;
       else
         sp = log1p(exp(t));
-      sum += sp + 0.1 / fma(t, t, 1.0);
+      const double dd = fma(t, t, 1.0);  // as bbh_fatplus_core (bbh_acq.hip): rcp seed + two Newton steps
+      double yy = __builtin_amdgcn_rcp(dd);
+      yy = fma(fma(-dd, yy, 1.0), yy, yy);
+      yy = fma(fma(-dd, yy, 1.0), yy, yy);
+      sum += fma(0.1, yy, sp);
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
@@ -709,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
 // one launcher per translation unit (KD = compile-time k-steps of the distance GEMM; 0 = runtime k-steps,
 // every kernel kind).  m52: Matérn-5/2 instantiation, otherwise the runtime-kind one (KD = 0 only).
 void bbh_fused_launch_kd0(bool has_tbl, bool m52, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd2(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd4(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd6(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd8(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);

@@ -1,0 +1,9 @@
+// Software-pipelined fused posterior kernel, Matérn-5/2, 2 k-steps in the distance GEMM (d <= 6).
+#include "bbh_fused.h"
+
+void bbh_fused_launch_kd2(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a) {
+  if (has_tbl)
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52, 2>), grid, block, lds, s, a);
+  else
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52, 2>), grid, block, lds, s, a);
+}

@@ -311,7 +311,9 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   }
   h->kd = (h->dn + 2 + 3) / 4;
   // round up to a k-step count the software-pipelined kernel is instantiated for (zero-padded dims)
-  if (h->kd <= 4)
+  if (h->kd <= 2)
+    h->kd = 2;
+  else if (h->kd <= 4)
     h->kd = 4;
   else if (h->kd <= 6)
     h->kd = 6;

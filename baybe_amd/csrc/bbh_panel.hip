@@ -262,9 +262,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
   const size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0));
   const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
-  // software-pipelined instantiations exist for the default kernel with kd in {4, 6, 8}
+  // software-pipelined instantiations exist for the default kernel with kd in {2, 4, 6, 8}
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
-  const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 4 || h->kd == 6 || h->kd == 8)) ? h->kd : 0;
+  const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
   a.kvcache = nullptr;
@@ -298,7 +298,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     hipEventCreate(&e1);
     hipEventRecord(e0, h->stream);
   }
-  if (kdp == 4)
+  if (kdp == 2)
+    bbh_fused_launch_kd2(has_tbl, grid, block, lds, h->stream, a);
+  else if (kdp == 4)
     bbh_fused_launch_kd4(has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 6)
     bbh_fused_launch_kd6(has_tbl, grid, block, lds, h->stream, a);
