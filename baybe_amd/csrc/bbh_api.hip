@@ -23,6 +23,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) h->num_cu = cus;
   }
+  if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');
   if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
   if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
   *out = h;

@@ -100,6 +100,7 @@ struct bbh_handle {
   double* d_kvcache = nullptr;    // kernel-value cache of the multi-pass fused kernel (grow-only)
   size_t kvcache_bytes = 0;
   int* d_slab_flags = nullptr;    // claim flags of the cache slabs (zero = free)
+  bool use_mean_valu = true;      // env BBH_MEAN_VALU=0: mean contraction through the MFMA form (A/B)
   bool use_kvcache = true;        // env BBH_KVCACHE=0: recompute kernel values in every pass (A/B)
   int num_cu = 256;               // compute units of the device (persistent-grid size)
   int jbw = 16;                   // j-blocks per pass of the fused kernel

@@ -50,6 +50,7 @@ struct FusedArgs {
   int nslab, nxcc;  // slabs in total, XCD partitions
   int ncache;    // k-blocks cached per wave = first column block of the last pass
   int64_t nblk;  // 64-candidate blocks = workgroups
+  int mean_valu;  // no pending columns: the mean contraction runs on the VALU against alpha in LDS
 };
 
 struct WaveCtx {
@@ -59,6 +60,7 @@ struct WaveCtx {
   const double* tbl;
   const int* taskext;
   double* kvc;  // this wave's kernel-value cache slab, + lane
+  const double* al;  // alpha in LDS + (lane >> 4), or nullptr: mean through the MFMA form (pending columns)
   int kd, kind, T, tc, q, l, dn;
 };
 
@@ -408,8 +410,13 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
   static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     if (DO_MEAN && r == 3) {
+      if (c.al) {  // wave-uniform: alpha[16 tb + 4 rr + (lane >> 4)] from LDS (lgkmcnt, not the vmcnt ring)
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) mbv[rr] = c.mb[(int64_t)(4 * tb + rr) * 64];
+        for (int rr = 0; rr < 4; rr++) mbv[rr] = c.al[16 * tb + 4 * rr];
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) mbv[rr] = c.mb[(int64_t)(4 * tb + rr) * 64];
+      }
     }
     static_for<0, CNT>([&](auto jc) __attribute__((always_inline)) {
       constexpr int jj = decltype(jc)::value;
@@ -434,8 +441,17 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
     });
     if (NEXT == BBH_NEXT_COMPUTE && r == 0) kvp_dist<KD>(c, tfv, r2v);
     if (DO_MEAN && r == 3) {
+      if (c.al) {
+        // Without pending points only column 0 of [alpha | -beta] is wanted: 4 FMAs on this lane's slice of
+        // the k range instead of 4 MFMAs whose other 15 columns are zeros (the two cost 20 vs 256 cycles
+        // of the shared DP pipe); accm[0] carries the partial sum, reduced over the four lanes of a
+        // candidate after the last pass.
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) accm = mfma_f64(kv[rr], mbv[rr], accm);
+        for (int rr = 0; rr < 4; rr++) accm[0] = fma(kv[rr], mbv[rr], accm[0]);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) accm = mfma_f64(kv[rr], mbv[rr], accm);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -510,8 +526,12 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cnd = l & 15, q = l >> 4;
   double* s_z = s_cand + 4 * (int64_t)a.kd * 64;
-  if (a.qz) {  // the only workgroup barrier, before any wave may leave
-    for (int s = threadIdx.x; s < a.qS; s += 256) s_z[s] = a.qz[s];
+  double* s_alpha = s_z + (a.qz ? a.qS : 0);
+  if (a.qz || a.mean_valu) {  // the only workgroup barrier, before any wave may leave
+    if (a.qz)
+      for (int s = threadIdx.x; s < a.qS; s += 256) s_z[s] = a.qz[s];
+    if (a.mean_valu)
+      for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
     __syncthreads();
   }
   // per-wave state only from here on: no workgroup barrier is used below.  (A persistent variant - two
@@ -573,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     slab = __builtin_amdgcn_readfirstlane(slab);
   }
   c.kvc = a.kvcache ? a.kvcache + (int64_t)slab * a.ncache * 256 + l : nullptr;
+  c.al = a.mean_valu ? s_alpha + q : nullptr;
   c.kd = a.kd;
   c.kind = a.kind;
   c.T = a.T;
@@ -630,6 +651,13 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
   }
 
   if (a.kvcache && l == 0) atomicExch(&a.slab_flags[slab], 0);  // every cached value has been read back
+  if (c.al && a.with_var) {  // VALU mean: lane (q, cnd) holds a quarter of candidate cnd's sum in accm[0]
+    double mp = accm[0];
+    mp += __shfl_xor(mp, 16, 64);
+    mp += __shfl_xor(mp, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; r++) accm[r] = __shfl(mp, q + 4 * r, 64);  // epilogue layout: reg r <-> candidate q + 4 r
+  }
   // ---- epilogue: lane (q, cnd), reg r  <->  candidate q + 4 r, column cnd -------------------
 #pragma unroll
   for (int r = 0; r < 4; r++) {

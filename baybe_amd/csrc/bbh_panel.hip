@@ -260,13 +260,15 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     a.q_scores = h->fuse_scores;
   }
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
-  const size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0));
+  // (set below once the kernel form is known)
   const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
   // software-pipelined instantiations exist for the default kernel with kd in {2, 4, 6, 8}
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
   const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
+  a.mean_valu = (kdp && h->p == 0 && !cross_dev && h->use_mean_valu) ? 1 : 0;
+  const size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0) + (a.mean_valu ? 16 * h->nb : 0));
   a.kvcache = nullptr;
   a.ncache = 0;
   a.slab_flags = nullptr;
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedAr
   c.tbl = a.tasktbl;
   c.taskext = a.taskext;
   c.kvc = nullptr;
+  c.al = nullptr;
   c.kd = a.kd;
   c.kind = a.kind;
   c.T = a.T;
