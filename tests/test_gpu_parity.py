@@ -205,6 +205,26 @@ def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
     assert np.array_equal(out["pipelined"][1], out["no_cache"][1])
 
 
+@pytest.mark.parametrize("N,d,n", [(1, 4, 300), (63, 6, 257), (65, 3, 320), (1000, 7, 513), (130, 20, 777),
+                                   (4097, 14, 272), (17, 30, 1041)])
+def test_multi_pass_edges_fused_matches_unfused(gp, N, d, n):
+    """Ragged candidate counts (partial tiles, partial workgroups) against every pass layout of the
+    fused kernel (last-pass widths 4/8/12/16, 2-5 passes, slab cache in use): the fused launch must agree
+    with the unfused reference path (explicit K*, GEMM with L^-1, row reductions)."""
+    from baybe_amd import gp_spec
+
+    X, Xt, y = make_problem(max(N, n + 1), d, n, seed=13)
+    X = X[:N]
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    gp.set_model(spec, Xt, y)
+    gp.factorize(gp_spec.GPParams(np.full(d, ls), nz, 0.1))
+    m, v = gp.posterior(X)
+    mu, vu = gp.posterior(X, unfused=True)
+    assert np.allclose(_np(m), _np(mu), rtol=1e-10, atol=1e-12)
+    assert np.allclose(_np(v), _np(vu), rtol=1e-8, atol=1e-13)
+
+
 def test_posterior_scaling_bounds_and_strided_input(gp):
     """Normalize uses the search-space bounds (not the candidate range) and honours ldx > d."""
     import torch
