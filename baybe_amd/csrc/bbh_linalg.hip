@@ -143,8 +143,12 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag_kernel(double* A, int64_t 
     for (int j = 0; j < 64; j++) {
       const double djj = bbh_readlane_f64(row[j], j);  // wave-uniform
       bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
-      const double sj = sqrt(djj);
-      const double rs = 1.0 / sj;
+      // 1/sqrt(d) from the rsq seed with two Newton steps, sqrt(d) = d * rs: the pivot chain
+      // (broadcast -> sqrt -> reciprocal -> scale) is serial, library sqrt + division cost ~300 cycles of it
+      double rs = __builtin_amdgcn_rsq(djj);
+      rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+      rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+      const double sj = djj * rs;
       row[j] = (t == j) ? sj : row[j] * rs;  // l_ij for i > j (rows above the pivot are never read)
       if (t == j) rdiag[j] = rs;
       __builtin_amdgcn_sched_barrier(0);
@@ -170,10 +174,14 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag_kernel(double* A, int64_t 
     double xc[64];
 #pragma unroll
     for (int r = 0; r < 64; r++) {
-      double acc = (r == t) ? 1.0 : 0.0;
+      double acc = (r == t) ? 1.0 : 0.0, acc1 = 0.0;  // two chains: the FMA latency is the critical path
 #pragma unroll
-      for (int k = 0; k < r; k++) acc = fma(-a[r][k], xc[k], acc);  // xc[k] == 0 for k < t
-      xc[r] = (r >= t) ? acc * rdiag[r] : 0.0;
+      for (int k = 0; k + 1 < r; k += 2) {
+        acc = fma(-a[r][k], xc[k], acc);  // xc[k] == 0 for k < t
+        acc1 = fma(-a[r][k + 1], xc[k + 1], acc1);
+      }
+      if (r & 1) acc = fma(-a[r][r - 1], xc[r - 1], acc);
+      xc[r] = (r >= t) ? (acc + acc1) * rdiag[r] : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 64; r++) x[r][t] = xc[r];
