@@ -170,8 +170,18 @@ class Campaign:
         self.measurements = pd.concat([self.measurements, df], ignore_index=True)
         self._meta.loc[self._match(df), "measured"] = True
 
+    def toggle_discrete_candidates(self, constraints, exclude, complement=False):
+        """``Campaign.toggle_discrete_candidates`` (campaign.py:404-470) for a dataframe of rows."""
+        hit = np.zeros(len(self._meta), bool)
+        hit[self._meta.index.get_indexer(self._match(constraints))] = True
+        if complement:
+            hit = ~hit
+        self._meta["excluded"] = self._meta.get("excluded", False) | hit if exclude else self._meta.get("excluded", False) & ~hit
+
     def recommend(self, batch_size, pending_experiments=None):
         drop = self._meta["recommended"] | self._meta["measured"]
+        if "excluded" in self._meta:
+            drop = drop | self._meta["excluded"]
         if pending_experiments is not None:
             drop = drop.copy()
             drop.loc[self._match(pending_experiments)] = True

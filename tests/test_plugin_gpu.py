@@ -291,3 +291,56 @@ def test_surrogate_presets_recommend_like_the_oracle(preset):
     assert got.index.tolist() == cand.index[ref.indices].tolist()
     with pytest.raises(ValueError):
         HipGaussianProcessSurrogate(preset="EDBO", kernel="rbf").fit(space, camp.objective, meas)
+
+
+def test_backtesting_loop_matches_an_oracle_driven_loop():
+    """``simulate_experiment`` (simulation/core.py:27-240) over the HIP recommender: four closed-loop
+    iterations with refits must visit exactly the experiments an oracle-driven loop visits, and the
+    result frame has the reference's columns."""
+    import torch
+
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from baybe_amd.simulation import simulate_experiment
+    from oracle import gp_oracle as go
+
+    rng = np.random.default_rng(2)
+    space = _space3()
+    exp = space.discrete.exp_rep
+
+    def truth(df):
+        X = df[["x0", "x1", "x2"]].to_numpy(dtype=float)
+        return pd.DataFrame({"yield": -((X - 0.4) ** 2).sum(1) + 0.1 * np.sin(5.0 * X[:, 1])}, index=df.index)
+
+    init = exp.iloc[rng.choice(len(exp), 12, replace=False)].copy()
+    init["yield"] = truth(init)["yield"]
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), HipBotorchRecommender())
+    res = simulate_experiment(camp, truth, batch_size=2, n_doe_iterations=4, initial_data=init, random_seed=99)
+    assert list(res.columns) == ["Iteration", "Num_Experiments", "yield_Measurements", "yield_IterBest", "yield_CumBest"]
+    assert res["Num_Experiments"].tolist() == [2, 4, 6, 8] and (np.diff(res["yield_CumBest"]) >= 0).all()
+    assert camp.measurements.empty  # the caller's campaign is not mutated
+
+    # the same loop with the oracle in the recommender's place
+    torch.manual_seed(99)
+    meas, taken, ref_rows = init.copy(), set(space.discrete.exp_rep.index[camp._match(init)]), []
+    spec = go.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
+    for _ in range(4):
+        seed = int(torch.randint(0, 1000000, (1,)).item())
+        cand = exp.loc[[i for i in exp.index if i not in taken]]
+        m = go.fit_gp(spec, space.transform(meas).to_numpy(dtype=float), meas["yield"].to_numpy(dtype=float))
+        r = go.optimize_acqf_discrete_qlogei(m, space.transform(cand).to_numpy(dtype=float), 2, seed=seed)
+        picked = cand.iloc[r.indices].copy()
+        picked["yield"] = truth(picked)["yield"]
+        ref_rows.append(picked["yield"].tolist())
+        taken |= set(picked.index)
+        meas = pd.concat([meas, picked], ignore_index=True)
+    assert np.allclose(np.array(res["yield_Measurements"].tolist()), np.array(ref_rows), rtol=0, atol=1e-12)
+
+    # dataframe lookup restricted to a subset: impute_mode="ignore" never leaves it
+    sub = exp.iloc[rng.choice(len(exp), 60, replace=False)].copy()
+    sub["yield"] = truth(sub)["yield"]
+    res2 = simulate_experiment(camp, sub, batch_size=3, n_doe_iterations=3, initial_data=sub.iloc[:10],
+                               random_seed=5, impute_mode="ignore")
+    seen = np.concatenate(res2["yield_Measurements"].tolist())
+    assert np.isin(np.round(seen, 12), np.round(sub["yield"].to_numpy(), 12)).all()
+    with pytest.raises(IndexError):
+        simulate_experiment(camp, sub, batch_size=3, n_doe_iterations=2, initial_data=sub.iloc[:10], random_seed=5)
