@@ -1,7 +1,11 @@
 """CPU oracle: numpy/scipy fp64 restatement of BayBE's GP recommend() hot path.
 
 TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  PARITY UNPINNED (no botorch /
-gpytorch importable; no golden vectors in the reference's tests).
+gpytorch importable; no golden vectors in the reference's tests).  Partial independent pin: the GP
+algebra (Matérn / RBF ARD kernels with outputscale, exact posterior mean, latent variance and joint
+covariance, log marginal likelihood) agrees with scikit-learn's GaussianProcessRegressor to 1e-9
+(``tests/test_oracle_cpu.py::test_gp_algebra_is_pinned_against_scikit_learn``); the BoTorch-specific
+pieces (qLogEI smoothing constants, sampler seeding, NEHVI) remain restated from memory.
 
 What is restated, and the reference call site it follows
 ---------------------------------------------------------

@@ -216,3 +216,38 @@ def test_fitted_hyperparameters_of_cfg1_are_reproduced():
     m = go.fit_gp(spec, g["Xt"], g["y"])
     assert np.allclose(m.params.lengthscale, g["ls"], rtol=1e-6)
     assert math.isclose(m.params.noise, float(g["noise"]), rel_tol=1e-6)
+
+
+@pytest.mark.parametrize("kernel,nu", [("matern52", 2.5), ("matern32", 1.5), ("rbf", None)])
+def test_gp_algebra_is_pinned_against_scikit_learn(kernel, nu):
+    """Independent pin of the oracle's GP algebra (kernel definition with ARD lengthscales and an
+    outputscale, exact posterior mean / latent variance / joint covariance, log marginal likelihood)
+    against scikit-learn's GaussianProcessRegressor at fixed hyper-parameters.  botorch/gpytorch are not
+    importable here, so the BoTorch-specific pieces (qLogEI smoothing, samplers, NEHVI) stay unpinned;
+    this covers the part of the path every other result is built on."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+
+    d, n = 5, 40
+    X, Xt, y = make_problem(300, d, n, seed=12)
+    lo, hi = np.full(d, -0.5), np.full(d, 2.0)  # scaling bounds different from the data range
+    spec = go.GPSpec.baybe_default(d, lo, hi, kernel=kernel)
+    spec.use_outputscale = True
+    rng = np.random.default_rng(0)
+    p = go.GPParams(lengthscale=0.3 + rng.random(d), noise=0.037, mean=0.0, outputscale=1.7)
+    m = go.GPModel(spec, p, Xt, y)
+    base = RBF(length_scale=p.lengthscale) if nu is None else Matern(length_scale=p.lengthscale, nu=nu)
+    gpr = GaussianProcessRegressor(kernel=ConstantKernel(p.outputscale) * base, alpha=p.noise, optimizer=None)
+    Xn, Xcn = (Xt - lo) / (hi - lo), (X - lo) / (hi - lo)
+    ystd = (y - y.mean()) / y.std(ddof=1)
+    gpr.fit(Xn, ystd)
+    mu_s, cov_s = gpr.predict(Xcn[:64], return_cov=True)
+    mu, var = m.posterior(X)
+    _, std_all = gpr.predict(Xcn, return_std=True)
+    s = y.std(ddof=1)
+    assert np.allclose(mu[:64], y.mean() + s * mu_s, rtol=1e-9, atol=1e-11)
+    assert np.allclose(var, (s * std_all) ** 2, rtol=1e-7, atol=1e-12)
+    _, cov = m.posterior_joint(X[:64])
+    assert np.allclose(cov, s * s * cov_s, rtol=1e-7, atol=1e-11)
+    lml = gpr.log_marginal_likelihood(gpr.kernel_.theta)
+    assert math.isclose(go.data_term(spec, p, m.Xn, m.ystd).value, lml, rel_tol=1e-10)
