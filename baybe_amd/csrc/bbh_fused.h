@@ -50,8 +50,11 @@ struct FusedArgs {
   int nslab, nxcc;  // slabs in total, XCD partitions
   int ncache;    // k-blocks cached per wave = first column block of the last pass
   int64_t nblk;  // 64-candidate blocks = workgroups
+  int nl;         // kernel-value cache: k-blocks [0, nl) live in wave-private LDS, [nl, ncache) in the global slab
   int mean_valu;  // no pending columns: the mean contraction runs on the VALU against alpha in LDS
 };
+
+typedef __attribute__((address_space(3))) double bbh_lds_double;
 
 struct WaveCtx {
   const double* tf;     // trainfrag + lane
@@ -59,8 +62,12 @@ struct WaveCtx {
   const double* mb;     // meanB + lane
   const double* tbl;
   const int* taskext;
-  double* kvc;  // this wave's kernel-value cache slab, + lane
-  const double* al;  // alpha in LDS + (lane >> 4), or nullptr: mean through the MFMA form (pending columns)
+  double* kvc;  // this wave's kernel-value cache slab, + lane, shifted so that it is indexed by k-block like kvl
+  bbh_lds_double* kvl;  // LDS part of the cache (k-blocks < nl), + lane (explicit address space: a select
+                        // between this and the global slab pointer would otherwise become flat accesses,
+                        // which count in vmcnt and lgkmcnt and wreck the counted waits of the operand ring)
+  int nl, ncache;  // k-blocks [0, ncache) are cached at all
+  const bbh_lds_double* al;  // alpha in LDS + (lane >> 4), or null: mean through the MFMA form (pending columns)
   int kd, kind, T, tc, q, l, dn;
 };
 
@@ -399,12 +406,22 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
   KvState<BBH_KV_NU> P;
   if (NEXT == BBH_NEXT_COMPUTE) kvp_load<KD>(c, tb + 1, tfv);
   if (NEXT == BBH_NEXT_LOAD) {
+    if (tb + 1 < c.nl) {  // wave-uniform
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) kvn[rr] = c.kvc[(int64_t)(tb + 1) * 256 + rr * 64];
+      for (int rr = 0; rr < 4; rr++) kvn[rr] = c.kvl[(tb + 1) * 256 + rr * 64];
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) kvn[rr] = c.kvc[(int64_t)(tb + 1) * 256 + rr * 64];
+    }
   }
-  if (store) {  // wave-uniform
+  if (store && tb < c.ncache) {  // wave-uniform
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) c.kvc[(int64_t)tb * 256 + rr * 64] = kv[rr];
+    for (int rr = 0; rr < 4; rr++) {
+      if (tb < c.nl)
+        c.kvl[tb * 256 + rr * 64] = kv[rr];
+      else
+        c.kvc[(int64_t)tb * 256 + rr * 64] = kv[rr];
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
@@ -490,7 +507,12 @@ __device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, 
   for (int i = 0; i < BBH_RING; i++) ring[i] = rf[i * 64];
   if (cache && j0 > 0) {  // cache: the launch has more than one pass and slabs are in use (wave-uniform)
 #pragma unroll
-    for (int r = 0; r < 4; r++) kv[r] = c.kvc[r * 64];
+    for (int r = 0; r < 4; r++) {
+      if (c.nl > 0)
+        kv[r] = c.kvl[r * 64];
+      else
+        kv[r] = c.kvc[r * 64];
+    }
   } else {  // first k-block of the pass: not overlapped
     double tfv[KD], r2v[4];
     kvp_load<KD>(c, 0, tfv);
@@ -499,7 +521,7 @@ __device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, 
   }
   // rectangular region (k-blocks left of the window); the block after it is this pass's first diagonal
   // block, whose values nobody has computed yet
-  const int nload = cache ? j0 - 1 : 0;
+  const int nload = cache ? (j0 < c.ncache ? j0 : c.ncache) - 1 : 0;  // blocks whose successor is cached
   int tb = 0;
   for (; tb < nload; tb++) {  // next block's values come from the cache
     kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_LOAD, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring, false);
@@ -592,8 +614,11 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     }
     slab = __builtin_amdgcn_readfirstlane(slab);
   }
-  c.kvc = a.kvcache ? a.kvcache + (int64_t)slab * a.ncache * 256 + l : nullptr;
-  c.al = a.mean_valu ? s_alpha + q : nullptr;
+  c.kvc = a.kvcache ? a.kvcache + ((int64_t)slab * (a.ncache - a.nl) - a.nl) * 256 + l : nullptr;
+  c.kvl = (bbh_lds_double*)(s_alpha + (a.mean_valu ? 16 * a.nb : 0) + (int64_t)w * a.nl * 256 + l);
+  c.nl = a.nl;
+  c.ncache = a.ncache;
+  c.al = a.mean_valu ? (const bbh_lds_double*)(s_alpha + q) : (const bbh_lds_double*)nullptr;
   c.kd = a.kd;
   c.kind = a.kind;
   c.T = a.T;
@@ -613,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       const double* rf = a.rfrag + a.pass_off[ps] + l;
       const bool last = (ps == a.npass - 1);
       if constexpr (KD > 0) {  // software-pipelined passes
-        const bool use_cache = (a.kvcache != nullptr);
+        const bool use_cache = (a.ncache > 0);
         if (!last) {
           pass_body_p<16, KD, HAS_TBL, false>(c, rf, j0, ss, accm, use_cache);
         } else {
@@ -737,6 +762,13 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
   }
 }
 
+
+// dynamic LDS beyond 64 KB has to be requested per kernel (the kernel-value cache may use up to half a CU's LDS)
+#define BBH_FUSED_ALLOW_LDS(KERNEL, BYTES)                                                              \
+  do {                                                                                                 \
+    if ((BYTES) > 48 * 1024)                                                                           \
+      (void)hipFuncSetAttribute((const void*)(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
+  } while (0)
 
 // one launcher per translation unit (KD = compile-time k-steps of the distance GEMM; 0 = runtime k-steps,
 // every kernel kind).  m52: Matérn-5/2 instantiation, otherwise the runtime-kind one (KD = 0 only).

@@ -2,8 +2,11 @@
 #include "bbh_fused.h"
 
 void bbh_fused_launch_kd8(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a) {
-  if (has_tbl)
+  if (has_tbl) {
+    BBH_FUSED_ALLOW_LDS((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52, 8>), lds);
     hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52, 8>), grid, block, lds, s, a);
-  else
+  } else {
+    BBH_FUSED_ALLOW_LDS((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52, 8>), lds);
     hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52, 8>), grid, block, lds, s, a);
+  }
 }

@@ -268,17 +268,34 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
   a.mean_valu = (kdp && h->p == 0 && !cross_dev && h->use_mean_valu) ? 1 : 0;
-  const size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0) + (a.mean_valu ? 16 * h->nb : 0));
+  size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0) + (a.mean_valu ? 16 * h->nb : 0));
   a.kvcache = nullptr;
   a.ncache = 0;
+  a.nl = 0;
   a.slab_flags = nullptr;
   a.nslab = 0;
   a.nxcc = 1;
-  if (kdp && h->npass > 1 && h->use_kvcache) {  // kernel-value cache: slabs of ncache k-blocks, claimed per wave
+  if (kdp && h->npass > 1 && h->use_kvcache) {
+    // Kernel-value cache for the k-blocks left of the last pass.  As many of them as fit next to the other
+    // LDS users without costing the second workgroup per CU (half of the CU's LDS per workgroup) stay in
+    // wave-private LDS (2 KB per k-block and wave); the rest goes to slabs in global memory claimed per wave.
     a.ncache = (int)(h->nb - h->pass_w_last);
+    const size_t budget = h->lds_per_block / 2 > lds ? h->lds_per_block / 2 - lds : 0;
+    int nl = (int)(budget / (4 * 256 * sizeof(double)));
+    if (h->kv_lds_blocks >= 0 && nl > h->kv_lds_blocks) nl = h->kv_lds_blocks;
+    a.nl = nl < a.ncache ? nl : a.ncache;
+    // The k-blocks that do not fit LDS go to global slabs only when there are many of them (n >= ~768:
+    // -5 % at n = 1024, -2.5 % at n = 2048); for a few (n = 512: 8 blocks) recomputing them is as fast as
+    // streaming them through the fabric (5.17 vs 5.18 ms) and moves 4 GB less per launch.
+    const int rest = a.ncache - a.nl;
+    const bool global_part = h->kv_global_mode == 1 || (h->kv_global_mode < 0 && rest >= 24);
+    if (!global_part) a.ncache = a.nl;
+    lds += sizeof(double) * 4 * 256 * (size_t)a.nl;
+  }
+  if (a.ncache > a.nl) {
     a.nslab = 2 * 8 * h->num_cu;  // twice the resident waves (8 per CU under these launch bounds)
     a.nxcc = (h->num_cu % 8 == 0 && h->num_cu >= 64) ? 8 : 1;  // MI355X: 8 XCDs x 32 CUs
-    const size_t need = sizeof(double) * (size_t)a.nslab * (size_t)a.ncache * 256;
+    const size_t need = sizeof(double) * (size_t)a.nslab * (size_t)(a.ncache - a.nl) * 256;
     if (need > h->kvcache_bytes) {
       if (h->d_kvcache) BBH_HIP_TRY(h, hipFree(h->d_kvcache));
       h->d_kvcache = nullptr;
@@ -562,7 +579,10 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedAr
   c.tbl = a.tasktbl;
   c.taskext = a.taskext;
   c.kvc = nullptr;
-  c.al = nullptr;
+  c.kvl = (bbh_lds_double*)nullptr;
+  c.nl = 0;
+  c.ncache = 0;
+  c.al = (const bbh_lds_double*)nullptr;
   c.kd = a.kd;
   c.kind = a.kind;
   c.T = a.T;

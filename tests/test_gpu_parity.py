@@ -174,7 +174,8 @@ def test_posterior_fused_and_unfused_match_oracle(gp, N, d, n):
 @pytest.mark.parametrize("N,d,n", [(20_000, 20, 600), (30_000, 6, 1100), (4_000, 28, 300)])
 def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
     """The software-pipelined fused kernel (staged rsq/Taylor Matérn evaluation, kernel-value cache
-    slabs claimed per wave) against the same launch with libm sqrt/exp and no cache; the switches are
+    in wave-private LDS and in global slabs claimed per wave) against the same launch with libm sqrt/exp and
+    no cache; the switches are
     read when the handle is created.  Enough candidates to keep every CU busy, several passes."""
     from baybe_amd import engine, gp_spec
 
@@ -183,8 +184,9 @@ def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
     ls, nz, _ = fixed_theta(d)
     p = gp_spec.GPParams(np.full(d, ls), nz, 0.0)
     out = {}
-    for name, env in (("pipelined", {}), ("no_cache", {"BBH_KVCACHE": "0"}), ("plain", {"BBH_PIPELINE": "0"})):
-        for k in ("BBH_KVCACHE", "BBH_PIPELINE"):
+    for name, env in (("pipelined", {}), ("slabs", {"BBH_KV_GLOBAL": "1", "BBH_KV_LDS": "3"}),
+                      ("no_cache", {"BBH_KVCACHE": "0"}), ("plain", {"BBH_PIPELINE": "0"})):
+        for k in ("BBH_KVCACHE", "BBH_PIPELINE", "BBH_KV_GLOBAL", "BBH_KV_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -198,11 +200,12 @@ def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
         finally:
             g.close()
     scale = float(np.std(y))
-    for name in ("pipelined", "no_cache"):
+    for name in ("pipelined", "slabs", "no_cache"):
         assert np.max(np.abs(out[name][0] - out["plain"][0])) <= 1e-11 * scale
         assert np.max(np.abs(out[name][1] - out["plain"][1])) <= 1e-11 * scale**2
-    assert np.array_equal(out["pipelined"][0], out["no_cache"][0])  # cached values are the computed ones
-    assert np.array_equal(out["pipelined"][1], out["no_cache"][1])
+    for name in ("pipelined", "slabs"):  # cached values (LDS / global slabs) are the computed ones
+        assert np.array_equal(out[name][0], out["no_cache"][0])
+        assert np.array_equal(out[name][1], out["no_cache"][1])
 
 
 @pytest.mark.parametrize("N,d,n", [(1, 4, 300), (63, 6, 257), (65, 3, 320), (1000, 7, 513), (130, 20, 777),
