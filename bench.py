@@ -179,7 +179,7 @@ def main():
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
         "traffic": traffic,
         "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json; algorithmic = %d; "
-                        "4.1e9 of it is the kernel-value cache, Infinity-Cache resident - the kernel is fp64-pipe bound)" % (rows_local * (8 * d + 16)),
+                        "the excess is scratch traffic of 76 spilled VGPRs - the kernel is fp64-pipe bound)" % (rows_local * (8 * d + 16)),
         "kernel": "bbh_fused_posterior_kernel",
         "avg_launch_ms": avg_ms,
         "launches": fused_launches,
