@@ -27,6 +27,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && v > 0) h->lds_per_block = (size_t)v;
   }
+  if (const char* e = getenv("BBH_PENDING_LDS")) h->pending_lds_form = (e[0] != '0');
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
   if (const char* e = getenv("BBH_KV_LDS")) h->kv_lds_blocks = atoi(e);
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');

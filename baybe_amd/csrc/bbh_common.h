@@ -103,6 +103,7 @@ struct bbh_handle {
   bool use_mean_valu = true;      // env BBH_MEAN_VALU=0: mean contraction through the MFMA form (A/B)
   bool use_kvcache = true;        // env BBH_KVCACHE=0: recompute kernel values in every pass (A/B)
   size_t lds_per_block = 65536;   // LDS a workgroup may use (device property; 160 KB on gfx950)
+  bool pending_lds_form = false;  // env BBH_PENDING_LDS=1: generic LDS form of the pending qLogEI kernel (A/B)
   int kv_global_mode = -1;        // env BBH_KV_GLOBAL: 0 never use global slabs, 1 always, unset: by size
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
   int num_cu = 256;               // compute units of the device (persistent-grid size)
