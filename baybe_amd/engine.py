@@ -462,10 +462,11 @@ class HipGP:
         def get_z(qp: int) -> np.ndarray:
             return z_by_q[qp] if z_by_q is not None else sobol_normal_base_samples(S, qp, seed)
 
+        z_next = get_z(1 + base.shape[0])
         for _step in range(q):
             pend = np.vstack([base] + chosen_rows) if chosen_rows else base
             p = pend.shape[0]
-            z = get_z(1 + p)
+            z = z_next
             if p == 0:
                 self.set_pending(None)
                 if mean is None:  # first step: posterior of every candidate, cached for the later steps
@@ -477,6 +478,8 @@ class HipGP:
                 self.set_pending(pend)
                 cross = self.cross_cov(X)
                 scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
+            if _step + 1 < q:  # host-side Sobol scrambling of the next step overlaps the device work of this one
+                z_next = get_z(2 + p)
             val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
             if shard is not None:
                 val, gidx, row = shard.global_argmax(val, idx, X)
