@@ -31,6 +31,7 @@ __device__ __forceinline__ double bbh_fatplus_core(double t) {
   double y = __builtin_amdgcn_rcp(d);
   y = fma(fma(-d, y, 1.0), y, y);
   y = fma(fma(-d, y, 1.0), y, y);
+  y = (d < INFINITY) ? y : 0.0;  // |t| = inf (unbounded cell): the Newton step would produce inf * 0
   return fma(0.1, y, sp);
 }
 
@@ -194,7 +195,8 @@ __device__ __forceinline__ double bbh_fast_log_pos(double x) {
   r = fma(r, z, 1.0 / 3.0);
   const double lm = fma(2.0 * s * z, r, 2.0 * s);
   const double ed = (double)e;
-  return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+  const double r2 = fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+  return (x < INFINITY) ? r2 : x;  // log(inf) = inf (NaN propagates)
 }
 
 // Register-resident form of the kernel above for q' = Q <= 8 (the usual batch sizes): the packed Cholesky
@@ -639,8 +641,10 @@ __device__ __forceinline__ double bbh_fatmin2(double a, double b) {
   const double mn = fmin(a, b);
   double diff = fabs(a - b);
   if (!(diff == diff)) diff = INFINITY;  // (-inf) - (-inf)
-  const double u = 2.0 / (2.0 + diff * (1.0 / TAU_MAX));
-  return mn - TAU_MAX * log1p(u * u);
+  // u = 2 / (2 + diff / tau) and log1p(u^2) through the short reciprocal / logarithm sequences (u^2 in (0, 1]:
+  // forming 1 + u^2 costs at most 1e-16 absolute, times tau = 1e-2); diff = inf gives u = 0 exactly
+  const double u = (diff < INFINITY) ? (2.0 * TAU_MAX) * bbh_fast_recip(fma(2.0, TAU_MAX, diff)) : 0.0;
+  return fma(-TAU_MAX, bbh_fast_log_pos(fma(u, u, 1.0)), mn);
 }
 
 template <int M>
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_kernel(const NehviArgs a) {
 #pragma unroll
       for (int o = 0; o < M; o++) {
         const double t = (f[o] - a.cell_lo[c * M + o]) * inv_tau;
-        const double li = log_tau + log(bbh_fatplus_core(t));
+        const double li = log_tau + bbh_fast_log_pos(bbh_fatplus_core(t));
         la += bbh_fatmin2(li, a.cell_ll[c * M + o]);
       }
       if (la > cref) {
