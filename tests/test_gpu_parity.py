@@ -365,7 +365,8 @@ def test_argmax_ties_nan_and_all_masked(gp):
         assert i[:kk].tolist() == order[:kk].tolist() and np.array_equal(v[:kk], xs[order[:kk]])
 
 
-@pytest.mark.parametrize("N,d,n,q,minimize", [(2000, 5, 40, 4, False), (3000, 8, 100, 3, True)])
+@pytest.mark.parametrize("N,d,n,q,minimize", [(2000, 5, 40, 4, False), (3000, 8, 100, 3, True),
+                                               (700, 4, 30, 10, False)])  # q' = 9, 10: generic LDS form
 def test_greedy_with_pending_matches_oracle(gp, N, d, n, q, minimize):
     from baybe_amd import gp_spec
     from oracle import gp_oracle as go
