@@ -106,7 +106,7 @@ struct bbh_handle {
   bool pending_lds_form = false;  // env BBH_PENDING_LDS=1: generic LDS form of the pending qLogEI kernel (A/B)
   int kv_global_mode = -1;        // env BBH_KV_GLOBAL: 0 never use global slabs, 1 always, unset: by size
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
-  int num_cu = 256;               // compute units of the device (persistent-grid size)
+  int num_cu = 256;               // compute units of the device (sizes the slab pool of the kernel-value cache)
   int jbw = 16;                   // j-blocks per pass of the fused kernel
   int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
   // pending state

@@ -1,6 +1,6 @@
 // Device code of the fused posterior kernel (see bbh_panel.hip for the design notes).  It lives in a
 // header so that the instantiations can be compiled as separate translation units in parallel
-// (bbh_fused_kd{0,4,6,8}.hip): the unrolled triangular region makes each one minutes of compile time.
+// (bbh_fused_kd{0,2,4,6,8}.hip): the unrolled triangular region makes each one minutes of compile time.
 #pragma once
 #include <math.h>
 #include <string.h>

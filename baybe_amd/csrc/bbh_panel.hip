@@ -26,7 +26,7 @@
 // stage (2) is not hidden but minimised: software-pipelined micro-steps between the MFMAs, a staged
 // rsq/Taylor Matérn evaluation, and a per-wave cache of kernel values instead of recomputation in later
 // passes.  K(X*,X) is never materialised.  Device code: bbh_fused.h (instantiated per k-step count in
-// bbh_fused_kd{0,4,6,8}.hip); this file holds operand packing, launch logic and the related kernels.
+// bbh_fused_kd{0,2,4,6,8}.hip); this file holds operand packing, launch logic and the related kernels.
 #include "bbh_fused.h"
 
 // ---- operand packing ------------------------------------------------------------------------
