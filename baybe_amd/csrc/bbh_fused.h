@@ -1,6 +1,6 @@
 // Device code of the fused posterior kernel (see bbh_panel.hip for the design notes).  It lives in a
 // header so that the instantiations can be compiled as separate translation units in parallel
-// (bbh_fused_kd{0,2,4,6,8}.hip): the unrolled triangular region makes each one minutes of compile time.
+// (bbh_fused_kd{0,2,4,6,8,12,16}.hip): the unrolled triangular region makes each one minutes of compile time.
 #pragma once
 #include <math.h>
 #include <string.h>
@@ -777,3 +777,5 @@ void bbh_fused_launch_kd2(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipSt
 void bbh_fused_launch_kd4(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd6(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd8(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd12(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd16(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);

@@ -319,6 +319,10 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->kd = 6;
   else if (h->kd <= 8)
     h->kd = 8;
+  else if (h->kd <= 12)
+    h->kd = 12;
+  else if (h->kd <= 16)
+    h->kd = 16;
   // Standardize(m=1): Bessel-corrected std, < 1e-8 (or undefined) -> 1
   double ybar = 0.0;
   for (int64_t i = 0; i < n; i++) ybar += y_train_host[i];

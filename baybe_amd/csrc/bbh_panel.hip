@@ -26,7 +26,7 @@
 // stage (2) is not hidden but minimised: software-pipelined micro-steps between the MFMAs, a staged
 // rsq/Taylor Matérn evaluation, and a per-wave cache of kernel values instead of recomputation in later
 // passes.  K(X*,X) is never materialised.  Device code: bbh_fused.h (instantiated per k-step count in
-// bbh_fused_kd{0,2,4,6,8}.hip); this file holds operand packing, launch logic and the related kernels.
+// bbh_fused_kd{0,2,4,6,8,12,16}.hip); this file holds operand packing, launch logic and the related kernels.
 #include "bbh_fused.h"
 
 // ---- operand packing ------------------------------------------------------------------------
@@ -262,9 +262,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
   // (set below once the kernel form is known)
   const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
-  // software-pipelined instantiations exist for the default kernel with kd in {2, 4, 6, 8}
+  // software-pipelined instantiations exist for the default kernel with kd in {2, 4, 6, 8, 12, 16}
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
-  const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8)) ? h->kd : 0;
+  const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
   a.mean_valu = (kdp && h->p == 0 && !cross_dev && h->use_mean_valu) ? 1 : 0;
@@ -325,6 +325,10 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     bbh_fused_launch_kd6(has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 8)
     bbh_fused_launch_kd8(has_tbl, grid, block, lds, h->stream, a);
+  else if (kdp == 12)
+    bbh_fused_launch_kd12(has_tbl, grid, block, lds, h->stream, a);
+  else if (kdp == 16)
+    bbh_fused_launch_kd16(has_tbl, grid, block, lds, h->stream, a);
   else
     bbh_fused_launch_kd0(has_tbl, m52, grid, block, lds, h->stream, a);
   if (timed) {

@@ -149,7 +149,8 @@ def test_preset_fit_on_device_reaches_the_oracle_optimum(gp, preset):
 
 # ---- posterior -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,d,n", [(3000, 5, 40), (3000, 15, 200), (3000, 20, 300), (5000, 20, 512),
-                                   (2000, 3, 20), (1000, 9, 700), (777, 2, 1), (513, 30, 65), (64, 4, 1030)])
+                                   (2000, 3, 20), (1000, 9, 700), (777, 2, 1), (513, 30, 65), (64, 4, 1030),
+                                   (600, 45, 300), (300, 62, 280), (200, 70, 100)])  # 12 / 16 k-steps, plain form
 def test_posterior_fused_and_unfused_match_oracle(gp, N, d, n):
     from baybe_amd import gp_spec
     from oracle import gp_oracle as go
