@@ -41,10 +41,18 @@ def sobol_normal_base_samples(S: int, q: int, seed: int) -> np.ndarray:
     one BoTorch uses) -> v = 0.5 + (1 - eps)(u - 0.5) -> sqrt(2) erfinv(2 v - 1).  [S, q] fp64."""
     import torch
 
-    eng = torch.quasirandom.SobolEngine(dimension=q, scramble=True, seed=int(seed))
-    u = eng.draw(S, dtype=torch.float64)
-    v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
-    return (torch.erfinv(2 * v - 1) * math.sqrt(2)).numpy().copy()
+    # The engine's scrambling runs a few tiny tensor ops (tril of a [q, 30, 30] matrix ...); with torch's
+    # intra-op pool at its default size each of them wakes every host thread - 17 ms per engine on the
+    # 128-thread GPU box, 1.3 ms on one thread.  The values do not depend on the thread count.
+    nthreads = torch.get_num_threads()
+    try:
+        torch.set_num_threads(1)
+        eng = torch.quasirandom.SobolEngine(dimension=q, scramble=True, seed=int(seed))
+        u = eng.draw(S, dtype=torch.float64)
+        v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
+        return (torch.erfinv(2 * v - 1) * math.sqrt(2)).numpy().copy()
+    finally:
+        torch.set_num_threads(nthreads)
 
 
 def draw_sampler_seed() -> int:
