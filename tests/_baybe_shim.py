@@ -55,6 +55,11 @@ class SubspaceDiscrete:
         self.comp_rep = comp
         self._mask = mask_keep
 
+    @property
+    def mask_keep(self):
+        """``FilteredSubspaceDiscrete.mask_keep`` (searchspace/_filtered.py:17-22); None when unfiltered."""
+        return self._mask
+
     def filtered(self, mask_keep):
         sub = SubspaceDiscrete.__new__(SubspaceDiscrete)
         sub.parameters, sub.exp_rep, sub.comp_rep, sub._mask = self.parameters, self.exp_rep, self.comp_rep, mask_keep
