@@ -267,7 +267,8 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   const int kdp = (m52 && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
-  a.mean_valu = (kdp && h->p == 0 && !cross_dev && h->use_mean_valu) ? 1 : 0;
+  // alpha in LDS costs 8 n bytes: beyond n = 4096 it would crowd out the candidate fragments / the cache
+  a.mean_valu = (kdp && h->p == 0 && !cross_dev && h->use_mean_valu && h->nb <= 256) ? 1 : 0;
   size_t lds = sizeof(double) * (4 * h->kd * 64 + (a.qz ? a.qS : 0) + (a.mean_valu ? 16 * h->nb : 0));
   a.kvcache = nullptr;
   a.ncache = 0;
