@@ -1,3 +1,7 @@
+// SUPERSEDED by scripts/mfma_valu_overlap_probe.hip / mfma_stream_probe.hip: with at most 8 accumulators per
+// wave this probe is latency-bound and under-measures the pipe (47-49 TFLOP/s); 16 independent accumulators
+// reach 77.8.  Kept because profiles/r01_fp64_peak_microbench.log and DESIGN.md refer to it.
+//
 // Micro-benchmark: sustained fp64 MFMA (v_mfma_f64_16x16x4_f64) and fp64 VALU FMA rates on
 // this GPU — grounds the `peak` of bench.py's roofline (the guide lists no fp64 figure).
 // Build: hipcc --offload-arch=gfx950 -O3 scripts/fp64_peak.hip -o scripts/fp64_peak.bin
