@@ -51,6 +51,7 @@ struct FusedArgs {
   int ncache;    // k-blocks cached per wave = first column block of the last pass
   int64_t nblk;  // 64-candidate blocks = workgroups
   int nl;         // kernel-value cache: k-blocks [0, nl) live in wave-private LDS, [nl, ncache) in the global slab
+  int has_tbl;    // task / outputscale table in use
   int mean_valu;  // no pending columns: the mean contraction runs on the VALU against alpha in LDS
 };
 
@@ -257,9 +258,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <bool HAS_TBL, int NU, int step>
+template <int KVF, int NU, int step>
 __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int tb, int r0, const double (&r2v)[4],
                                          double (&out)[4]) {
+  constexpr bool HAS_TBL = (KVF & 1) != 0, RBFK = (KVF & 2) != 0;  // table multiply / RBF instead of Matern
   constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
                    LN2_LO = 1.90821492927058770002e-10;
   // register roles: t = 5 r2, later the reduced argument r; g = sqrt estimate, later s; h = half
@@ -268,29 +270,37 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
     case 0:
 #pragma unroll
       BBH_KV_EACH {
-        P.t[u] = __builtin_fmax(5.0 * r2v[r0 + u], 1e-300);
+        if (RBFK)
+          P.g[u] = __builtin_fmin(__builtin_fmax(0.5 * r2v[r0 + u], 0.0), 800.0);  // RBF: s = r2 / 2, no sqrt
+        else
+          P.t[u] = __builtin_fmax(5.0 * r2v[r0 + u], 1e-300);
         if (HAS_TBL) P.te[u] = c.taskext[16 * tb + 4 * (r0 + u) + c.q];
       }
       break;
     case 1:
+      if (RBFK) break;
 #pragma unroll
       BBH_KV_EACH P.y[u] = __builtin_amdgcn_rsq(P.t[u]);
       break;
 #if BBH_KV_SQRT_NR  // s = u + (u/2)(1 - u y), u = t y: error 1.5 eps^2 with eps = 2^-26 of v_rsq_f64
     case 2:
+      if (RBFK) break;
 #pragma unroll
       BBH_KV_EACH P.g[u] = P.t[u] * P.y[u];
       break;
     case 3:
+      if (RBFK) break;
 #pragma unroll
       BBH_KV_EACH P.y[u] = fma(-P.g[u], P.y[u], 1.0);
       break;
     case 4:
+      if (RBFK) break;
 #pragma unroll
       BBH_KV_EACH P.h[u] = 0.5 * P.g[u];
       break;
     case 5: break;
     case 6:
+      if (RBFK) break;
 #pragma unroll
       BBH_KV_EACH P.g[u] = __builtin_fmin(fma(P.h[u], P.y[u], P.g[u]), 800.0);  // g = s from here on
       break;
@@ -323,14 +333,18 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
     case 7:
 #pragma unroll
       BBH_KV_EACH P.kf[u] = __builtin_rint(P.g[u] * -LOG2E);
+      if (!RBFK) {
 #pragma unroll
-      BBH_KV_EACH P.q[u] = fma(P.g[u], 1.0 / 3.0, 1.0);
+        BBH_KV_EACH P.q[u] = fma(P.g[u], 1.0 / 3.0, 1.0);
+      }
       break;
     case 8:
 #pragma unroll
       BBH_KV_EACH P.t[u] = fma(P.kf[u], -LN2_HI, -P.g[u]);  // t = reduced argument r from here on
+      if (!RBFK) {
 #pragma unroll
-      BBH_KV_EACH P.q[u] = fma(P.q[u], P.g[u], 1.0);
+        BBH_KV_EACH P.q[u] = fma(P.q[u], P.g[u], 1.0);
+      }
       break;
     case 9:
 #pragma unroll
@@ -356,8 +370,10 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
     case 16: BBH_KV_HORNER2(1.0, 1.0) break;
 #undef BBH_KV_HORNER2
     default:
+      if (!RBFK) {
 #pragma unroll
-      BBH_KV_EACH P.h[u] *= P.q[u];
+        BBH_KV_EACH P.h[u] *= P.q[u];
+      }
 #pragma unroll
       BBH_KV_EACH {
         double v = __builtin_ldexp(P.h[u], P.ki[u]);
@@ -370,11 +386,11 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
 #undef BBH_KV_EACH
 
 // all micro-steps of the four values back to back (first k-block of a pass)
-template <bool HAS_TBL>
+template <int KVF>
 __device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const double (&r2v)[4], double (&out)[4]) {
   KvState<4> P;
   static_for<0, BBH_KV_STEPS>([&](auto st) __attribute__((always_inline)) {
-    kv_micro<HAS_TBL, 4, decltype(st)::value>(P, c, tb, 0, r2v, out);
+    kv_micro<KVF, 4, decltype(st)::value>(P, c, tb, 0, r2v, out);
   });
 }
 
@@ -390,7 +406,7 @@ __device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const double (&
 #define BBH_NEXT_NONE 0
 #define BBH_NEXT_COMPUTE 1
 #define BBH_NEXT_LOAD 2
-template <int W, int CNT, int TT, int KD, bool HAS_TBL, bool DO_MEAN, int NEXT, int BASE, int REM>
+template <int W, int CNT, int TT, int KD, int KVF, bool DO_MEAN, int NEXT, int BASE, int REM>
 __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int tb, const double (&kv)[4],
                                          double (&kvn)[4], d4 (&acc)[W], d4& accm, double (&ring)[BBH_RING], bool store) {
   // The R fragments of a pass are one linear stream (k-block, k-step, column block); they flow through
@@ -445,12 +461,12 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
           constexpr int m = (r - 1) * CNT + jj;
           static_for<(m * BBH_KV_STEPS) / (2 * CNT), ((m + 1) * BBH_KV_STEPS) / (2 * CNT)>(
               [&](auto st) __attribute__((always_inline)) {
-                kv_micro<HAS_TBL, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 0, r2v, kvn);
+                kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 0, r2v, kvn);
               });
         } else {  // two values per slice
           static_for<(jj * BBH_KV_STEPS) / CNT, ((jj + 1) * BBH_KV_STEPS) / CNT>(
               [&](auto st) __attribute__((always_inline)) {
-                kv_micro<HAS_TBL, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 2 * (r - 1), r2v, kvn);
+                kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 2 * (r - 1), r2v, kvn);
               });
         }
       }
@@ -474,7 +490,7 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
   });
 }
 
-template <int W, int TT, int KD, bool HAS_TBL, bool DO_MEAN>
+template <int W, int TT, int KD, int KVF, bool DO_MEAN>
 __device__ __forceinline__ void diag_steps_p(const WaveCtx& c, const double* rf, int j0, double (&kv)[4], d4 (&acc)[W],
                                              d4& accm, double (&ring)[BBH_RING], bool store) {
   if constexpr (TT < W) {
@@ -482,12 +498,12 @@ __device__ __forceinline__ void diag_steps_p(const WaveCtx& c, const double* rf,
     constexpr int NEXT = (TT + 1 < W) ? BBH_NEXT_COMPUTE : BBH_NEXT_NONE;
     constexpr int BASE = (4 * (TT * W - (TT * (TT - 1)) / 2)) % BBH_RING;  // slot of the first fragment
     constexpr int REM = 2 * (W - TT) * (W - TT - 1);  // fragments of this pass after this block
-    kblock_p<W, W - TT, TT, KD, HAS_TBL, DO_MEAN, NEXT, BASE, REM>(c, rf, j0 + TT, kv, kvn, acc, accm, ring, store);
+    kblock_p<W, W - TT, TT, KD, KVF, DO_MEAN, NEXT, BASE, REM>(c, rf, j0 + TT, kv, kvn, acc, accm, ring, store);
     if (NEXT) {
 #pragma unroll
       for (int r = 0; r < 4; r++) kv[r] = kvn[r];
     }
-    diag_steps_p<W, TT + 1, KD, HAS_TBL, DO_MEAN>(c, rf + 4 * (W - TT) * 64, j0, kv, acc, accm, ring, store);
+    diag_steps_p<W, TT + 1, KD, KVF, DO_MEAN>(c, rf + 4 * (W - TT) * 64, j0, kv, acc, accm, ring, store);
   }
 }
 
@@ -496,7 +512,7 @@ __device__ __forceinline__ void diag_steps_p(const WaveCtx& c, const double* rf,
 // cache slab (CACHE), and the rectangular region of later passes (k-blocks < j0) reads them back one
 // block ahead instead of redoing the distance GEMM and the Matérn evaluation (fp64 VALU work is not
 // hidden behind fp64 MFMAs on gfx950 - both issue to the same DP pipe, scripts/mfma_valu_overlap_probe.hip).
-template <int W, int KD, bool HAS_TBL, bool DO_MEAN>
+template <int W, int KD, int KVF, bool DO_MEAN>
 __device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, int j0, double (&ss)[4], d4& accm,
                                             bool cache) {
   d4 acc[W];
@@ -517,25 +533,25 @@ __device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, 
     double tfv[KD], r2v[4];
     kvp_load<KD>(c, 0, tfv);
     kvp_dist<KD>(c, tfv, r2v);
-    kv_all<HAS_TBL>(c, 0, r2v, kv);
+    kv_all<KVF>(c, 0, r2v, kv);
   }
   // rectangular region (k-blocks left of the window); the block after it is this pass's first diagonal
   // block, whose values nobody has computed yet
   const int nload = cache ? (j0 < c.ncache ? j0 : c.ncache) - 1 : 0;  // blocks whose successor is cached
   int tb = 0;
   for (; tb < nload; tb++) {  // next block's values come from the cache
-    kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_LOAD, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring, false);
+    kblock_p<W, W, 0, KD, KVF, DO_MEAN, BBH_NEXT_LOAD, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring, false);
 #pragma unroll
     for (int r = 0; r < 4; r++) kv[r] = kvn[r];
     rf += 4 * W * 64;
   }
   for (; tb < j0; tb++) {  // next block's values are computed between this block's MFMAs
-    kblock_p<W, W, 0, KD, HAS_TBL, DO_MEAN, BBH_NEXT_COMPUTE, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring, false);
+    kblock_p<W, W, 0, KD, KVF, DO_MEAN, BBH_NEXT_COMPUTE, 0, 1 << 20>(c, rf, tb, kv, kvn, acc, accm, ring, false);
 #pragma unroll
     for (int r = 0; r < 4; r++) kv[r] = kvn[r];
     rf += 4 * W * 64;
   }
-  diag_steps_p<W, 0, KD, HAS_TBL, DO_MEAN>(c, rf, j0, kv, acc, accm, ring, cache && !DO_MEAN);
+  diag_steps_p<W, 0, KD, KVF, DO_MEAN>(c, rf, j0, kv, acc, accm, ring, cache && !DO_MEAN);
 #pragma unroll
   for (int jj = 0; jj < W; jj++)
 #pragma unroll
@@ -586,7 +602,8 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     if (q == q2) candw[k2 * 64 + l] = nbsum;
   }
   int tc = 0;
-  if (HAS_TBL && a.task_col >= 0) {
+  constexpr bool has_tbl = HAS_TBL;
+  if (has_tbl && a.task_col >= 0) {
     tc = (int)xr[a.task_col];
     tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
   }
@@ -640,13 +657,13 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       if constexpr (KD > 0) {  // software-pipelined passes
         const bool use_cache = (a.ncache > 0);
         if (!last) {
-          pass_body_p<16, KD, HAS_TBL, false>(c, rf, j0, ss, accm, use_cache);
+          pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), false>(c, rf, j0, ss, accm, use_cache);
         } else {
           switch (W) {
-            case 4: pass_body_p<4, KD, HAS_TBL, true>(c, rf, j0, ss, accm, use_cache); break;
-            case 8: pass_body_p<8, KD, HAS_TBL, true>(c, rf, j0, ss, accm, use_cache); break;
-            case 12: pass_body_p<12, KD, HAS_TBL, true>(c, rf, j0, ss, accm, use_cache); break;
-            default: pass_body_p<16, KD, HAS_TBL, true>(c, rf, j0, ss, accm, use_cache); break;
+            case 4: pass_body_p<4, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            case 8: pass_body_p<8, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            case 12: pass_body_p<12, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            default: pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
           }
         }
       } else if (!last) {
@@ -663,7 +680,14 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     }
     // pending block(s): mean/cross columns only
     for (int tb = a.nb; tb < a.nb_ext; tb++) {
-      compute_kv<HAS_TBL, KIND>(c, tb, kv);
+      if constexpr (KD > 0) {  // pipelined instantiations serve several kernel kinds: run-time kind / table flag
+        if (has_tbl)
+          compute_kv<true, -1>(c, tb, kv);
+        else
+          compute_kv<false, -1>(c, tb, kv);
+      } else {
+        compute_kv<HAS_TBL, KIND>(c, tb, kv);
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
     }
@@ -701,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     const int tcm = __shfl(tc, m, 64);
     const int64_t gi = tile0 + m;
     double pv = a.prior_scale;
-    if (HAS_TBL) pv = a.tasktbl[tcm * a.T + tcm];
+    if (has_tbl) pv = a.tasktbl[tcm * a.T + tcm];
     mval[r] = a.ybar + a.ysd * (a.mean_const + accm[r]);  // meaningful in the cnd == 0 lanes
     vval[r] = s2 * (pv - ss[r]);
     if (gi < a.N) {
@@ -772,10 +796,13 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
 
 // one launcher per translation unit (KD = compile-time k-steps of the distance GEMM; 0 = runtime k-steps,
 // every kernel kind).  m52: Matérn-5/2 instantiation, otherwise the runtime-kind one (KD = 0 only).
+// KD > 0: rbf selects the RBF instantiation (without table only), otherwise the Matérn-5/2 one with or without
+// the task / outputscale table.  (A run-time table flag inside the micro-steps cost the default kernel 7 %, so
+// it stays a template parameter; Matérn-3/2, Matérn-1/2 and RBF with a table take the plain form.)
 void bbh_fused_launch_kd0(bool has_tbl, bool m52, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd2(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd4(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd6(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd8(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd12(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd16(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd2(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd4(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd6(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd8(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd12(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd16(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);

@@ -1,12 +1,17 @@
-// Software-pipelined fused posterior kernel, Matérn-5/2, 16 k-steps in the distance GEMM (d <= 62).
+// Software-pipelined fused posterior kernel, Matérn-5/2 and RBF, 16 k-steps in the distance GEMM (d <= 62).
 #include "bbh_fused.h"
 
-void bbh_fused_launch_kd16(bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a) {
-  if (has_tbl) {
-    BBH_FUSED_ALLOW_LDS((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52, 16>), lds);
-    hipLaunchKernelGGL((bbh_fused_posterior_kernel<true, BBH_KERNEL_MATERN52, 16>), grid, block, lds, s, a);
-  } else {
-    BBH_FUSED_ALLOW_LDS((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52, 16>), lds);
-    hipLaunchKernelGGL((bbh_fused_posterior_kernel<false, BBH_KERNEL_MATERN52, 16>), grid, block, lds, s, a);
-  }
+#define BBH_LAUNCH(TBL, KND)                                                                      \
+  do {                                                                                            \
+    BBH_FUSED_ALLOW_LDS((bbh_fused_posterior_kernel<TBL, KND, 16>), lds);                          \
+    hipLaunchKernelGGL((bbh_fused_posterior_kernel<TBL, KND, 16>), grid, block, lds, s, a);        \
+  } while (0)
+
+void bbh_fused_launch_kd16(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a) {
+  if (rbf)
+    BBH_LAUNCH(false, BBH_KERNEL_RBF);  // RBF with a task / outputscale table takes the plain form (caller)
+  else if (has_tbl)
+    BBH_LAUNCH(true, BBH_KERNEL_MATERN52);
+  else
+    BBH_LAUNCH(false, BBH_KERNEL_MATERN52);
 }

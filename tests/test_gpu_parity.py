@@ -172,8 +172,9 @@ def test_posterior_fused_and_unfused_match_oracle(gp, N, d, n):
     assert math.isclose(gp.best_f(-1.0), go.best_f_from_model(om, -1.0), rel_tol=1e-9, abs_tol=1e-12)
 
 
-@pytest.mark.parametrize("N,d,n", [(20_000, 20, 600), (30_000, 6, 1100), (4_000, 28, 300)])
-def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
+@pytest.mark.parametrize("N,d,n,kernel", [(20_000, 20, 600, "matern52"), (30_000, 6, 1100, "matern52"),
+                                          (4_000, 28, 300, "matern52"), (20_000, 12, 600, "rbf"), (5_000, 40, 520, "rbf")])
+def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n, kernel):
     """The software-pipelined fused kernel (staged rsq/Taylor Matérn evaluation, kernel-value cache
     in wave-private LDS and in global slabs claimed per wave) against the same launch with libm sqrt/exp and
     no cache; the switches are
@@ -181,7 +182,7 @@ def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n):
     from baybe_amd import engine, gp_spec
 
     X, Xt, y = make_problem(N, d, n, seed=11)
-    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), kernel=kernel)
     ls, nz, _ = fixed_theta(d)
     p = gp_spec.GPParams(np.full(d, ls), nz, 0.0)
     out = {}
