@@ -921,6 +921,105 @@ __global__ __launch_bounds__(64) void bbh_mc_pending_kernel(int kind, const doub
   scores[i] = sum / (double)S;
 }
 
+// Register-resident form of bbh_mc_pending_kernel for q' = Q <= 8 (see bbh_qlogei_pending_q_kernel): same
+// arithmetic in the same order, factor and per-point values in registers, base samples in LDS.
+template <int Q>
+__global__ __launch_bounds__(256) void bbh_mc_pending_q_kernel(int kind, const double* __restrict__ mean,
+                                                              const double* __restrict__ var, const double* __restrict__ cross,
+                                                              int64_t N, const double* __restrict__ mean_p,
+                                                              const double* __restrict__ cov_pp, const double* __restrict__ z,
+                                                              const double* __restrict__ zbar, int S, double best_f, double sign,
+                                                              double cu, const uint8_t* __restrict__ alive,
+                                                              double* __restrict__ scores) {
+  extern __shared__ double s_zq[];  // [S * Q] base samples, then zbar [Q], mean_p [Q - 1], cov_pp [(Q - 1)^2]
+  constexpr int P = Q - 1;
+  double* s_zb = s_zq + (int64_t)S * Q;
+  double* s_mp = s_zb + Q;
+  double* s_cpp = s_mp + P;
+  for (int e = threadIdx.x; e < S * Q; e += 256) s_zq[e] = z[e];
+  for (int e = threadIdx.x; e < Q; e += 256) s_zb[e] = zbar[e];
+  for (int e = threadIdx.x; e < P; e += 256) s_mp[e] = mean_p[e];
+  for (int e = threadIdx.x; e < P * P; e += 256) s_cpp[e] = cov_pp[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  double L[Q * (Q + 1) / 2], A[Q * (Q + 1) / 2];
+  A[0] = var[i];
+#pragma unroll
+  for (int r = 1; r < Q; r++) {
+    A[r * (r + 1) / 2] = cross[i * P + (r - 1)];
+#pragma unroll
+    for (int c = 1; c <= r; c++) A[r * (r + 1) / 2 + c] = s_cpp[(r - 1) * P + (c - 1)];
+  }
+  double jitter = 0.0;
+  bool ok = false;
+  for (int attempt = 0; attempt < 4 && !ok; attempt++) {
+    ok = true;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+#pragma unroll
+      for (int c = 0; c <= r; c++) {
+        double sacc = A[r * (r + 1) / 2 + c];
+        if (r == c) sacc += jitter;
+#pragma unroll
+        for (int k = 0; k < c; k++) sacc -= L[r * (r + 1) / 2 + k] * L[c * (c + 1) / 2 + k];
+        if (r == c) {
+          if (!(sacc > 0.0)) ok = false;
+          L[r * (r + 1) / 2 + r] = sqrt(sacc);
+        } else {
+          L[r * (r + 1) / 2 + c] = sacc / L[c * (c + 1) / 2 + c];
+        }
+      }
+    }
+    if (!ok) jitter = 1e-8 * pow(10.0, (double)attempt);
+  }
+  if (!ok) {
+    scores[i] = NAN;
+    return;
+  }
+  double m[Q], mbar[Q];
+  m[0] = mean[i];
+#pragma unroll
+  for (int r = 1; r < Q; r++) m[r] = s_mp[r - 1];
+#pragma unroll
+  for (int r = 0; r < Q; r++) {
+    double y = m[r];
+#pragma unroll
+    for (int c = 0; c <= r; c++) y = fma(L[r * (r + 1) / 2 + c], s_zb[c], y);
+    mbar[r] = sign * y;
+  }
+  double sum = 0.0;
+  for (int s = 0; s < S; s++) {
+    const double* zs = s_zq + (int64_t)s * Q;
+    double zr[Q];
+#pragma unroll
+    for (int c = 0; c < Q; c++) zr[c] = zs[c];
+    double mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+      double y = m[r];
+#pragma unroll
+      for (int c = 0; c <= r; c++) y = fma(L[r * (r + 1) / 2 + c], zr[c], y);
+      mx = fmax(mx, bbh_mc_utility(kind, sign * y, mbar[r], best_f, cu));
+    }
+    sum += mx;
+  }
+  scores[i] = sum / (double)S;
+}
+
+template <int Q>
+static void bbh_launch_mc_pending_q(hipStream_t st, int kind, const double* mean, const double* var, const double* cross,
+                                    int64_t N, const double* mp, const double* cpp, const double* z, const double* zbar, int S,
+                                    double best_f, double sign, double cu, const uint8_t* alive, double* scores) {
+  const size_t lds = sizeof(double) * ((size_t)S * Q + Q + (Q - 1) + (size_t)(Q - 1) * (Q - 1));
+  hipLaunchKernelGGL((bbh_mc_pending_q_kernel<Q>), dim3((unsigned)((N + 255) / 256)), dim3(256), lds, st, kind, mean, var,
+                     cross, N, mp, cpp, z, zbar, S, best_f, sign, cu, alive, scores);
+}
+
 __device__ __forceinline__ double bbh_log_h(double u) {
   // log(phi(u) + u Phi(u)), asymptotic branch for u < -1 (BoTorch _log_ei_helper)
   const double inv_sqrt2 = 0.7071067811865476, half_log_2pi = 0.9189385332046727;
@@ -1021,9 +1120,29 @@ extern "C" int bbh_mc_acq_pending(bbh_handle* h, int32_t kind, const double* mea
   int rc = bbh_upload_z(h, buf.data(), buf.size());
   if (rc) return rc;
   const double* dz = h->d_z;
-  hipLaunchKernelGGL(bbh_mc_pending_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, kind, mean_dev, var_dev,
-                     cross_dev, N, p, dz + S * q + q, dz + S * q + q + p, dz, dz + S * q, (int)S, best_f, sign,
-                     bbh_mc_cu(kind, beta), alive_dev, scores_dev);
+  const double* dzb = dz + S * q;
+  const double* dmp = dzb + q;
+  const double* dcpp = dmp + p;
+  const double cu = bbh_mc_cu(kind, beta);
+  const bool fits = sizeof(double) * buf.size() <= 60 * 1024;  // base samples in LDS
+#define BBH_MC_PENDING_Q(QV)                                                                                     \
+  case QV:                                                                                                       \
+    bbh_launch_mc_pending_q<QV>(h->stream, kind, mean_dev, var_dev, cross_dev, N, dmp, dcpp, dz, dzb, (int)S,    \
+                                best_f, sign, cu, alive_dev, scores_dev);                                        \
+    break;
+  switch (fits && !h->pending_lds_form ? q : 0) {
+    BBH_MC_PENDING_Q(2)
+    BBH_MC_PENDING_Q(3)
+    BBH_MC_PENDING_Q(4)
+    BBH_MC_PENDING_Q(5)
+    BBH_MC_PENDING_Q(6)
+    BBH_MC_PENDING_Q(7)
+    BBH_MC_PENDING_Q(8)
+    default:
+      hipLaunchKernelGGL(bbh_mc_pending_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, kind, mean_dev,
+                         var_dev, cross_dev, N, p, dmp, dcpp, dz, dzb, (int)S, best_f, sign, cu, alive_dev, scores_dev);
+  }
+#undef BBH_MC_PENDING_Q
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
 }
