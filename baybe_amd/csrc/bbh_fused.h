@@ -790,8 +790,14 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
 // dynamic LDS beyond 64 KB has to be requested per kernel (the kernel-value cache may use up to half a CU's LDS)
 #define BBH_FUSED_ALLOW_LDS(KERNEL, BYTES)                                                              \
   do {                                                                                                 \
-    if ((BYTES) > 48 * 1024)                                                                           \
+    static size_t allowed[64]; /* per kernel instantiation (one expansion each) and device */           \
+    int dev_ = 0;                                                                                      \
+    (void)hipGetDevice(&dev_);                                                                         \
+    dev_ &= 63;                                                                                        \
+    if ((size_t)(BYTES) > 48 * 1024 && (size_t)(BYTES) > allowed[dev_]) {                              \
       (void)hipFuncSetAttribute((const void*)(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
+      allowed[dev_] = (size_t)(BYTES);                                                                 \
+    }                                                                                                  \
   } while (0)
 
 // one launcher per translation unit (KD = compile-time k-steps of the distance GEMM; 0 = runtime k-steps,
