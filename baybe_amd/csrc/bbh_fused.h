@@ -680,14 +680,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
     }
     // pending block(s): mean/cross columns only
     for (int tb = a.nb; tb < a.nb_ext; tb++) {
-      if constexpr (KD > 0) {  // pipelined instantiations serve several kernel kinds: run-time kind / table flag
-        if (has_tbl)
-          compute_kv<true, -1>(c, tb, kv);
-        else
-          compute_kv<false, -1>(c, tb, kv);
-      } else {
-        compute_kv<HAS_TBL, KIND>(c, tb, kv);
-      }
+      compute_kv<HAS_TBL, KIND>(c, tb, kv);
 #pragma unroll
       for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
     }
