@@ -262,6 +262,8 @@ template <int KVF, int NU, int step>
 __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int tb, int r0, const double (&r2v)[4],
                                          double (&out)[4]) {
   constexpr bool HAS_TBL = (KVF & 1) != 0, RBFK = (KVF & 2) != 0;  // table multiply / RBF instead of Matern
+  constexpr bool M32K = (KVF & 4) != 0;  // Matern-3/2: k = (1 + s) exp(-s), s = sqrt(3 r2)  (5/2: 1 + s + s^2/3, s = sqrt(5 r2))
+  constexpr double KC1 = M32K ? 3.0 : 5.0, KC2 = M32K ? 0.0 : 1.0 / 3.0;
   constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
                    LN2_LO = 1.90821492927058770002e-10;
   // register roles: t = 5 r2, later the reduced argument r; g = sqrt estimate, later s; h = half
@@ -273,7 +275,7 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
         if (RBFK)
           P.g[u] = __builtin_fmin(__builtin_fmax(0.5 * r2v[r0 + u], 0.0), 800.0);  // RBF: s = r2 / 2, no sqrt
         else
-          P.t[u] = __builtin_fmax(5.0 * r2v[r0 + u], 1e-300);
+          P.t[u] = __builtin_fmax(KC1 * r2v[r0 + u], 1e-300);
         if (HAS_TBL) P.te[u] = c.taskext[16 * tb + 4 * (r0 + u) + c.q];
       }
       break;
@@ -335,7 +337,7 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
       BBH_KV_EACH P.kf[u] = __builtin_rint(P.g[u] * -LOG2E);
       if (!RBFK) {
 #pragma unroll
-        BBH_KV_EACH P.q[u] = fma(P.g[u], 1.0 / 3.0, 1.0);
+        BBH_KV_EACH P.q[u] = M32K ? 1.0 : fma(P.g[u], KC2, 1.0);
       }
       break;
     case 8:
@@ -657,13 +659,13 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       if constexpr (KD > 0) {  // software-pipelined passes
         const bool use_cache = (a.ncache > 0);
         if (!last) {
-          pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), false>(c, rf, j0, ss, accm, use_cache);
+          pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0), false>(c, rf, j0, ss, accm, use_cache);
         } else {
           switch (W) {
-            case 4: pass_body_p<4, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
-            case 8: pass_body_p<8, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
-            case 12: pass_body_p<12, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
-            default: pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            case 4: pass_body_p<4, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            case 8: pass_body_p<8, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            case 12: pass_body_p<12, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
+            default: pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0), true>(c, rf, j0, ss, accm, use_cache); break;
           }
         }
       } else if (!last) {
@@ -795,13 +797,13 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
 
 // one launcher per translation unit (KD = compile-time k-steps of the distance GEMM; 0 = runtime k-steps,
 // every kernel kind).  m52: Matérn-5/2 instantiation, otherwise the runtime-kind one (KD = 0 only).
-// KD > 0: rbf selects the RBF instantiation (without table only), otherwise the Matérn-5/2 one with or without
-// the task / outputscale table.  (A run-time table flag inside the micro-steps cost the default kernel 7 %, so
-// it stays a template parameter; Matérn-3/2, Matérn-1/2 and RBF with a table take the plain form.)
+// KD > 0: kind selects the RBF / Matérn-3/2 instantiation (both without table only), otherwise the Matérn-5/2 one
+// with or without the task / outputscale table.  (A run-time table flag inside the micro-steps cost the default kernel 7 %, so
+// it stays a template parameter; Matérn-1/2 and RBF / Matérn-3/2 with a table take the plain form.)
 void bbh_fused_launch_kd0(bool has_tbl, bool m52, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd2(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd4(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd6(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd8(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd12(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-void bbh_fused_launch_kd16(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd2(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd4(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd6(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd8(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd12(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+void bbh_fused_launch_kd16(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);

@@ -1,4 +1,4 @@
-// Software-pipelined fused posterior kernel, Matérn-5/2 and RBF, 4 k-steps in the distance GEMM (d <= 14).
+// Software-pipelined fused posterior kernel, Matérn-5/2, Matérn-3/2 and RBF, 4 k-steps in the distance GEMM (d <= 14).
 #include "bbh_fused.h"
 
 #define BBH_LAUNCH(TBL, KND)                                                                      \
@@ -7,9 +7,11 @@
     hipLaunchKernelGGL((bbh_fused_posterior_kernel<TBL, KND, 4>), grid, block, lds, s, a);        \
   } while (0)
 
-void bbh_fused_launch_kd4(bool rbf, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a) {
-  if (rbf)
-    BBH_LAUNCH(false, BBH_KERNEL_RBF);  // RBF with a task / outputscale table takes the plain form (caller)
+void bbh_fused_launch_kd4(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a) {
+  if (kind == BBH_KERNEL_RBF)  // RBF / Matérn-3/2 with a task / outputscale table take the plain form (caller)
+    BBH_LAUNCH(false, BBH_KERNEL_RBF);
+  else if (kind == BBH_KERNEL_MATERN32)
+    BBH_LAUNCH(false, BBH_KERNEL_MATERN32);
   else if (has_tbl)
     BBH_LAUNCH(true, BBH_KERNEL_MATERN52);
   else

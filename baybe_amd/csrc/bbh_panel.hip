@@ -262,12 +262,12 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
   // (set below once the kernel form is known)
   const bool m52 = (a.kind == BBH_KERNEL_MATERN52);
-  // software-pipelined instantiations exist for Matérn-5/2 (with / without table) and RBF (without) with kd in
+  // software-pipelined instantiations exist for Matérn-5/2 (with / without table), Matérn-3/2 and RBF (without) with kd in
   // {2, 4, 6, 8, 12, 16}
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
-  const bool rbf = (a.kind == BBH_KERNEL_RBF);
+  const bool rbf = (a.kind == BBH_KERNEL_RBF), m32 = (a.kind == BBH_KERNEL_MATERN32);
   a.has_tbl = has_tbl ? 1 : 0;
-  const int kdp = ((m52 || (rbf && !has_tbl)) && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
+  const int kdp = ((m52 || ((rbf || m32) && !has_tbl)) && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
   // alpha in LDS costs 8 n bytes: beyond n = 4096 it would crowd out the candidate fragments / the cache
@@ -322,17 +322,17 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     hipEventRecord(e0, h->stream);
   }
   if (kdp == 2)
-    bbh_fused_launch_kd2(rbf, has_tbl, grid, block, lds, h->stream, a);
+    bbh_fused_launch_kd2(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 4)
-    bbh_fused_launch_kd4(rbf, has_tbl, grid, block, lds, h->stream, a);
+    bbh_fused_launch_kd4(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 6)
-    bbh_fused_launch_kd6(rbf, has_tbl, grid, block, lds, h->stream, a);
+    bbh_fused_launch_kd6(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 8)
-    bbh_fused_launch_kd8(rbf, has_tbl, grid, block, lds, h->stream, a);
+    bbh_fused_launch_kd8(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 12)
-    bbh_fused_launch_kd12(rbf, has_tbl, grid, block, lds, h->stream, a);
+    bbh_fused_launch_kd12(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 16)
-    bbh_fused_launch_kd16(rbf, has_tbl, grid, block, lds, h->stream, a);
+    bbh_fused_launch_kd16(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else
     bbh_fused_launch_kd0(has_tbl, m52, grid, block, lds, h->stream, a);
   if (timed) {

@@ -173,7 +173,8 @@ def test_posterior_fused_and_unfused_match_oracle(gp, N, d, n):
 
 
 @pytest.mark.parametrize("N,d,n,kernel", [(20_000, 20, 600, "matern52"), (30_000, 6, 1100, "matern52"),
-                                          (4_000, 28, 300, "matern52"), (20_000, 12, 600, "rbf"), (5_000, 40, 520, "rbf")])
+                                          (4_000, 28, 300, "matern52"), (20_000, 12, 600, "rbf"), (5_000, 40, 520, "rbf"),
+                                          (20_000, 9, 600, "matern32")])
 def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n, kernel):
     """The software-pipelined fused kernel (staged rsq/Taylor Matérn evaluation, kernel-value cache
     in wave-private LDS and in global slabs claimed per wave) against the same launch with libm sqrt/exp and
