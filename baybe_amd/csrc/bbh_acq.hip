@@ -392,9 +392,20 @@ static int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
     BBH_HIP_TRY(h, hipMalloc((void**)&h->d_z, bytes));
     h->z_bytes = bytes;
   }
-  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_z, z_host, bytes, hipMemcpyHostToDevice, h->stream));
-  // the host buffer may be released by the caller right after return
-  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // Staged through a pinned buffer of the handle, so that the call neither waits for the kernels already in
+  // the stream (a synchronous copy would: it is ordered behind them) nor depends on the caller's buffer.
+  if (!h->z_evt) BBH_HIP_TRY(h, hipEventCreateWithFlags(&h->z_evt, hipEventDisableTiming));
+  else BBH_HIP_TRY(h, hipEventSynchronize(h->z_evt));  // previous staged copy has been consumed
+  if (bytes > h->zstage_bytes) {
+    if (h->h_zstage) hipHostFree(h->h_zstage);
+    h->h_zstage = nullptr;
+    h->zstage_bytes = 0;
+    BBH_HIP_TRY(h, hipHostMalloc((void**)&h->h_zstage, bytes, hipHostMallocDefault));
+    h->zstage_bytes = bytes;
+  }
+  memcpy(h->h_zstage, z_host, bytes);
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_z, h->h_zstage, bytes, hipMemcpyHostToDevice, h->stream));
+  BBH_HIP_TRY(h, hipEventRecord(h->z_evt, h->stream));
   return 0;
 }
 

@@ -53,6 +53,8 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   if (h->d_kvcache) hipFree(h->d_kvcache);
   if (h->d_slab_flags) hipFree(h->d_slab_flags);
   if (h->d_z) hipFree(h->d_z);
+  if (h->h_zstage) hipHostFree(h->h_zstage);
+  if (h->z_evt) hipEventDestroy(h->z_evt);
   if (h->d_red) hipFree(h->d_red);
   if (h->d_redi) hipFree(h->d_redi);
   delete h;

@@ -131,6 +131,9 @@ struct bbh_handle {
   size_t ws_bytes = 0;
   double* d_z = nullptr;
   size_t z_bytes = 0;
+  double* h_zstage = nullptr;     // pinned staging copy of the last upload (the async copy reads it later)
+  size_t zstage_bytes = 0;
+  hipEvent_t z_evt = nullptr;     // recorded after the staged copy: the staging buffer may be rewritten once it fired
   double* d_red = nullptr;        // argmax partials
   int64_t* d_redi = nullptr;
   // timing
