@@ -122,9 +122,10 @@ def main():
         shard.start, shard.stop = rank * rows_local, (rank + 1) * rows_local
 
     def step():
-        # two kernels: measured 3 % faster than the single fused posterior+qLogEI kernel
-        # (scripts/gpu_ab_fused_acq.py: 6.64 vs 6.84 ms/step) because a 2-waves-per-SIMD epilogue
-        # is latency-bound while a separate launch runs the same VALU work at full occupancy
+        # two kernels: measured 1.5 % faster than the single fused posterior+qLogEI kernel
+        # (scripts/gpu_ab_fused_acq.py: 5.64 vs 5.73 ms/step): the epilogue's VALU work costs the shared fp64
+        # pipe the same either way, but a separate launch runs it at full occupancy and leaves the fused
+        # kernel's LDS to the kernel-value cache
         mean, var = gp.posterior(Xd)
         scores = gp.qlogei(mean, var, z, best_f, 1.0)
         vals, idx = gp.topk(scores, TOPK)
