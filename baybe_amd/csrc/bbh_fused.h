@@ -227,10 +227,11 @@ __device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[K
   for (int r = 0; r < 4; r++) r2v[r] = da[r] + db[r];
 }
 
-// Matérn-5/2 of two scaled squared distances, cut into BBH_KV_STEPS micro-steps of 2-4 VALU
-// instructions so that the caller can place them between MFMAs in program order (the compiler's
+// Kernel values of NU (= 4) scaled squared distances in lockstep, cut into BBH_KV_STEPS micro-steps of NU to
+// 2 NU VALU instructions so that the caller can place them between MFMAs in program order (the compiler's
 // scheduler clumps library sqrt()/exp() calls behind the MFMAs even when asked to interleave them
-// with sched_group_barrier).  k(r2) = (1 + s + s^2/3) exp(-s), s = sqrt(5 r2):
+// with sched_group_barrier).  Matérn-5/2: k(r2) = (1 + s + s^2/3) exp(-s), s = sqrt(5 r2); Matérn-3/2:
+// (1 + s) exp(-s), s = sqrt(3 r2); RBF: exp(-r2 / 2) (the sqrt steps are skipped):
 //   sqrt: v_rsq_f64 seed and one Newton step (error 1.5 eps^2 = 3e-16; the Goldschmidt + Newton form
 //         with error O(eps^4) is kept behind BBH_KV_SQRT_NR=0 and measured 1 % slower);
 //   exp:  -s = k ln2 + r, |r| <= ln2/2, Taylor degree 13 (truncation 4e-18), scaled with v_ldexp_f64;
