@@ -96,17 +96,25 @@ __device__ __forceinline__ void compute_kv(const WaveCtx& c, int tb, double (&kv
       const double rr = sqrt(r2);
       v = (1.0 + BBH_SQRT5 * rr + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * rr);
     } else if (c.kind == BBH_KERNEL_MATERN12) {
-      // exp(-r) is not smooth at r = 0: the |a|^2 + |b|^2 - 2ab form loses ~sqrt(eps) there, so
-      // this (rare) kernel recomputes the distance from direct differences of the same operands
-      // (a_i = -0.5 * A_aug, b_c from LDS) — exact zeros for coinciding points.
-      const double* tfb = tf - c.l;
-      const double* cb = c.candl - c.l;
-      const int il = c.q + 4 * r, cl = c.l & 15;
-      double d2 = 0.0;
-      for (int dim = 0; dim < c.dn; dim++) {
-        const int o = (dim >> 2) * 64 + (dim & 3) * 16;
-        const double df = cb[o + cl] + 0.5 * tfb[o + il];
-        d2 = fma(df, df, d2);
+      // exp(-r) is not smooth at r = 0: the |a|^2 + |b|^2 - 2ab form has an absolute error of ~1e-16 (|a|^2 +
+      // |b|^2) in r2, i.e. ~1e-11 / r in r - harmless except for (nearly) coinciding points.  Lanes with
+      // r2 < 1e-2 recompute the distance from direct differences of the same operands (a_i = -0.5 * A_aug,
+      // b_c from LDS; exact zeros for coinciding points); the test is wave-uniform so that the loop is only
+      // entered where some lane needs it (it used to run for every pair: 15 ms instead of 6 for this kernel).
+      double d2 = r2;
+      const bool nearp = r2 < 1e-2;
+      if (__builtin_amdgcn_ballot_w64(nearp) != 0) {
+        if (nearp) {
+          const double* tfb = tf - c.l;
+          const double* cb = c.candl - c.l;
+          const int il = c.q + 4 * r, cl = c.l & 15;
+          d2 = 0.0;
+          for (int dim = 0; dim < c.dn; dim++) {
+            const int o = (dim >> 2) * 64 + (dim & 3) * 16;
+            const double df = cb[o + cl] + 0.5 * tfb[o + il];
+            d2 = fma(df, df, d2);
+          }
+        }
       }
       v = (r2 > 1e7) ? 0.0 : exp(-sqrt(d2));  // r2 > 1e7 marks padding (A_aug norm slot = 1e8)
     } else {
