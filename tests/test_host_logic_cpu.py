@@ -139,3 +139,33 @@ def test_preset_raw_parameterisation_round_trip_and_oracle_gradient(preset):
         e[i] = 1e-6
         fd = (go.fit_objective(ospec, raw + e, Xn, ys)[0] - go.fit_objective(ospec, raw - e, Xn, ys)[0]) / 2e-6
         assert math.isclose(fd, g0[i], rel_tol=2e-5, abs_tol=1e-8)
+
+
+# ---- backtesting driver: lookup semantics (simulation/lookup.py:19-150), no device needed ---------------
+def test_lookup_dataframe_callable_and_impute_modes():
+    import pandas as pd
+
+    from baybe_amd.simulation import _cumargmax, look_up_targets
+
+    class T:  # NumericalTarget-shaped
+        def __init__(self, name, minimize=False):
+            self.name, self.minimize = name, minimize
+
+    lookup = pd.DataFrame({"x": [1, 2, 3], "c": ["a", "b", "a"], "y": [10.0, 20.0, 5.0], "z": [1.0, 2.0, 3.0]})
+    q = pd.DataFrame({"x": [2, 1], "c": ["b", "a"]}, index=[7, 9])
+    look_up_targets(q, [T("y"), T("z")], lookup)
+    assert q["y"].tolist() == [20.0, 10.0] and q["z"].tolist() == [2.0, 1.0] and q.index.tolist() == [7, 9]
+    q = pd.DataFrame({"x": [3, 4], "c": ["a", "a"]})
+    with pytest.raises(IndexError):
+        look_up_targets(q.copy(), [T("y")], lookup[["x", "c", "y"]])
+    for mode, want in (("worst", 5.0), ("best", 20.0), ("mean", 35.0 / 3)):
+        qq = q.copy()
+        look_up_targets(qq, [T("y")], lookup[["x", "c", "y"]], mode)
+        assert qq["y"].tolist() == [5.0, pytest.approx(want)]
+    qq = q.copy()
+    look_up_targets(qq, [T("y", minimize=True)], lookup[["x", "c", "y"]], "worst")
+    assert qq["y"].tolist() == [5.0, 20.0]  # worst for a minimised target is the largest value
+    qq = q.copy()
+    look_up_targets(qq, [T("y")], lambda df: pd.DataFrame({"y": df["x"] * 2.0}, index=df.index))
+    assert qq["y"].tolist() == [6.0, 8.0]
+    assert _cumargmax(np.array([1.0, 3.0, 2.0, 3.0, 5.0])).tolist() == [0, 1, 1, 3, 4]
