@@ -110,6 +110,9 @@ SIGNATURES = {
          C.c_void_p, C.c_void_p],
     ),
     "bbh_pareto_frequency": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
+    "bbh_cells_create": (C.c_int, [c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, C.POINTER(C.c_void_p), c_int64_p]),
+    "bbh_cells_get": (C.c_int, [C.c_void_p, c_int64_p, c_double_p, c_double_p]),
+    "bbh_cells_destroy": (C.c_int, [C.c_void_p]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
     "bbh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

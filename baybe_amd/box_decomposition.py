@@ -76,3 +76,31 @@ def pack_cells(obj_b: np.ndarray, ref: np.ndarray):
     if los:
         return off, np.ascontiguousarray(np.concatenate(los)), np.ascontiguousarray(np.concatenate(lls))
     return off, np.zeros((0, m)), np.zeros((0, m))
+
+
+def pack_cells_native(obj_b: np.ndarray, ref: np.ndarray):
+    """``pack_cells`` through the library's host code (``bbh_cells_create`` / ``_get`` / ``_destroy``,
+    csrc/bbh_cells.hip): the same algorithm and visiting order in C++, ~100x faster than the numpy form above,
+    which stays as the readable statement of the algorithm and as its cross-check in the tests."""
+    import ctypes as C
+
+    from baybe_amd import _lib
+
+    lib = _lib.load_library()
+    obj_b = np.ascontiguousarray(obj_b, dtype=np.float64)
+    ref = np.ascontiguousarray(ref, dtype=np.float64)
+    S, n, m = obj_b.shape
+    handle, total = C.c_void_p(), C.c_int64()
+    rc = lib.bbh_cells_create(obj_b.ctypes.data_as(_lib.c_double_p), S, n, m, ref.ctypes.data_as(_lib.c_double_p),
+                              C.byref(handle), C.byref(total))
+    if rc != 0:
+        raise ValueError("bbh_cells_create: bad arguments (1 <= m <= 4)")
+    try:
+        K = int(total.value)
+        off = np.zeros(S + 1, dtype=np.int64)
+        lo, ll = np.zeros((K, m)), np.zeros((K, m))
+        lib.bbh_cells_get(handle, off.ctypes.data_as(_lib.c_int64_p), lo.ctypes.data_as(_lib.c_double_p),
+                          ll.ctypes.data_as(_lib.c_double_p))
+    finally:
+        lib.bbh_cells_destroy(handle)
+    return off, lo, ll

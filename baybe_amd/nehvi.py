@@ -25,7 +25,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from baybe_amd import _lib
-from baybe_amd.box_decomposition import pack_cells, pareto_mask
+from baybe_amd.box_decomposition import pack_cells_native, pareto_mask
 from baybe_amd.engine import GreedyResult, HipGP, _dp, draw_sampler_seed, sobol_normal_base_samples
 
 PRUNE_SAMPLES = 2048  # prune_inferior_points_multi_objective(num_samples=2048)
@@ -93,10 +93,11 @@ class HipNEHVI:
         of 2048 joint posterior samples (``prune_inferior_points_multi_objective``)."""
         nb = len(Xb)
         z = sobol_normal_base_samples(PRUNE_SAMPLES, nb * self.m, seed).reshape(PRUNE_SAMPLES, nb, self.m)
+        zc = np.ascontiguousarray(z.transpose(2, 0, 1))  # [m, S, nb]: contiguous operands for the BLAS products
         mus, Ls = self._baseline_posteriors(Xb)
         obj = np.empty((PRUNE_SAMPLES, nb, self.m))
         for o in range(self.m):
-            obj[:, :, o] = (mus[o][None, :] + z[:, :, o] @ Ls[o].T) * self.signs[o]
+            obj[:, :, o] = (mus[o][None, :] + zc[o] @ Ls[o].T) * self.signs[o]
         counts = np.zeros(nb, dtype=np.int64)
         obj = np.ascontiguousarray(obj)
         ref = np.ascontiguousarray(self.ref, dtype=np.float64)
@@ -127,7 +128,7 @@ class HipNEHVI:
             mus, Ls = self._baseline_posteriors(Xb)
             for o in range(self.m):
                 Fb[:, :, o] = mus[o][None, :] + z[:, :nb, o] @ Ls[o].T
-        self.cell_off, self.cell_lo, self.cell_ll = pack_cells(Fb * self.signs[None, None, :], self.ref)
+        self.cell_off, self.cell_lo, self.cell_ll = pack_cells_native(Fb * self.signs[None, None, :], self.ref)
         for o, out in enumerate(self.outputs):
             eng = out.engine
             Xt, yt = eng._X_train, eng._y_train

@@ -207,6 +207,17 @@ int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat
 int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64_t S, int64_t n, int32_t m,
                          const double* ref_host, int64_t* counts_host);
 
+/* Box decomposition of the non-dominated region, one per MC sample (host code, no device work; BoTorch's
+ * FastNondominatedPartitioning inside qLogNoisyExpectedHypervolumeImprovement, built at
+ * baybe/acquisition/_builder.py:319-324).  obj_host [S, n, m] oriented baseline objective samples, ref_host [m].
+ * bbh_cells_create computes every sample's disjoint boxes and returns an opaque object and the total box count;
+ * bbh_cells_get copies them out in the layout bbh_qlognehvi takes (off_host [S+1], lo_host / loglen_host
+ * [total, m], loglen = log(min(upper, 1e10) - lower)); bbh_cells_destroy frees the object. */
+int bbh_cells_create(const double* obj_host, int64_t S, int64_t n, int32_t m, const double* ref_host,
+                     void** cells_out, int64_t* total_out);
+int bbh_cells_get(void* cells, int64_t* off_host, double* lo_host, double* loglen_host);
+int bbh_cells_destroy(void* cells);
+
 /* ---- selection --------------------------------------------------------------------- */
 /* First-index argmax of scores_dev [N] (NaN never wins) -> host. */
 int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,

@@ -101,3 +101,23 @@ def test_joint_sampling_equals_conditioning_on_sampled_baseline():
         ye = np.concatenate([model.ystd, (orc.Fb[s, :, 0] - model.ybar) / model.ysd]) - p.mean
         mean_s = model.ybar + model.ysd * (p.mean + kx @ sla.cho_solve((L, True), ye))
         assert math.isclose(mean_s + math.sqrt(var) * z[s, -1, 0], f_joint[s], rel_tol=1e-6, abs_tol=1e-8)
+
+
+@pytest.mark.parametrize("m,n,S", [(2, 12, 40), (3, 25, 60), (4, 10, 30), (3, 1, 5)])
+def test_native_box_decomposition_equals_the_numpy_form(m, n, S):
+    """``bbh_cells_create`` (host code of the library, no device needed) against the numpy statement of the
+    same algorithm: identical offsets and lower bounds, log lengths equal to rounding; includes duplicated
+    points, points below the reference point and a sample without any point above it."""
+    from baybe_amd import box_decomposition as bd
+
+    rng = np.random.default_rng(m * 100 + n)
+    obj = rng.normal(0.3, 1.0, size=(S, n, m))
+    obj[0] = -5.0  # nothing above the reference point: a single box [ref, inf)
+    if n > 2:
+        obj[1, 1] = obj[1, 0]  # duplicate
+        obj[2, :, 0] = np.round(obj[2, :, 0], 1)  # ties in one objective (not in general position)
+    ref = np.full(m, -0.5)
+    o1, lo1, ll1 = bd.pack_cells(obj, ref)
+    o2, lo2, ll2 = bd.pack_cells_native(obj, ref)
+    assert np.array_equal(o1, o2) and np.array_equal(lo1, lo2)
+    assert np.allclose(ll1, ll2, rtol=1e-14, atol=1e-15)
