@@ -2,7 +2,7 @@
 Parity against the oracle on a sample + timing (fit on the device with the LOO criterion)."""
 import sys, time
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch
 from _problems import make_tl_problem

@@ -1,5 +1,5 @@
 """Stage-by-stage GPU bring-up: prints the error of every device stage against the oracle.
-Run on the GPU box:  python scripts/gpu_first_light.py  (writes gpurun_out/first_light.log too)."""
+Run on the GPU box:  python tests/gpu_scripts/gpu_first_light.py  (writes gpurun_out/first_light.log too)."""
 
 import math
 import os
@@ -7,7 +7,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
