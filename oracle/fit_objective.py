@@ -1,0 +1,175 @@
+"""CPU oracle, part 2: the objective ``botorch.fit.fit_gpytorch_mll`` minimises, built from library parts.
+
+TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  PARITY UNPINNED against gpytorch itself (not importable
+here), but *independent of the product*: nothing in this file is hand-derived.  The module tree of the model
+BayBE assembles (``baybe/surrogates/gaussian_process/core.py:301-341``) is restated as a list of raw
+parameters in ``mll.named_parameters()`` order; every piece of arithmetic comes from torch:
+
+* constraint transforms: ``torch.nn.functional.softplus`` (gpytorch ``Positive`` / ``GreaterThan`` with the
+  default transform) or the identity for ``transform=None`` constraints, which become L-BFGS-B box bounds
+  (``presets/baybe.py:78-80,129-132`` build them that way);
+* priors: ``torch.distributions.Gamma`` / ``LogNormal`` ``.log_prob`` — gpytorch's ``GammaPrior`` and
+  ``LogNormalPrior`` are subclasses of exactly these;
+* ExactMarginalLogLikelihood (``components/fit_criterion.py:31-41``, one task):
+  ``MultivariateNormal(c 1, K + s2 I).log_prob(y)``;
+* LeaveOneOutPseudoLikelihood (several tasks, ``presets/baybe.py:277-281``): ``Normal(mu_-i, sd_-i).log_prob(y_i)``
+  with the leave-one-out moments from ``torch.cholesky_inverse``;
+* ``(log-likelihood + sum of prior log-densities) / n``, negated; the **gradient is autograd's**.
+
+The product's host code (``baybe_amd/gp_spec.py``: hand-written chain rules and prior derivatives around the
+device's data term) is tested against this file; a mistake there cannot be mirrored here.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+from torch.distributions import Gamma, LogNormal, MultivariateNormal, Normal
+from torch.nn import functional as F
+
+F64 = torch.float64
+
+
+@dataclass
+class RawParameter:
+    """One ``nn.Parameter`` of the model as gpytorch registers it."""
+
+    name: str  # gpytorch's dotted path
+    shape: tuple
+    lower: float | None  # GreaterThan(lower) / Positive() (lower = 0); None = unconstrained (the mean constant)
+    transformed: bool  # True: natural = lower + softplus(raw); False: natural = raw and `lower` is an optimiser bound
+    prior: torch.distributions.Distribution | None
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape)) if self.shape else 1
+
+
+def _prior(desc):
+    if desc is None:
+        return None
+    family, a, b = desc
+    if family == "gamma":
+        return Gamma(torch.tensor(a, dtype=F64), torch.tensor(b, dtype=F64))  # GammaPrior(concentration, rate)
+    if family == "lognormal":
+        return LogNormal(torch.tensor(a, dtype=F64), torch.tensor(b, dtype=F64))  # LogNormalPrior(loc, scale)
+    raise ValueError(f"no torch distribution for prior family {family!r}")
+
+
+def parameter_layout(spec) -> list[RawParameter]:
+    """Raw parameters in ``named_parameters()`` order: likelihood, mean module, covariance module (a
+    ``ScaleKernel`` registers its own ``raw_outputscale`` before its ``base_kernel``; the ICM product of
+    ``components/kernel.py:298-337`` is ``kernels.0`` = numerical kernel, ``kernels.1`` = index kernel with
+    ``raw_covar_factor`` [T, rank = T] and ``raw_var`` [T], ``kernels/basic.py:239-248``)."""
+    T = int(spec.n_tasks)
+    box_noise = spec.noise_constraint == "box"
+    box_ls = spec.ls_constraint == "box"
+    base = "covar_module.kernels.0" if T > 1 else "covar_module"
+    out = [
+        RawParameter("likelihood.noise_covar.raw_noise", (1,), spec.noise_lower, not box_noise, _prior(spec.noise_prior)),
+        RawParameter("mean_module.raw_constant", (), None, False, None),
+    ]
+    if spec.use_outputscale:
+        out.append(RawParameter(f"{base}.raw_outputscale", (), 0.0, True, _prior(spec.outputscale_prior)))
+        base += ".base_kernel"
+    out.append(RawParameter(f"{base}.raw_lengthscale", (1, spec.dn), spec.ls_lower if box_ls else 0.0, not box_ls,
+                            _prior(spec.ls_prior)))
+    if T > 1:
+        out.append(RawParameter("covar_module.kernels.1.raw_covar_factor", (T, T), 0.0, True, None))
+        out.append(RawParameter("covar_module.kernels.1.raw_var", (T,), 0.0, True, None))
+    return out
+
+
+def optimiser_bounds(spec) -> list[tuple]:
+    """Box bounds of L-BFGS-B: one per raw scalar, from the constraints that carry no transform."""
+    b = []
+    for prm in parameter_layout(spec):
+        b += [((prm.lower, None) if (prm.lower is not None and not prm.transformed) else (None, None))] * prm.size
+    return b
+
+
+def split_raw(spec, raw: torch.Tensor) -> dict:
+    """Flat raw vector -> {name: natural-valued tensor of the parameter's shape}."""
+    out, i = {}, 0
+    for prm in parameter_layout(spec):
+        chunk = raw[i : i + prm.size].reshape(prm.shape)
+        i += prm.size
+        out[prm.name.rsplit(".raw_", 1)[1]] = (prm.lower + F.softplus(chunk)) if prm.transformed else chunk
+    if i != raw.numel():
+        raise ValueError(f"raw vector has {raw.numel()} entries, the model has {i}")
+    return out
+
+
+def natural_to_raw(spec, natural: dict) -> np.ndarray:
+    """Inverse of ``split_raw`` (``softplus^-1(y) = y + log(-expm1(-y))``) for start points given naturally."""
+    parts = []
+    for prm in parameter_layout(spec):
+        v = torch.as_tensor(natural[prm.name.rsplit(".raw_", 1)[1]], dtype=F64).reshape(-1)
+        if prm.transformed:
+            y = v - prm.lower
+            v = y + torch.log(-torch.expm1(-y))
+        parts.append(v)
+    return torch.cat(parts).numpy().copy()
+
+
+def _base_kernel(kernel: str, r2: torch.Tensor) -> torch.Tensor:
+    if kernel == "rbf":
+        return torch.exp(-0.5 * r2)
+    r = torch.sqrt(torch.clamp_min(r2, 1e-30))  # gpytorch clamps before the root as well
+    nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5}[kernel]
+    e = torch.exp(-math.sqrt(2.0 * nu) * r)
+    if nu == 0.5:
+        return e
+    if nu == 1.5:
+        return (1.0 + math.sqrt(3.0) * r) * e
+    return (1.0 + math.sqrt(5.0) * r + (5.0 / 3.0) * r2) * e
+
+
+def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
+    """K(X, X) without noise on the normalised inputs: stationary ARD kernel (x outputscale) (x B[t, t'])."""
+    Xs = Xn[:, torch.as_tensor(np.asarray(spec.num_idx))] / nat["lengthscale"].reshape(1, -1)
+    diff = Xs[:, None, :] - Xs[None, :, :]
+    K = _base_kernel(spec.kernel, (diff * diff).sum(-1))
+    if spec.use_outputscale:
+        K = K * nat["outputscale"]
+    if spec.n_tasks > 1:
+        W, v = nat["covar_factor"], nat["var"]
+        B = W @ W.T + torch.diag(v)
+        t = Xn[:, spec.task_idx].to(torch.long)
+        K = K * B[t][:, t]
+    return K
+
+
+def log_likelihood(spec, nat: dict, Xn: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    n = y.shape[0]
+    Ky = train_covariance(spec, nat, Xn) + nat["noise"].reshape(()) * torch.eye(n, dtype=F64)
+    mean = nat["constant"].reshape(()) * torch.ones(n, dtype=F64)
+    if spec.criterion == "mll":
+        return MultivariateNormal(mean, covariance_matrix=Ky).log_prob(y)
+    if spec.criterion == "loo":
+        Kinv = torch.cholesky_inverse(torch.linalg.cholesky(Ky))
+        s2 = 1.0 / torch.diagonal(Kinv)
+        mu = y - (Kinv @ (y - mean)) * s2
+        return Normal(mu, torch.sqrt(s2)).log_prob(y).sum()
+    raise ValueError(spec.criterion)
+
+
+def log_prior(spec, nat: dict) -> torch.Tensor:
+    total = torch.zeros((), dtype=F64)
+    for prm in parameter_layout(spec):
+        if prm.prior is not None:
+            total = total + prm.prior.log_prob(nat[prm.name.rsplit(".raw_", 1)[1]]).sum()
+    return total
+
+
+def objective(spec, raw, Xn, ystd):
+    """(value, gradient) of ``-(log-likelihood + log-prior) / n`` at the flat raw vector; autograd gradient."""
+    x = torch.tensor(np.asarray(raw, dtype=np.float64), dtype=F64, requires_grad=True)
+    Xt, yt = torch.as_tensor(np.asarray(Xn), dtype=F64), torch.as_tensor(np.asarray(ystd), dtype=F64)
+    nat = split_raw(spec, x)
+    loss = -(log_likelihood(spec, nat, Xt, yt) + log_prior(spec, nat)) / yt.shape[0]
+    (g,) = torch.autograd.grad(loss, x)
+    return float(loss.detach()), g.numpy().copy()

@@ -45,7 +45,6 @@ from dataclasses import dataclass, field
 import numpy as np
 from scipy import linalg as sla
 from scipy import optimize as sopt
-from scipy.special import gammaln
 
 SQRT3 = math.sqrt(3.0)
 SQRT5 = math.sqrt(5.0)
@@ -53,7 +52,7 @@ TAU_RELU = 1e-6  # [UPSTREAM] botorch.acquisition.logei.TAU_RELU
 TAU_MAX = 1e-2  # [UPSTREAM] botorch.acquisition.logei.TAU_MAX
 FAT_ALPHA_PLUS = 0.1  # [UPSTREAM] botorch.utils.safe_math.fatplus alpha
 FAT_ALPHA_MAX = 2.0  # [UPSTREAM] botorch.utils.safe_math.fatmax alpha
-MIN_INFERRED_NOISE_LEVEL = 1e-4  # [UPSTREAM] botorch.models.utils.gpytorch_modules
+MIN_INFERRED_NOISE_LEVEL = 0.0001  # [UPSTREAM] botorch.models.utils.gpytorch_modules.MIN_INFERRED_NOISE_LEVEL
 MAX_BATCH_SIZE = 2048  # [UPSTREAM] optimize_acqf_discrete(max_batch_size=2048)
 
 KERNELS = ("matern12", "matern32", "matern52", "rbf")
@@ -63,124 +62,121 @@ KERNELS = ("matern12", "matern32", "matern52", "rbf")
 # model specification (what BayBE's factories decide) and parameters (what the fit finds)
 # --------------------------------------------------------------------------------------
 @dataclass
+class Hyper:
+    """One positive hyper-parameter as gpytorch sees it: constraint, prior, start value.
+
+    ``transformed=False`` is ``GreaterThan(lower, transform=None)`` (BayBE / BoTorch presets: the raw parameter
+    IS the value and ``lower`` becomes an optimiser bound); ``transformed=True`` is ``value = lower +
+    softplus(raw)`` (gpytorch's ``Positive()`` with ``lower = 0``, its default ``GreaterThan(1e-4)`` noise
+    constraint).  ``prior`` is ``("gamma", concentration, rate)`` / ``("lognormal", loc, scale)`` / ``None``;
+    ``init=None`` means "raw parameter 0" (gpytorch's default initialisation)."""
+
+    lower: float = 0.0
+    transformed: bool = True
+    prior: tuple | None = None
+    init: float | None = None
+
+    def start(self) -> float:
+        if self.init is not None:
+            return float(self.init)
+        if not self.transformed:
+            raise ValueError("an un-transformed constraint needs an explicit start value")
+        return self.lower + math.log(2.0)  # softplus(0)
+
+
+@dataclass
 class GPSpec:
-    """Architecture + priors + constraints of one single-output GP.
+    """Architecture + priors + constraints of one single-output GP (``baybe_default`` = presets/baybe.py)."""
 
-    ``baybe_default`` reproduces ``presets/baybe.py`` (the reference default).
-    """
-
-    d: int  # number of comp-rep columns (incl. the task column if any)
+    d: int  # comp-rep columns (incl. the task column if any)
     num_idx: np.ndarray  # numerical columns = kernel active dims = Normalize indices
     lo: np.ndarray  # scaling bounds of the numerical columns (searchspace.scaling_bounds)
     hi: np.ndarray
     kernel: str = "matern52"
     task_idx: int | None = None
     n_tasks: int = 1
-    use_outputscale: bool = False  # ScaleKernel wrapper (user kernels); default preset: none
-    ls_constraint: str = "box"  # "box": l >= ls_lower, no transform | "softplus": Positive()
-    ls_lower: float = 2.5e-2
-    ls_prior: tuple | None = None  # ("gamma", concentration, rate)
-    ls_init: float | None = None
-    noise_lower: float = MIN_INFERRED_NOISE_LEVEL
-    noise_constraint: str = "box"  # "box": sigma^2 >= lower, no transform | "softplus": lower + softplus(raw)
-    noise_prior: tuple | None = None
-    noise_init: float | None = None
-    outputscale_prior: tuple | None = None
-    outputscale_init: float | None = None
-    criterion: str = "mll"  # "mll" | "loo"
+    use_outputscale: bool = bool(0)  # ScaleKernel wrapper
+    lengthscale: Hyper = field(default_factory=Hyper)
+    noise: Hyper = field(default_factory=lambda: Hyper(lower=MIN_INFERRED_NOISE_LEVEL))
+    outputscale: Hyper = field(default_factory=Hyper)
+    criterion: str = "mll"  # "mll" (ExactMarginalLogLikelihood) | "loo" (LeaveOneOutPseudoLikelihood)
 
     @property
     def dn(self) -> int:
         return len(self.num_idx)
 
+    # flat views used by oracle/fit_objective.py
+    ls_constraint = property(lambda self: "softplus" if self.lengthscale.transformed else "box")
+    ls_lower = property(lambda self: self.lengthscale.lower)
+    ls_prior = property(lambda self: self.lengthscale.prior)
+    noise_constraint = property(lambda self: "softplus" if self.noise.transformed else "box")
+    noise_lower = property(lambda self: self.noise.lower)
+    noise_prior = property(lambda self: self.noise.prior)
+    outputscale_prior = property(lambda self: self.outputscale.prior)
+
     @classmethod
     def baybe_default(cls, d, lo, hi, task_idx=None, n_tasks=1, kernel="matern52"):
-        """The BAYBE preset (presets/baybe.py:56-144, 203-230, 269-281)."""
-        num_idx = np.array([i for i in range(d) if i != task_idx], dtype=np.int64)
-        dn = len(num_idx)
-        conc = 3.0
-        rate = (conc - 1.0) / math.exp(math.sqrt(2.0) - 3.0) / math.sqrt(dn)
-        nconc = 2.0
-        nrate = (nconc - 1.0) / math.exp(-4.0 - 1.0**2)
+        """BayBEKernelFactory / BayBELikelihoodFactory / criterion switch, presets/baybe.py:95-144, 269-281:
+        ``lengthscale_prior = GammaPrior(3, 2 / x / sqrt(d))`` with ``x = exp(sqrt(2) - 3)`` (mode ``x sqrt(d)`` =
+        the start value), ``GreaterThan(2.5e-2, transform=None)``; ``noise_prior = GammaPrior(2, 1 / exp(-5))``
+        (mode ``exp(-5)`` = the start value), ``GreaterThan(1e-4, transform=None)``."""
+        numerical = [j for j in range(int(d)) if j != task_idx]
+        x = math.exp(math.sqrt(2.0) - 3.0)
+        sd = math.sqrt(len(numerical))
+        lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
         return cls(
-            d=d,
-            num_idx=num_idx,
-            lo=np.asarray(lo, dtype=np.float64)[num_idx] if len(lo) == d else np.asarray(lo, np.float64),
-            hi=np.asarray(hi, dtype=np.float64)[num_idx] if len(hi) == d else np.asarray(hi, np.float64),
+            d=int(d),
+            num_idx=np.array(numerical, dtype=np.int64),
+            lo=lo[numerical] if lo.size == d else lo,
+            hi=hi[numerical] if hi.size == d else hi,
             kernel=kernel,
             task_idx=task_idx,
-            n_tasks=n_tasks,
-            ls_prior=("gamma", conc, rate),
-            ls_init=(conc - 1.0) / rate,  # prior mode (presets/baybe.py:100-105)
-            noise_prior=("gamma", nconc, nrate),
-            noise_init=(nconc - 1.0) / nrate,  # prior mode (presets/baybe.py:134-142)
-            criterion="mll" if n_tasks == 1 else "loo",
+            n_tasks=int(n_tasks),
+            lengthscale=Hyper(2.5e-2, False, ("gamma", 3.0, 2.0 / x / sd), x * sd),
+            noise=Hyper(MIN_INFERRED_NOISE_LEVEL, False, ("gamma", 2.0, math.exp(5.0)), math.exp(-5.0)),
+            criterion="loo" if n_tasks > 1 else "mll",
         )
 
 
 @dataclass
 class GPParams:
-    """Natural (constrained) hyper-parameters of the standardised/normalised GP."""
+    """Natural (constrained) hyper-parameters of the standardised / normalised GP."""
 
     lengthscale: np.ndarray  # [dn]
-    noise: float
-    mean: float = 0.0
+    noise: float  # sigma^2
+    mean: float = 0.0  # ConstantMean
     outputscale: float = 1.0
-    task_W: np.ndarray | None = None  # [T, R]
-    task_v: np.ndarray | None = None  # [T]
+    task_W: "np.ndarray | None" = None  # PositiveIndexKernel covar_factor [T, rank = T]
+    task_v: "np.ndarray | None" = None  # PositiveIndexKernel var [T]
 
     def task_B(self) -> np.ndarray | None:
-        if self.task_W is None:
-            return None
-        return self.task_W @ self.task_W.T + np.diag(self.task_v)
+        return None if self.task_W is None else self.task_W @ self.task_W.T + np.diag(self.task_v)
 
     def copy(self) -> "GPParams":
-        return GPParams(
-            self.lengthscale.copy(),
-            float(self.noise),
-            float(self.mean),
-            float(self.outputscale),
-            None if self.task_W is None else self.task_W.copy(),
-            None if self.task_v is None else self.task_v.copy(),
-        )
+        dup = lambda a: None if a is None else np.array(a, dtype=np.float64, copy=True)  # noqa: E731
+        return GPParams(dup(self.lengthscale), float(self.noise), float(self.mean), float(self.outputscale),
+                        dup(self.task_W), dup(self.task_v))
 
 
 def softplus(x):
-    x = np.asarray(x, dtype=np.float64)
-    return np.where(x > 20.0, x, np.log1p(np.exp(np.minimum(x, 20.0))))
+    return np.logaddexp(0.0, np.asarray(x, dtype=np.float64))
 
 
-def inv_softplus(y):
-    y = np.asarray(y, dtype=np.float64)
-    return np.where(y > 20.0, y, np.log(np.expm1(np.minimum(y, 20.0))))
+def initial_params(spec, task_init=1.0):
+    """Start of the fit: the values the presets set explicitly (prior modes for the BAYBE preset,
+    presets/baybe.py:100-105, 134-142), raw = 0 for everything else [UPSTREAM].
 
-
-def sigmoid(x):
-    return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))
-
-
-def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
-    """Initial values: prior modes for the default preset (presets/baybe.py:100-105,
-    134-142); softplus(0) for Positive()-constrained user kernels [UPSTREAM].
-
-    Task factors: gpytorch draws raw W/v randomly; the oracle (and the HIP path)
-    use a deterministic start (W = task_init * ones, v = softplus(0)) — documented
-    deviation, unpinned.
-    """
-    ls0 = spec.ls_init if spec.ls_init is not None else float(softplus(0.0))
-    nz0 = spec.noise_init if spec.noise_init is not None else 1e-2
-    p = GPParams(
-        lengthscale=np.full(spec.dn, ls0, dtype=np.float64),
-        noise=nz0,
+    Task factors: gpytorch draws raw W / v randomly; the oracle (and the HIP path) start deterministically at
+    W = task_init / sqrt(T), v = softplus(0) — documented deviation, unpinned."""
+    T = int(spec.n_tasks)
+    return GPParams(
+        lengthscale=np.full(spec.dn, spec.lengthscale.start()),
+        noise=spec.noise.start(),
         mean=0.0,
-        outputscale=(float(spec.outputscale_init) if spec.outputscale_init is not None else float(softplus(0.0)))
-        if spec.use_outputscale else 1.0,
+        outputscale=spec.outputscale.start() if spec.use_outputscale else 1.0,
+        task_W=np.full((T, T), task_init / math.sqrt(T)) if T > 1 else None,
+        task_v=np.full(T, math.log(2.0)) if T > 1 else None,
     )
-    if spec.n_tasks > 1:
-        T = spec.n_tasks
-        p.task_W = np.full((T, T), task_init / math.sqrt(T), dtype=np.float64)
-        p.task_v = np.full(T, float(softplus(0.0)), dtype=np.float64)
-    return p
 
 
 # --------------------------------------------------------------------------------------
@@ -272,27 +268,6 @@ def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
-# priors
-# --------------------------------------------------------------------------------------
-def _prior_logp_and_grad(prior, x: np.ndarray) -> tuple[float, np.ndarray]:
-    """sum log p(x) and d/dx; gpytorch GammaPrior / LogNormalPrior [UPSTREAM]."""
-    x = np.asarray(x, dtype=np.float64)
-    if prior is None:
-        return 0.0, np.zeros_like(x)
-    kind = prior[0]
-    if kind == "gamma":
-        _, c, r = prior
-        lp = c * math.log(r) + (c - 1.0) * np.log(x) - r * x - gammaln(c)
-        return float(lp.sum()), (c - 1.0) / x - r
-    if kind == "lognormal":
-        _, mu, sd = prior
-        lx = np.log(x)
-        lp = -lx - math.log(sd) - 0.5 * math.log(2 * math.pi) - 0.5 * ((lx - mu) / sd) ** 2
-        return float(lp.sum()), (-1.0 - (lx - mu) / sd**2) / x
-    raise ValueError(kind)
-
-
-# --------------------------------------------------------------------------------------
 # fit objective: data term (this is what the device computes) + priors (host)
 # --------------------------------------------------------------------------------------
 @dataclass
@@ -367,88 +342,52 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     return DataTerm(value, g_ls, g_noise, g_mean, g_os, g_B)
 
 
-# ---- raw <-> natural packing (order = mll.named_parameters(): noise, mean, kernel) ----
-def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
-    # gpytorch's default noise constraint GreaterThan(1e-4) has a softplus transform (EDBO likelihoods,
-    # presets/edbo.py:170-172); botorch's / BayBE's own likelihoods use transform=None [UPSTREAM A6]
-    nz = np.array([p.noise]) if spec.noise_constraint == "box" else inv_softplus(np.array([p.noise - spec.noise_lower]))
-    parts = [nz, np.array([p.mean])]
+# ---- the optimiser's view: raw vector <-> natural parameters, objective, bounds -----------------------
+# All of it is oracle/fit_objective.py (torch.distributions + autograd); these wrappers only translate between
+# GPParams and the gpytorch-named parameter dictionary.
+def _natural_dict(spec: GPSpec, p: GPParams) -> dict:
+    nat = {"noise": [p.noise], "constant": p.mean, "lengthscale": p.lengthscale}
     if spec.use_outputscale:
-        parts.append(inv_softplus(np.array([p.outputscale])))
-    parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
+        nat["outputscale"] = p.outputscale
     if spec.n_tasks > 1:
-        parts.append(inv_softplus(p.task_W).reshape(-1))
-        parts.append(inv_softplus(p.task_v))
-    return np.concatenate(parts).astype(np.float64)
+        nat["covar_factor"], nat["var"] = p.task_W, p.task_v
+    return nat
 
 
-def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
-    raw = np.asarray(raw, dtype=np.float64)
-    i = 0
-    noise = float(raw[i]) if spec.noise_constraint == "box" else spec.noise_lower + float(softplus(raw[i]))
-    i += 1
-    mean = float(raw[i]); i += 1
-    os_ = 1.0
-    if spec.use_outputscale:
-        os_ = float(softplus(raw[i])); i += 1
-    ls_raw = raw[i : i + spec.dn]; i += spec.dn
-    ls = ls_raw.copy() if spec.ls_constraint == "box" else softplus(ls_raw)
-    W = v = None
-    if spec.n_tasks > 1:
-        T = spec.n_tasks
-        W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
-        v = softplus(raw[i : i + T]); i += T
-    return GPParams(ls, noise, mean, os_, W, v)
+def pack_raw(spec, p):
+    from oracle import fit_objective as fo
+
+    return fo.natural_to_raw(spec, _natural_dict(spec, p))
 
 
-def raw_bounds(spec: GPSpec) -> list[tuple[float | None, float | None]]:
-    """L-BFGS-B bounds: only constraints with transform=None become bounds [UPSTREAM A6]."""
-    b: list[tuple[float | None, float | None]] = [
-        (spec.noise_lower, None) if spec.noise_constraint == "box" else (None, None), (None, None)]
-    if spec.use_outputscale:
-        b.append((None, None))
-    b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
-    if spec.n_tasks > 1:
-        b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
-    return b
+def unpack_raw(spec, raw):
+    import torch
+
+    from oracle import fit_objective as fo
+
+    nat = {k: v.detach().numpy() for k, v in fo.split_raw(spec, torch.as_tensor(np.asarray(raw, dtype=np.float64))).items()}
+    return GPParams(
+        lengthscale=nat["lengthscale"].reshape(-1).copy(),
+        noise=float(nat["noise"].reshape(-1)[0]),
+        mean=float(nat["constant"]),
+        outputscale=float(nat["outputscale"]) if spec.use_outputscale else 1.0,
+        task_W=nat["covar_factor"].copy() if spec.n_tasks > 1 else None,
+        task_v=nat["var"].copy() if spec.n_tasks > 1 else None,
+    )
 
 
-def fit_objective(spec: GPSpec, raw: np.ndarray, Xn: np.ndarray, ystd: np.ndarray, data_term_fn=data_term):
-    """-(data term + log priors)/n and its gradient w.r.t. the raw vector.
+def raw_bounds(spec):
+    from oracle import fit_objective as fo
 
-    gpytorch: ``res = output.log_prob(target); res += sum(prior.log_prob); res / n``.
-    """
-    p = unpack_raw(spec, raw)
-    n = Xn.shape[0]
-    dt = data_term_fn(spec, p, Xn, ystd)
-    lp_ls, glp_ls = _prior_logp_and_grad(spec.ls_prior, p.lengthscale)
-    lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.array([p.noise]))
-    lp_os, glp_os = (0.0, np.zeros(1))
-    if spec.use_outputscale:
-        lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
-    total = dt.value + lp_ls + lp_nz + lp_os
-    g_nz = dt.g_noise + glp_nz[0]
-    if spec.noise_constraint != "box":
-        g_nz = g_nz * float(sigmoid(raw[0]))
-    g = [np.array([g_nz]), np.array([dt.g_mean])]
-    i = 2
-    if spec.use_outputscale:
-        g.append(np.array([(dt.g_outputscale + glp_os[0]) * float(sigmoid(raw[i]))]))
-        i += 1
-    g_ls = dt.g_ls + glp_ls
-    if spec.ls_constraint != "box":
-        g_ls = g_ls * sigmoid(raw[i : i + spec.dn])
-    g.append(g_ls)
-    i += spec.dn
-    if spec.n_tasks > 1:
-        T = spec.n_tasks
-        S = dt.g_task_B
-        gW = (S + S.T) @ p.task_W
-        g.append((gW * sigmoid(raw[i : i + T * T]).reshape(T, T)).reshape(-1))
-        i += T * T
-        g.append(np.diag(S) * sigmoid(raw[i : i + T]))
-    grad = np.concatenate(g)
-    return -total / n, -grad / n
+    return fo.optimiser_bounds(spec)
+
+
+def fit_objective(spec: GPSpec, raw: np.ndarray, Xn: np.ndarray, ystd: np.ndarray):
+    """-(log-likelihood + log-priors)/n and its autograd gradient w.r.t. the raw vector (gpytorch:
+    ``res = output.log_prob(target); res += sum(prior.log_prob); res / n``)."""
+    from oracle import fit_objective as fo
+
+    return fo.objective(spec, raw, Xn, ystd)
 
 
 @dataclass
@@ -461,26 +400,18 @@ class FitResult:
     message: str
 
 
-def fit_hyperparameters(
-    spec: GPSpec,
-    Xn: np.ndarray,
-    ystd: np.ndarray,
-    p0: GPParams | None = None,
-    data_term_fn=data_term,
-    maxiter: int = 15000,
-) -> FitResult:
+def fit_hyperparameters(spec: GPSpec, Xn: np.ndarray, ystd: np.ndarray, p0: GPParams | None = None,
+                        maxiter: int = 15000) -> FitResult:
     """botorch.fit.fit_gpytorch_mll -> scipy L-BFGS-B with scipy defaults [UPSTREAM A6]."""
-    p0 = p0 or initial_params(spec)
-    x0 = pack_raw(spec, p0)
-    bounds = raw_bounds(spec)
 
-    def fun(raw):
+    def closure(raw):
         try:
-            return fit_objective(spec, raw, Xn, ystd, data_term_fn)
-        except (np.linalg.LinAlgError, sla.LinAlgError, FloatingPointError):
-            return float("inf"), np.zeros_like(raw)
+            return fit_objective(spec, raw, Xn, ystd)
+        except (RuntimeError, ValueError):  # torch: Cholesky of a non-PD matrix / invalid distribution argument
+            return np.inf, np.zeros(len(raw))
 
-    res = sopt.minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": maxiter})
+    res = sopt.minimize(closure, pack_raw(spec, p0 or initial_params(spec)), jac=True, method="L-BFGS-B",
+                        bounds=raw_bounds(spec), options={"maxiter": maxiter})
     return FitResult(unpack_raw(spec, res.x), float(res.fun), int(res.nit), int(res.nfev), int(res.status), str(res.message))
 
 
@@ -551,35 +482,31 @@ def fit_gp(spec: GPSpec, X_train, y_train, params: GPParams | None = None, p0: G
     """Fit (or, with ``params`` given, just factorise) a GP on raw data."""
     X_train = np.ascontiguousarray(X_train, dtype=np.float64)
     if params is None:
-        Xn = normalize_inputs(spec, X_train)
         ystd, _, _ = standardize_targets(y_train)
-        params = fit_hyperparameters(spec, Xn, ystd, p0).params
+        params = fit_hyperparameters(spec, normalize_inputs(spec, X_train), ystd, p0).params
     return GPModel(spec, params, X_train, np.asarray(y_train, dtype=np.float64).reshape(-1))
 
 
 # --------------------------------------------------------------------------------------
 # MC acquisition: qLogEI
 # --------------------------------------------------------------------------------------
-def sobol_normal_base_samples(S: int, q: int, seed: int) -> np.ndarray:
-    """botorch SobolQMCNormalSampler base samples [UPSTREAM A8]; uses torch's SobolEngine.
-
-    z = sqrt(2) erfinv(2 v - 1),  v = 0.5 + (1 - eps)(u - 0.5),  u ~ scrambled Sobol(q, seed).
-    Returns [S, q] float64.
-    """
+def sobol_normal_base_samples(S, q, seed):
+    """botorch SobolQMCNormalSampler base samples [UPSTREAM A8]: scrambled Sobol points u (torch's engine, the one
+    BoTorch uses), pulled off the boundary, v = 0.5 + (1 - eps)(u - 0.5), and pushed through the standard normal
+    quantile function (``Normal.icdf`` = sqrt(2) erfinv(2 v - 1)).  Returns [S, q] float64."""
     import torch
 
-    eng = torch.quasirandom.SobolEngine(dimension=q, scramble=True, seed=int(seed))
-    u = eng.draw(S, dtype=torch.float64)
-    v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
-    z = torch.erfinv(2 * v - 1) * math.sqrt(2)
-    return z.numpy().copy()
+    engine = torch.quasirandom.SobolEngine(q, scramble=True, seed=int(seed))
+    points = engine.draw(int(S), dtype=torch.float64)
+    inner = 0.5 + (points - 0.5) * (1.0 - torch.finfo(torch.float64).eps)
+    return torch.distributions.Normal(0.0, 1.0).icdf(inner).numpy().copy()
 
 
-def draw_sampler_seed() -> int:
+def draw_sampler_seed():
     """MCSampler seed when none is given: torch.randint(0, 1000000, (1,)) [UPSTREAM A8]."""
     import torch
 
-    return int(torch.randint(0, 1000000, (1,)).item())
+    return torch.randint(0, 1000000, (1,)).item()
 
 
 def log_fatplus(x: np.ndarray, tau: float = TAU_RELU) -> np.ndarray:
@@ -704,7 +631,7 @@ def optimize_acqf_discrete_qlogei(
     seed: int | None = None,
     S: int = 512,
     sign: float = 1.0,
-    X_pending: np.ndarray | None = None,
+    X_pending=None,
     best_f: float | None = None,
     keep_scores: bool = False,
 ) -> GreedyResult:
@@ -716,8 +643,8 @@ def optimize_acqf_discrete_qlogei(
     """
     Xcand = np.ascontiguousarray(Xcand, dtype=np.float64)
     N = Xcand.shape[0]
-    if seed is None and z_by_q is None:
-        seed = draw_sampler_seed()
+    if z_by_q is None and seed is None:
+        seed = int(draw_sampler_seed())
     if best_f is None:
         best_f = best_f_from_model(model, sign)
     base_pending = np.zeros((0, Xcand.shape[1])) if X_pending is None else np.atleast_2d(X_pending)
@@ -726,7 +653,7 @@ def optimize_acqf_discrete_qlogei(
     values: list[float] = []
     first_scores = None
 
-    def get_z(qp: int) -> np.ndarray:
+    def get_z(qp):
         if z_by_q is not None:
             return z_by_q[qp]
         return sobol_normal_base_samples(S, qp, seed)

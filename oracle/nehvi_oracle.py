@@ -39,13 +39,16 @@ UPPER_CLAMP = 1e10  # cell_upper_bounds.clamp_max(1e10) for double [UPSTREAM]
 
 
 # ---- reference point (BayBE side, exact) ----------------------------------------------------------
-def compute_ref_point(array: np.ndarray, maximize=None, factor: float = 0.1) -> np.ndarray:
-    """``_ExpectedHypervolumeImprovement.compute_ref_point`` (acqfs.py:369-426)."""
-    array = np.asarray(array, dtype=np.float64)
-    mx = np.where(np.ones(array.shape[1], bool) if maximize is None else np.asarray(maximize), 1.0, -1.0)
-    a = array * mx[None, :]
-    lo, hi = a.min(axis=0), a.max(axis=0)
-    return (lo - factor * (hi - lo)) * mx
+def compute_ref_point(array, maximize=None, factor=0.1):
+    """``_ExpectedHypervolumeImprovement.compute_ref_point`` (acqfs.py:369-426), stated the way its docstring does:
+    per target, the reference value lies ``factor`` x (best - worst) beyond the worst observed value."""
+    columns = np.asarray(array, dtype=np.float64).T
+    upward = [True] * len(columns) if maximize is None else [bool(f) for f in maximize]
+    point = []
+    for col, up in zip(columns, upward):
+        worst, best = (col.min(), col.max()) if up else (col.max(), col.min())
+        point.append(worst - factor * (best - worst))
+    return np.array(point)
 
 
 # ---- Pareto front & box decomposition (maximisation) -----------------------------------------------
@@ -61,7 +64,7 @@ def pareto_front(Y: np.ndarray) -> np.ndarray:
     return Y[keep]
 
 
-def nondominated_cells(Y: np.ndarray, ref: np.ndarray):
+def nondominated_cells(Y, ref):
     """Disjoint boxes [l, u) (u may be +inf) tiling {y >= ref : y not dominated by the front of Y}.
 
     Local upper bounds of the negated (minimisation) problem, incremental algorithm of
@@ -70,7 +73,7 @@ def nondominated_cells(Y: np.ndarray, ref: np.ndarray):
       z_1 in (-inf, u_1),  z_j in [max_{k<j} z^k(u)_j, u_j)  (j >= 2),
     which tiles the search region.  Returned in maximisation coordinates.
     """
-    ref = np.asarray(ref, dtype=np.float64)
+    ref = np.array(ref, dtype=np.float64, copy=True)
     m = ref.shape[0]
     P = pareto_front(Y) if len(Y) else np.zeros((0, m))
     P = P[(P > ref).all(1)] if len(P) else P
@@ -110,7 +113,7 @@ def nondominated_cells(Y: np.ndarray, ref: np.ndarray):
 
 def hypervolume(Y: np.ndarray, ref: np.ndarray) -> float:
     """Exact dominated hypervolume by recursive slicing (independent of the decomposition)."""
-    ref = np.asarray(ref, dtype=np.float64)
+    ref = np.array(ref, dtype=np.float64, copy=True)
     P = pareto_front(Y) if len(Y) else np.zeros((0, len(ref)))
     P = P[(P > ref).all(1)] if len(P) else P
     if len(P) == 0:
@@ -179,8 +182,7 @@ class NEHVIOracle:
         ref_point is given in *objective* space (i.e. after orientation by ``signs``)."""
         self.models, self.signs = models, np.asarray(signs, dtype=np.float64)
         self.Xb = np.atleast_2d(np.asarray(X_baseline, dtype=np.float64))
-        self.ref = np.asarray(ref_point, dtype=np.float64)
-        self.z = z
+        self.ref, self.z = np.array(ref_point, dtype=np.float64), z
         S, nb1, m = z.shape
         assert nb1 == len(self.Xb) + 1 and m == len(models)
         self.mu_b, self.L_b, self.Fb = [], [], np.empty((S, len(self.Xb), m))

@@ -38,3 +38,19 @@ def fixed_theta(d: int):
     import math
 
     return math.exp(math.sqrt(2.0) - 3.0) * math.sqrt(d), math.exp(-5.0), 0.0
+
+
+def oracle_spec(spec):
+    """The oracle's description (oracle.gp_oracle.GPSpec: gpytorch-shaped ``Hyper`` objects) of a model given as the
+    product's ``baybe_amd.gp_spec.GPSpec`` (flat fields).  Lives with the tests: neither side knows the other."""
+    from oracle import gp_oracle as go
+
+    num = np.asarray(spec.num_idx)
+    return go.GPSpec(
+        d=spec.d, num_idx=num, lo=np.asarray(spec.lo)[num], hi=np.asarray(spec.hi)[num], kernel=spec.kernel,
+        task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
+        lengthscale=go.Hyper(spec.ls_lower if spec.ls_constraint == "box" else 0.0, spec.ls_constraint != "box",
+                             spec.ls_prior, spec.ls_init),
+        noise=go.Hyper(spec.noise_lower, spec.noise_constraint != "box", spec.noise_prior, spec.noise_init),
+        outputscale=go.Hyper(0.0, True, spec.outputscale_prior, spec.outputscale_init),
+        criterion=spec.criterion)

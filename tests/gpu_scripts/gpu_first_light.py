@@ -29,13 +29,9 @@ def absd(a, b):
 
 
 def o_spec_from(spec):
-    return go.GPSpec(
-        d=spec.d, num_idx=spec.num_idx, lo=spec.lo[spec.num_idx], hi=spec.hi[spec.num_idx], kernel=spec.kernel,
-        task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
-        ls_constraint=spec.ls_constraint, ls_lower=spec.ls_lower, ls_prior=spec.ls_prior, ls_init=spec.ls_init,
-        noise_lower=spec.noise_lower, noise_prior=spec.noise_prior, noise_init=spec.noise_init,
-        outputscale_prior=spec.outputscale_prior, criterion=spec.criterion,
-    )
+    from _problems import oracle_spec
+
+    return oracle_spec(spec)
 
 
 def o_params(p):

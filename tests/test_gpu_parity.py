@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from _problems import fixed_theta, make_problem, make_tl_problem
+from _problems import fixed_theta, make_problem, make_tl_problem, oracle_spec
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
@@ -32,15 +32,7 @@ def gp():
 
 
 def _ospec(spec):
-    from oracle import gp_oracle as go
-
-    return go.GPSpec(
-        d=spec.d, num_idx=spec.num_idx, lo=spec.lo[spec.num_idx], hi=spec.hi[spec.num_idx], kernel=spec.kernel,
-        task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
-        ls_constraint=spec.ls_constraint, ls_lower=spec.ls_lower, ls_prior=spec.ls_prior, ls_init=spec.ls_init,
-        noise_lower=spec.noise_lower, noise_constraint=spec.noise_constraint, noise_prior=spec.noise_prior,
-        noise_init=spec.noise_init, outputscale_prior=spec.outputscale_prior, outputscale_init=spec.outputscale_init,
-        criterion=spec.criterion)
+    return oracle_spec(spec)
 
 
 def _oparams(p):

@@ -6,19 +6,13 @@ import math
 import numpy as np
 import pytest
 
-from _problems import make_problem, make_tl_problem
+from _problems import make_problem, make_tl_problem, oracle_spec
 from baybe_amd import gp_spec
 from oracle import gp_oracle as go
 
 
 def _ospec(spec):
-    return go.GPSpec(
-        d=spec.d, num_idx=spec.num_idx, lo=spec.lo[spec.num_idx], hi=spec.hi[spec.num_idx], kernel=spec.kernel,
-        task_idx=spec.task_idx, n_tasks=spec.n_tasks, use_outputscale=spec.use_outputscale,
-        ls_constraint=spec.ls_constraint, ls_lower=spec.ls_lower, ls_prior=spec.ls_prior, ls_init=spec.ls_init,
-        noise_lower=spec.noise_lower, noise_constraint=spec.noise_constraint, noise_prior=spec.noise_prior,
-        noise_init=spec.noise_init, outputscale_prior=spec.outputscale_prior, outputscale_init=spec.outputscale_init,
-        criterion=spec.criterion)
+    return oracle_spec(spec)
 
 
 @pytest.mark.parametrize("tl", [False, True])
@@ -118,8 +112,8 @@ def test_preset_tables_follow_the_reference():
 
 @pytest.mark.parametrize("preset", ["EDBO", "EDBO_SMOOTHED", "CHEN", "HVARFNER"])
 def test_preset_raw_parameterisation_round_trip_and_oracle_gradient(preset):
-    """pack/unpack are inverse for every constraint kind, host and oracle agree on the raw vector, and the
-    oracle's objective gradient matches finite differences (softplus noise / outputscale chain rules)."""
+    """pack/unpack are inverse for every constraint kind, host and oracle agree on the raw vector, and the host's
+    analytic objective (chain rules, prior derivatives) equals the oracle's autograd objective."""
     d, n = 4, 25
     rng = np.random.default_rng(3)
     X, y = rng.random((n, d)), rng.standard_normal(n)
@@ -133,12 +127,17 @@ def test_preset_raw_parameterisation_round_trip_and_oracle_gradient(preset):
     assert np.allclose(go.pack_raw(ospec, go.initial_params(ospec)), raw)
     Xn, ys = go.normalize_inputs(ospec, X), go.standardize_targets(y)[0]
     raw = raw + 0.05 * rng.standard_normal(raw.shape)
-    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
-    for i in range(len(raw)):
+    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)  # torch.distributions + autograd (oracle/fit_objective.py)
+    # the product's hand-written chain rules / prior derivatives around a data term (here the oracle's numpy one)
+    dt = go.data_term(ospec, go.unpack_raw(ospec, raw), Xn, ys)
+    f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value,
+                                              np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls]))
+    assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    for i in range(len(raw)):  # and a coarse finite-difference sanity check (these objectives are ill-conditioned)
         e = np.zeros_like(raw)
-        e[i] = 1e-6
-        fd = (go.fit_objective(ospec, raw + e, Xn, ys)[0] - go.fit_objective(ospec, raw - e, Xn, ys)[0]) / 2e-6
-        assert math.isclose(fd, g0[i], rel_tol=2e-5, abs_tol=1e-8)
+        e[i] = 1e-5
+        fd = (go.fit_objective(ospec, raw + e, Xn, ys)[0] - go.fit_objective(ospec, raw - e, Xn, ys)[0]) / 2e-5
+        assert math.isclose(fd, g0[i], rel_tol=1e-3, abs_tol=1e-5)
 
 
 # ---- backtesting driver: lookup semantics (simulation/lookup.py:19-150), no device needed ---------------

@@ -34,7 +34,7 @@ def test_fit_objective_gradient_matches_finite_differences(criterion, kernel):
     spec = go.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=T, kernel=kernel)
     spec.criterion = criterion
     spec.use_outputscale = True
-    spec.ls_constraint = "softplus"
+    spec.lengthscale = go.Hyper(0.0, True, spec.lengthscale.prior, spec.lengthscale.init)  # Positive()
     Xn = go.normalize_inputs(spec, X)
     ystd, _, _ = go.standardize_targets(y)
     p0 = go.initial_params(spec)
@@ -83,8 +83,10 @@ def test_loo_value_matches_explicit_leave_one_out():
 def test_default_preset_constants():
     """presets/baybe.py:95-106,134-144: prior modes are the initial values."""
     spec = go.GPSpec.baybe_default(20, np.zeros(20), np.ones(20))
-    assert math.isclose(spec.ls_init, math.exp(math.sqrt(2) - 3) * math.sqrt(20))
-    assert math.isclose(spec.noise_init, math.exp(-5.0))
+    assert math.isclose(spec.lengthscale.init, math.exp(math.sqrt(2) - 3) * math.sqrt(20))
+    assert math.isclose(spec.noise.init, math.exp(-5.0))
+    assert not spec.lengthscale.transformed and spec.lengthscale.lower == 2.5e-2
+    assert not spec.noise.transformed and spec.noise.lower == 1e-4
     assert spec.ls_prior == ("gamma", 3.0, 2.0 / math.exp(math.sqrt(2) - 3) / math.sqrt(20))
     assert math.isclose(spec.noise_prior[2], math.exp(5.0))
     assert spec.criterion == "mll" and go.GPSpec.baybe_default(5, np.zeros(5), np.ones(5), 4, 3).criterion == "loo"

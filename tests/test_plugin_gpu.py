@@ -204,10 +204,9 @@ def test_user_kernel_specifications_fit_like_the_oracle():
         sur = HipGaussianProcessSurrogate(kernel=kern)
         sur.fit(space, obj, meas)
         spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3)), kern)
-        ospec = go.GPSpec(d=3, num_idx=spec.num_idx, lo=spec.lo, hi=spec.hi, kernel=spec.kernel,
-                          use_outputscale=spec.use_outputscale, ls_constraint=spec.ls_constraint, ls_prior=spec.ls_prior,
-                          ls_init=spec.ls_init, noise_prior=spec.noise_prior, noise_init=spec.noise_init,
-                          outputscale_prior=spec.outputscale_prior, outputscale_init=spec.outputscale_init)
+        from _problems import oracle_spec
+
+        ospec = oracle_spec(spec)
         fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
         fi = sur._fit_info
         assert np.isclose(fi.fun, fo.fun, rtol=1e-7), (kern, fi.fun, fo.fun)
