@@ -107,7 +107,8 @@ struct bbh_handle {
   int kv_global_mode = -1;        // env BBH_KV_GLOBAL: 0 never use global slabs, 1 always, unset: by size
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
   int num_cu = 256;               // compute units of the device (sizes the slab pool of the kernel-value cache)
-  int jbw = 16;                   // j-blocks per pass of the fused kernel
+  int wmax = 16;                  // column blocks per pass of the fused kernel: 16 (two waves per SIMD) or 32 (one)
+  bool use_w32 = false;           // env BBH_W32=1: one-wave-per-SIMD form where instantiated (A/B; measured slower so far)
   int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
   // pending state
   int p = 0;

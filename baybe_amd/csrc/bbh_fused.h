@@ -10,6 +10,9 @@
 #include "bbh_common.h"
 
 #define BBH_MAX_PASS 64
+#ifndef BBH_W32_REMAINDERS
+#define BBH_W32_REMAINDERS 0
+#endif
 
 __device__ __forceinline__ double bbh_kfun_p(int kind, double r2) {
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
@@ -70,7 +73,20 @@ struct WaveCtx {
   int nl, ncache;  // k-blocks [0, ncache) are cached at all
   const bbh_lds_double* al;  // alpha in LDS + (lane >> 4), or null: mean through the MFMA form (pending columns)
   int kd, kind, T, tc, q, l, dn;
+  double cf[16];  // BBH_CANDREG: the wave's candidate fragments in registers (pipelined forms, KD <= 16)
 };
+
+// Per translation unit (defined before this header is included): BBH_CANDREG = 1 keeps the candidate fragments of
+// the distance GEMM in registers instead of re-reading them from wave-private LDS for every k-block (the LDS
+// latency is exposed when a SIMD holds a single wave).
+#ifndef BBH_CANDREG
+#define BBH_CANDREG 0
+#endif
+// BBH_MEAN_VALU_ONLY = 1: the translation unit's kernels are only launched with the mean contraction on the VALU
+// (FusedArgs::mean_valu), so the MFMA form of the mean - and its accumulator - is not compiled in.
+#ifndef BBH_MEAN_VALU_ONLY
+#define BBH_MEAN_VALU_ONLY 0
+#endif
 
 // KIND >= 0: compile-time kernel kind (branch-free fast path); KIND < 0: runtime c.kind.
 template <bool HAS_TBL, int KIND>
@@ -223,16 +239,42 @@ __device__ __forceinline__ void kvp_load(const WaveCtx& c, int tb, double (&tfv)
   for (int k = 0; k < KD; k++) tfv[k] = tf[k * 64];
 }
 
+#if BBH_CANDREG
+// VGPR-form MFMA through inline assembly.  With 32 column blocks the variance accumulators fill the whole
+// AGPR half of the register file (256); the compiler gives every MFMA *intrinsic* of such a kernel an AGPR
+// destination, so the two distance accumulators would push accumulators out to VGPRs and back around every
+// use.  The "v" constraints keep these in arch VGPRs.  Hazards: the compiler does not see an MFMA here, so the
+// consumers are placed by hand - the two accumulator chains alternate (a dependent MFMA follows a full 16-pass
+// MFMA), and the VALU reads of the results happen after the next variance MFMA in program order (kblock_p).
+__device__ __forceinline__ void mfma_f64_v0(d4& acc, double a, double b) {
+  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_f64_v(d4& acc, double a, double b) {
+  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+#endif
+
+// r2 = da + db: the sum is left to the caller (first kernel-value micro-step), see above
 template <int KD>
-__device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[KD], double (&r2v)[4]) {
-  d4 da = {0.0, 0.0, 0.0, 0.0}, db = {0.0, 0.0, 0.0, 0.0};
+__device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[KD], d4& da, d4& db) {
+#if BBH_CANDREG
+  static_assert(KD >= 2, "two accumulator chains");
+  mfma_f64_v0(da, tfv[0], c.cf[0]);
+  mfma_f64_v0(db, tfv[1], c.cf[1]);
+#pragma unroll
+  for (int k = 2; k < KD; k += 2) {
+    mfma_f64_v(da, tfv[k], c.cf[k]);
+    if (k + 1 < KD) mfma_f64_v(db, tfv[k + 1], c.cf[k + 1]);
+  }
+#else
+  da = (d4){0.0, 0.0, 0.0, 0.0};
+  db = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < KD; k += 2) {
     da = mfma_f64(tfv[k], c.candl[k * 64], da);
     if (k + 1 < KD) db = mfma_f64(tfv[k + 1], c.candl[(k + 1) * 64], db);
   }
-#pragma unroll
-  for (int r = 0; r < 4; r++) r2v[r] = da[r] + db[r];
+#endif
 }
 
 // Kernel values of NU (= 4) scaled squared distances in lockstep, cut into BBH_KV_STEPS micro-steps of NU to
@@ -268,7 +310,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int KVF, int NU, int step>
-__device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int tb, int r0, const double (&r2v)[4],
+__device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int tb, int r0, const d4& da, const d4& db,
                                          double (&out)[4]) {
   constexpr bool HAS_TBL = (KVF & 1) != 0, RBFK = (KVF & 2) != 0;  // table multiply / RBF instead of Matern
   constexpr bool M32K = (KVF & 4) != 0;  // Matern-3/2: k = (1 + s) exp(-s), s = sqrt(3 r2)  (5/2: 1 + s + s^2/3, s = sqrt(5 r2))
@@ -279,12 +321,20 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
   // reciprocal sqrt, later the exp polynomial; y = rsq seed / residuals
   switch (step) {
     case 0:
+#if BBH_CANDREG
+      // The distance MFMAs are inline assembly (kvp_dist): the compiler's hazard recogniser does not know that da / db
+      // come from a 16-pass MFMA, whose VALU consumers must be >= 19 wait states behind it.  These issue
+      // slots overlap with the variance MFMA that precedes this micro-step in program order.
+      asm volatile("s_nop 15");
+      asm volatile("s_nop 3");
+#endif
 #pragma unroll
       BBH_KV_EACH {
+        const double r2 = da[r0 + u] + db[r0 + u];
         if (RBFK)
-          P.g[u] = __builtin_fmin(__builtin_fmax(0.5 * r2v[r0 + u], 0.0), 800.0);  // RBF: s = r2 / 2, no sqrt
+          P.g[u] = __builtin_fmin(__builtin_fmax(0.5 * r2, 0.0), 800.0);  // RBF: s = r2 / 2, no sqrt
         else
-          P.t[u] = __builtin_fmax(KC1 * r2v[r0 + u], 1e-300);
+          P.t[u] = __builtin_fmax(KC1 * r2, 1e-300);
         if (HAS_TBL) P.te[u] = c.taskext[16 * tb + 4 * (r0 + u) + c.q];
       }
       break;
@@ -398,10 +448,10 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
 
 // all micro-steps of the four values back to back (first k-block of a pass)
 template <int KVF>
-__device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const double (&r2v)[4], double (&out)[4]) {
+__device__ __forceinline__ void kv_all(const WaveCtx& c, int tb, const d4& da, const d4& db, double (&out)[4]) {
   KvState<4> P;
   static_for<0, BBH_KV_STEPS>([&](auto st) __attribute__((always_inline)) {
-    kv_micro<KVF, 4, decltype(st)::value>(P, c, tb, 0, r2v, out);
+    kv_micro<KVF, 4, decltype(st)::value>(P, c, tb, 0, da, db, out);
   });
 }
 
@@ -428,7 +478,7 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
   constexpr int D = BBH_RING;
   constexpr int TOT = 4 * CNT;
   double tfv[KD];
-  double r2v[4];
+  d4 dsa, dsb;  // the two accumulator chains of the next block's distance GEMM
   double mbv[4];
   KvState<BBH_KV_NU> P;
   if (NEXT == BBH_NEXT_COMPUTE) kvp_load<KD>(c, tb + 1, tfv);
@@ -454,7 +504,7 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
   static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     if (DO_MEAN && r == 3) {
-      if (c.al) {  // wave-uniform: alpha[16 tb + 4 rr + (lane >> 4)] from LDS (lgkmcnt, not the vmcnt ring)
+      if (BBH_MEAN_VALU_ONLY || c.al) {  // wave-uniform: alpha[16 tb + 4 rr + (lane >> 4)] from LDS (lgkmcnt, not the vmcnt ring)
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) mbv[rr] = c.al[16 * tb + 4 * rr];
       } else {
@@ -472,20 +522,20 @@ __device__ __forceinline__ void kblock_p(const WaveCtx& c, const double* rf, int
           constexpr int m = (r - 1) * CNT + jj;
           static_for<(m * BBH_KV_STEPS) / (2 * CNT), ((m + 1) * BBH_KV_STEPS) / (2 * CNT)>(
               [&](auto st) __attribute__((always_inline)) {
-                kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 0, r2v, kvn);
+                kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 0, dsa, dsb, kvn);
               });
         } else {  // two values per slice
           static_for<(jj * BBH_KV_STEPS) / CNT, ((jj + 1) * BBH_KV_STEPS) / CNT>(
               [&](auto st) __attribute__((always_inline)) {
-                kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 2 * (r - 1), r2v, kvn);
+                kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tb + 1, 2 * (r - 1), dsa, dsb, kvn);
               });
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (NEXT == BBH_NEXT_COMPUTE && r == 0) kvp_dist<KD>(c, tfv, r2v);
+    if (NEXT == BBH_NEXT_COMPUTE && r == 0) kvp_dist<KD>(c, tfv, dsa, dsb);
     if (DO_MEAN && r == 3) {
-      if (c.al) {
+      if (BBH_MEAN_VALU_ONLY || c.al) {
         // Without pending points only column 0 of [alpha | -beta] is wanted: 4 FMAs on this lane's slice of
         // the k range instead of 4 MFMAs whose other 15 columns are zeros (the two cost 20 vs 256 cycles
         // of the shared DP pipe); accm[0] carries the partial sum, reduced over the four lanes of a
@@ -541,10 +591,11 @@ __device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, 
         kv[r] = c.kvc[r * 64];
     }
   } else {  // first k-block of the pass: not overlapped
-    double tfv[KD], r2v[4];
+    double tfv[KD];
+    d4 dsa, dsb;
     kvp_load<KD>(c, 0, tfv);
-    kvp_dist<KD>(c, tfv, r2v);
-    kv_all<KVF>(c, 0, r2v, kv);
+    kvp_dist<KD>(c, tfv, dsa, dsb);
+    kv_all<KVF>(c, 0, dsa, dsb, kv);
   }
   // rectangular region (k-blocks left of the window); the block after it is this pass's first diagonal
   // block, whose values nobody has computed yet
@@ -569,8 +620,11 @@ __device__ __forceinline__ void pass_body_p(const WaveCtx& c, const double* rf, 
     for (int r = 0; r < 4; r++) ss[r] = fma(acc[jj][r], acc[jj][r], ss[r]);
 }
 
-template <bool HAS_TBL, int KIND, int KD>
-__global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const FusedArgs a) {
+// WMAX: column blocks per pass.  16: 128 accumulator registers, two waves per SIMD (256 registers each).
+// 32: 256 accumulator registers (the AGPR half of the 512-register budget of a lone wave), one wave per SIMD:
+// n <= 512 is a single pass - no kernel-value cache, no recomputation, no spills.
+template <bool HAS_TBL, int KIND, int KD, int WMAX = 16>
+__global__ __launch_bounds__(256, (WMAX > 16 ? 1 : 2)) void bbh_fused_posterior_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_cand[];  // [4 waves][kd][64] (+ z[qS])
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cnd = l & 15, q = l >> 4;
@@ -654,6 +708,12 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
   c.q = q;
   c.l = l;
   c.dn = a.dn;
+#if BBH_CANDREG
+  if constexpr (KD > 0) {  // lane l wrote exactly the LDS words it reads back: wave-private, no barrier needed
+#pragma unroll
+    for (int k = 0; k < KD; k++) c.cf[k] = candw[k * 64 + l];
+  }
+#endif
 
   double ss[4] = {0.0, 0.0, 0.0, 0.0};
   d4 accm = {0.0, 0.0, 0.0, 0.0};
@@ -665,7 +725,22 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       const int W = a.pass_w[ps];
       const double* rf = a.rfrag + a.pass_off[ps] + l;
       const bool last = (ps == a.npass - 1);
-      if constexpr (KD > 0) {  // software-pipelined passes
+      if constexpr (KD > 0 && WMAX == 32) {  // one wave per SIMD: windows of 32 column blocks (remainders: 8, 16, 24)
+        constexpr int KVF = (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0);
+        const bool use_cache = (a.ncache > 0);
+        if (!last) {
+          pass_body_p<32, KD, KVF, false>(c, rf, j0, ss, accm, use_cache);
+        } else {
+          switch (W) {
+#if BBH_W32_REMAINDERS
+            case 8: pass_body_p<8, KD, KVF, true>(c, rf, j0, ss, accm, use_cache); break;
+            case 16: pass_body_p<16, KD, KVF, true>(c, rf, j0, ss, accm, use_cache); break;
+            case 24: pass_body_p<24, KD, KVF, true>(c, rf, j0, ss, accm, use_cache); break;
+#endif
+            default: pass_body_p<32, KD, KVF, true>(c, rf, j0, ss, accm, use_cache); break;
+          }
+        }
+      } else if constexpr (KD > 0) {  // software-pipelined passes
         const bool use_cache = (a.ncache > 0);
         if (!last) {
           pass_body_p<16, KD, (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0), false>(c, rf, j0, ss, accm, use_cache);
@@ -690,12 +765,14 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_posterior_kernel(const Fused
       j0 += W;
     }
     // pending block(s): mean/cross columns only
-    for (int tb = a.nb; tb < a.nb_ext; tb++) {
-      compute_kv<HAS_TBL, KIND>(c, tb, kv);
+    if constexpr (WMAX <= 16) {
+      for (int tb = a.nb; tb < a.nb_ext; tb++) {
+        compute_kv<HAS_TBL, KIND>(c, tb, kv);
 #pragma unroll
-      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
+        for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
+      }
     }
-  } else {
+  } else if constexpr (WMAX <= 16) {  // (the one-wave form is launched for variance passes without pending columns only)
     for (int tb = 0; tb < a.nb_ext; tb++) {
       compute_kv<HAS_TBL, KIND>(c, tb, kv);
 #pragma unroll
@@ -816,3 +893,5 @@ void bbh_fused_launch_kd6(int kind, bool has_tbl, dim3 grid, dim3 block, size_t 
 void bbh_fused_launch_kd8(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd12(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd16(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
+// one wave per SIMD, windows of 32 column blocks (WMAX = 32); returns false when there is no such instantiation
+bool bbh_fused_launch_w32(int kd, int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);

@@ -129,10 +129,17 @@ int bbh_pack_operands(bbh_handle* h) {
   // ---- pass decomposition: full 16-block windows first, the remainder last ----
   std::vector<int> widths;
   {
+    // One wave per SIMD with windows of 32 column blocks (bbh_fused.h, WMAX = 32) when there is such an
+    // instantiation for this model and more than one 16-block window would be needed otherwise.
+    const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
+    h->wmax = (h->use_w32 && h->use_pipeline && nb > 16 && nb % 32 == 0 &&
+               bbh_fused_launch_w32(h->kd, h->desc.kernel_kind, has_tbl0, dim3(0), dim3(0), 0, nullptr, FusedArgs{}))
+                  ? 32
+                  : 16;
     int64_t left = nb;
-    while (left >= 16) {
-      widths.push_back(16);
-      left -= 16;
+    while (left >= h->wmax) {
+      widths.push_back(h->wmax);
+      left -= h->wmax;
     }
     if (left > 0) widths.push_back((int)left);
   }
@@ -284,7 +291,8 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     // LDS users without costing the second workgroup per CU (half of the CU's LDS per workgroup) stay in
     // wave-private LDS (2 KB per k-block and wave); the rest goes to slabs in global memory claimed per wave.
     a.ncache = (int)(h->nb - h->pass_w_last);
-    const size_t budget = h->lds_per_block / 2 > lds ? h->lds_per_block / 2 - lds : 0;
+    const size_t lds_wg = (h->wmax == 32) ? h->lds_per_block : h->lds_per_block / 2;  // workgroups per CU: 1 / 2
+    const size_t budget = lds_wg > lds ? lds_wg - lds : 0;
     int nl = (int)(budget / (4 * 256 * sizeof(double)));
     if (h->kv_lds_blocks >= 0 && nl > h->kv_lds_blocks) nl = h->kv_lds_blocks;
     a.nl = nl < a.ncache ? nl : a.ncache;
@@ -297,7 +305,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     lds += sizeof(double) * 4 * 256 * (size_t)a.nl;
   }
   if (a.ncache > a.nl) {
-    a.nslab = 2 * 8 * h->num_cu;  // twice the resident waves (8 per CU under these launch bounds)
+    a.nslab = 2 * 8 * h->num_cu;  // at least twice the resident waves (8 or 4 per CU under the launch bounds)
     a.nxcc = (h->num_cu % 8 == 0 && h->num_cu >= 64) ? 8 : 1;  // MI355X: 8 XCDs x 32 CUs
     const size_t need = sizeof(double) * (size_t)a.nslab * (size_t)(a.ncache - a.nl) * 256;
     if (need > h->kvcache_bytes) {
@@ -321,7 +329,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     hipEventCreate(&e1);
     hipEventRecord(e0, h->stream);
   }
-  if (kdp == 2)
+  if (kdp && h->wmax == 32)
+    bbh_fused_launch_w32(kdp, a.kind, has_tbl, grid, block, lds, h->stream, a);
+  else if (kdp == 2)
     bbh_fused_launch_kd2(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 4)
     bbh_fused_launch_kd4(a.kind, has_tbl, grid, block, lds, h->stream, a);
