@@ -1,0 +1,230 @@
+"""BASELINE.json configs[1], [3] and [4] asserted at their full sizes (cfg4 / cfg5 only existed as
+scripts that printed).  The oracle is the checker: live on samples / slices it finishes in seconds, and through
+tests/golden/cfg2_full_ranking.npz, for which it ranked ALL 1e5 rows offline (make_golden_full_ranking.py).
+
+Tolerances: posterior 1e-9 / 1e-8 relative, qLogEI scores 1e-8 absolute, qLogNEHVI scores 2e-5 absolute (log of a
+sum over boxes of products of smoothed side lengths; BoTorch's own fat-tail constants), indices identical."""
+
+import math
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from _problems import fixed_theta, make_grid, make_problem, make_tl_problem, oracle_spec
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+# ---- configs[1]: 1e5 x 15, n = 256, Matérn-5/2, qLogEI — the oracle ranked the FULL set -----------------------
+def test_cfg2_full_set_ranking_matches_the_oracle():
+    import torch
+
+    from baybe_amd import engine, gp_spec
+
+    g = np.load(GOLD / "cfg2_full_ranking.npz")
+    N, d, n, q, seed = (int(g[k]) for k in ("N", "d", "n", "q", "seed"))
+    X, Xt, y = make_problem(N, d, n, seed=0)
+    ls, nz, c = fixed_theta(d)
+    gp = engine.HipGP(0)
+    gp.set_model(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), Xt, y)
+    gp.factorize(gp_spec.GPParams(np.full(d, ls), nz, c))
+    Xd = torch.from_numpy(X).cuda()
+    assert math.isclose(gp.best_f(), float(g["best_f"]), rel_tol=1e-10)
+    # q = 1 scores of every row: ranking head, a strided sample and the checksums of all 1e5 oracle scores
+    m, v = gp.posterior(Xd)
+    s = _np(gp.qlogei(m, v, engine.sobol_normal_base_samples(512, 1, seed)[:, 0], gp.best_f()))
+    assert float(g["min_gap_top16"]) > 1e-6  # the head of the ranking is not a numerical coin toss
+    vals, idx = gp.topk(torch.from_numpy(s).cuda(), 16)
+    assert np.array_equal(idx, g["top_idx"][:16]) and np.allclose(vals, g["top_val"][:16], rtol=0, atol=1e-8)
+    assert np.allclose(s[::64], g["sample_scores"], rtol=0, atol=1e-8)
+    assert math.isclose(float(s.sum()), float(g["score_sum"]), rel_tol=1e-10)
+    assert math.isclose(float(np.abs(s).sum()), float(g["score_abs_sum"]), rel_tol=1e-10)
+    # optimize_acqf_discrete(q = 5): every greedy step of the oracle ran over all remaining rows
+    res = gp.greedy_qlogei(Xd, q, seed=seed)
+    assert res.indices == g["greedy_idx"].tolist()
+    assert np.allclose(res.values, g["greedy_val"], rtol=0, atol=1e-8)
+    gp.close()
+
+
+# ---- configs[3]: transfer learning, ICM over 4 tasks, 1e5 x (15 + task), n = 1024, LOO criterion -----------------
+@pytest.fixture(scope="module")
+def cfg4():
+    from baybe_amd import engine, gp_spec
+
+    N, dnum, T, per_task = 100_000, 15, 4, 256
+    X, Xt, y = make_tl_problem(N, dnum, per_task, T=T, seed=0)
+    d = dnum + 1
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=dnum, n_tasks=T)
+    assert spec.criterion == "loo" and len(y) == 1024  # presets/baybe.py:277-281
+    gp = engine.HipGP(0)
+    gp.set_model(spec, Xt, y)
+    yield X, Xt, y, spec, gp
+    gp.close()
+
+
+def test_cfg4_loo_data_term_and_gradient_at_n1024(cfg4):
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    X, Xt, y, spec, gp = cfg4
+    rng = np.random.default_rng(4)
+    p = gp_spec.initial_params(spec)
+    p.lengthscale = p.lengthscale * (0.8 + 0.4 * rng.random(spec.dn))
+    p.task_W = 0.3 + rng.random((4, 4))
+    p.mean = 0.05
+    val, g = gp.data_term(p)
+    ospec = oracle_spec(spec)
+    op = go.GPParams(p.lengthscale.copy(), p.noise, p.mean, 1.0, p.task_W.copy(), p.task_v.copy())
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    dt = go.data_term(ospec, op, Xn, ys)
+    gref = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls, dt.g_task_B.reshape(-1)])
+    assert math.isclose(val, dt.value, rel_tol=1e-10)
+    assert np.allclose(g, gref, rtol=1e-8, atol=1e-9 * np.abs(gref).max())
+    # and through the host's chain rules against the oracle's independent torch / autograd objective
+    raw = gp_spec.pack_raw(spec, p)
+    f, gr = gp_spec.objective_from_data_term(spec, raw, len(y), val, g)
+    fo, gro = go.fit_objective(ospec, raw, Xn, ys)
+    assert math.isclose(f, fo, rel_tol=1e-10) and np.allclose(gr, gro, rtol=1e-7, atol=1e-9 * np.abs(gro).max())
+
+
+def test_cfg4_fit_posterior_and_greedy_at_full_size(cfg4):
+    import torch
+
+    from baybe_amd import engine
+    from oracle import gp_oracle as go
+
+    X, Xt, y, spec, gp = cfg4
+    N = len(X)
+    fi = gp.fit(maxiter=40)  # a few dozen L-BFGS-B iterations of the LOO objective on the device
+    assert np.isfinite(fi.fun) and (fi.params.task_B().diagonal() > 0).all()
+    ospec = oracle_spec(spec)
+    om = go.GPModel(ospec, go.GPParams(fi.params.lengthscale, fi.params.noise, fi.params.mean, 1.0, fi.params.task_W,
+                                       fi.params.task_v), Xt, y)
+    Xd = torch.from_numpy(X).cuda()
+    m, v = gp.posterior(Xd)  # nb = 64: four 16-block windows, kernel values cached between the passes (HAS_TBL form)
+    pick = np.random.default_rng(0).choice(N, 2000, replace=False)
+    mo, vo = om.posterior(X[pick])
+    assert np.allclose(_np(m)[pick], mo, rtol=1e-9, atol=1e-12) and np.allclose(_np(v)[pick], vo, rtol=1e-8)
+    # the same launch with the overflow of the kernel-value cache in global slabs / without any cache: identical
+    for env in ({"BBH_KV_GLOBAL": "1"}, {"BBH_KVCACHE": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            g2 = engine.HipGP(0)
+        finally:
+            for k, val in old.items():
+                os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
+        g2.set_model(spec, Xt, y)
+        g2.factorize(fi.params)
+        m2, v2 = g2.posterior(Xd)
+        assert torch.allclose(m2, m, rtol=1e-12, atol=1e-13) and torch.allclose(v2, v, rtol=1e-10, atol=1e-14), env
+        g2.close()
+    # optimize_acqf_discrete(q = 3): oracle over a 20k-row slice, device over the same slice and over the full set
+    ro = go.optimize_acqf_discrete_qlogei(om, X[:20000], 3, seed=5)
+    r2 = gp.greedy_qlogei(Xd[:20000], 3, seed=5)
+    assert r2.indices == ro.indices and np.allclose(r2.values, ro.values, rtol=0, atol=1e-8)
+    r = gp.greedy_qlogei(Xd, 3, seed=5)
+    assert len(set(r.indices)) == 3 and all(v1 >= v2 - 1e-12 for v1, v2 in zip(r.values, r2.values))
+    # the full-set picks are at least as good as the slice's, and the oracle reproduces their values
+    best_f = gp.best_f()
+    z1 = engine.sobol_normal_base_samples(512, 1, 5)
+    mo1, vo1 = om.posterior(X[r.indices[:1]])
+    assert math.isclose(go.qlogei_q1(mo1, vo1, z1[:, 0], go.best_f_from_model(om))[0], r.values[0], abs_tol=1e-8)
+    assert math.isclose(best_f, go.best_f_from_model(om), rel_tol=1e-9)
+    z3 = engine.sobol_normal_base_samples(512, 3, 5)
+    s3 = go.qlogei_with_pending(om, X[r.indices[2:3]], X[r.indices[:2]], z3, go.best_f_from_model(om))
+    assert math.isclose(s3[0], r.values[2], abs_tol=1e-8)
+
+
+# ---- configs[4]: ParetoObjective, qLogNEHVI, 3 targets, 1e5 x 15, n = 256, S = 128 (BoTorch default) and 512 ------
+@pytest.fixture(scope="module")
+def cfg5():
+    from baybe_amd import engine, gp_spec
+    from oracle import gp_oracle as go
+
+    N, d, n, m = 100_000, 15, 256, 3
+    rng = np.random.default_rng(0)
+    X = make_grid(N, d, 0)
+    Xt = X[np.random.default_rng(1).choice(N, n, replace=False)]
+    Y = np.stack([-((Xt - 0.25) ** 2).sum(1), -((Xt - 0.75) ** 2).sum(1), -np.abs(Xt - 0.5).sum(1)], 1)
+    Y = Y + 0.05 * rng.standard_normal(Y.shape)
+    engines, models = [], []
+    for o in range(m):
+        spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+        g = engine.HipGP(0)
+        g.set_model(spec, Xt, Y[:, o])
+        fi = g.fit()
+        engines.append(g)
+        models.append(go.fit_gp(oracle_spec(spec), Xt, Y[:, o],
+                                params=go.GPParams(fi.params.lengthscale, fi.params.noise, fi.params.mean)))
+    yield X, Xt, Y, engines, models
+    for g in engines:
+        g.close()
+
+
+@pytest.mark.parametrize("S", [128, 512])
+def test_cfg5_qlognehvi_scores_at_full_size(cfg5, S):
+    import torch
+
+    from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+    from oracle import nehvi_oracle as no
+
+    X, Xt, Y, engines, models = cfg5
+    N, m = len(X), 3
+    signs = np.ones(m)
+    ref = compute_ref_point(Y)
+    assert np.allclose(ref, no.compute_ref_point(Y))
+    seed, pseed = 1234, 99
+    hv = HipNEHVI(engines, signs, Xt, ref, n_mc_samples=S, prune_baseline=True)  # acqfs.py:477-484
+    hv.prepare(seed, prune_seed=pseed)
+    Xd = torch.from_numpy(X).cuda()
+    sg = _np(hv.score(Xd))
+    assert np.isfinite(sg).all()
+    keep = no.prune_baseline(models, signs, Xt, ref, pseed)
+    assert np.array_equal(hv._pruned, Xt[keep]) and 0 < len(keep) < len(Xt)
+    orc = no.NEHVIOracle(models, signs, Xt[keep], ref, no.sobol_normal_base_samples_nd(S, len(keep) + 1, m, seed))
+    assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)  # same box decompositions, sample by sample
+    top = np.argsort(-sg, kind="stable")[:12]
+    pick = np.concatenate([np.random.default_rng(S).choice(N, 500, replace=False), top])
+    so = orc.values(X[pick])
+    dup = np.array([(np.abs(Xt - x).sum(1) < 1e-12).any() for x in X[pick]])  # training rows are part of the grid
+    assert np.allclose(sg[pick][~dup], so[~dup], rtol=0, atol=2e-5), np.abs(sg[pick] - so)[~dup].max()
+    # among the sample and the head of the device's ranking, oracle and device agree on the best row
+    assert int(np.argmax(so[~dup])) == int(np.argmax(sg[pick][~dup]))
+
+
+def test_cfg5_greedy_pair_matches_the_oracle(cfg5):
+    import torch
+
+    from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+    from oracle import nehvi_oracle as no
+
+    X, Xt, Y, engines, models = cfg5
+    m, S, seed, pseed, NS = 3, 128, 1234, 99, 3000
+    signs = np.ones(m)
+    ref = compute_ref_point(Y)
+    hv = HipNEHVI(engines, signs, Xt, ref, n_mc_samples=S, prune_baseline=True)
+    Xd = torch.from_numpy(X).cuda()
+    res = hv.greedy(Xd[:NS], 2, seed=seed, prune_seed=pseed)
+    keep = no.prune_baseline(models, signs, Xt, ref, pseed)
+    alive = np.ones(NS, bool)
+    picks, vals = [], []
+    for _ in range(2):  # the oracle's optimize_acqf_discrete: picks join the baseline (cache_pending), same seed
+        Xb = np.vstack([Xt[keep]] + [X[i][None, :] for i in picks])
+        orc = no.NEHVIOracle(models, signs, Xb, ref, no.sobol_normal_base_samples_nd(S, len(Xb) + 1, m, seed))
+        v = np.full(NS, -np.inf)
+        v[alive] = orc.values(X[:NS][alive])
+        picks.append(int(np.argmax(v)))
+        vals.append(v[picks[-1]])
+        alive[picks[-1]] = False
+    assert res.indices == picks and np.allclose(res.values, vals, rtol=0, atol=2e-5)
+    # full set: two distinct rows, each at least as good as the slice's pick of the same step
+    full = hv.greedy(Xd, 2, seed=seed, prune_seed=pseed)
+    assert len(set(full.indices)) == 2 and full.values[0] >= res.values[0] - 1e-12
