@@ -99,8 +99,10 @@ def from_preset(preset: str, d: int, lo, hi, task_idx: int | None = None, n_task
       space has a substance parameter with a MORDRED/RDKIT encoding (presets/edbo.py:39-54);
     * ``EDBO_SMOOTHED`` — the same moments interpolated linearly between d = 8 and d = 75
       (presets/edbo_smoothed.py:60-72, :118-123);
-    * ``CHEN`` — lengthscale 0.4 sqrt(d) + 4, Gamma(2 l, 2) / Gamma(l, 1) priors (presets/chen.py:43-60),
-      default BayBE likelihood;
+    * ``CHEN`` — lengthscale 0.4 sqrt(d) + 4, Gamma(2 l, 2) / Gamma(l, 1) priors (presets/chen.py:43-60), plain
+      gpytorch ``GaussianLikelihood()`` (no noise prior, softplus-transformed ``GreaterThan(1e-4)``, raw noise 0).  The
+      BAYBE preset itself dispatches to these components when the search space has a ``SubstanceParameter``
+      (presets/baybe.py:150-171, ``baybe_amd.surrogates``);
     * ``HVARFNER`` / ``BOTORCH`` (single task) — BoTorch's dimension-scaled defaults: RBF ARD,
       LogNormal(sqrt 2 + log(d)/2, sqrt 3) lengthscale prior with l >= 0.025 (no transform), noise
       LogNormal(-4, 1) with sigma^2 >= 1e-4, both started at the prior mode, plain MLL
@@ -134,7 +136,11 @@ def from_preset(preset: str, d: int, lo, hi, task_idx: int | None = None, n_task
         ls = 0.4 * math.sqrt(dn) + 4.0
         spec.ls_prior, spec.ls_init = ("gamma", 2.0 * ls, 2.0), ls
         spec.outputscale_prior, spec.outputscale_init = ("gamma", 1.0 * ls, 1.0), ls
-        return spec  # likelihood: the BayBE default (LazyGaussianLikelihoodFactory)
+        # ChenLikelihoodFactory is LazyGaussianLikelihoodFactory (presets/chen.py:78-79, components/likelihood.py:33-43): a
+        # bare gpytorch GaussianLikelihood() - no noise prior, GreaterThan(1e-4) WITH its softplus transform, raw noise 0
+        spec.noise_constraint, spec.noise_prior = "softplus", None
+        spec.noise_init = MIN_INFERRED_NOISE_LEVEL + float(softplus(0.0))
+        return spec
     spec.noise_constraint = "softplus"
     if name == "EDBO":
         switching = bool(edbo_encodings) and dn >= 50

@@ -18,9 +18,10 @@ from __future__ import annotations
 
 from typing import ClassVar
 
+import attrs
 import numpy as np
 import pandas as pd
-from attrs import define, field
+from attrs import field
 from attrs.validators import ge, instance_of
 
 from baybe_amd import _lib
@@ -31,59 +32,86 @@ from baybe_amd.exceptions import (
     IncompatibleAcquisitionFunctionError,
     NotEnoughPointsLeftError,
 )
-from baybe_amd.surrogates import HipCompositeSurrogate, HipGaussianProcessSurrogate
+from baybe_amd.surrogates import HipCompositeImpl, HipGaussianProcessSurrogate, _availability_property
 
 
-def _autoreplicate(surrogate):
-    """``pure/bayesian/base.py:35-39``: single-output surrogates are replicated lazily per target."""
-    return surrogate
+def _is_multi_output(objective) -> bool:
+    """``Objective.is_multi_output`` (objectives/base.py): False for single-target AND desirability objectives."""
+    flag = getattr(objective, "is_multi_output", None)
+    return bool(flag) if flag is not None else len(objective.targets) > 1
 
 
-@define(kw_only=True, slots=False)
-class HipBotorchRecommender:
-    """Bayesian recommender scoring the full discrete candidate set on an MI355X."""
+def _check_objective(objective, acqf) -> None:
+    """What of ``baybe.objectives`` is on the device path, checked before anything is fitted: single targets and
+    Pareto stacking of identity / negated targets.  A ``DesirabilityObjective`` is
+    single-output in the reference (scalarised, optimised with qLogEI, ``objectives/desirability.py:222-265``) -
+    treating it as Pareto because it has several targets would answer a different question."""
+    kind = type(objective).__name__
+    if kind == "DesirabilityObjective" or (len(objective.targets) > 1 and not _is_multi_output(objective)):
+        raise IncompatibilityError(
+            f"Objectives of type '{kind}' scalarise several targets; the HIP path supports single-target and Pareto "
+            f"objectives. Use BotorchRecommender, or 'DesirabilityObjective(as_pre_transformation=True)' upstream of a "
+            f"single-target objective."
+        )
+    if _is_multi_output(objective) and not acqf.supports_multi_output:
+        raise IncompatibleAcquisitionFunctionError(
+            f"You attempted to use a single-output acquisition function in a "
+            f"{len(objective.targets)}-target multi-output context."
+        )
+    if not _is_multi_output(objective) and acqf.supports_multi_output:
+        raise IncompatibleAcquisitionFunctionError(
+            f"The acquisition function '{type(acqf).__name__}' needs a multi-output objective, but a single-target "
+            f"objective was given."
+        )
+    from baybe_amd.surrogates import _target_sign
 
-    compatibility: ClassVar[str] = "DISCRETE"
+    for target in objective.targets:  # identity transformations (+ minimisation) only: raises IncompatibilityError
+        _target_sign(target)
+
+
+class HipRecommenderImpl:
+    """Behaviour of the Bayesian recommender scoring the full discrete candidate set on an MI355X.  No fields: they
+    are attached by ``attrs.make_class`` - below for the stand-alone class, in ``baybe_amd.plugin`` on top of BayBE's
+    ``BayesianRecommender``, whose ``recommend`` (``pure/bayesian/base.py:130-197``) then drives the overrides
+    ``_setup_botorch_acqf`` / ``_recommend_with_discrete_parts`` / ``_recommend_discrete`` defined here."""
+
+    __slots__ = ()
+
     supports_discrete_subset_generating_constraints: ClassVar[bool] = True
-
-    _surrogate_model = field(alias="surrogate_model", factory=HipGaussianProcessSurrogate, converter=_autoreplicate)
-    acquisition_function = field(default=None, converter=convert_acqf)
-    max_n_subsets: int = field(default=10, validator=[instance_of(int), ge(1)])
-    shard = field(default=None, eq=False, repr=False)
-    """Optional ``baybe_amd.distributed.RowShard``: this process scores only its row range and
-    joins one all-gather per selection step (multi-GPU)."""
-
-    _objective = field(default=None, init=False, eq=False, repr=False)
-    _best_f = field(default=None, init=False, eq=False, repr=False)
-    _pending_comp = field(default=None, init=False, eq=False, repr=False)
-    _cand_cache = field(default=None, init=False, eq=False, repr=False)
-    _nehvi = field(default=None, init=False, eq=False, repr=False)
-
-    @classmethod
-    def is_available(cls) -> bool:
-        return _lib.is_available()
+    is_available = _availability_property()
 
     # ---- BayesianRecommender surface -----------------------------------------------------------
-    def _get_acquisition_function(self, objective):
-        if self.acquisition_function is None:  # pure/bayesian/base.py:70-74
-            return qLogNoisyExpectedHypervolumeImprovement() if len(objective.targets) > 1 else qLogExpectedImprovement()
-        return self.acquisition_function
+    def _get_acquisition_function(self, objective, override=None):
+        """Native acquisition spec for the context (default choice: pure/bayesian/base.py:70-74); BayBE's own
+        acquisition objects are mapped by class name (``baybe_amd.acquisition.convert_acqf``)."""
+        chosen = override if override is not None else self.acquisition_function
+        if chosen is None:
+            return qLogNoisyExpectedHypervolumeImprovement() if _is_multi_output(objective) else qLogExpectedImprovement()
+        return convert_acqf(chosen)
 
     def get_surrogate(self, searchspace, objective, measurements):
-        if len(objective.targets) > 1 and not self._surrogate_model.supports_multi_output:
+        if _is_multi_output(objective) and not self._surrogate_model.supports_multi_output:
             self._surrogate_model = self._surrogate_model.replicate()  # pure/bayesian/base.py:35-39
         self._surrogate_model.fit(searchspace, objective, measurements)
         return self._surrogate_model
 
-    def _setup_acqf(self, searchspace, objective, measurements, pending_experiments=None):
+    def _setup_botorch_acqf(self, searchspace, objective, measurements, pending_experiments=None) -> None:
+        """Override point of ``BayesianRecommender.recommend`` (base.py:87-111, called at base.py:166-168): the native
+        set-up instead of ``acqf.to_botorch(...)``."""
+        self._setup_acqf(searchspace, objective, measurements, pending_experiments)
+
+    def _setup_acqf(self, searchspace, objective, measurements, pending_experiments=None, acquisition_function=None):
         """Native counterpart of ``_setup_botorch_acqf``: fit (cached), best_f, pending rows."""
-        self._objective = objective
-        acqf = self._get_acquisition_function(objective)
-        if len(objective.targets) > 1 and not acqf.supports_multi_output:
-            raise IncompatibleAcquisitionFunctionError(
-                f"You attempted to use a single-output acquisition function in a "
-                f"{len(objective.targets)}-target multi-output context."
+        cont = getattr(searchspace, "continuous", None)
+        if cont is not None and not getattr(cont, "is_empty", True):
+            raise IncompatibilityError(
+                "HipBotorchRecommender handles purely discrete search spaces; use BotorchRecommender for "
+                "continuous / hybrid spaces."
             )
+        self._objective = objective
+        acqf = self._get_acquisition_function(objective, acquisition_function)
+        _check_objective(objective, acqf)
+        self._acqf_in_use = acqf
         if pending_experiments is not None and not acqf.supports_pending_experiments:
             raise IncompatibleAcquisitionFunctionError(
                 f"The chosen acquisition function of type '{type(acqf).__name__}' does not support pending experiments."
@@ -94,7 +122,7 @@ class HipBotorchRecommender:
             pend = searchspace.transform(pending_experiments, allow_extra=True)  # _builder.py:326-334
             self._pending_comp = np.ascontiguousarray(pend.to_numpy(dtype=np.float64))
         self._nehvi = None
-        if len(objective.targets) > 1:
+        if _is_multi_output(objective):
             from baybe_amd.nehvi import HipNEHVI, compute_ref_point
 
             models = surrogate.models
@@ -119,6 +147,21 @@ class HipBotorchRecommender:
             self._best_f = surrogate.engine.best_f(surrogate.sign)  # _builder.py:141-161, 256-265
         return surrogate, acqf
 
+    def _check_batch_size(self, batch_size, pending_experiments=None) -> None:
+        """The joint q'-batch kernels hold 1 + (pending + earlier picks) <= 16 points; the reference has no such
+        limit, so say so before any candidate is scored (single-target MC acquisition functions only: qLogNEHVI
+        caches picks into its baseline and analytic functions have q = 1)."""
+        n_pend = len(self._pending_comp) if self._pending_comp is not None else (
+            0 if pending_experiments is None else len(pending_experiments))
+        acqf = self._acqf_in_use
+        if acqf is not None and (acqf.supports_multi_output or getattr(acqf, "is_analytic", False)):
+            return
+        if batch_size + n_pend > _lib.MAX_PENDING + 1:
+            raise IncompatibilityError(
+                f"batch_size ({batch_size}) + pending experiments ({n_pend}) exceeds {_lib.MAX_PENDING + 1}, the largest "
+                f"joint q-batch of the HIP kernels; recommend in smaller batches (marking earlier ones as pending)."
+            )
+
     def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None) -> pd.DataFrame:
         if objective is None:
             raise NotImplementedError(
@@ -126,17 +169,15 @@ class HipBotorchRecommender:
             )
         if measurements is None or measurements.empty:
             raise NotImplementedError("Recommenders of type 'BayesianRecommender' do not support empty training data.")
-        cont = getattr(searchspace, "continuous", None)
-        if cont is not None and not getattr(cont, "is_empty", True):
-            raise IncompatibilityError(
-                "HipBotorchRecommender handles purely discrete search spaces; use BotorchRecommender for "
-                "continuous / hybrid spaces."
-            )
-        self._setup_acqf(searchspace, objective, measurements, pending_experiments)
-        return self._recommend_with_discrete_parts(searchspace, batch_size)
+        self._acqf_in_use = self._get_acquisition_function(objective)
+        self._pending_comp = None
+        self._check_batch_size(batch_size, pending_experiments)  # before the fit
+        self._setup_botorch_acqf(searchspace, objective, measurements, pending_experiments)
+        return self._recommend_with_discrete_parts(searchspace, batch_size, pending_experiments=pending_experiments)
 
-    def _recommend_with_discrete_parts(self, searchspace, batch_size) -> pd.DataFrame:
+    def _recommend_with_discrete_parts(self, searchspace, batch_size, pending_experiments=None) -> pd.DataFrame:
         sd = searchspace.discrete
+        self._check_batch_size(batch_size)
         mask = getattr(sd, "mask_keep", None)  # FilteredSubspaceDiscrete (searchspace/_filtered.py:14-44)
         if (isinstance(mask, np.ndarray) and mask.dtype == bool and len(mask) == len(sd.exp_rep)
                 and getattr(sd, "n_subsets", 0) == 0):
@@ -203,11 +244,11 @@ class HipBotorchRecommender:
     @property
     def _engine(self):
         model = self._surrogate_model
-        return model.models[0].engine if isinstance(model, HipCompositeSurrogate) else model.engine
+        return model.models[0].engine if isinstance(model, HipCompositeImpl) else model.engine
 
     def _recommend_discrete(self, subspace_discrete, candidates_exp: pd.DataFrame, batch_size: int) -> pd.Index:
         assert self._objective is not None
-        acqf = self._get_acquisition_function(self._objective)
+        acqf = self._acqf_in_use
         if batch_size > 1 and not acqf.supports_batching:
             raise IncompatibleAcquisitionFunctionError(
                 f"The '{self.__class__.__name__}' only works with Monte Carlo acquisition functions for batch sizes > 1."
@@ -220,7 +261,7 @@ class HipBotorchRecommender:
     def _recommend_discrete_without_subsets(self, subspace_discrete, candidates_exp, batch_size, return_values=False,
                                             keep_mask=None):
         surrogate = self._surrogate_model
-        acqf = self._get_acquisition_function(self._objective)
+        acqf = self._acqf_in_use
         Xd, alive, labels = self._candidates_on_device(subspace_discrete, candidates_exp, keep_mask)
         if self._nehvi is not None:
             res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp, alive=alive, shard=self.shard)
@@ -280,7 +321,7 @@ class HipBotorchRecommender:
             return float(sc.cpu().numpy()[0])
         surrogate = self._surrogate_model
         eng = surrogate.engine
-        acqf = self._get_acquisition_function(self._objective)
+        acqf = self._acqf_in_use
         base = self._pending_comp if self._pending_comp is not None else np.zeros((0, comp.shape[1]))
         pend = np.vstack([comp[1:], base])
         seed = draw_sampler_seed()
@@ -304,9 +345,7 @@ class HipBotorchRecommender:
     def acquisition_values(self, candidates: pd.DataFrame, searchspace, objective, measurements,
                            pending_experiments=None, acquisition_function=None) -> pd.Series:
         """``BayesianRecommender.acquisition_values`` (base.py:199-238): one value per candidate."""
-        if acquisition_function is not None:
-            convert_acqf(acquisition_function)
-        surrogate, acqf = self._setup_acqf(searchspace, objective, measurements, pending_experiments)
+        surrogate, acqf = self._setup_acqf(searchspace, objective, measurements, pending_experiments, acquisition_function)
         comp = np.ascontiguousarray(searchspace.transform(candidates, allow_extra=True).to_numpy(dtype=np.float64))
         if self._nehvi is not None:
             self._nehvi.prepare(draw_sampler_seed(), self._pending_comp)
@@ -333,6 +372,35 @@ class HipBotorchRecommender:
     def joint_acquisition_value(self, candidates: pd.DataFrame, searchspace, objective, measurements,
                                 pending_experiments=None, acquisition_function=None) -> float:
         """``BayesianRecommender.joint_acquisition_value`` (base.py:240-269)."""
-        self._setup_acqf(searchspace, objective, measurements, pending_experiments)
+        self._setup_acqf(searchspace, objective, measurements, pending_experiments, acquisition_function)
         comp = np.ascontiguousarray(searchspace.transform(candidates, allow_extra=True).to_numpy(dtype=np.float64))
         return self._joint_value(comp)
+
+
+def recommender_fields(with_base_fields: bool = True, surrogate_factory=HipGaussianProcessSurrogate) -> dict:
+    """attrs fields of the recommender.  ``with_base_fields=False`` leaves out what BayBE's ``BayesianRecommender``
+    declares itself (``acquisition_function``, ``_objective``; pure/bayesian/base.py:46-66); ``_surrogate_model`` is
+    redeclared in both cases because its default is the HIP surrogate."""
+    f = {
+        "_surrogate_model": field(alias="surrogate_model", factory=surrogate_factory),
+        "max_n_subsets": field(default=10, validator=[instance_of(int), ge(1)], kw_only=True),  # botorch/core.py:93-98
+        # optional baybe_amd.distributed.RowShard: this process scores only its row range and joins one all-gather
+        # per selection step (multi-GPU)
+        "shard": field(default=None, eq=False, repr=False, kw_only=True),
+        "_best_f": field(default=None, init=False, eq=False, repr=False),
+        "_pending_comp": field(default=None, init=False, eq=False, repr=False),
+        "_cand_cache": field(default=None, init=False, eq=False, repr=False),
+        "_nehvi": field(default=None, init=False, eq=False, repr=False),
+        "_acqf_in_use": field(default=None, init=False, eq=False, repr=False),
+    }
+    if with_base_fields:
+        f["acquisition_function"] = field(default=None, converter=convert_acqf, kw_only=True)
+        f["_objective"] = field(default=None, init=False, eq=False, repr=False)
+    return f
+
+
+HipBotorchRecommender = attrs.make_class("HipBotorchRecommender", recommender_fields(), bases=(HipRecommenderImpl,),
+                                         kw_only=True, slots=False)
+HipBotorchRecommender.__doc__ = "Bayesian recommender scoring the full discrete candidate set on an MI355X (stand-alone)."
+HipBotorchRecommender.__module__ = __name__
+HipBotorchRecommender.compatibility = "DISCRETE"

@@ -9,7 +9,14 @@ caching / validation behaviour as ``Surrogate.fit`` (``base.py:387-465``), and t
 
 Search space / objective / targets are duck-typed on the attributes BayBE's own classes expose
 (``transform``, ``scaling_bounds``, ``task_idx``, ``n_tasks``, ``targets``, ``minimize``), so real
-BayBE objects work unchanged; INTEGRATION.md shows the subclassing stub for serialisation.
+BayBE objects work unchanged.
+
+Layout: the behaviour lives in field-less mixins with empty ``__slots__`` (``HipGPSurrogateImpl``,
+``HipCompositeImpl``); the attrs fields are attached by ``attrs.make_class`` — here onto a bare base
+(the stand-alone classes below), and in ``baybe_amd.plugin.make_baybe_classes`` onto BayBE's own slotted
+``Surrogate`` (``surrogates/base.py:81-82``), whose runtime fields (``_searchspace``, ``_objective``,
+``_measurements_hash``) are then inherited instead of redeclared.  Two slotted attrs bases cannot be combined
+("multiple bases have instance lay-out conflict"); one slotted base plus a slot-less mixin can.
 """
 
 from __future__ import annotations
@@ -18,7 +25,8 @@ from typing import ClassVar
 
 import numpy as np
 import pandas as pd
-from attrs import define, field
+import attrs
+from attrs import field
 
 from baybe_amd import _lib
 from baybe_amd.exceptions import IncompatibilityError, IncompatibleSurrogateError, ModelNotTrainedError
@@ -29,6 +37,14 @@ def _frame_hash(df: pd.DataFrame) -> str:
     import joblib
 
     return joblib.hash(df)
+
+
+def _has_substance_parameter(searchspace) -> bool:
+    """``_dispatch`` of the BAYBE preset (presets/baybe.py:150-171): any ``SubstanceParameter`` in the search space."""
+    params = getattr(searchspace, "parameters", None)
+    if params is None:
+        params = getattr(getattr(searchspace, "discrete", None), "parameters", ()) or ()
+    return any(type(prm).__name__ == "SubstanceParameter" for prm in params)
 
 
 def _has_edbo_encoding(searchspace) -> bool:
@@ -42,6 +58,25 @@ def _has_edbo_encoding(searchspace) -> bool:
     return False
 
 
+class _Availability:
+    """Value of the ``is_available`` class attribute: truthy / falsy like BayBE's ``classproperty``
+    (``if not cls.is_available: skip``, ``surrogates/base.py:121-128``, ``tests/test_iterations.py:75-88``) and
+    callable for the stand-alone spelling ``cls.is_available()``."""
+
+    def __bool__(self) -> bool:
+        return _lib.is_available()
+
+    __call__ = __bool__
+
+    def __repr__(self) -> str:
+        return f"<is_available: {bool(self)}>"
+
+
+class _availability_property:
+    def __get__(self, _obj, _cls):
+        return _Availability()
+
+
 def _target_sign(target) -> float:
     """+1 maximise / -1 minimise.  Only identity transformations are on the HIP path (row a9)."""
     tr = getattr(target, "transformation", None)
@@ -53,50 +88,20 @@ def _target_sign(target) -> float:
     return -1.0 if getattr(target, "minimize", False) else 1.0
 
 
-@define
-class HipGaussianProcessSurrogate:
-    """A Gaussian process surrogate evaluated on an MI355X (BAYBE preset)."""
+class HipGPSurrogateImpl:
+    """Behaviour of the GP surrogate evaluated on an MI355X (no fields: see the module docstring)."""
+
+    __slots__ = ()
 
     supports_transfer_learning: ClassVar[bool] = True
     supports_multi_output: ClassVar[bool] = False
-
-    kernel = field(default="matern52")
-    """``"matern12" | "matern32" | "matern52" | "rbf"`` within the BAYBE preset (box constraints,
-    dimension-scaled Gamma priors), or a kernel specification object — ``baybe_amd.kernels`` or
-    BayBE's own ``MaternKernel`` / ``RBFKernel`` / ``ScaleKernel`` — handled like ``Kernel.to_gpytorch``."""
-
-    use_outputscale: bool = field(default=False)
-    """Wrap the base kernel in a ScaleKernel (user kernels); the BAYBE preset has none."""
-
-    preset: str = field(default="BAYBE", converter=lambda v: str(getattr(v, "value", v)).upper())
-    """``GaussianProcessPreset`` (presets/core.py:8-27): BAYBE | BOTORCH | CHEN | EDBO | EDBO_SMOOTHED |
-    HVARFNER — prior tables, constraints and initial values as data (``gp_spec.from_preset``)."""
-
-    device: int = field(default=0)
-    """HIP device ordinal."""
-
-    fixed_hyperparameters = field(default=None, eq=False)
-    """Optional ``GPParams`` to skip the fit (kernel-parity / benchmarking mode)."""
-
-    # runtime state (not part of the specification; mirrors gaussian_process/core.py:211-212)
-    _engine = field(init=False, default=None, eq=False, repr=False)
-    _searchspace = field(init=False, default=None, eq=False, repr=False)
-    _objective = field(init=False, default=None, eq=False, repr=False)
-    _measurements_hash = field(init=False, default=None, eq=False, repr=False)
-    _fit_info = field(init=False, default=None, eq=False, repr=False)
-    _target_index = field(default=None, eq=False, repr=False)
-    """Which target of a multi-target objective this (replicated) model represents (None = the
-    single target of a single-target objective)."""
+    is_available = _availability_property()
+    """False without the shared library or a HIP device (``surrogates/base.py:121-128``)."""
 
     @classmethod
     def from_preset(cls, preset, **kwargs):
         """``GaussianProcessSurrogate.from_preset`` (gaussian_process/core.py:215-246)."""
         return cls(preset=preset, **kwargs)
-
-    @classmethod
-    def is_available(cls) -> bool:
-        """False without the shared library or a HIP device (``surrogates/base.py:121-128``)."""
-        return _lib.is_available()
 
     # ---- SurrogateProtocol ---------------------------------------------------------------------
     def fit(self, searchspace, objective, measurements: pd.DataFrame) -> None:
@@ -143,6 +148,11 @@ class HipGaussianProcessSurrogate:
                 raise ValueError("a preset fixes the kernel; pass either preset=... or kernel=...")
             spec = from_preset(self.preset, train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
                                edbo_encodings=_has_edbo_encoding(searchspace))
+        elif self.kernel == "matern52" and not self.use_outputscale and _has_substance_parameter(searchspace):
+            # BayBE{Kernel,Mean,Likelihood}Factory delegate to the Chen components for chemical search spaces
+            from baybe_amd.gp_spec import from_preset
+
+            spec = from_preset("CHEN", train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks)
         elif isinstance(self.kernel, str):
             spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
                                         kernel=self.kernel)
@@ -217,28 +227,65 @@ class HipGaussianProcessSurrogate:
                 raise TypeError(f"The HIP posterior does not support the statistic '{s}'.")
         return out
 
+    _composite_class: ClassVar[type] = None  # set below / by make_baybe_classes
+
     def replicate(self):
         """One independent copy per target (``surrogates/base.py:136-150``, ``composite.py:101-134``)."""
-        return HipCompositeSurrogate(template=self)
+        return type(self)._composite_class(template=self)
+
+    # ---- abstract hooks of baybe.surrogates.base.Surrogate (base.py:274-306, 467-469) ------------------------
+    def _fit(self, train_x, train_y) -> None:
+        raise NotImplementedError("HipGaussianProcessSurrogate.fit() builds and fits the device model itself.")
+
+    def _posterior_comp(self, candidates_comp, /):
+        """BoTorch ``Posterior`` for comp-rep candidates [..., q, d] - compatibility read-back only (needs
+        botorch; the hot path never constructs it): t-batches of q = 1 use the fused kernel, q-batches the joint
+        posterior."""
+        import torch
+        from botorch.posteriors import GPyTorchPosterior
+        from gpytorch.distributions import MultivariateNormal
+
+        eng = self.engine
+        X = torch.as_tensor(candidates_comp, dtype=torch.float64)
+        batch, q, d = X.shape[:-2], X.shape[-2], X.shape[-1]
+        flat = X.reshape(-1, q, d)
+        if q == 1:
+            mean, var = eng.posterior(flat[:, 0, :].contiguous())
+            mean, cov = mean.cpu().reshape(*batch, 1), var.cpu().clamp_min(0.0).reshape(*batch, 1, 1)
+        else:
+            ms, cs = zip(*(eng.posterior_joint(x.numpy()) for x in flat))
+            mean = torch.as_tensor(np.stack(ms)).reshape(*batch, q)
+            cov = torch.as_tensor(np.stack(cs)).reshape(*batch, q, q)
+        return GPyTorchPosterior(MultivariateNormal(mean, cov))
+
+    _posterior = _posterior_comp  # no scaler sits in front of the device model (gp/core.py:253-265 returns None)
+
+    def posterior(self, candidates: pd.DataFrame, *, joint: bool = True):
+        """``Surrogate.posterior`` (surrogates/base.py:213-247)."""
+        import torch
+
+        _ = self.engine  # ModelNotTrainedError before training
+        comp = self._searchspace.transform(candidates, allow_extra=True)
+        t = torch.as_tensor(np.ascontiguousarray(comp.to_numpy(dtype=np.float64)))
+        return self._posterior_comp(t if joint else t.unsqueeze(-2))
 
 
-@define
-class HipCompositeSurrogate:
+class HipCompositeImpl:
     """Per-target replication of a single-output HIP surrogate (``surrogates/composite.py``)."""
+
+    __slots__ = ()
 
     supports_transfer_learning: ClassVar[bool] = True
     supports_multi_output: ClassVar[bool] = True
-
-    template: HipGaussianProcessSurrogate = field(factory=HipGaussianProcessSurrogate)
-    _models: list = field(init=False, factory=list, eq=False, repr=False)
-    _objective = field(init=False, default=None, eq=False, repr=False)
+    is_available = _availability_property()
 
     def fit(self, searchspace, objective, measurements: pd.DataFrame) -> None:
         m = len(objective.targets)
         if len(self._models) != m:
+            t = self.template
             self._models = [
-                HipGaussianProcessSurrogate(kernel=self.template.kernel, use_outputscale=self.template.use_outputscale,
-                                            preset=self.template.preset, device=self.template.device, target_index=i)
+                type(t)(kernel=t.kernel, use_outputscale=t.use_outputscale, preset=t.preset, device=t.device,
+                        fixed_hyperparameters=_per_target(t.fixed_hyperparameters, i), target_index=i)
                 for i in range(m)
             ]
         for model in self._models:
@@ -256,3 +303,54 @@ class HipCompositeSurrogate:
 
     def posterior_stats(self, candidates: pd.DataFrame, stats=("mean", "std")) -> pd.DataFrame:
         return pd.concat([m.posterior_stats(candidates, stats) for m in self.models], axis=1)
+
+
+def _per_target(fixed, i):
+    """``fixed_hyperparameters`` of a replicated surrogate: one ``GPParams`` for every target, or a sequence
+    with one entry per target."""
+    return fixed[i] if isinstance(fixed, (list, tuple)) else fixed
+
+
+def gp_surrogate_fields(with_runtime_state: bool = True) -> dict:
+    """attrs fields of the GP surrogate.  ``with_runtime_state=False`` leaves out the fields BayBE's ``Surrogate``
+    base already declares (``surrogates/base.py:93-103``)."""
+    f = {
+        # "matern12" | "matern32" | "matern52" | "rbf" within the BAYBE preset (box constraints, dimension-scaled
+        # Gamma priors), or a kernel specification object - baybe_amd.kernels or BayBE's own MaternKernel /
+        # RBFKernel / ScaleKernel / ProductKernel - handled like Kernel.to_gpytorch
+        "kernel": field(default="matern52"),
+        # wrap the base kernel in a ScaleKernel (user kernels); the BAYBE preset has none
+        "use_outputscale": field(default=False),
+        # GaussianProcessPreset (presets/core.py:8-27): BAYBE | BOTORCH | CHEN | EDBO | EDBO_SMOOTHED | HVARFNER
+        "preset": field(default="BAYBE", converter=lambda v: str(getattr(v, "value", v)).upper()),
+        "device": field(default=0),  # HIP device ordinal
+        "fixed_hyperparameters": field(default=None, eq=False),  # GPParams: skip the fit (parity / benchmarking)
+        # runtime state, not part of the specification (pattern of gaussian_process/core.py:211-212)
+        "_engine": field(init=False, default=None, eq=False, repr=False),
+        "_fit_info": field(init=False, default=None, eq=False, repr=False),
+        # which target of a multi-target objective this (replicated) model represents
+        "_target_index": field(default=None, eq=False, repr=False),
+    }
+    if with_runtime_state:
+        for name in ("_searchspace", "_objective", "_measurements_hash"):
+            f[name] = field(init=False, default=None, eq=False, repr=False)
+    return f
+
+
+def composite_fields(template_factory) -> dict:
+    return {
+        "template": field(factory=template_factory),
+        "_models": field(init=False, factory=list, eq=False, repr=False),
+        "_objective": field(init=False, default=None, eq=False, repr=False),
+    }
+
+
+HipGaussianProcessSurrogate = attrs.make_class("HipGaussianProcessSurrogate", gp_surrogate_fields(),
+                                               bases=(HipGPSurrogateImpl,), slots=True)
+HipGaussianProcessSurrogate.__doc__ = "A Gaussian process surrogate evaluated on an MI355X (stand-alone class)."
+HipCompositeSurrogate = attrs.make_class("HipCompositeSurrogate", composite_fields(HipGaussianProcessSurrogate),
+                                         bases=(HipCompositeImpl,), slots=True)
+HipCompositeSurrogate.__doc__ = "Per-target replication of ``HipGaussianProcessSurrogate`` (stand-alone class)."
+for _c in (HipGaussianProcessSurrogate, HipCompositeSurrogate):
+    _c.__module__ = __name__
+HipGPSurrogateImpl._composite_class = HipCompositeSurrogate

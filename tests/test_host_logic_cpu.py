@@ -95,7 +95,10 @@ def test_preset_tables_follow_the_reference():
     assert 1.2 < mid.ls_prior[1] < 2.5 and 0.2 < mid.ls_init < 6.0
     ch = gp_spec.from_preset("CHEN", 16, lo[:16], hi[:16])
     assert ch.ls_init == pytest.approx(5.6) and ch.ls_prior == ("gamma", pytest.approx(11.2), 2.0)
-    assert ch.outputscale_prior == ("gamma", pytest.approx(5.6), 1.0) and ch.noise_constraint == "box"
+    assert ch.outputscale_prior == ("gamma", pytest.approx(5.6), 1.0)
+    # ChenLikelihoodFactory = bare gpytorch GaussianLikelihood(): softplus-transformed GreaterThan(1e-4), no prior, raw 0
+    assert ch.noise_constraint == "softplus" and ch.noise_prior is None
+    assert ch.noise_init == pytest.approx(1e-4 + math.log(2.0)) and gp_spec.pack_raw(ch, gp_spec.initial_params(ch))[0] == pytest.approx(0.0, abs=1e-12)
     hv = gp_spec.from_preset("HVARFNER", 10, lo[:10], hi[:10])
     assert hv.kernel == "rbf" and not hv.use_outputscale and hv.ls_constraint == "box"
     assert hv.ls_prior == ("lognormal", pytest.approx(math.sqrt(2) + 0.5 * math.log(10)), pytest.approx(math.sqrt(3)))

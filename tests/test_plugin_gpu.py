@@ -343,3 +343,97 @@ def test_backtesting_loop_matches_an_oracle_driven_loop():
     assert np.isin(np.round(seen, 12), np.round(sub["yield"].to_numpy(), 12)).all()
     with pytest.raises(IndexError):
         simulate_experiment(camp, sub, batch_size=3, n_doe_iterations=2, initial_data=sub.iloc[:10], random_seed=5)
+
+
+# ---- the same surface as genuine subclasses of BayBE's bases (baybe_amd/plugin.py) ------------------------------------
+def test_baybe_typed_subclasses_recommend_like_the_standalone_classes():
+    """``make_baybe_classes`` on the layout replicas of ``Surrogate`` / ``BayesianRecommender`` (tests/_baybe_layout.py):
+    the base's own ``recommend`` drives the native overrides and returns what the stand-alone recommender returns;
+    ``Campaign.get_surrogate``-style ``isinstance`` checks hold."""
+    import torch
+
+    import _baybe_layout as bl
+    from baybe_amd import plugin
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    Sur, Comp, Rec = plugin.make_baybe_classes(bl.Surrogate, bl.BayesianRecommender, "DISCRETE")
+    assert Sur.is_available and Rec.is_available
+    rng = np.random.default_rng(5)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 20, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    out = []
+    for rec in (Rec(), HipBotorchRecommender()):
+        camp = Campaign(space, obj, rec)
+        camp.add_measurements(meas)
+        torch.manual_seed(99)
+        first = camp.recommend(3)
+        torch.manual_seed(100)
+        out.append((first, camp.recommend(2, pending_experiments=first)))
+    assert out[0][0].index.tolist() == out[1][0].index.tolist() and out[0][1].index.tolist() == out[1][1].index.tolist()
+    rec = Rec()
+    rec.recommend(1, space, obj, meas)
+    assert rec.calls[:2] == ["BayesianRecommender.recommend", "PureRecommender.recommend"]
+    sur = rec.get_surrogate(space, obj, meas)
+    assert isinstance(sur, bl.Surrogate) and isinstance(rec, bl.BayesianRecommender) and sur._searchspace is space
+    stats = sur.posterior_stats(exp.iloc[:7])
+    assert list(stats.columns) == ["yield_mean", "yield_std"] and np.isfinite(stats.to_numpy()).all()
+
+
+def test_acquisition_values_evaluate_the_function_that_was_passed():
+    """``BayesianRecommender.acquisition_values(..., acquisition_function=...)`` (pure/bayesian/base.py:199-238) scores
+    with the function given, not with the recommender's own."""
+    import torch
+
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    rng = np.random.default_rng(6)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 15, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    cand = exp.iloc[:40]
+    torch.manual_seed(3)
+    own = HipBotorchRecommender().acquisition_values(cand, space, obj, meas)
+    torch.manual_seed(3)
+    passed = HipBotorchRecommender().acquisition_values(cand, space, obj, meas, acquisition_function="qUCB")
+    torch.manual_seed(3)
+    configured = HipBotorchRecommender(acquisition_function="qUCB").acquisition_values(cand, space, obj, meas)
+    assert np.allclose(passed.to_numpy(), configured.to_numpy(), rtol=0, atol=1e-12)
+    assert not np.allclose(passed.to_numpy(), own.to_numpy())
+    torch.manual_seed(3)
+    j1 = HipBotorchRecommender().joint_acquisition_value(cand.iloc[:3], space, obj, meas, acquisition_function="qEI")
+    torch.manual_seed(3)
+    j2 = HipBotorchRecommender(acquisition_function="qEI").joint_acquisition_value(cand.iloc[:3], space, obj, meas)
+    assert j1 == pytest.approx(j2, abs=1e-12)
+
+
+def test_substance_search_spaces_get_the_chen_components():
+    """BayBE{Kernel,Likelihood}Factory dispatch (presets/baybe.py:150-171): a ``SubstanceParameter`` switches the default
+    preset to ScaleKernel(Matérn-5/2) with the 0.4 sqrt(d) + 4 priors and a plain GaussianLikelihood."""
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate
+
+    class SubstanceParameter(NumericalDiscreteParameter):  # comp rep of a descriptor-encoded substance: numeric columns
+        pass
+
+    rng = np.random.default_rng(7)
+    vals = np.arange(6) / 5.0
+    space = SearchSpace.from_product([SubstanceParameter("s0", vals), NumericalDiscreteParameter("x1", vals),
+                                      NumericalDiscreteParameter("x2", vals)])
+    exp = space.discrete.exp_rep
+    meas = exp.iloc[rng.choice(len(exp), 12, replace=False)].copy()
+    meas["yield"] = rng.standard_normal(12)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    sur, chen = HipGaussianProcessSurrogate(), HipGaussianProcessSurrogate(preset="CHEN")
+    sur.fit(space, obj, meas)
+    chen.fit(space, obj, meas)
+    spec = sur.engine.spec
+    ls = 0.4 * np.sqrt(3) + 4.0
+    assert spec.use_outputscale and spec.ls_prior == ("gamma", pytest.approx(2 * ls), 2.0) and spec.noise_prior is None
+    assert spec.noise_constraint == "softplus" and spec.ls_constraint == "softplus"
+    assert np.allclose(sur._fit_info.params.lengthscale, chen._fit_info.params.lengthscale)
+    plain = HipGaussianProcessSurrogate()
+    plain.fit(SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(3)]), obj,
+              meas.rename(columns={"s0": "x0"}))
+    assert not plain.engine.spec.use_outputscale and plain.engine.spec.noise_constraint == "box"

@@ -1,0 +1,139 @@
+"""The drop-in boundary in BayBE's own types: ``baybe_amd.plugin.make_baybe_classes`` builds subclasses of
+``Surrogate`` / ``BayesianRecommender`` without the "multiple bases have instance lay-out conflict" of two slotted
+attrs bases, constructible as ``cls()`` like BayBE's test loops do (tests/test_iterations.py:75-105).
+Runs against layout replicas of the bases (tests/_baybe_layout.py); on a GPU box tests/test_plugin_gpu.py drives the
+same classes end to end."""
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import _baybe_layout as bl
+from _baybe_shim import NumericalDiscreteParameter, NumericalTarget, SearchSpace, SingleTargetObjective
+from baybe_amd import plugin
+from baybe_amd.exceptions import IncompatibilityError, IncompatibleAcquisitionFunctionError
+
+
+@pytest.fixture(scope="module")
+def classes():
+    return plugin.make_baybe_classes(bl.Surrogate, bl.BayesianRecommender, "DISCRETE")
+
+
+def test_two_slotted_attrs_bases_do_conflict_which_is_why_the_mixins_have_no_fields():
+    from attrs import define, field
+
+    @define
+    class Impl:
+        x = field(default=0)
+
+    with pytest.raises(TypeError, match="lay-out conflict"):
+        define(type("Broken", (Impl, bl.Surrogate), {}))
+
+
+def test_subclasses_construct_like_baybes_test_loops_do(classes):
+    Sur, Comp, Rec = classes
+    s = Sur()
+    assert isinstance(s, bl.Surrogate) and issubclass(Sur, bl.Surrogate) and not hasattr(s, "__dict__")  # still slotted
+    assert s.preset == "BAYBE" and s.kernel == "matern52" and s._searchspace is None and s._measurements_hash is None
+    assert Sur.supports_transfer_learning is True and Sur.supports_multi_output is False
+    assert not Sur.is_available and Sur.is_available() is False  # no HIP device here: skipped, not crashing
+    assert isinstance(Sur.from_preset("EDBO"), Sur) and Sur.from_preset("EDBO").preset == "EDBO"
+    assert s.to_dict() == {"type": "HipGaussianProcessSurrogate"}  # the serialisation mixin of the base is inherited
+    c = s.replicate()
+    assert isinstance(c, Comp) and c.template is s and Comp.supports_multi_output
+    r = Rec()
+    assert isinstance(r, bl.BayesianRecommender) and isinstance(r, bl.PureRecommender) and isinstance(r, bl.RecommenderProtocol)
+    assert isinstance(r._surrogate_model, Sur) and r.acquisition_function is None and r._objective is None
+    assert Rec.compatibility == "DISCRETE" and Rec.supports_discrete_subset_generating_constraints is True
+    assert Rec(surrogate_model=Sur(preset="CHEN"), acquisition_function="qUCB", max_n_subsets=3).max_n_subsets == 3
+    with pytest.raises(RuntimeError, match="deprecated"):
+        Rec(allow_repeated_recommendations=True)  # the base's __attrs_post_init__ still runs
+    with pytest.raises(TypeError):
+        Rec(Sur())  # keyword-only, as BotorchRecommender (botorch/core.py:46)
+
+
+def _context():
+    vals = np.arange(6) / 5.0
+    space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(2)])
+    meas = space.discrete.exp_rep.iloc[[1, 7, 20, 33]].copy()
+    meas["y"] = [0.1, 0.4, 0.3, 0.2]
+    return space, SingleTargetObjective(NumericalTarget("y")), meas
+
+
+def test_baybes_recommend_drives_the_native_overrides(classes):
+    """``BayesianRecommender.recommend`` is the base's own method; it must reach the HIP surrogate's ``fit`` through
+    the overridden ``_setup_botorch_acqf`` - which, without a HIP device, fails loudly (no CPU fallback)."""
+    from baybe_amd import HipUnavailableError
+
+    Sur, _, Rec = classes
+    assert Rec.recommend is bl.BayesianRecommender.recommend
+    space, obj, meas = _context()
+    r = Rec()
+    with pytest.raises(NotImplementedError, match="objective"):
+        r.recommend(2, space, None, meas)
+    with pytest.raises(NotImplementedError, match="empty training data"):
+        r.recommend(2, space, obj, pd.DataFrame())
+    with pytest.raises(HipUnavailableError):
+        r.recommend(2, space, obj, meas)
+    assert r.calls == ["BayesianRecommender.recommend"] and r._objective is obj
+
+
+def test_native_flow_after_the_fit_uses_the_reference_signatures(classes, monkeypatch):
+    """With the device work stubbed out: base.recommend -> _setup_botorch_acqf (ours) -> PureRecommender.recommend ->
+    _recommend_with_discrete_parts(searchspace, batch_size, pending_experiments=...) (ours) -> exp_rep rows."""
+    Sur, _, Rec = classes
+    space, obj, meas = _context()
+    r = Rec()
+    seen = {}
+
+    def fake_setup(self, searchspace, objective, measurements, pending_experiments=None, acquisition_function=None):
+        self._objective, self._acqf_in_use, self._pending_comp = objective, self._get_acquisition_function(objective), None
+        seen["setup"] = True
+
+    def fake_without_subsets(self, sd, cand, batch_size, return_values=False, keep_mask=None):
+        seen["n_candidates"] = len(cand)
+        return cand.index[:batch_size]
+
+    monkeypatch.setattr(Rec, "_setup_acqf", fake_setup)
+    monkeypatch.setattr(Rec, "_recommend_discrete_without_subsets", fake_without_subsets)
+    rec = r.recommend(3, space, obj, meas)
+    assert seen == {"setup": True, "n_candidates": 36} and list(rec.index) == [0, 1, 2]
+    assert r.calls == ["BayesianRecommender.recommend", "PureRecommender.recommend"]
+    with pytest.raises(IncompatibilityError, match="exceeds 16"):
+        r.recommend(17, space, obj, meas)
+
+
+def test_objective_and_acquisition_checks_happen_before_any_fit(classes):
+    from _baybe_shim import ParetoObjective
+
+    _, _, Rec = classes
+    space, obj, meas = _context()
+
+    class DesirabilityObjective:  # several targets, single output (objectives/desirability.py)
+        is_multi_output = False
+        targets = (NumericalTarget("y"), NumericalTarget("z"))
+
+    with pytest.raises(IncompatibilityError, match="scalarise"):
+        Rec()._setup_botorch_acqf(space, DesirabilityObjective(), meas)
+    with pytest.raises(IncompatibleAcquisitionFunctionError, match="multi-output objective"):
+        Rec(acquisition_function="qLogNEHVI")._setup_botorch_acqf(space, obj, meas)
+    with pytest.raises(IncompatibleAcquisitionFunctionError, match="single-output acquisition"):
+        Rec(acquisition_function="qLogEI")._setup_botorch_acqf(space, ParetoObjective([NumericalTarget("y"), NumericalTarget("z")]), meas)
+
+    class Transformed:
+        name, minimize = "y", False
+        transformation = type("BellTransformation", (), {})()
+
+    with pytest.raises(IncompatibilityError, match="BellTransformation"):
+        Rec()._setup_botorch_acqf(space, SingleTargetObjective(Transformed()), meas)
+
+
+def test_standalone_classes_share_the_implementation(classes):
+    from baybe_amd.recommenders import HipBotorchRecommender, HipRecommenderImpl
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate, HipGPSurrogateImpl
+
+    Sur, _, Rec = classes
+    assert HipGPSurrogateImpl in Sur.__mro__ and HipGPSurrogateImpl in HipGaussianProcessSurrogate.__mro__
+    assert HipRecommenderImpl in Rec.__mro__ and HipRecommenderImpl in HipBotorchRecommender.__mro__
+    assert Sur.fit is HipGaussianProcessSurrogate.fit and Rec._recommend_discrete is HipBotorchRecommender._recommend_discrete
+    assert HipBotorchRecommender().max_n_subsets == 10 and HipBotorchRecommender.compatibility == "DISCRETE"

@@ -1,0 +1,139 @@
+"""Opt-in pin against the REAL reference: runs only where ``baybe`` + ``botorch`` + ``gpytorch`` import (they do not in
+the build container nor on the GPU box: no ``cattrs`` / ``botorch`` wheels, no network — SURVEY.md §8c), and then
+compares, on BASELINE configs[0] (3 discrete parameters, 1000 candidates, n_train = 20):
+
+* the oracle (``oracle/gp_oracle.py``) with BayBE's ``GaussianProcessSurrogate`` / BoTorch's ``qLogExpectedImprovement`` /
+  ``optimize_acqf_discrete`` — fitted hyper-parameters, posterior mean / variance at 1e-5 relative (north_star's
+  tolerance), qLogEI values with an injected Sobol sampler, greedy indices;
+* on a GPU, the HIP recommender with ``BotorchRecommender.recommend``.
+
+Mirrors the reference's own differential pins: ``tests/test_gp.py:203-225`` (BayBE GP == raw BoTorch posterior) and
+``tests/integration/test_minimization.py:41-78`` (sign symmetry).  Until this module runs somewhere, the oracle stays
+"parity unpinned" (DESIGN.md §2)."""
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytest.importorskip("gpytorch")
+pytest.importorskip("botorch")
+pytest.importorskip("baybe")
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    import torch
+    from baybe.parameters import NumericalDiscreteParameter
+    from baybe.searchspace import SearchSpace
+    from baybe.targets import NumericalTarget
+
+    rng = np.random.default_rng(0)
+    vals = tuple(np.arange(10) / 9.0)
+    space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(3)])
+    exp = space.discrete.exp_rep
+    meas = exp.iloc[rng.choice(len(exp), 20, replace=False)].copy()
+    X = meas[["x0", "x1", "x2"]].to_numpy(dtype=float)
+    meas["yield"] = -((X - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * X[:, 0]) + 0.05 * rng.standard_normal(20)
+    torch.manual_seed(0)
+    return space, NumericalTarget("yield").to_objective(), meas
+
+
+def _oracle_model(space, meas, params=None):
+    from oracle import gp_oracle as go
+
+    d = 3
+    Xt = space.transform(meas[["x0", "x1", "x2"]]).to_numpy(dtype=float)
+    bounds = space.scaling_bounds.to_numpy(dtype=float)
+    return go.fit_gp(go.GPSpec.baybe_default(d, bounds[0], bounds[1]), Xt, meas["yield"].to_numpy(dtype=float), params=params)
+
+
+def test_oracle_fit_and_posterior_match_baybe_gp(cfg1):
+    from baybe.surrogates import GaussianProcessSurrogate
+
+    from oracle import gp_oracle as go
+
+    space, obj, meas = cfg1
+    sur = GaussianProcessSurrogate()
+    sur.fit(space, obj, meas)
+    model = sur.to_botorch()
+    ls = model.covar_module.lengthscale.detach().numpy().reshape(-1)
+    noise = float(model.likelihood.noise.detach().reshape(-1)[0])
+    const = float(model.mean_module.constant.detach())
+    own = _oracle_model(space, meas)  # the oracle's own L-BFGS-B fit from the preset's start values
+    assert np.allclose(own.params.lengthscale, ls, rtol=1e-3) and np.isclose(own.params.noise, noise, rtol=1e-3, atol=1e-7)
+    assert np.isclose(own.params.mean, const, rtol=1e-3, atol=1e-6)
+    # posterior with the reference's fitted hyper-parameters: isolates the GP algebra (Normalize / Standardize / Matérn)
+    om = _oracle_model(space, meas, go.GPParams(ls, noise, const))
+    cand = space.discrete.exp_rep
+    stats = sur.posterior_stats(cand)
+    mo, vo = om.posterior(space.transform(cand).to_numpy(dtype=float))
+    assert np.allclose(stats["yield_mean"].to_numpy(), mo, rtol=1e-5, atol=1e-8)
+    assert np.allclose(stats["yield_std"].to_numpy() ** 2, vo, rtol=1e-5, atol=1e-10)
+
+
+def test_oracle_qlogei_and_greedy_match_botorch(cfg1):
+    import torch
+    from baybe.surrogates import GaussianProcessSurrogate
+    from botorch.acquisition.logei import qLogExpectedImprovement
+    from botorch.optim import optimize_acqf_discrete
+    from botorch.sampling import SobolQMCNormalSampler
+
+    from oracle import gp_oracle as go
+
+    space, obj, meas = cfg1
+    sur = GaussianProcessSurrogate()
+    sur.fit(space, obj, meas)
+    model = sur.to_botorch()
+    ls = model.covar_module.lengthscale.detach().numpy().reshape(-1)
+    om = _oracle_model(space, meas, go.GPParams(ls, float(model.likelihood.noise.detach().reshape(-1)[0]),
+                                                 float(model.mean_module.constant.detach())))
+    X = space.transform(space.discrete.exp_rep).to_numpy(dtype=float)
+    Xt = torch.from_numpy(X)
+    train = torch.from_numpy(space.transform(meas[["x0", "x1", "x2"]]).to_numpy(dtype=float))
+    best_f = float(model.posterior(train).mean.max())  # acquisition/_builder.py:141-161, 256-265
+    assert np.isclose(best_f, go.best_f_from_model(om), rtol=1e-6)
+    seed = 1234
+    acqf = qLogExpectedImprovement(model, best_f=best_f, sampler=SobolQMCNormalSampler(torch.Size([512]), seed=seed))
+    with torch.no_grad():
+        ref = acqf(Xt.unsqueeze(-2)).numpy()
+    mo, vo = om.posterior(X)
+    mine = go.qlogei_q1(mo, vo, go.sobol_normal_base_samples(512, 1, seed)[:, 0], go.best_f_from_model(om))
+    assert np.allclose(mine, ref, rtol=0, atol=1e-5), np.abs(mine - ref).max()
+    # optimize_acqf_discrete(q = 3): sequential greedy, pending points, first-index ties, unique rows
+    acqf = qLogExpectedImprovement(model, best_f=best_f, sampler=SobolQMCNormalSampler(torch.Size([512]), seed=seed))
+    picked, _ = optimize_acqf_discrete(acqf, q=3, choices=Xt, max_batch_size=2048, unique=True)
+    rows = [int(np.argmin(np.abs(X - p.numpy()).sum(1))) for p in picked]
+    res = go.optimize_acqf_discrete_qlogei(om, X, 3, seed=seed)
+    assert res.indices == rows
+
+
+def test_oracle_sign_symmetry_matches_baybe(cfg1):
+    """tests/integration/test_minimization.py:41-78 on the oracle: minimising -y == maximising y."""
+    from oracle import gp_oracle as go
+
+    space, _, meas = cfg1
+    flipped = meas.assign(**{"yield": -meas["yield"]})
+    a, b = _oracle_model(space, meas), _oracle_model(space, flipped)
+    X = space.transform(space.discrete.exp_rep).to_numpy(dtype=float)
+    (ma, va), (mb, vb) = a.posterior(X), b.posterior(X)
+    assert np.allclose(ma, -mb, rtol=1e-6, atol=1e-9) and np.allclose(va, vb, rtol=1e-6)
+    z = go.sobol_normal_base_samples(512, 1, 7)[:, 0]
+    sa = go.qlogei_q1(ma, va, z, go.best_f_from_model(a, 1.0), 1.0)
+    sb = go.qlogei_q1(mb, vb, -z, go.best_f_from_model(b, -1.0), -1.0)
+    assert np.allclose(sa, sb, rtol=1e-4, atol=0.1)
+
+
+@pytest.mark.gpu
+def test_hip_recommender_matches_botorch_recommender(cfg1):
+    import torch
+    from baybe.recommenders import BotorchRecommender
+
+    from baybe_amd.plugin import make_baybe_classes
+
+    space, obj, meas = cfg1
+    _, _, Rec = make_baybe_classes()
+    torch.manual_seed(1337)
+    ref = BotorchRecommender().recommend(3, space, obj, meas)
+    torch.manual_seed(1337)
+    got = Rec().recommend(3, space, obj, meas)
+    assert isinstance(got, pd.DataFrame) and got.index.tolist() == ref.index.tolist()
