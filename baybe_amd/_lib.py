@@ -42,6 +42,7 @@ KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3}
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15
 MAX_OBJECTIVES = 4
+TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2}  # enum bbh_timed_family
 ACQ_KINDS = {"qLogEI": 0, "qEI": 1, "qPI": 2, "qSR": 3, "qUCB": 4, "qPSTD": 5,
              "PM": 10, "PSTD": 11, "UCB": 12, "EI": 13, "LogEI": 14, "PI": 15}
 
@@ -115,8 +116,17 @@ SIGNATURES = {
     "bbh_cells_destroy": (C.c_int, [C.c_void_p]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
+    "bbh_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int64]),
+    "bbh_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+    "bbh_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bbh_allgather_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
+    "bbh_allgather_argmax": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, c_double_p, c_int64_p, c_double_p],
+    ),
     "bbh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bbh_timing_read": (C.c_int, [C.c_void_p, c_double_p, c_int64_p, C.c_int]),
+    "bbh_timing_read_family": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p, C.c_int]),
 }
 
 

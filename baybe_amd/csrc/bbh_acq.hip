@@ -13,6 +13,9 @@
 #define TAU_RELU 1e-6
 #define TAU_MAX 1e-2
 #define LOG_TAU_RELU -13.815510557964274  // log(1e-6)
+#ifndef BBH_PENDING_LSE
+#define BBH_PENDING_LSE 0
+#endif
 
 // fatplus(x; tau) / tau = softplus(t) + 0.1 / (1 + t^2),  t = x / tau; torch softplus threshold 20
 __device__ __forceinline__ double bbh_fatplus_core(double t) {
@@ -264,22 +267,34 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
 #pragma unroll
   for (int r = 1; r < Q; r++) m[r] = s_mp[r - 1];
   const double inv_tau = 1.0 / TAU_RELU;
-  double sum = 0.0, ref = -INFINITY;
+  // exp(fatmax_s) = exp(mx_s) acc_s^tau_max with exp(mx_s) = tau_relu max_r fatplus_core(t_sr): the per-sample
+  // exponential of the streaming log-sum-exp and the logarithm of the largest term are not needed.  The terms
+  // tau_relu^-1 exp(fatmax_s) lie in [1e-41, 1e7) for every reachable t, so the plain sum neither overflows nor
+  // loses its smallest terms to underflow (BBH_PENDING_LSE=1 at compile time restores the streaming form).
+  double sum = 0.0;
+#if BBH_PENDING_LSE
+  double ref = -INFINITY;
+#endif
   for (int s = 0; s < S; s++) {
     const double* zs = s_zq + (int64_t)s * Q;
-    double zr[Q], li[Q];
+    double zr[Q], li[Q], fp[Q];
 #pragma unroll
     for (int c = 0; c < Q; c++) zr[c] = zs[c];
-    double mx = -INFINITY;
+    double fmx = 0.0;
 #pragma unroll
     for (int r = 0; r < Q; r++) {
       double y = m[r];
 #pragma unroll
       for (int c = 0; c <= r; c++) y = fma(L[r * (r + 1) / 2 + c], zr[c], y);
       const double tt = (sign * y - best_f) * inv_tau;
-      const double v = LOG_TAU_RELU + bbh_fast_log_pos(bbh_fatplus_core(tt));
-      li[r] = v;
-      mx = fmax(mx, v);
+      fp[r] = bbh_fatplus_core(tt);
+      fmx = fmax(fmx, fp[r]);
+    }
+    double mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+      li[r] = bbh_fast_log_pos(fp[r]);
+      mx = fmax(mx, li[r]);
     }
     double acc = 0.0;
 #pragma unroll
@@ -287,15 +302,31 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
       const double u = (2.0 * TAU_MAX) * bbh_fast_recip(2.0 * TAU_MAX + (mx - li[r]));
       acc = fma(u, u, acc);
     }
-    const double fm = fma(TAU_MAX, bbh_fast_log_pos(acc), mx);
+#if BBH_PENDING_LSE
+    const double fm = fma(TAU_MAX, bbh_fast_log_pos(acc), mx + LOG_TAU_RELU);
     if (fm > ref) {
       sum = sum * exp(ref - fm) + 1.0;
       ref = fm;
     } else {
       sum += exp(fm - ref);
     }
+#else
+    // acc in [1, Q]: acc^0.01 = exp(0.01 log acc), argument in [0, 0.021) - Taylor to the 6th power (1e-17)
+    const double w = TAU_MAX * bbh_fast_log_pos(acc);
+    double e = fma(w, 1.0 / 720.0, 1.0 / 120.0);
+    e = fma(e, w, 1.0 / 24.0);
+    e = fma(e, w, 1.0 / 6.0);
+    e = fma(e, w, 0.5);
+    e = fma(e, w, 1.0);
+    e = fma(e, w, 1.0);
+    sum = fma(fmx, e, sum);
+#endif
   }
+#if BBH_PENDING_LSE
   scores[i] = ref + log(sum) - log((double)S);
+#else
+  scores[i] = LOG_TAU_RELU + log(sum) - log((double)S);
+#endif
 }
 
 template <int Q>
@@ -452,6 +483,7 @@ extern "C" int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const d
   const double* dmp = dz + S * (p + 1);
   const double* dcpp = dmp + p;
   const bool fits = sizeof(double) * ((size_t)S * (p + 1) + p + (size_t)p * p) <= 60 * 1024;  // z in LDS
+  bbh_timed_scope timed(h, BBH_TIMED_PENDING);
 #define BBH_PENDING_Q(QV)                                                                                        \
   case QV:                                                                                                       \
     bbh_launch_pending_q<QV>(h->stream, mean_dev, var_dev, cross_dev, N, dmp, dcpp, dz, (int)S, best_f, sign,    \
@@ -578,10 +610,9 @@ __global__ __launch_bounds__(256) void bbh_topk_stage2(double* __restrict__ pv, 
   }
 }
 
-extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
-                        int64_t* idx_host) {
-  if (!h) return -1;
-  if (!scores_dev || N < 1 || k < 1 || k > N || k > TOPK_MAXK || !vals_host || !idx_host) {
+// k best scores on the device: *vals_dev / *idx_dev point into the handle's workspace (valid until its next use)
+int bbh_topk_device(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double** vals_dev, int64_t** idx_dev) {
+  if (!scores_dev || N < 1 || k < 1 || k > N || k > TOPK_MAXK) {
     h->err = "bbh_topk: bad arguments (1 <= k <= min(N, 64))";
     return -1;
   }
@@ -597,6 +628,22 @@ extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int6
   hipLaunchKernelGGL(bbh_topk_stage1, dim3((unsigned)blocks), dim3(256), 0, h->stream, scores_dev, N, (int)k, pv, pi);
   hipLaunchKernelGGL(bbh_topk_stage2, dim3(1), dim3(256), 0, h->stream, pv, pi, blocks * k, (int)k, outv, outi);
   BBH_HIP_TRY(h, hipGetLastError());
+  *vals_dev = outv;
+  *idx_dev = outi;
+  return 0;
+}
+
+extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
+                        int64_t* idx_host) {
+  if (!h) return -1;
+  if (!vals_host || !idx_host) {
+    h->err = "bbh_topk: bad arguments (1 <= k <= min(N, 64))";
+    return -1;
+  }
+  double* outv = nullptr;
+  int64_t* outi = nullptr;
+  int rc = bbh_topk_device(h, scores_dev, N, k, &outv, &outi);
+  if (rc) return rc;
   BBH_HIP_TRY(h, hipMemcpyAsync(vals_host, outv, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
   BBH_HIP_TRY(h, hipMemcpyAsync(idx_host, outi, sizeof(int64_t) * k, hipMemcpyDeviceToHost, h->stream));
   BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1136,6 +1183,7 @@ extern "C" int bbh_mc_acq_pending(bbh_handle* h, int32_t kind, const double* mea
   const double* dcpp = dmp + p;
   const double cu = bbh_mc_cu(kind, beta);
   const bool fits = sizeof(double) * buf.size() <= 60 * 1024;  // base samples in LDS
+  bbh_timed_scope timed(h, BBH_TIMED_PENDING);
 #define BBH_MC_PENDING_Q(QV)                                                                                     \
   case QV:                                                                                                       \
     bbh_launch_mc_pending_q<QV>(h->stream, kind, mean_dev, var_dev, cross_dev, N, dmp, dcpp, dz, dzb, (int)S,    \

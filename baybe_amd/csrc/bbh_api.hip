@@ -34,6 +34,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
   if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
   if (const char* e = getenv("BBH_W32")) h->use_w32 = (e[0] != '0');
+  if (const char* e = getenv("BBH_COOP")) h->use_coop = (e[0] != '0');
   *out = h;
   return 0;
 }
@@ -45,10 +46,11 @@ extern "C" int bbh_destroy(bbh_handle* h) {
     hipStreamSynchronize(h->stream);
   else
     hipDeviceSynchronize();
-  for (auto& pr : h->pending_events) {
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
+  for (auto& sp : h->pending_events) {
+    hipEventDestroy(sp.e0);
+    hipEventDestroy(sp.e1);
   }
+  bbh_comm_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
   if (h->d_kvcache) hipFree(h->d_kvcache);
@@ -191,24 +193,32 @@ extern "C" int bbh_timing_enable(bbh_handle* h, int enable) {
   return 0;
 }
 
-extern "C" int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset) {
+extern "C" int bbh_timing_read_family(bbh_handle* h, int32_t family, double* ms_total, int64_t* launches, int reset) {
   if (!h) return -1;
+  if (family < 0 || family >= BBH_TIMED_FAMILIES) {
+    h->err = "bbh_timing_read_family: unknown kernel family";
+    return -1;
+  }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
-  for (auto& pr : h->pending_events) {
-    BBH_HIP_TRY(h, hipEventSynchronize(pr.second));
+  for (auto& sp : h->pending_events) {
+    BBH_HIP_TRY(h, hipEventSynchronize(sp.e1));
     float ms = 0.f;
-    BBH_HIP_TRY(h, hipEventElapsedTime(&ms, pr.first, pr.second));
-    h->fused_ms += (double)ms;
-    h->fused_launches += 1;
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
+    BBH_HIP_TRY(h, hipEventElapsedTime(&ms, sp.e0, sp.e1));
+    h->timed_ms[sp.family] += (double)ms;
+    h->timed_launches[sp.family] += 1;
+    hipEventDestroy(sp.e0);
+    hipEventDestroy(sp.e1);
   }
   h->pending_events.clear();
-  if (fused_ms_total) *fused_ms_total = h->fused_ms;
-  if (fused_launches) *fused_launches = h->fused_launches;
+  if (ms_total) *ms_total = h->timed_ms[family];
+  if (launches) *launches = h->timed_launches[family];
   if (reset) {
-    h->fused_ms = 0.0;
-    h->fused_launches = 0;
+    h->timed_ms[family] = 0.0;
+    h->timed_launches[family] = 0;
   }
   return 0;
+}
+
+extern "C" int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset) {
+  return bbh_timing_read_family(h, BBH_TIMED_POSTERIOR, fused_ms_total, fused_launches, reset);
 }

@@ -108,6 +108,11 @@ struct bbh_handle {
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
   int num_cu = 256;               // compute units of the device (sizes the slab pool of the kernel-value cache)
   int wmax = 16;                  // column blocks per pass of the fused kernel: 16 (two waves per SIMD) or 32 (one)
+  bool use_coop = false;          // env BBH_COOP=1: cooperative form (one workgroup per 16 candidates) where instantiated
+  bool coop_ready = false;        // operand slices of the cooperative form are packed for the current factorisation
+  double* d_rstream = nullptr;    // [4 waves][rstream_frags][64]
+  int64_t rstream_frags = 0;
+  int coop_g0 = 0;
   bool use_w32 = false;           // env BBH_W32=1: one-wave-per-SIMD form where instantiated (A/B; measured slower so far)
   int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
   // pending state
@@ -137,12 +142,37 @@ struct bbh_handle {
   hipEvent_t z_evt = nullptr;     // recorded after the staged copy: the staging buffer may be rewritten once it fired
   double* d_red = nullptr;        // argmax partials
   int64_t* d_redi = nullptr;
+  void* comm_state = nullptr;     // RCCL communicator + exchange buffers (bbh_comm.hip), null until bbh_comm_init
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double fused_ms = 0.0;
-  int64_t fused_launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+  double timed_ms[BBH_TIMED_FAMILIES] = {0.0, 0.0, 0.0};
+  int64_t timed_launches[BBH_TIMED_FAMILIES] = {0, 0, 0};
+  struct TimedSpan {
+    hipEvent_t e0, e1;
+    int family;
+  };
+  std::vector<TimedSpan> pending_events;
+};
+
+// Brackets the launches of one kernel family with HIP events on the handle's stream while timing is enabled.
+struct bbh_timed_scope {
+  bbh_handle* h;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int family;
+  bbh_timed_scope(bbh_handle* h_, int family_, bool wanted = true) : h(h_), family(family_) {
+    if (h->timing && wanted) {
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      hipEventRecord(e0, h->stream);
+    }
+  }
+  ~bbh_timed_scope() {
+    if (e0) {
+      hipEventRecord(e1, h->stream);
+      h->pending_events.push_back({e0, e1, family});
+    }
+  }
 };
 
 inline int64_t bbh_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

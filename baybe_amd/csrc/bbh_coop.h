@@ -1,0 +1,232 @@
+// Cooperative form of the fused posterior kernel: one workgroup (4 waves) per tile of 16 candidates, n <= 512.
+//
+// The two-pass form (bbh_fused.h, 16-block windows, one wave per tile) needs every kernel value of the first 16
+// k-blocks twice at n = 512; its wave-private LDS cache holds 8 of them, the other 8 are recomputed (48 MFMAs + 1088
+// VALU instructions per tile, ~4 % of the fp64 pipe), and its 128 accumulator registers leave the pass bodies ~76 VGPRs
+// short.  Here the 32 column blocks of L^-T are dealt to the four waves of a workgroup (8 each: 64 accumulator
+// registers), every kernel value is computed exactly once per tile - the waves take turns, one k-block in four - and
+// travels to the other waves through a double-buffered 2 KB slot in LDS.  No second pass, no cache, no recomputation,
+// no spills; n <= 512 only (larger models keep the windowed form).
+//
+//   columns   round rho = j / 4 of column block j belongs to slot rho of every wave; within a round the four column
+//             blocks are dealt boustrophedon (wave w owns 4 rho + w in even rounds, 4 rho + 3 - w in odd ones), which
+//             balances the triangular work exactly: 528 variance MFMAs per wave at n = 512.
+//   k-blocks  in groups of four (group g = round g).  While a wave consumes group g (its slots rho >= g; the diagonal
+//             slot rho = g only for the k-blocks not above its column block) it produces the kernel values of k-block
+//             4 (g + 1) + w for the next group in micro-steps between its MFMAs, adds their share of the mean, and
+//             stores them; one workgroup barrier per group.
+//   operands  each wave streams its own slice of L^-T, packed in consumption order (bbh_pack_coop_kernel), through the
+//             8-deep register ring of the windowed form.  The slice has the same shape for every wave (the inactive
+//             part of the diagonal slot is stored as zeros and skipped by a wave-uniform branch), so ring slots and
+//             accumulators stay compile-time indices.
+//   smaller n the model occupies the LAST rounds: groups [8 - nb / 4, 8) run, entered by wave-uniform branches.
+#pragma once
+#define BBH_CANDREG 1
+#include "bbh_fused.h"
+
+#define BBH_COOP_ROUNDS 8  // 8 rounds x 4 column blocks x 16 = 512 training points
+
+struct CoopArgs {
+  FusedArgs f;
+  const double* rstream;  // [4 waves][frags][64] operand slices
+  int64_t frags;          // fragments per wave
+  int g0;                 // first group that exists: 8 - nb / 4
+};
+
+// fragments of the groups before G (in the full 8-round numbering)
+__host__ __device__ constexpr int coop_frags_before(int G) { return 16 * (G * BBH_COOP_ROUNDS - (G * (G - 1)) / 2); }
+
+template <int G, int KD, int KVF, bool PRODUCE>
+__device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, const bbh_lds_double* kv_cur,
+                                           bbh_lds_double* kv_mine_next, const bbh_lds_double* alpha_next, int tbn, int cw,
+                                           d4 (&acc)[BBH_COOP_ROUNDS], double (&ring)[BBH_RING], double& accm) {
+  constexpr int D = BBH_RING;
+  constexpr int CNT = BBH_COOP_ROUNDS - G;  // ring fragments per (k-block, k-step): slots G .. 7
+  constexpr int FULL = CNT - 1;             // of which always multiplied
+  constexpr int TOT = 16 * CNT;
+  constexpr int REM = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(G + 1);  // fragments after this group
+  constexpr int HOSTS = 12 * FULL;  // MFMAs of k-blocks 1..3 that carry the micro-steps of the production
+  double tfv[KD];
+  d4 dsa, dsb;
+  KvState<BBH_KV_NU> P;
+  double kv[4], kvx[4], kvn[4], alv[4];
+  if (PRODUCE) kvp_load<KD>(c, tbn, tfv);
+#pragma unroll
+  for (int r = 0; r < 4; r++) kv[r] = kv_cur[r * 64];
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < 3) {  // the next k-block's values are requested one block ahead
+#pragma unroll
+      for (int r = 0; r < 4; r++) kvx[r] = kv_cur[(i + 1) * 256 + r * 64];
+    } else if constexpr (PRODUCE) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) alv[r] = alpha_next[4 * r];
+    }
+    static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      static_for<0, CNT>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int f = (i * 4 + r) * CNT + s;
+        if constexpr (s == 0) {  // diagonal slot: column block 4 G + cw, zero (and skipped) for k-blocks above it
+          if (cw >= i) acc[G] = mfma_f64(kv[r], ring[f % D], acc[G]);
+        } else {
+          acc[G + s] = mfma_f64(kv[r], ring[f % D], acc[G + s]);
+        }
+        if constexpr (f + D < TOT + REM) ring[f % D] = rs[(f + D) * 64];
+        if constexpr (PRODUCE && i >= 1 && s >= 1) {
+          constexpr int m = ((i - 1) * 4 + r) * FULL + (s - 1);
+          static_for<(m * BBH_KV_STEPS) / HOSTS, ((m + 1) * BBH_KV_STEPS) / HOSTS>([&](auto st) __attribute__((always_inline)) {
+            kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tbn, 0, dsa, dsb, kvn);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (PRODUCE && i == 0 && r == 3) kvp_dist<KD>(c, tfv, dsa, dsb);
+    });
+    if constexpr (i < 3) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) kv[r] = kvx[r];
+    }
+  });
+  if constexpr (PRODUCE) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      kv_mine_next[r * 64] = kvn[r];
+      accm = fma(kvn[r], alv[r], accm);
+    }
+  }
+}
+
+template <int KD, int KVF>
+__global__ __launch_bounds__(256, 2) void bbh_coop_posterior_kernel(const CoopArgs ca) {
+  const FusedArgs& a = ca.f;
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];  // alpha [16 nb] | kv [2][4][256] | red [4][16] x 2
+  const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cnd = l & 15, q = l >> 4;
+  double* s_alpha = s_mem;
+  double* s_kv = s_alpha + 16 * a.nb;
+  double* s_red = s_kv + 2 * 4 * 256;
+  for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
+  const int64_t tile0 = (int64_t)blockIdx.x * 16;
+  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
+  const double* xr = a.X + row * a.ldx;
+
+  WaveCtx c;
+  // candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2]; every wave builds the tile's fragments itself
+  double nbsum = 0.0;
+#pragma unroll
+  for (int k = 0; k < KD; k++) {
+    const int dim = 4 * k + q;
+    double v = 0.0;
+    if (dim < a.dn) {
+      v = fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
+      nbsum = fma(v, v, nbsum);
+    }
+    c.cf[k] = v;
+  }
+  nbsum += __shfl_xor(nbsum, 16, 64);
+  nbsum += __shfl_xor(nbsum, 32, 64);
+#pragma unroll
+  for (int k = 0; k < KD; k++) {
+    if (4 * k + q == a.dn) c.cf[k] = 1.0;
+    if (4 * k + q == a.dn + 1) c.cf[k] = nbsum;
+  }
+  c.tf = a.trainfrag + l;
+  c.candl = nullptr;
+  c.mb = nullptr;
+  c.tbl = a.tasktbl;
+  c.taskext = a.taskext;
+  c.kvc = nullptr;
+  c.kvl = (bbh_lds_double*)nullptr;
+  c.nl = 0;
+  c.ncache = 0;
+  c.al = (const bbh_lds_double*)nullptr;
+  c.kd = KD;
+  c.kind = a.kind;
+  c.T = a.T;
+  c.tc = 0;
+  c.q = q;
+  c.l = l;
+  c.dn = a.dn;
+
+  bbh_lds_double* kvb = (bbh_lds_double*)(s_kv + l);           // [buffer][k-block of the group][4 values x 64 lanes]
+  const bbh_lds_double* alq = (const bbh_lds_double*)(s_alpha + q);  // alpha[16 tb + 4 r + q]
+  const int g0 = ca.g0;
+  double accm = 0.0;
+  {  // the first group's kernel values: wave w produces k-block w, not overlapped with anything
+    double tfv[KD], kv0[4];
+    d4 dsa, dsb;
+    kvp_load<KD>(c, w, tfv);
+    kvp_dist<KD>(c, tfv, dsa, dsb);
+    kv_all<KVF>(c, w, dsa, dsb, kv0);
+    __syncthreads();  // alpha is in LDS
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      kvb[((g0 & 1) * 4 + w) * 256 + r * 64] = kv0[r];
+      accm = fma(kv0[r], alq[16 * w + 4 * r], accm);
+    }
+  }
+  d4 acc[BBH_COOP_ROUNDS];
+#pragma unroll
+  for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* rs = ca.rstream + (int64_t)w * ca.frags * 64 + l;
+  double ring[BBH_RING];
+#pragma unroll
+  for (int i = 0; i < BBH_RING; i++) ring[i] = rs[i * 64];
+  __syncthreads();  // group g0 is complete in LDS
+
+  static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+    if (G >= g0) {  // wave-uniform: a smaller model occupies the last rounds only
+      const int cw = (G & 1) ? 3 - w : w;
+      const int tbn = 4 * (G + 1 - g0) + w;  // real k-block this wave produces for the next group
+      constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
+      coop_group<G, KD, KVF, PRODUCE>(c, rs, kvb + (G & 1) * 4 * 256, kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn,
+                                      cw, acc, ring, accm);
+      rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
+      if constexpr (PRODUCE) __syncthreads();
+    }
+  });
+
+  // ---- ||v||^2 over this wave's column blocks, then over the 16 columns of a block (lanes), then over the waves ----
+  double ss[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < BBH_COOP_ROUNDS; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) ss[r] = fma(acc[s][r], acc[s][r], ss[r]);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double v = ss[r];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    ss[r] = v;  // candidate q + 4 r
+  }
+  double mp = accm;  // lane (q, cnd): a quarter of this wave's share of candidate cnd's mean
+  mp += __shfl_xor(mp, 16, 64);
+  mp += __shfl_xor(mp, 32, 64);
+  double* red_v = s_red;        // [4 waves][16 candidates]
+  double* red_m = s_red + 64;
+  if (cnd == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) red_v[w * 16 + q + 4 * r] = ss[r];
+  }
+  if (q == 0) red_m[w * 16 + cnd] = mp;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int m = threadIdx.x;
+    const int64_t gi = tile0 + m;
+    if (gi < a.N) {
+      const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
+      const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
+      if (a.mean) a.mean[gi] = a.ybar + a.ysd * (a.mean_const + sm);
+      if (a.var) a.var[gi] = a.ysd * a.ysd * (a.prior_scale - sv);
+    }
+  }
+}
+
+// one launcher per translation unit (bbh_fused_coop_kd*.hip); false: no instantiation for this model.  grid.x == 0
+// asks only whether there is one.
+bool bbh_coop_launch(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);

@@ -82,6 +82,10 @@ struct WaveCtx {
 #ifndef BBH_CANDREG
 #define BBH_CANDREG 0
 #endif
+// BBH_DIST_ASM = 1 (with BBH_CANDREG): the distance MFMAs are VGPR-form inline assembly, see mfma_f64_v below
+#ifndef BBH_DIST_ASM
+#define BBH_DIST_ASM 0
+#endif
 // BBH_MEAN_VALU_ONLY = 1: the translation unit's kernels are only launched with the mean contraction on the VALU
 // (FusedArgs::mean_valu), so the MFMA form of the mean - and its accumulator - is not compiled in.
 #ifndef BBH_MEAN_VALU_ONLY
@@ -239,7 +243,7 @@ __device__ __forceinline__ void kvp_load(const WaveCtx& c, int tb, double (&tfv)
   for (int k = 0; k < KD; k++) tfv[k] = tf[k * 64];
 }
 
-#if BBH_CANDREG
+#if BBH_DIST_ASM
 // VGPR-form MFMA through inline assembly.  With 32 column blocks the variance accumulators fill the whole
 // AGPR half of the register file (256); the compiler gives every MFMA *intrinsic* of such a kernel an AGPR
 // destination, so the two distance accumulators would push accumulators out to VGPRs and back around every
@@ -257,7 +261,15 @@ __device__ __forceinline__ void mfma_f64_v(d4& acc, double a, double b) {
 // r2 = da + db: the sum is left to the caller (first kernel-value micro-step), see above
 template <int KD>
 __device__ __forceinline__ void kvp_dist(const WaveCtx& c, const double (&tfv)[KD], d4& da, d4& db) {
-#if BBH_CANDREG
+#if BBH_CANDREG && !BBH_DIST_ASM
+  da = (d4){0.0, 0.0, 0.0, 0.0};
+  db = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < KD; k += 2) {
+    da = mfma_f64(tfv[k], c.cf[k], da);
+    if (k + 1 < KD) db = mfma_f64(tfv[k + 1], c.cf[k + 1], db);
+  }
+#elif BBH_CANDREG
   static_assert(KD >= 2, "two accumulator chains");
   mfma_f64_v0(da, tfv[0], c.cf[0]);
   mfma_f64_v0(db, tfv[1], c.cf[1]);
@@ -321,7 +333,7 @@ __device__ __forceinline__ void kv_micro(KvState<NU>& P, const WaveCtx& c, int t
   // reciprocal sqrt, later the exp polynomial; y = rsq seed / residuals
   switch (step) {
     case 0:
-#if BBH_CANDREG
+#if BBH_DIST_ASM
       // The distance MFMAs are inline assembly (kvp_dist): the compiler's hazard recogniser does not know that da / db
       // come from a 16-pass MFMA, whose VALU consumers must be >= 19 wait states behind it.  These issue
       // slots overlap with the variance MFMA that precedes this micro-step in program order.
@@ -771,6 +783,22 @@ __global__ __launch_bounds__(256, (WMAX > 16 ? 1 : 2)) void bbh_fused_posterior_
 #pragma unroll
         for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], c.mb[(int64_t)(4 * tb + r) * 64], accm);
       }
+    }
+  } else if constexpr (KD > 0 && WMAX <= 16) {
+    // mean-only pass (cross-covariances with the pending points of a greedy step, conditional means of qLogNEHVI):
+    // the staged kernel-value evaluation of the pipelined form instead of the libm one (1.65 -> ~1.1 ms per 1e6
+    // candidates on the bench shape); nothing to overlap it with but the other wave of the SIMD
+    constexpr int KVF = (HAS_TBL ? 1 : 0) | (KIND == BBH_KERNEL_RBF ? 2 : 0) | (KIND == BBH_KERNEL_MATERN32 ? 4 : 0);
+    for (int tb = 0; tb < a.nb_ext; tb++) {
+      double tfv[KD], mbv[4];
+      d4 dsa, dsb;
+      kvp_load<KD>(c, tb, tfv);
+#pragma unroll
+      for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * tb + r) * 64];
+      kvp_dist<KD>(c, tfv, dsa, dsb);
+      kv_all<KVF>(c, tb, dsa, dsb, kv);
+#pragma unroll
+      for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
     }
   } else if constexpr (WMAX <= 16) {  // (the one-wave form is launched for variance passes without pending columns only)
     for (int tb = 0; tb < a.nb_ext; tb++) {

@@ -1,6 +1,7 @@
 // One-wave-per-SIMD form of the software-pipelined fused posterior kernel (WMAX = 32: windows of 32 column
 // blocks, 256 accumulator registers), 6 k-steps in the distance GEMM (d <= 22), Matérn-5/2 without table.
 #define BBH_CANDREG 1
+#define BBH_DIST_ASM 1
 #define BBH_MEAN_VALU_ONLY 1
 #ifndef BBH_W32_REMAINDERS
 #define BBH_W32_REMAINDERS 0

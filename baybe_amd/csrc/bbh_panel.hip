@@ -27,7 +27,7 @@
 // rsq/Taylor Matérn evaluation, and a per-wave cache of kernel values instead of recomputation in later
 // passes.  K(X*,X) is never materialised.  Device code: bbh_fused.h (instantiated per k-step count in
 // bbh_fused_kd{0,2,4,6,8,12,16}.hip); this file holds operand packing, launch logic and the related kernels.
-#include "bbh_fused.h"
+#include "bbh_coop.h"
 
 // ---- operand packing ------------------------------------------------------------------------
 // R fragments of one pass: for tb in [0, j1), r in 0..3, jb in [max(j0, tb), j1):
@@ -48,6 +48,22 @@ __global__ void bbh_pack_rfrag_kernel(const double* __restrict__ X, int64_t np, 
   for (int jb = lo; jb < j1; jb++) {
     const int64_t j = 16 * (int64_t)jb + (l & 15);
     out[(off + (jb - lo)) * 64 + l] = (k <= j) ? X[j * np + k] : 0.0;
+  }
+}
+
+// Operand slices of the cooperative form (bbh_coop.h): wave w, group G >= g0, k-block i, k-step r, slot rho = G + s
+//   lane l <- R[k = 16 tb + 4 r + (l>>4)][j = 16 jb + (l&15)],  tb = 4 (G - g0) + i,  jb = 4 (rho - g0) + (rho odd ? 3 - w : w)
+__global__ void bbh_pack_coop_kernel(const double* __restrict__ X, int64_t np, int g0, int64_t frags, double* __restrict__ out) {
+  const int w = blockIdx.z, G = g0 + blockIdx.y, ir = blockIdx.x, l = threadIdx.x;
+  const int i = ir >> 2, r = ir & 3;
+  const int cnt = BBH_COOP_ROUNDS - G;
+  const int64_t base = (int64_t)(coop_frags_before(G) - coop_frags_before(g0)) + (int64_t)ir * cnt;
+  const int64_t k = 16 * (int64_t)(4 * (G - g0) + i) + 4 * r + (l >> 4);
+  for (int s = 0; s < cnt; s++) {
+    const int rho = G + s;
+    const int64_t jb = 4 * (rho - g0) + ((rho & 1) ? 3 - w : w);
+    const int64_t j = 16 * jb + (l & 15);
+    out[((int64_t)w * frags + base + s) * 64 + l] = (k <= j) ? X[j * np + k] : 0.0;
   }
 }
 
@@ -188,6 +204,26 @@ int bbh_pack_operands(bbh_handle* h) {
       j0 += W;
     }
   }
+  // ---- operand slices of the cooperative form (n <= 512, instantiated models only) ----
+  h->coop_ready = false;
+  {
+    const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
+    if (h->use_coop && h->use_pipeline && nb <= 4 * BBH_COOP_ROUNDS && nb % 4 == 0 &&
+        bbh_coop_launch(h->kd, h->desc.kernel_kind, has_tbl0, dim3(0), 0, nullptr, CoopArgs{})) {
+      const int g0 = BBH_COOP_ROUNDS - (int)(nb / 4);
+      const int64_t frags = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(g0);
+      if (!h->d_rstream || h->rstream_frags != frags) {
+        if (h->d_rstream) hipFree(h->d_rstream);
+        h->d_rstream = nullptr;
+        BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rstream, sizeof(double) * 4 * frags * 64));
+        h->rstream_frags = frags;
+      }
+      hipLaunchKernelGGL(bbh_pack_coop_kernel, dim3(16, (unsigned)(BBH_COOP_ROUNDS - g0), 4), dim3(64), 0, s, h->d_X, np, g0, frags,
+                         h->d_rstream);
+      h->coop_g0 = g0;
+      h->coop_ready = true;
+    }
+  }
   // ---- training fragments (+ one all-padding block reserved for pending points) ----
   std::vector<double> tf;
   host_pack_trainfrag(h, h->xn_host.data(), h->n, 0, nb + 1, tf);
@@ -274,7 +310,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
   const bool rbf = (a.kind == BBH_KERNEL_RBF), m32 = (a.kind == BBH_KERNEL_MATERN32);
   a.has_tbl = has_tbl ? 1 : 0;
-  const int kdp = ((m52 || ((rbf || m32) && !has_tbl)) && with_var && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
+  const int kdp = ((m52 || ((rbf || m32) && !has_tbl)) && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
   // alpha in LDS costs 8 n bytes: beyond n = 4096 it would crowd out the candidate fragments / the cache
@@ -286,7 +322,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   a.slab_flags = nullptr;
   a.nslab = 0;
   a.nxcc = 1;
-  if (kdp && h->npass > 1 && h->use_kvcache) {
+  if (kdp && with_var && h->npass > 1 && h->use_kvcache) {
     // Kernel-value cache for the k-blocks left of the last pass.  As many of them as fit next to the other
     // LDS users without costing the second workgroup per CU (half of the CU's LDS per workgroup) stay in
     // wave-private LDS (2 KB per k-block and wave); the rest goes to slabs in global memory claimed per wave.
@@ -322,14 +358,23 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     a.kvcache = h->d_kvcache;
     a.slab_flags = h->d_slab_flags;
   }
-  const bool timed = h->timing && with_var;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (timed) {
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, h->stream);
+  bbh_timed_scope timed(h, with_var ? BBH_TIMED_POSTERIOR : BBH_TIMED_CROSS);
+  if (h->coop_ready && kdp && with_var && a.mean_valu && !a.qz) {  // variance pass without pending columns, n <= 512
+    CoopArgs ca;
+    ca.f = a;
+    ca.rstream = h->d_rstream;
+    ca.frags = h->rstream_frags;
+    ca.g0 = h->coop_g0;
+    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + 2 * 4 * 256 + 128);
+    bbh_coop_launch(kdp, a.kind, has_tbl, dim3((unsigned)((N + 15) / 16)), clds, h->stream, ca);
+    BBH_HIP_TRY(h, hipGetLastError());
+    return 0;
   }
-  if (kdp && h->wmax == 32)
+  if (h->wmax == 32 && with_var && !(kdp && a.mean_valu)) {
+    h->err = "BBH_W32=1 (experimental one-wave-per-SIMD form): variance passes without pending columns only";
+    return -6;
+  }
+  if (kdp && h->wmax == 32 && with_var)
     bbh_fused_launch_w32(kdp, a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 2)
     bbh_fused_launch_kd2(a.kind, has_tbl, grid, block, lds, h->stream, a);
@@ -345,10 +390,6 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     bbh_fused_launch_kd16(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else
     bbh_fused_launch_kd0(has_tbl, m52, grid, block, lds, h->stream, a);
-  if (timed) {
-    hipEventRecord(e1, h->stream);
-    h->pending_events.emplace_back(e0, e1);
-  }
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
 }

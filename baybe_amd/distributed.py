@@ -7,7 +7,13 @@ exchange per selection step: an all-gather of every rank's local winner
 first-index tie-break, so all ranks agree on the pick without a broadcast; global index order
 equals shard order, hence ties resolve exactly as a single-GPU argmax would.
 The collective runs through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm,
-"gloo" for the CPU tests); the payload is a few hundred bytes, i.e. latency-bound.
+"gloo" for the CPU tests); the payload is a few hundred bytes, i.e. latency-bound.  The library's
+own RCCL entry points (``bbh_comm_init`` / ``bbh_allgather_topk`` / ``bbh_allgather_argmax``, payload built
+on the device) do the same exchange without torch once ``RowShard.bind_rccl(engine)`` has run.
+
+Agreement does not rest on coincidence: whatever a rank derives from its private state - fitted
+hyper-parameters (a fit retry re-samples start points from the priors), MC sampler seeds - is taken
+from rank 0 (``RowShard.agree``) before it is used.
 """
 
 from __future__ import annotations
@@ -34,6 +40,17 @@ class RowShard:
         self.world = dist.get_world_size(group) if world is None else world
         self.N_total = int(N_total)
         self.start, self.stop = shard_bounds(N_total, self.rank, self.world)
+        self.use_rccl = False  # True: selections go through the library's own communicator (bbh_allgather_*)
+
+    def bind_rccl(self, engine) -> None:
+        """Create the library-side RCCL communicator of ``engine`` (a ``HipGP`` handle) for this shard layout: rank 0's
+        ncclUniqueId travels through ``agree`` (one torch.distributed broadcast), then every rank joins."""
+        uid = self.agree(engine.comm_unique_id() if self.rank == 0 else None)
+        engine.comm_init(self.rank, self.world, uid)
+        self.use_rccl = True
+
+    def rccl_bound(self, engine) -> bool:
+        return self.use_rccl and getattr(engine, "_comm", None) == (self.rank, self.world)
 
     @property
     def n_local(self) -> int:
@@ -71,22 +88,33 @@ class RowShard:
                 best = r
         return best
 
-    def global_argmax(self, val: float, lidx: int, X_local):
-        """All-gather the local winners; returns (score, global index, row[d]) of the global one."""
+    def agree(self, value):
+        """Rank 0's ``value`` on every rank (one broadcast of a pickled object: hyper-parameters, seeds)."""
+        if self.world == 1:
+            return value
+        box = [value if self.rank == 0 else None]
+        src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        self._dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+    def _payload_to_backend(self, payload_host: np.ndarray, device):
+        """One host array -> one tensor where the backend wants it (a single H2D copy for RCCL)."""
         import torch
 
+        t = torch.from_numpy(np.ascontiguousarray(payload_host, dtype=np.float64))
+        if self._dist.get_backend(self.group) != "gloo" and device is not None and torch.device(device).type == "cuda":
+            t = t.to(device)
+        return t
+
+    def global_argmax(self, val: float, lidx: int, X_local):
+        """All-gather the local winners; returns (score, global index, row[d]) of the global one."""
         d = X_local.shape[1]
-        dev = X_local.device
-        payload = torch.empty(2 + d, dtype=torch.float64, device=dev)
-        if lidx is None or lidx < 0 or self.n_local == 0:
-            payload.fill_(0.0)
-            payload[0] = -math.inf
-            payload[1] = -1.0
-        else:
-            payload[0] = val
-            payload[1] = float(self.to_global(lidx))
-            payload[2:] = X_local[lidx, :d]
-        g = self._all_gather(payload).cpu().numpy()
+        payload = np.zeros(2 + d)
+        payload[0], payload[1] = -math.inf, -1.0
+        if lidx is not None and lidx >= 0 and self.n_local > 0:
+            payload[0], payload[1] = val, float(self.to_global(lidx))
+            payload[2:] = X_local[lidx, :d].cpu().numpy()  # one D2H of the winner's row
+        g = self._all_gather(self._payload_to_backend(payload, X_local.device)).cpu().numpy()
         w = self.pick_winner(g)
         if w < 0:
             raise RuntimeError("no rank has a candidate left")
@@ -101,10 +129,12 @@ class RowShard:
         m = min(k, len(vals))
         buf[:m, 0] = vals[:m]
         buf[:m, 1] = np.asarray(lidx[:m], dtype=np.float64) + self.start
-        payload = torch.from_numpy(buf.reshape(-1))
-        if device is not None:
-            payload = payload.to(device)
-        g = self._all_gather(payload).cpu().numpy().reshape(-1, 2)
-        g = g[g[:, 1] >= 0]
+        g = self._all_gather(self._payload_to_backend(buf.reshape(-1), device)).cpu().numpy().reshape(-1, 2)
+        return self.merge_topk(g, k)
+
+    @staticmethod
+    def merge_topk(gathered: np.ndarray, k: int):
+        """Rows (score, global index) of all ranks -> the k best, ties to the lower global index."""
+        g = gathered[gathered[:, 1] >= 0]
         order = np.lexsort((g[:, 1], -g[:, 0]))[:k]
         return g[order, 0], g[order, 1].astype(np.int64)

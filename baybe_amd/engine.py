@@ -103,6 +103,7 @@ class HipGP:
         self.ybar = 0.0
         self.ysd = 1.0
         self.jitter = 0.0
+        self._comm = None  # (rank, world) once bbh_comm_init has run on this handle
 
     # ---- plumbing -------------------------------------------------------------------------
     def close(self):
@@ -419,13 +420,50 @@ class HipGP:
         )
         return vals, idx
 
+    # ---- row-sharded selection through the library's own RCCL communicator ---------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(256)
+        n = self._lib.bbh_comm_unique_id(buf, 256)
+        if n <= 0:
+            raise HipError("bbh_comm_unique_id failed: RCCL (librccl.so.1) could not be loaded")
+        return buf.raw[:n]
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        self._check(self._lib.bbh_comm_init(self._h, int(rank), int(world), unique_id, len(unique_id)), "bbh_comm_init")
+        self._comm = (int(rank), int(world))
+
+    def allgather_topk(self, scores, row_offset: int, k: int):
+        """Global top-k over all shards (one ncclAllGather of k (score, global index) pairs per rank)."""
+        vals, idx = np.empty(k), np.empty(k, dtype=np.int64)
+        self._check(
+            self._lib.bbh_allgather_topk(self._h, scores.data_ptr() if scores.shape[0] else None, scores.shape[0],
+                                         int(row_offset), int(k), _dp(vals), idx.ctypes.data_as(_lib.c_int64_p)),
+            "bbh_allgather_topk",
+        )
+        return vals, idx
+
+    def allgather_argmax(self, scores, row_offset: int, X):
+        """One greedy step over all shards: (score, global row index, comp-rep row [d]) of the global winner."""
+        val, gidx, row = C.c_double(), C.c_int64(), np.empty(self.spec.d)
+        N = scores.shape[0]
+        self._check(
+            self._lib.bbh_allgather_argmax(self._h, scores.data_ptr() if N else None, N, int(row_offset),
+                                           X.data_ptr() if N else None, X.stride(0) if N else self.spec.d, C.byref(val),
+                                           C.byref(gidx), _dp(row)),
+            "bbh_allgather_argmax",
+        )
+        return val.value, gidx.value, row
+
     # ---- instrumentation ------------------------------------------------------------------
     def timing(self, enable: bool):
         self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")
 
-    def timing_read(self, reset: bool = True):
+    def timing_read(self, reset: bool = True, family: str = "posterior"):
+        """(total ms, launches) of one kernel family since the last reset: ``"posterior"`` (variance passes of the fused
+        kernel), ``"cross"`` (its mean-only passes), ``"pending"`` (joint q'-batch acquisition kernels)."""
         ms, cnt = C.c_double(), C.c_int64()
-        self._check(self._lib.bbh_timing_read(self._h, C.byref(ms), C.byref(cnt), 1 if reset else 0), "bbh_timing_read")
+        self._check(self._lib.bbh_timing_read_family(self._h, _lib.TIMED_FAMILIES[family], C.byref(ms), C.byref(cnt),
+                                                     1 if reset else 0), "bbh_timing_read_family")
         return ms.value, cnt.value
 
     # ---- optimize_acqf_discrete with qLogEI -----------------------------------------------
@@ -488,13 +526,19 @@ class HipGP:
                 scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
             if _step + 1 < q:  # host-side Sobol scrambling of the next step overlaps the device work of this one
                 z_next = get_z(2 + p)
-            val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
-            if shard is not None:
+            if shard is not None and shard.rccl_bound(self):  # payload built on the device, one ncclAllGather
+                val, gidx, row = self.allgather_argmax(scores, shard.start, X)
+                if shard.owns(gidx):
+                    alive[shard.to_local(gidx)] = 0
+                idx = gidx
+            elif shard is not None:
+                val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
                 val, gidx, row = shard.global_argmax(val, idx, X)
                 if shard.owns(gidx):
                     alive[shard.to_local(gidx)] = 0
                 idx = gidx
             else:
+                val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
                 row = X[idx, :d].cpu().numpy()
                 alive[idx] = 0
             indices.append(int(idx))

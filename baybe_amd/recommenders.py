@@ -93,6 +93,14 @@ class HipRecommenderImpl:
         if _is_multi_output(objective) and not self._surrogate_model.supports_multi_output:
             self._surrogate_model = self._surrogate_model.replicate()  # pure/bayesian/base.py:35-39
         self._surrogate_model.fit(searchspace, objective, measurements)
+        if self.shard is not None and self.shard.world > 1:
+            # every rank fitted the same data, but a fit retry re-samples its start point from the priors (private
+            # RNG): rank 0's hyper-parameters are the model on every rank
+            model = self._surrogate_model
+            for sub in (model.models if isinstance(model, HipCompositeImpl) else [model]):
+                params = self.shard.agree(sub.engine.params)
+                if self.shard.rank != 0:
+                    sub.engine.factorize(params)
         return self._surrogate_model
 
     def _setup_botorch_acqf(self, searchspace, objective, measurements, pending_experiments=None) -> None:
@@ -199,6 +207,11 @@ class HipRecommenderImpl:
         return searchspace.discrete.exp_rep.loc[idxs, :]
 
     # ---- discrete optimisation -----------------------------------------------------------------
+    def _sampler_seed(self) -> int:
+        """MC sampler seed from torch's global RNG (``engine.draw_sampler_seed``); with row shards rank 0's draw."""
+        seed = draw_sampler_seed()
+        return int(self.shard.agree(seed)) if self.shard is not None else seed
+
     def _candidates_on_device(self, subspace_discrete, candidates_exp, keep_mask=None):
         """(X_dev, alive, labels): the *whole* comp rep of the discrete subspace as a device-resident
         fp64 matrix (uploaded once per search space, cached), plus a uint8 mask of the rows that are
@@ -264,7 +277,8 @@ class HipRecommenderImpl:
         acqf = self._acqf_in_use
         Xd, alive, labels = self._candidates_on_device(subspace_discrete, candidates_exp, keep_mask)
         if self._nehvi is not None:
-            res = self._nehvi.greedy(Xd, batch_size, X_pending=self._pending_comp, alive=alive, shard=self.shard)
+            res = self._nehvi.greedy(Xd, batch_size, seed=self._sampler_seed(), prune_seed=self._sampler_seed(),
+                                     X_pending=self._pending_comp, alive=alive, shard=self.shard)
             idxs = labels[np.asarray(res.indices, dtype=np.int64)]
             return (idxs, res) if return_values else idxs
         if acqf.is_analytic:  # q = 1 by construction (supports_batching is False)
@@ -279,7 +293,7 @@ class HipRecommenderImpl:
             res = GreedyResult([int(idx)], [float(val)])
         else:
             res = surrogate.engine.greedy_qlogei(
-                Xd, batch_size, S=acqf.n_mc_samples, seed=draw_sampler_seed(), sign=surrogate.sign,
+                Xd, batch_size, S=acqf.n_mc_samples, seed=self._sampler_seed(), sign=surrogate.sign,
                 X_pending=self._pending_comp, best_f=self._best_f, shard=self.shard, kind=acqf.kind,
                 beta=getattr(acqf, "beta", 0.2), alive=alive,
             )
@@ -316,7 +330,7 @@ class HipRecommenderImpl:
         """qLogEI of one q-batch (candidate = first row, the others enter as pending rows)."""
         if self._nehvi is not None:
             # incremental NEHVI: the batch value is the value of its last point given the others
-            self._nehvi.prepare(draw_sampler_seed(), np.vstack([comp[:-1]] + ([self._pending_comp] if self._pending_comp is not None else [])) if len(comp) > 1 or self._pending_comp is not None else None)
+            self._nehvi.prepare(self._sampler_seed(), np.vstack([comp[:-1]] + ([self._pending_comp] if self._pending_comp is not None else [])) if len(comp) > 1 or self._pending_comp is not None else None)
             sc = self._nehvi.score(self._nehvi.outputs[0].engine._as_dev(comp[-1:]))
             return float(sc.cpu().numpy()[0])
         surrogate = self._surrogate_model
@@ -324,7 +338,7 @@ class HipRecommenderImpl:
         acqf = self._acqf_in_use
         base = self._pending_comp if self._pending_comp is not None else np.zeros((0, comp.shape[1]))
         pend = np.vstack([comp[1:], base])
-        seed = draw_sampler_seed()
+        seed = self._sampler_seed()
         mean, var = eng.posterior(comp[:1])
         if acqf.is_analytic:
             if len(pend):
@@ -348,7 +362,7 @@ class HipRecommenderImpl:
         surrogate, acqf = self._setup_acqf(searchspace, objective, measurements, pending_experiments, acquisition_function)
         comp = np.ascontiguousarray(searchspace.transform(candidates, allow_extra=True).to_numpy(dtype=np.float64))
         if self._nehvi is not None:
-            self._nehvi.prepare(draw_sampler_seed(), self._pending_comp)
+            self._nehvi.prepare(self._sampler_seed(), self._pending_comp)
             sc = self._nehvi.score(self._nehvi.outputs[0].engine._as_dev(comp))
             return pd.Series(sc.cpu().numpy(), index=candidates.index)
         eng = surrogate.engine
@@ -356,7 +370,7 @@ class HipRecommenderImpl:
         if acqf.is_analytic:
             s = self._analytic_scores(eng, acqf, mean, var, surrogate.sign)
             return pd.Series(s.cpu().numpy(), index=candidates.index)
-        seed = draw_sampler_seed()
+        seed = self._sampler_seed()
         beta = getattr(acqf, "beta", 0.2)
         if self._pending_comp is None:
             z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]

@@ -12,8 +12,9 @@ GPU (weak scaling: the global grid has N * 1e6 rows), d = 20, n_train = 512, Mat
 fixed-theta mode (prior modes of the BAYBE preset), qLogEI, fp64.
 
   python bench.py                       # 1 GPU
+  python bench.py --gpus N              # spawns one rank per GPU itself (torch.multiprocessing, 127.0.0.1 rendezvous)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W      # or under torchrun: RANK / WORLD_SIZE from the env
 """
 
 from __future__ import annotations
@@ -36,17 +37,18 @@ TOPK = 8
 
 
 def synth_problem(rows: int, d: int, n: int, rank: int):
-    """Deterministic synthetic grid: 11 levels per dimension in [0,1]; the training
-    set is identical on every rank (drawn from rank 0's stream), the shard differs per rank."""
-    X0 = np.random.default_rng(0).integers(0, 11, size=(max(n * 4, 4096), d)) / 10.0
-    idx = np.random.default_rng(1).choice(X0.shape[0], n, replace=False)
-    Xt = X0[idx]
+    """Deterministic synthetic workload: a grid with 11 levels per dimension in [0,1] per rank; the
+    training inputs are n rows of rank 0's candidate grid (``default_rng(1).choice``), identical on every rank."""
+    def grid(r):
+        return np.random.default_rng(1000 + r).integers(0, 11, size=(rows, d)) / 10.0
+
+    X0 = grid(0)
+    Xt = X0[np.random.default_rng(1).choice(rows, n, replace=False)]
     y = -((Xt - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * Xt[:, 0]) + 0.05 * np.random.default_rng(2).standard_normal(n)
-    X = np.random.default_rng(1000 + rank).integers(0, 11, size=(rows, d)) / 10.0
-    return X, Xt, y
+    return (X0 if rank == 0 else grid(rank)), Xt, y
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -58,17 +60,39 @@ def main():
     ap.add_argument("--strong", action="store_true", help="fixed global grid of --rows rows, split over the GPUs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--fit", action="store_true", help="also time a device hyper-parameter fit (extra)")
-    args = ap.parse_args()
+    ap.add_argument("--greedy", type=int, default=5, help="also time a greedy batch of this size (extra; 0 = skip)")
+    return ap.parse_args(argv)
 
+
+def _spawned_rank(local_rank: int, world: int, port: int, argv):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    run(parse_args(argv))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: become the launcher - one process per GPU, rendezvous on 127.0.0.1
+        import socket
+
+        import torch.multiprocessing as mp
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        mp.spawn(_spawned_rank, args=(args.gpus, port, sys.argv[1:]), nprocs=args.gpus, join=True)
+        return
+    run(args)
+
+
+def run(args):
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     # BENCH_SINGLE_DEVICE=1: dry run of the N > 1 code path on ONE GPU (all ranks on cuda:0, gloo
@@ -121,6 +145,12 @@ def main():
     if shard is not None and not args.strong:
         shard.start, shard.stop = rank * rows_local, (rank + 1) * rows_local
 
+    # BBH_COLLECTIVE=rccl: the exchange through the library's own communicator (bbh_allgather_topk: device payload, one
+    # ncclAllGather, one read-back); default: torch.distributed (the same RCCL underneath, host-staged payload)
+    use_rccl = shard is not None and os.environ.get("BBH_COLLECTIVE", "torch") == "rccl" and not single_dev
+    if use_rccl:
+        shard.bind_rccl(gp)
+
     def step():
         # two kernels: measured 1.5 % faster than the single fused posterior+qLogEI kernel
         # (scripts/gpu_ab_fused_acq.py: 5.64 vs 5.73 ms/step): the epilogue's VALU work costs the shared fp64
@@ -128,6 +158,8 @@ def main():
         # kernel's LDS to the kernel-value cache
         mean, var = gp.posterior(Xd)
         scores = gp.qlogei(mean, var, z, best_f, 1.0)
+        if use_rccl:
+            return gp.allgather_topk(scores, shard.start, TOPK)
         vals, idx = gp.topk(scores, TOPK)
         if shard is not None:
             vals, idx = shard.global_topk(vals, idx, TOPK, device=Xd.device)
@@ -158,6 +190,40 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = total_rows * args.steps / dt
+
+    # ---- extra: one greedy batch (optimize_acqf_discrete, q = --greedy) on the same shard, timed per kernel family ----
+    pending_roofline = None
+    if args.greedy > 1:
+        gp.timing(True)
+        for fam in ("posterior", "cross", "pending"):
+            gp.timing_read(reset=True, family=fam)
+        gp.greedy_qlogei(Xd, args.greedy, S=S, seed=1234, best_f=best_f, shard=shard)  # warm-up (instantiations, LDS limits)
+        for fam in ("posterior", "cross", "pending"):
+            gp.timing_read(reset=True, family=fam)
+        fence()
+        t0 = time.perf_counter()
+        gres = gp.greedy_qlogei(Xd, args.greedy, S=S, seed=1234, best_f=best_f, shard=shard)
+        fence()
+        g_wall = (time.perf_counter() - t0) * 1e3
+        fam_ms = {fam: gp.timing_read(reset=True, family=fam) for fam in ("posterior", "cross", "pending")}
+        gp.timing(False)
+        extra[f"greedy_q{args.greedy}_ms"] = g_wall
+        extra[f"greedy_q{args.greedy}_device_ms"] = {k: v[0] for k, v in fam_ms.items()}
+        extra[f"greedy_q{args.greedy}_indices"] = gres.indices
+        # Roofline of the joint q'-batch kernels (bbh_qlogei_pending_q_kernel<Q>), steps 2..q.  VALU-bound: per
+        # candidate, sample and step with q' = Q points: Q(Q+1)/2 FMAs (affine map) + Q (fatplus: 13) + Q (log: 26)
+        # + Q (fatmax term: 11) + 40 (log of the sum, power, accumulation) fp64 instructions; an FMA counts 2 flops
+        # against the 78.6 TFLOP/s vector peak, i.e. the instruction rate is priced at 39.3e12 / s.
+        inst = sum(S * (Q * (Q + 1) // 2 + Q * (13 + 26 + 11) + 40) + 3 * Q * Q * Q for Q in range(2, args.greedy + 1))
+        p_ms, p_n = fam_ms["pending"]
+        if p_n:
+            ach = rows_local * inst / (p_ms * 1e-3) / 1e12
+            pending_roofline = {
+                "kernel": "bbh_qlogei_pending_q_kernel<2..%d>" % args.greedy, "bound": "valu-fp64",
+                "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS / 2, "unit": "T fp64 instructions/s", "frac": ach / (FP64_MFMA_PEAK_TFLOPS / 2),
+                "instructions_per_candidate": inst, "launches": p_n, "total_ms": p_ms,
+                "hbm_bytes_per_candidate_algorithmic": sum(8 * (2 + (Q - 1)) + 8 for Q in range(2, args.greedy + 1)),
+            }
 
     # ---- roofline of the dominant kernel (fused posterior), algorithmic flops ----
     flops_per_cand = n * n + 2 * n * d + 16 * n + 16 * S
@@ -206,10 +272,13 @@ def main():
                         f"fixed-theta, top-{TOPK} to host",
             "global_rows": total_rows,
             "parallelism": f"row-shard x{world}",
+            "collective": "none" if world == 1 else ("rccl (library)" if use_rccl else "torch.distributed " + dist.get_backend()),
         },
         "roofline": roofline,
         "extra": extra,
     }
+    if pending_roofline is not None:
+        out["extra"]["roofline_pending_kernels"] = pending_roofline
 
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         from oracle import cpu_baseline as cb
@@ -217,14 +286,29 @@ def main():
 
         ospec = go.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
         om = go.fit_gp(ospec, Xt, y, params=go.GPParams(np.full(d, ls), math.exp(-5.0), 0.0))
-        cps, scored, threads = cb.time_cpu_baseline(om, X, z, go.best_f_from_model(om), budget_s=args.cpu_budget)
+        # the restated reference path at torch's default thread count (what a user gets) and at smaller pools (the
+        # b x 1 x n t-batches of 2048 do not feed 128 threads); the best one is the reported baseline
+        import torch as _t
+
+        default_threads = _t.get_num_threads()
+        sweep = sorted({default_threads, *[c for c in (8, 16, 32) if c < default_threads]})
+        by_threads = {}
+        for th in sweep:
+            _t.set_num_threads(th)
+            cps_t, scored_t, _ = cb.time_cpu_baseline(om, X, z, go.best_f_from_model(om), budget_s=args.cpu_budget / len(sweep))
+            by_threads[th] = (cps_t, scored_t)
+        _t.set_num_threads(default_threads)
+        threads = max(by_threads, key=lambda k: by_threads[k][0])
+        cps, scored = by_threads[threads]
         out["cpu_baseline"] = {
             "value": cps,
             "unit": "candidates/s",
             "cores": threads,
             "kind": "port",
             "sample": f"first {scored} rows of the same grid, chunks of 2048 (restated reference CPU path, torch-CPU fp64, "
-                      f"{os.cpu_count()} logical CPUs)",
+                      f"{os.cpu_count()} logical CPUs; best of the thread counts tried)",
+            "by_threads": {str(k): v[0] for k, v in by_threads.items()},
+            "default_threads": default_threads,
         }
         out["extra"]["speedup_vs_cpu_baseline"] = value / cps
     if rank == 0:

@@ -226,11 +226,37 @@ int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_
 int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
              int64_t* idx_host);
 
+/* ---- row-sharded selection over the GPUs of one node (RCCL over xGMI) ---------------------------
+ * No reference call site (BayBE is single-process): these belong to the argmax / top-k of
+ * optimize_acqf_discrete (baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126) once the candidate rows are
+ * sharded contiguously over the ranks.  One collective per selection step; ties resolve to the lowest GLOBAL row index,
+ * which follows shard order, i.e. exactly as on a single device.  RCCL is bound at run time (dlopen): without a
+ * communicator nothing here is needed. */
+/* rank 0: a fresh ncclUniqueId into id_out (bytes >= 128); returns its size, < 0 on error.  Ship it to the other
+ * ranks by any means (file, MPI, torch.distributed broadcast). */
+int bbh_comm_unique_id(void* id_out, int64_t bytes);
+int bbh_comm_init(bbh_handle* h, int32_t rank, int32_t world, const void* unique_id, int64_t bytes);
+int bbh_comm_destroy(bbh_handle* h);
+/* Global top-k (k <= 64) of the scores of all shards: this rank holds scores_dev [N] for the global rows
+ * [row_offset, row_offset + N).  Payload k x (score, global index) built on the device, one ncclAllGather, one
+ * read-back; every rank returns the same vals_host / idx_host [k] (descending; (-inf, -1) beyond the total count). */
+int bbh_allgather_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t row_offset, int64_t k,
+                       double* vals_host, int64_t* idx_host);
+/* One greedy step: the global first-index argmax and the winner's comp-rep row (row_host [d]; every rank appends it
+ * to its pending points).  X_dev [N, ldx] are this rank's rows; an empty shard (N = 0) still takes part. */
+int bbh_allgather_argmax(bbh_handle* h, const double* scores_dev, int64_t N, int64_t row_offset, const double* X_dev,
+                         int64_t ldx, double* val_host, int64_t* gidx_host, double* row_host);
+
 /* ---- instrumentation --------------------------------------------------------------- */
 /* Duration (ms) and launch count of the fused posterior kernel accumulated since the
  * last reset, measured with HIP events on the handle's stream when enabled. */
 int bbh_timing_enable(bbh_handle* h, int enable);
 int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset);
+/* The same per kernel family: BBH_TIMED_POSTERIOR = variance passes of the fused posterior kernel (what
+ * bbh_timing_read reports), BBH_TIMED_CROSS = its mean-only passes (bbh_cross_cov, bbh_posterior_columns),
+ * BBH_TIMED_PENDING = the joint q'-batch acquisition kernels (bbh_qlogei_pending, bbh_mc_acq_pending). */
+enum bbh_timed_family { BBH_TIMED_POSTERIOR = 0, BBH_TIMED_CROSS = 1, BBH_TIMED_PENDING = 2, BBH_TIMED_FAMILIES = 3 };
+int bbh_timing_read_family(bbh_handle* h, int32_t family, double* ms_total, int64_t* launches, int reset);
 
 #ifdef __cplusplus
 }

@@ -178,3 +178,55 @@ def test_campaign_iterations_loop():
         best.append(max(best[-1], rec["y"].max()))
     assert best[-1] >= best[0]
     assert len(camp.measurements) == 6 + 2 + 3 + 1 + 2
+
+
+def test_bench_starts_its_own_ranks_and_reports_one_json_line():
+    """``python bench.py --gpus 2`` without torchrun (the driver could not start it): bench.py spawns one
+    process per rank itself; BENCH_SINGLE_DEVICE=1 puts both ranks on cuda:0 with gloo standing in for RCCL."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["BENCH_SINGLE_DEVICE"] = "1"
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "150000",
+           "--cpu-budget", "0", "--greedy", "3"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "candidates/s"
+    assert rec["config"]["global_rows"] == 300000 and rec["value"] > 0 and rec["dtype"] == "f64"
+    assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
+    assert len(set(rec["extra"]["greedy_q3_indices"])) == 3
+    assert rec["extra"]["roofline_pending_kernels"]["launches"] == 2
+
+
+def test_library_rccl_entry_points_on_a_single_rank_communicator():
+    """``bbh_comm_init`` / ``bbh_allgather_topk`` / ``bbh_allgather_argmax`` (include/baybe_hip.h) with world = 1 - the
+    GPU box has one device: communicator set-up, device-side payload, ncclAllGather, read-back and merge all run; the
+    result must be the local selection shifted by the row offset."""
+    import torch
+
+    from baybe_amd import engine
+
+    N, d, n = 5000, 6, 40
+    X, Xt, y = make_problem(N, d, n, seed=4)
+    gp = engine.HipGP(0)
+    _model(gp, d, Xt, y)
+    Xd = torch.from_numpy(X).cuda()
+    m, v = gp.posterior(Xd)
+    s = gp.qlogei(m, v, engine.sobol_normal_base_samples(512, 1, 3)[:, 0], gp.best_f())
+    gp.comm_init(0, 1, gp.comm_unique_id())
+    vals, idx = gp.topk(s, 7)
+    gv, gi = gp.allgather_topk(s, 1000, 7)
+    assert np.array_equal(gi, idx + 1000) and np.array_equal(gv, vals)
+    val, i = gp.argmax(s)
+    gval, gidx, row = gp.allgather_argmax(s, 1000, Xd)
+    assert gidx == i + 1000 and gval == val and np.array_equal(row, X[i])
+    ev, ei = gp.allgather_topk(s[:3], 0, 5)  # fewer rows than k: padded with (-inf, -1)
+    assert ei[3:].tolist() == [-1, -1] and np.isneginf(ev[3:]).all() and set(ei[:3]) == {0, 1, 2}
+    gp.close()
