@@ -25,6 +25,28 @@
 #include "bbh_fused.h"
 
 #define BBH_COOP_ROUNDS 8  // 8 rounds x 4 column blocks x 16 = 512 training points
+#ifndef BBH_COOP_WAVES
+#define BBH_COOP_WAVES 2  // waves per SIMD the register budget is set for (workgroups per CU)
+#endif
+// BBH_COOP_ASM = 1: the operand loads of the main loop are inline assembly in the scalar-base form
+// (global_load_dwordx2 v, v_lane_offset, s[base:base+1] offset:imm) with counted s_waitcnt by hand.  The compiler
+// addresses the same loads through 64-bit VGPR pointers - 2 VALU instructions per 4 KB window and wave, 18 % of the
+// kernel's non-MFMA VALU work on a pipe that VALU and MFMA share - and cannot be talked into the scalar form.  The hand
+// counts rely on every VMEM load of the loop being issued here (operand ring + training fragments), in program order.
+#ifndef BBH_COOP_ASM
+#define BBH_COOP_ASM 1
+#endif
+
+template <int IMM>
+__device__ __forceinline__ void coop_gload(double& dst, const double* sbase, unsigned voff) {
+  static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate offset");
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
+}
+// at most N vector-memory loads may still be in flight afterwards; tied to the register that is about to be consumed
+template <int N>
+__device__ __forceinline__ void coop_vmwait(double& slot) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "n"(N));
+}
 
 struct CoopArgs {
   FusedArgs f;
@@ -37,20 +59,33 @@ struct CoopArgs {
 __host__ __device__ constexpr int coop_frags_before(int G) { return 16 * (G * BBH_COOP_ROUNDS - (G * (G - 1)) / 2); }
 
 template <int G, int KD, int KVF, bool PRODUCE>
-__device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, const bbh_lds_double* kv_cur,
+__device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, const double* tfn, const bbh_lds_double* kv_cur,
                                            bbh_lds_double* kv_mine_next, const bbh_lds_double* alpha_next, int tbn, int cw,
                                            d4 (&acc)[BBH_COOP_ROUNDS], double (&ring)[BBH_RING], double& accm) {
+  // rs: this wave's operand slice at the start of the group (wave-uniform); tfn: training fragments of k-block tbn
+  // (wave-uniform); the lane's 8-byte slot inside a 512-byte fragment is added by the load
   constexpr int D = BBH_RING;
   constexpr int CNT = BBH_COOP_ROUNDS - G;  // ring fragments per (k-block, k-step): slots G .. 7
   constexpr int FULL = CNT - 1;             // of which always multiplied
   constexpr int TOT = 16 * CNT;
   constexpr int REM = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(G + 1);  // fragments after this group
   constexpr int HOSTS = 12 * FULL;  // MFMAs of k-blocks 1..3 that carry the micro-steps of the production
+  static_assert(D == 8, "window arithmetic below assumes a ring of 8 fragments = one 4 KB window");
+  const unsigned lane8 = (unsigned)c.l * 8u;
   double tfv[KD];
   d4 dsa, dsb;
   KvState<BBH_KV_NU> P;
   double kv[4], kvx[4], kvn[4], alv[4];
-  if (PRODUCE) kvp_load<KD>(c, tbn, tfv);
+  if constexpr (PRODUCE) {
+#if BBH_COOP_ASM
+    static_for<0, KD>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      coop_gload<(k % 8) * 512>(tfv[k], tfn + (k / 8) * 512, lane8);
+    });
+#else
+    kvp_load<KD>(c, tbn, tfv);
+#endif
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) kv[r] = kv_cur[r * 64];
   __builtin_amdgcn_sched_barrier(0);
@@ -68,12 +103,25 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
       static_for<0, CNT>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         constexpr int f = (i * 4 + r) * CNT + s;
+#if BBH_COOP_ASM
+        // loads younger than fragment f: the D - 1 ring fragments behind it, plus - for the fragments that were already
+        // in flight when this group's training fragments were requested - those KD loads
+        // (at the very end of the slice there are fewer than D - 1 fragments behind f)
+        constexpr int BEHIND = (TOT + REM - 1 - f) < (D - 1) ? (TOT + REM - 1 - f) : (D - 1);
+        coop_vmwait<BEHIND + ((PRODUCE && f < D) ? KD : 0)>(ring[f % D]);
+#endif
         if constexpr (s == 0) {  // diagonal slot: column block 4 G + cw, zero (and skipped) for k-blocks above it
           if (cw >= i) acc[G] = mfma_f64(kv[r], ring[f % D], acc[G]);
         } else {
           acc[G + s] = mfma_f64(kv[r], ring[f % D], acc[G + s]);
         }
-        if constexpr (f + D < TOT + REM) ring[f % D] = rs[(f + D) * 64];
+        if constexpr (f + D < TOT + REM) {
+#if BBH_COOP_ASM
+          coop_gload<((f + D) % 8) * 512>(ring[f % D], rs + ((f + D) / 8) * 512, lane8);
+#else
+          ring[f % D] = rs[(f + D) * 64 + c.l];
+#endif
+        }
         if constexpr (PRODUCE && i >= 1 && s >= 1) {
           constexpr int m = ((i - 1) * 4 + r) * FULL + (s - 1);
           static_for<(m * BBH_KV_STEPS) / HOSTS, ((m + 1) * BBH_KV_STEPS) / HOSTS>([&](auto st) __attribute__((always_inline)) {
@@ -82,7 +130,13 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (PRODUCE && i == 0 && r == 3) kvp_dist<KD>(c, tfv, dsa, dsb);
+      if constexpr (PRODUCE && i == 0 && r == 3) {
+#if BBH_COOP_ASM
+        coop_vmwait<D>(tfv[KD - 1]);  // the D ring fragments in flight are all younger than the training fragments
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        kvp_dist<KD>(c, tfv, dsa, dsb);
+      }
     });
     if constexpr (i < 3) {
 #pragma unroll
@@ -99,7 +153,7 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
 }
 
 template <int KD, int KVF>
-__global__ __launch_bounds__(256, 2) void bbh_coop_posterior_kernel(const CoopArgs ca) {
+__global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel(const CoopArgs ca) {
   const FusedArgs& a = ca.f;
   extern __shared__ __attribute__((aligned(16))) double s_mem[];  // alpha [16 nb] | kv [2][4][256] | red [4][16] x 2
   const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,10 +224,18 @@ __global__ __launch_bounds__(256, 2) void bbh_coop_posterior_kernel(const CoopAr
   d4 acc[BBH_COOP_ROUNDS];
 #pragma unroll
   for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* rs = ca.rstream + (int64_t)w * ca.frags * 64 + l;
+  // wave-uniform stream pointer + lane index: scalar base / 32-bit lane offset addressing (no 64-bit VALU pointer arithmetic)
+  const double* rs = ca.rstream + (int64_t)w * ca.frags * 64;
   double ring[BBH_RING];
+#if BBH_COOP_ASM
+  static_for<0, BBH_RING>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    coop_gload<i * 512>(ring[i], rs, (unsigned)l * 8u);
+  });
+#else
 #pragma unroll
-  for (int i = 0; i < BBH_RING; i++) ring[i] = rs[i * 64];
+  for (int i = 0; i < BBH_RING; i++) ring[i] = rs[i * 64 + l];
+#endif
   __syncthreads();  // group g0 is complete in LDS
 
   static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
@@ -182,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void bbh_coop_posterior_kernel(const CoopAr
       const int cw = (G & 1) ? 3 - w : w;
       const int tbn = 4 * (G + 1 - g0) + w;  // real k-block this wave produces for the next group
       constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
-      coop_group<G, KD, KVF, PRODUCE>(c, rs, kvb + (G & 1) * 4 * 256, kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn,
-                                      cw, acc, ring, accm);
+      coop_group<G, KD, KVF, PRODUCE>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, kvb + (G & 1) * 4 * 256,
+                                      kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn, cw, acc, ring, accm);
       rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
       if constexpr (PRODUCE) __syncthreads();
     }
