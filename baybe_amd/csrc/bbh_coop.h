@@ -28,15 +28,45 @@
 #ifndef BBH_COOP_WAVES
 #define BBH_COOP_WAVES 2  // waves per SIMD the register budget is set for (workgroups per CU)
 #endif
-// BBH_COOP_ASM = 1: the operand loads of the main loop are inline assembly in the scalar-base form
-// (global_load_dwordx2 v, v_lane_offset, s[base:base+1] offset:imm) with counted s_waitcnt by hand.  The compiler
+// The operand loads of the main loop are inline assembly in the scalar-base form
+// (global_load_dwordx{2,4} v, v_lane_offset, s[base:base+1] offset:imm) with counted s_waitcnt by hand.  The compiler
 // addresses the same loads through 64-bit VGPR pointers - 2 VALU instructions per 4 KB window and wave, 18 % of the
-// kernel's non-MFMA VALU work on a pipe that VALU and MFMA share - and cannot be talked into the scalar form.  The hand
-// counts rely on every VMEM load of the loop being issued here (operand ring + training fragments), in program order.
-#ifndef BBH_COOP_ASM
-#define BBH_COOP_ASM 1
+// kernel's non-MFMA VALU work on a pipe that VALU and MFMA share - and cannot be talked into the scalar form
+// (5.05 -> 4.89 ms).  The hand counts rely on every VMEM load of the loop being issued here (operand ring + training
+// fragments), in program order, with sched_barrier fences between the MFMA slots.
+#ifndef BBH_COOP_PAIRS
+#define BBH_COOP_PAIRS 4  // operand ring: register pairs (two fragments each) in flight per wave
+#endif
+#ifndef BBH_COOP_ABLATE_BARRIER
+#define BBH_COOP_ABLATE_BARRIER 0
+#endif
+#ifndef BBH_COOP_ABLATE_MEM
+#define BBH_COOP_ABLATE_MEM 0  // timing experiment: every operand load hits the same 4 KB (L1-resident)
+#endif
+#ifndef BBH_COOP_ABLATE_LOADS
+#define BBH_COOP_ABLATE_LOADS 0  // timing experiment: no operand loads in the main loop at all
+#endif
+#ifndef BBH_COOP_ABLATE_CHAIN
+#define BBH_COOP_ABLATE_CHAIN 0
+#endif
+#ifndef BBH_COOP_ABLATE_KV
+#define BBH_COOP_ABLATE_KV 0
 #endif
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+// two consecutive fragments of the slice with one instruction: the slice stores fragment pairs lane-interleaved
+// (pair p, lane l: [fragment 2p | fragment 2p + 1] at byte 1024 p + 16 l).  Every vector-memory instruction costs the
+// MFMA stream issue bandwidth whatever it hits (measured: the same loads from one L1-resident window cost the same
+// 0.5 ms per launch as the real ones); pairs halve their number.
+template <int IMM>
+__device__ __forceinline__ void coop_gload2(d2& dst, const double* sbase, unsigned voff) {
+  static_assert(IMM >= 0 && IMM + 16 <= 4096, "13-bit signed immediate offset");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
+}
+template <int N>
+__device__ __forceinline__ void coop_vmwait2(d2& slot) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "n"(N));
+}
 template <int IMM>
 __device__ __forceinline__ void coop_gload(double& dst, const double* sbase, unsigned voff) {
   static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate offset");
@@ -61,30 +91,25 @@ __host__ __device__ constexpr int coop_frags_before(int G) { return 16 * (G * BB
 template <int G, int KD, int KVF, bool PRODUCE>
 __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, const double* tfn, const bbh_lds_double* kv_cur,
                                            bbh_lds_double* kv_mine_next, const bbh_lds_double* alpha_next, int tbn, int cw,
-                                           d4 (&acc)[BBH_COOP_ROUNDS], double (&ring)[BBH_RING], double& accm) {
+                                           d4 (&acc)[BBH_COOP_ROUNDS], d2 (&ring)[BBH_COOP_PAIRS], double& accm) {
   // rs: this wave's operand slice at the start of the group (wave-uniform); tfn: training fragments of k-block tbn
-  // (wave-uniform); the lane's 8-byte slot inside a 512-byte fragment is added by the load
-  constexpr int D = BBH_RING;
+  // (wave-uniform); the lane's slot inside a fragment (pair) is added by the load
+  constexpr int NP = BBH_COOP_PAIRS;        // ring: NP register pairs = 2 NP fragments in flight
   constexpr int CNT = BBH_COOP_ROUNDS - G;  // ring fragments per (k-block, k-step): slots G .. 7
   constexpr int FULL = CNT - 1;             // of which always multiplied
-  constexpr int TOT = 16 * CNT;
+  constexpr int TOT = 16 * CNT;             // fragments of this group (even: pairs never straddle groups)
   constexpr int REM = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(G + 1);  // fragments after this group
   constexpr int HOSTS = 12 * FULL;  // MFMAs of k-blocks 1..3 that carry the micro-steps of the production
-  static_assert(D == 8, "window arithmetic below assumes a ring of 8 fragments = one 4 KB window");
-  const unsigned lane8 = (unsigned)c.l * 8u;
+  const unsigned lane8 = (unsigned)c.l * 8u, lane16 = (unsigned)c.l * 16u;
   double tfv[KD];
   d4 dsa, dsb;
   KvState<BBH_KV_NU> P;
   double kv[4], kvx[4], kvn[4], alv[4];
   if constexpr (PRODUCE) {
-#if BBH_COOP_ASM
     static_for<0, KD>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       coop_gload<(k % 8) * 512>(tfv[k], tfn + (k / 8) * 512, lane8);
     });
-#else
-    kvp_load<KD>(c, tbn, tfv);
-#endif
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) kv[r] = kv_cur[r * 64];
@@ -102,27 +127,32 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
       constexpr int r = decltype(rc)::value;
       static_for<0, CNT>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        constexpr int f = (i * 4 + r) * CNT + s;
-#if BBH_COOP_ASM
-        // loads younger than fragment f: the D - 1 ring fragments behind it, plus - for the fragments that were already
-        // in flight when this group's training fragments were requested - those KD loads
-        // (at the very end of the slice there are fewer than D - 1 fragments behind f)
-        constexpr int BEHIND = (TOT + REM - 1 - f) < (D - 1) ? (TOT + REM - 1 - f) : (D - 1);
-        coop_vmwait<BEHIND + ((PRODUCE && f < D) ? KD : 0)>(ring[f % D]);
-#endif
-        if constexpr (s == 0) {  // diagonal slot: column block 4 G + cw, zero (and skipped) for k-blocks above it
-          if (cw >= i) acc[G] = mfma_f64(kv[r], ring[f % D], acc[G]);
+        constexpr int f = (i * 4 + r) * CNT + s;  // fragment index inside the group; pair f / 2, half f % 2
+        constexpr int pr = f / 2;
+        if constexpr (f % 2 == 0 && !BBH_COOP_ABLATE_LOADS) {
+          // pair loads younger than pair pr: NP - 1 (fewer at the very end of the slice), plus - for the pairs that
+          // were already in flight when this group's training fragments were requested - those KD loads
+          constexpr int BEHIND = ((TOT + REM) / 2 - 1 - pr) < (NP - 1) ? ((TOT + REM) / 2 - 1 - pr) : (NP - 1);
+          coop_vmwait2<BEHIND + ((PRODUCE && pr < NP) ? KD : 0)>(ring[pr % NP]);
+        }
+#if BBH_COOP_ABLATE_CHAIN  // timing experiment (wrong results): every MFMA goes to the accumulator (f mod 8)
+        if constexpr (s == 0) {
+          if (cw >= i) acc[f % 8] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[f % 8]);
         } else {
-          acc[G + s] = mfma_f64(kv[r], ring[f % D], acc[G + s]);
+          acc[f % 8] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[f % 8]);
         }
-        if constexpr (f + D < TOT + REM) {
-#if BBH_COOP_ASM
-          coop_gload<((f + D) % 8) * 512>(ring[f % D], rs + ((f + D) / 8) * 512, lane8);
 #else
-          ring[f % D] = rs[(f + D) * 64 + c.l];
-#endif
+        if constexpr (s == 0) {  // diagonal slot: column block 4 G + cw, zero (and skipped) for k-blocks above it
+          if (cw >= i) acc[G] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[G]);
+        } else {
+          acc[G + s] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[G + s]);
         }
-        if constexpr (PRODUCE && i >= 1 && s >= 1) {
+#endif
+        if constexpr (f % 2 == 1 && 2 * (pr + NP) < TOT + REM && !BBH_COOP_ABLATE_LOADS) {  // both halves are consumed
+          constexpr int np = pr + NP;  // pair to request, relative to the group start; 4 pairs per 4 KB window
+          coop_gload2<(np % 4) * 1024>(ring[pr % NP], BBH_COOP_ABLATE_MEM ? rs : rs + (np / 4) * 512, lane16);
+        }
+        if constexpr (PRODUCE && i >= 1 && s >= 1 && !BBH_COOP_ABLATE_KV) {
           constexpr int m = ((i - 1) * 4 + r) * FULL + (s - 1);
           static_for<(m * BBH_KV_STEPS) / HOSTS, ((m + 1) * BBH_KV_STEPS) / HOSTS>([&](auto st) __attribute__((always_inline)) {
             kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tbn, 0, dsa, dsb, kvn);
@@ -131,11 +161,9 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
         __builtin_amdgcn_sched_barrier(0);
       });
       if constexpr (PRODUCE && i == 0 && r == 3) {
-#if BBH_COOP_ASM
-        coop_vmwait<D>(tfv[KD - 1]);  // the D ring fragments in flight are all younger than the training fragments
+        coop_vmwait<NP>(tfv[KD - 1]);  // the NP pair loads in flight are all younger than the training fragments
         __builtin_amdgcn_sched_barrier(0);
-#endif
-        kvp_dist<KD>(c, tfv, dsa, dsb);
+        if constexpr (!BBH_COOP_ABLATE_KV) kvp_dist<KD>(c, tfv, dsa, dsb);
       }
     });
     if constexpr (i < 3) {
@@ -146,6 +174,7 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
   if constexpr (PRODUCE) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
+      if constexpr (BBH_COOP_ABLATE_KV) kvn[r] = tfv[r];
       kv_mine_next[r * 64] = kvn[r];
       accm = fma(kvn[r], alv[r], accm);
     }
@@ -226,16 +255,11 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
   // wave-uniform stream pointer + lane index: scalar base / 32-bit lane offset addressing (no 64-bit VALU pointer arithmetic)
   const double* rs = ca.rstream + (int64_t)w * ca.frags * 64;
-  double ring[BBH_RING];
-#if BBH_COOP_ASM
-  static_for<0, BBH_RING>([&](auto ic) __attribute__((always_inline)) {
+  d2 ring[BBH_COOP_PAIRS];
+  static_for<0, BBH_COOP_PAIRS>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    coop_gload<i * 512>(ring[i], rs, (unsigned)l * 8u);
+    coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, (unsigned)l * 16u);
   });
-#else
-#pragma unroll
-  for (int i = 0; i < BBH_RING; i++) ring[i] = rs[i * 64 + l];
-#endif
   __syncthreads();  // group g0 is complete in LDS
 
   static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
@@ -247,7 +271,9 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
       coop_group<G, KD, KVF, PRODUCE>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, kvb + (G & 1) * 4 * 256,
                                       kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn, cw, acc, ring, accm);
       rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
+#if !BBH_COOP_ABLATE_BARRIER  // (timing experiment only: wrong results without the barrier)
       if constexpr (PRODUCE) __syncthreads();
+#endif
     }
   });
 

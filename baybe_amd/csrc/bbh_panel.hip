@@ -52,7 +52,8 @@ __global__ void bbh_pack_rfrag_kernel(const double* __restrict__ X, int64_t np, 
 }
 
 // Operand slices of the cooperative form (bbh_coop.h): wave w, group G >= g0, k-block i, k-step r, slot rho = G + s
-//   lane l <- R[k = 16 tb + 4 r + (l>>4)][j = 16 jb + (l&15)],  tb = 4 (G - g0) + i,  jb = 4 (rho - g0) + (rho odd ? 3 - w : w)
+//   lane l <- R[k = 16 tb + 4 r + (l>>4)][j = 16 jb + (l&15)],  tb = 4 (G - g0) + i,  jb = 4 (rho - g0) + (rho odd ? 3 - w : w);
+// consecutive fragments are stored as lane-interleaved pairs (one global_load_dwordx4 fetches both)
 __global__ void bbh_pack_coop_kernel(const double* __restrict__ X, int64_t np, int g0, int64_t frags, double* __restrict__ out) {
   const int w = blockIdx.z, G = g0 + blockIdx.y, ir = blockIdx.x, l = threadIdx.x;
   const int i = ir >> 2, r = ir & 3;
@@ -63,7 +64,8 @@ __global__ void bbh_pack_coop_kernel(const double* __restrict__ X, int64_t np, i
     const int rho = G + s;
     const int64_t jb = 4 * (rho - g0) + ((rho & 1) ? 3 - w : w);
     const int64_t j = 16 * jb + (l & 15);
-    out[((int64_t)w * frags + base + s) * 64 + l] = (k <= j) ? X[j * np + k] : 0.0;
+    const int64_t fr = base + s;  // fragment pairs are stored lane-interleaved: pair fr / 2, lane l, half fr % 2
+    out[((int64_t)w * frags + (fr & ~(int64_t)1)) * 64 + 2 * l + (fr & 1)] = (k <= j) ? X[j * np + k] : 0.0;
   }
 }
 
