@@ -34,7 +34,8 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
   if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
   if (const char* e = getenv("BBH_W32")) h->use_w32 = (e[0] != '0');
-  if (const char* e = getenv("BBH_COOP")) h->use_coop = (e[0] != '0');
+  if (const char* e = getenv("BBH_COOP")) h->coop_mode = atoi(e);
+  if (const char* e = getenv("BBH_POTRF_REG")) h->potrf_register_form = (e[0] != '0');
   *out = h;
   return 0;
 }
@@ -53,6 +54,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   bbh_comm_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
+  if (h->d_rstream) hipFree(h->d_rstream);
   if (h->d_kvcache) hipFree(h->d_kvcache);
   if (h->d_slab_flags) hipFree(h->d_slab_flags);
   if (h->d_z) hipFree(h->d_z);

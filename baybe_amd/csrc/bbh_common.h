@@ -108,7 +108,8 @@ struct bbh_handle {
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
   int num_cu = 256;               // compute units of the device (sizes the slab pool of the kernel-value cache)
   int wmax = 16;                  // column blocks per pass of the fused kernel: 16 (two waves per SIMD) or 32 (one)
-  bool use_coop = false;          // env BBH_COOP=1: cooperative form (one workgroup per 16 candidates) where instantiated
+  bool potrf_register_form = false;  // env BBH_POTRF_REG=1: 64x64 diagonal blocks by the one-wave register kernel (A/B)
+  int coop_mode = 1;              // env BBH_COOP: 0 never use the cooperative form, 1 where it pays (default), 2 wherever instantiated
   bool coop_ready = false;        // operand slices of the cooperative form are packed for the current factorisation
   double* d_rstream = nullptr;    // [4 waves][rstream_frags][64]
   int64_t rstream_frags = 0;

@@ -215,6 +215,13 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
     if (4 * k + q == a.dn) c.cf[k] = 1.0;
     if (4 * k + q == a.dn + 1) c.cf[k] = nbsum;
   }
+  int tc = 0;
+  if constexpr ((KVF & 1) != 0) {  // task / outputscale table: the candidate's own task selects the table row
+    if (a.task_col >= 0) {
+      tc = (int)xr[a.task_col];
+      tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+    }
+  }
   c.tf = a.trainfrag + l;
   c.candl = nullptr;
   c.mb = nullptr;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   c.kd = KD;
   c.kind = a.kind;
   c.T = a.T;
-  c.tc = 0;
+  c.tc = tc;
   c.q = q;
   c.l = l;
   c.dn = a.dn;
@@ -310,11 +317,35 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
       const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
       const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
       if (a.mean) a.mean[gi] = a.ybar + a.ysd * (a.mean_const + sm);
-      if (a.var) a.var[gi] = a.ysd * a.ysd * (a.prior_scale - sv);
+      double pv = a.prior_scale;
+      if constexpr ((KVF & 1) != 0) {
+        const int tcm = __shfl(tc, m, 64);  // lane m of wave 0 holds candidate m's task (cnd = m, q = 0)
+        pv = a.tasktbl[tcm * a.T + tcm];
+      }
+      if (a.var) a.var[gi] = a.ysd * a.ysd * (pv - sv);
     }
   }
 }
 
-// one launcher per translation unit (bbh_fused_coop_kd*.hip); false: no instantiation for this model.  grid.x == 0
-// asks only whether there is one.
+// Instantiations (bbh_fused_coop_a.hip: 2, 4, 6 k-steps of the distance GEMM; _b: 8, 12, 16): Matérn-5/2 with and
+// without the task / outputscale table, RBF and Matérn-3/2 without - the set of the windowed pipelined form.
+// false: no instantiation for this model; grid.x == 0 only asks.
 bool bbh_coop_launch(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
+bool bbh_coop_launch_a(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
+bool bbh_coop_launch_b(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
+
+#define BBH_COOP_DISPATCH_KD(KDV)                                                                                        \
+  if (kd == KDV) {                                                                                                       \
+    const bool m52 = kind == BBH_KERNEL_MATERN52, plain = (kind == BBH_KERNEL_RBF || kind == BBH_KERNEL_MATERN32) && !has_tbl; \
+    if (!m52 && !plain) return false;                                                                                    \
+    if (grid.x == 0) return true;                                                                                        \
+    if (kind == BBH_KERNEL_RBF)                                                                                          \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 2>), grid, dim3(256), lds, s, a);                               \
+    else if (kind == BBH_KERNEL_MATERN32)                                                                                \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 4>), grid, dim3(256), lds, s, a);                               \
+    else if (has_tbl)                                                                                                    \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 1>), grid, dim3(256), lds, s, a);                               \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 0>), grid, dim3(256), lds, s, a);                               \
+    return true;                                                                                                         \
+  }

@@ -198,6 +198,141 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag_kernel(double* A, int64_t 
   }
 }
 
+// ---- the same 64x64 diagonal block, blocked 16 x 16 on the fp64 MFMA ------------------------------------
+// The register form above is one wave walking 64 dependent pivots and then 64 substitution steps: 46 us per block, 8
+// blocks in sequence at n = 512 = 47 % of a fit evaluation (profiles/r02_fit_kernel_stats.csv).  Here the block is a
+// 4 x 4 grid of 16 x 16 sub-blocks in LDS: per block column J the diagonal sub-block is factorised and inverted in the
+// registers of 16 lanes (16 pivots), the sub-diagonal panel is one MFMA chain per sub-block against that inverse, the
+// trailing sub-blocks take rank-16 updates on the MFMA, and L^-1 is assembled block column by block column from the
+// diagonal inverses - 4 short dependent stages instead of 128 long ones.
+//   fragment layouts (bbh_common.h): A (16x4) lane l <- A[l & 15][4 ks + (l >> 4)],  B (4x16) lane l <- B[4 ks + (l >> 4)][l & 15],
+//   C lane l, reg r <-> C[(l >> 4) + 4 r][l & 15]
+#define PD_LD 66  // LDS row pitch (doubles)
+__device__ __forceinline__ d4 pd_mul_nt(const double (*a)[PD_LD], int ar, int ac, const double (*b)[PD_LD], int br, int bc, int l) {
+  // C = A[ar.., ac..] (16x16) * B[br.., bc..]^T (16x16):  C[m][n] = sum_k A[m][k] B[n][k]
+  d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+    c = mfma_f64(a[ar + (l & 15)][ac + 4 * ks + (l >> 4)], b[br + (l & 15)][bc + 4 * ks + (l >> 4)], c);
+  return c;
+}
+__device__ __forceinline__ d4 pd_mul_nn(const double (*a)[PD_LD], int ar, int ac, const double (*b)[PD_LD], int br, int bc, int l, d4 c) {
+  // C += A[ar.., ac..] (16x16) * B[br.., bc..] (16x16):  C[m][n] += sum_k A[m][k] B[k][n]
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+    c = mfma_f64(a[ar + (l & 15)][ac + 4 * ks + (l >> 4)], b[br + 4 * ks + (l >> 4)][bc + (l & 15)], c);
+  return c;
+}
+
+__global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_t lda, int64_t J, double* D, double* X,
+                                                               int64_t ldx, int* info) {
+  __shared__ double a[64][PD_LD];  // the block: A -> L (lower), upper part zeroed at the end
+  __shared__ double x[64][PD_LD];  // L^-1 (lower)
+  __shared__ double s[64][PD_LD];  // products awaiting a second multiplication (inverse assembly)
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  double* Ajj = A + (J * 64) * lda + J * 64;
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    a[i][j] = Ajj[(int64_t)i * lda + j];
+    x[i][j] = 0.0;
+  }
+  __syncthreads();
+  for (int jb = 0; jb < 4; jb++) {
+    const int o = 16 * jb;
+    if (w == 0) {  // diagonal sub-block: lane i < 16 holds row i; pivots travel by v_readlane
+      double row[16];
+      const int i = l & 15;
+#pragma unroll
+      for (int k = 0; k < 16; k++) row[k] = a[o + i][o + k];
+      int bad = 0;
+      double rd[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const double djj = bbh_readlane_f64(row[j], j);
+        bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
+        double rs = __builtin_amdgcn_rsq(djj);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rd[j] = rs;  // wave-uniform 1 / l_jj
+        row[j] = (i == j) ? djj * rs : row[j] * rs;
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) {
+          const double lkj = bbh_readlane_f64(row[j], k);
+          row[k] = fma(-row[j], lkj, row[k]);  // meaningful for i >= k
+        }
+      }
+      if (l == 0 && bad) atomicCAS(info, 0, (int)(J * 64 + o + bad));
+      if (l < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
+      }
+      // inverse of the 16 x 16 factor: lane c < 16 owns column c (forward substitution, L rows by readlane)
+      double xc[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; k++) acc = fma(-bbh_readlane_f64(row[k], r), xc[k], acc);  // l_rk = row r, entry k
+        xc[r] = (r >= i) ? acc * rd[r] : 0.0;
+      }
+      if (l < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[o + r][o + i] = xc[r];
+      }
+    }
+    __syncthreads();
+    // panel: L_IJ = A_IJ T_J^T for the sub-blocks below the diagonal one, one wave each, in place (a wave's LDS
+    // operations complete in order: its operand reads precede its writes)
+    for (int ib = jb + 1 + w; ib < 4; ib += 4) {
+      const d4 c = pd_mul_nt(a, 16 * ib, o, x, o, o, l);
+#pragma unroll
+      for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][o + (l & 15)] = c[r];
+    }
+    __syncthreads();
+    // trailing update: A_IK -= L_IJ L_KJ^T for jb < K <= I (at most 6 sub-blocks, dealt to the waves)
+    int cnt = 0;
+    for (int ib = jb + 1; ib < 4; ib++)
+      for (int kb = jb + 1; kb <= ib; kb++, cnt++) {
+        if ((cnt & 3) != w) continue;
+        const d4 c = pd_mul_nt(a, 16 * ib, o, a, 16 * kb, o, l);
+#pragma unroll
+        for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][16 * kb + (l & 15)] -= c[r];
+      }
+    __syncthreads();
+  }
+  // zero the strict upper triangle of L
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    if (j > i) a[i][j] = 0.0;
+  }
+  __syncthreads();
+  // L^-1 by block columns: X_IJ = -T_I (sum_{K=J}^{I-1} L_IK X_KJ), wave J owns block column J (rows I = J+1..3 in turn)
+  {
+    const int jb = w, oj = 16 * jb;
+    for (int ib = jb + 1; ib < 4; ib++) {
+      d4 c = {0.0, 0.0, 0.0, 0.0};
+      for (int kb = jb; kb < ib; kb++) c = pd_mul_nn(a, 16 * ib, 16 * kb, x, 16 * kb, oj, l, c);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[16 * ib + (l >> 4) + 4 * r][oj + (l & 15)] = c[r];
+      // (wave-private region of s and x: block column jb; LDS operations of one wave complete in order)
+      d4 e = {0.0, 0.0, 0.0, 0.0};
+      e = pd_mul_nn(x, 16 * ib, 16 * ib, s, 16 * ib, oj, l, e);  // T_I is the diagonal sub-block of x
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[16 * ib + (l >> 4) + 4 * r][oj + (l & 15)] = -e[r];
+    }
+  }
+  __syncthreads();
+  double* Xjj = X + (J * 64) * ldx + J * 64;
+  double* Dj = D + J * 4096;
+  for (int e = t; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ajj[(int64_t)r * lda + c] = a[r][c];
+    const double xv = x[r][c];
+    Dj[e] = xv;
+    Xjj[(int64_t)r * ldx + c] = xv;
+  }
+}
+
 void bbh_potrf_trtri(bbh_handle* h) {
   hipStream_t s = h->stream;
   const int64_t np = h->np, nbk = np / 64;
@@ -205,7 +340,10 @@ void bbh_potrf_trtri(bbh_handle* h) {
   hipMemsetAsync(h->d_info, 0, sizeof(int), s);
   double* A = h->d_K;
   for (int64_t J = 0; J < nbk; J++) {
-    hipLaunchKernelGGL(bbh_potrf_diag_kernel, dim3(1), dim3(256), 0, s, A, np, J, h->d_D, h->d_X, np, h->d_info);
+    if (h->potrf_register_form)  // env BBH_POTRF_REG=1: the one-wave register form (A/B)
+      hipLaunchKernelGGL(bbh_potrf_diag_kernel, dim3(1), dim3(256), 0, s, A, np, J, h->d_D, h->d_X, np, h->d_info);
+    else
+      hipLaunchKernelGGL(bbh_potrf_diag16_kernel, dim3(1), dim3(256), 0, s, A, np, J, h->d_D, h->d_X, np, h->d_info);
     const int64_t rem = nbk - J - 1;
     if (rem > 0) {
       double* A21 = A + ((J + 1) * 64) * np + J * 64;

@@ -210,7 +210,7 @@ int bbh_pack_operands(bbh_handle* h) {
   h->coop_ready = false;
   {
     const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
-    if (h->use_coop && h->use_pipeline && nb <= 4 * BBH_COOP_ROUNDS && nb % 4 == 0 &&
+    if (h->coop_mode > 0 && h->use_pipeline && nb <= 4 * BBH_COOP_ROUNDS && nb % 4 == 0 &&
         bbh_coop_launch(h->kd, h->desc.kernel_kind, has_tbl0, dim3(0), 0, nullptr, CoopArgs{})) {
       const int g0 = BBH_COOP_ROUNDS - (int)(nb / 4);
       const int64_t frags = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(g0);
@@ -361,7 +361,11 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     a.slab_flags = h->d_slab_flags;
   }
   bbh_timed_scope timed(h, with_var ? BBH_TIMED_POSTERIOR : BBH_TIMED_CROSS);
-  if (h->coop_ready && kdp && with_var && a.mean_valu && !a.qz) {  // variance pass without pending columns, n <= 512
+  // Cooperative form (n <= 512, variance pass without pending columns): ahead of the windowed form once a second
+  // 16-block window would be needed (n > 256: 4.70 vs 5.17 ms on the bench shape), level at n = 256, a few per cent behind
+  // below; for small candidate sets its four waves per tile cut the latency to a third (0.016 vs 0.052 ms for 1000 rows).
+  const bool coop_pays = h->coop_mode == 2 || h->nb > 16 || N <= 16384;
+  if (h->coop_ready && coop_pays && kdp && with_var && a.mean_valu && !a.qz) {
     CoopArgs ca;
     ca.f = a;
     ca.rstream = h->d_rstream;

@@ -293,7 +293,9 @@ def test_golden_fixture(gp, name):
     assert np.allclose(_np(s), g["scores"], rtol=0, atol=SCORE_ATOL)
     sf, mf, vf = gp.score_qlogei(g["X"], g["z1"], float(g["best_f"]), sign)  # fused posterior + qLogEI
     assert np.allclose(_np(sf), g["scores"], rtol=0, atol=SCORE_ATOL)
-    assert torch.equal(mf, m) and torch.equal(vf, v)
+    # (the stand-alone posterior may run the cooperative kernel form, the fused epilogue always runs the windowed one:
+    #  same values up to the summation order of ||v||^2)
+    assert torch.allclose(mf, m, rtol=1e-12, atol=1e-13) and torch.allclose(vf, v, rtol=1e-11, atol=1e-15)
     sf2, none_m, _ = gp.score_qlogei(g["X"], g["z1"], float(g["best_f"]), sign, want_posterior=False)
     assert none_m is None and torch.equal(sf2, sf)
     assert gp.argmax(s)[1] == int(np.argmax(g["scores"]))
