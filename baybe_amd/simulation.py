@@ -117,3 +117,50 @@ def simulate_experiment(campaign, lookup, /, *, batch_size: int = 1, n_doe_itera
         results[f"{t.name}_IterBest"] = iterbest
         results[f"{t.name}_CumBest"] = iterbest[_cumargmax(np.max(tr, axis=1))]
     return results
+
+
+_DEFAULT_SEED = 1337  # baybe/simulation/scenarios.py:23
+
+
+def _rollout_cases(n_mc_iterations, n_initial_data, random_seed) -> list[dict]:
+    """``_Rollouts.cases`` (simulation/scenarios.py:26-91): seeds count up from the first one; with
+    ``n_mc_iterations=None`` every initial data set is paired with its own seed, otherwise seeds x data sets."""
+    first = _DEFAULT_SEED if random_seed is None else int(random_seed)
+    if n_mc_iterations is None:
+        if n_initial_data is None:
+            raise ValueError(
+                "Setting the number of Monte Carlo iterations to `None` requires that initial data is specified. "
+                "Perhaps you forgot to do so? If not, consider setting the number of iterations to 1."
+            )
+        return [{"Random_Seed": first + i, "Initial_Data": i} for i in range(n_initial_data)]
+    if int(n_mc_iterations) < 1:
+        raise ValueError("n_mc_iterations must be >= 1")
+    data = range(n_initial_data) if n_initial_data else [float("nan")]
+    return [{"Random_Seed": first + s, "Initial_Data": i} for s in range(int(n_mc_iterations)) for i in data]
+
+
+def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe_iterations: int | None = None,
+                       initial_data: list | None = None, n_mc_iterations: int | None = 1, random_seed: int | None = None,
+                       impute_mode: str = "error") -> pd.DataFrame:
+    """``baybe.simulation.scenarios.simulate_scenarios`` (simulation/scenarios.py:94-232) for discrete GP campaigns:
+    every scenario (a campaign) is run once per rollout case (random seed x initial data set) through
+    ``simulate_experiment``; the result frames are concatenated with the leading columns ``Scenario``, ``Random_Seed``
+    and ``Initial_Data`` (NaN without initial data), as the reference's ``unpack_simulation_results`` does.
+
+    The reference fans the cases out to worker processes (xyzpy) when ``parallelize_simulation_runs`` is set; here they
+    run one after the other on the device, where a case is a few milliseconds per iteration, and the recommender
+    objects of the scenarios keep their device handles (each case works on a deep copy of the campaign's host state
+    only).  ``groupby`` partitions and ``noise_percent`` of the reference are not part of this driver."""
+    if not scenarios:
+        raise ValueError("no scenarios given")
+    cases = _rollout_cases(n_mc_iterations, len(initial_data) if initial_data is not None else None, random_seed)
+    frames = []
+    for name, campaign in scenarios.items():
+        for case in cases:
+            idx = case["Initial_Data"]
+            data = None if initial_data is None else initial_data[int(idx)]
+            res = simulate_experiment(campaign, lookup, batch_size=batch_size, n_doe_iterations=n_doe_iterations,
+                                      initial_data=data, random_seed=case["Random_Seed"], impute_mode=impute_mode)
+            head = pd.DataFrame({"Scenario": name, "Random_Seed": case["Random_Seed"], "Initial_Data": idx}, index=res.index)
+            frames.append(pd.concat([head, res], axis=1))
+    return pd.concat(frames, ignore_index=True)

@@ -171,3 +171,20 @@ def test_lookup_dataframe_callable_and_impute_modes():
     look_up_targets(qq, [T("y")], lambda df: pd.DataFrame({"y": df["x"] * 2.0}, index=df.index))
     assert qq["y"].tolist() == [6.0, 8.0]
     assert _cumargmax(np.array([1.0, 3.0, 2.0, 3.0, 5.0])).tolist() == [0, 1, 1, 3, 4]
+
+
+def test_scenario_rollout_cases_and_content_hash():
+    """``_Rollouts.cases`` of simulation/scenarios.py:26-91 and the content key of the resident candidate matrix."""
+    from baybe_amd.recommenders import _content_hash
+    from baybe_amd.simulation import _rollout_cases
+
+    assert _rollout_cases(2, 2, 11) == [{"Random_Seed": 11, "Initial_Data": 0}, {"Random_Seed": 11, "Initial_Data": 1},
+                                        {"Random_Seed": 12, "Initial_Data": 0}, {"Random_Seed": 12, "Initial_Data": 1}]
+    assert [c["Random_Seed"] for c in _rollout_cases(None, 3, None)] == [1337, 1338, 1339]
+    assert len(_rollout_cases(3, None, 5)) == 3 and all(np.isnan(c["Initial_Data"]) for c in _rollout_cases(3, None, 5))
+    with pytest.raises(ValueError):
+        _rollout_cases(None, None, 1)
+    a = np.random.default_rng(0).random((5000, 7))
+    h = _content_hash(a)
+    a[4321, 5] += 1e-12  # any row, any column
+    assert _content_hash(a) != h and _content_hash(a) == _content_hash(a.copy())

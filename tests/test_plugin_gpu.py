@@ -437,3 +437,39 @@ def test_substance_search_spaces_get_the_chen_components():
     plain.fit(SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(3)]), obj,
               meas.rename(columns={"s0": "x0"}))
     assert not plain.engine.spec.use_outputscale and plain.engine.spec.noise_constraint == "box"
+
+
+def test_simulate_scenarios_runs_every_case_and_matches_single_runs():
+    """``simulate_scenarios`` (simulation/scenarios.py:94-232): scenarios x random seeds x initial data sets, each case
+    equal to the ``simulate_experiment`` run with that seed; leading columns as the reference's result frame."""
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from baybe_amd.simulation import simulate_experiment, simulate_scenarios
+
+    rng = np.random.default_rng(8)
+    space = _space3()
+    exp = space.discrete.exp_rep
+
+    def truth(df):
+        X = df[["x0", "x1", "x2"]].to_numpy(dtype=float)
+        return pd.DataFrame({"yield": -((X - 0.6) ** 2).sum(1) + 0.1 * np.cos(4.0 * X[:, 0])}, index=df.index)
+
+    inits = []
+    for _ in range(2):
+        init = exp.iloc[rng.choice(len(exp), 10, replace=False)].copy()
+        init["yield"] = truth(init)["yield"]
+        inits.append(init)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    scenarios = {"qLogEI": Campaign(space, obj, HipBotorchRecommender()),
+                 "qUCB": Campaign(space, obj, HipBotorchRecommender(acquisition_function="qUCB"))}
+    res = simulate_scenarios(scenarios, truth, batch_size=2, n_doe_iterations=3, initial_data=inits, n_mc_iterations=2,
+                             random_seed=11)
+    assert list(res.columns[:3]) == ["Scenario", "Random_Seed", "Initial_Data"]
+    assert len(res) == 2 * 2 * 2 * 3 and set(res["Random_Seed"]) == {11, 12} and set(res["Initial_Data"]) == {0, 1}
+    one = simulate_experiment(scenarios["qUCB"], truth, batch_size=2, n_doe_iterations=3, initial_data=inits[1], random_seed=12)
+    sel = res[(res["Scenario"] == "qUCB") & (res["Random_Seed"] == 12) & (res["Initial_Data"] == 1)].reset_index(drop=True)
+    assert sel["yield_Measurements"].tolist() == one["yield_Measurements"].tolist()
+    assert np.allclose(sel["yield_CumBest"], one["yield_CumBest"])
+    paired = simulate_scenarios({"a": scenarios["qLogEI"]}, truth, n_doe_iterations=2, initial_data=inits, n_mc_iterations=None)
+    assert paired[["Random_Seed", "Initial_Data"]].drop_duplicates().to_numpy().tolist() == [[1337, 0], [1338, 1]]
+    with pytest.raises(ValueError):
+        simulate_scenarios({"a": scenarios["qLogEI"]}, truth, n_mc_iterations=None)
