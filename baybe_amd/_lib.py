@@ -124,6 +124,7 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, c_double_p, c_int64_p, c_double_p],
     ),
+    "bbh_last_posterior_form": (C.c_int, [C.c_void_p]),
     "bbh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bbh_timing_read": (C.c_int, [C.c_void_p, c_double_p, c_int64_p, C.c_int]),
     "bbh_timing_read_family": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p, C.c_int]),

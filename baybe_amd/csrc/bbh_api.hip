@@ -189,6 +189,8 @@ extern "C" int bbh_train_posterior_mean(bbh_handle* h, double* mean_host) {
 }
 
 // ---- instrumentation ------------------------------------------------------------------------
+extern "C" int bbh_last_posterior_form(bbh_handle* h) { return h ? h->last_form : -1; }
+
 extern "C" int bbh_timing_enable(bbh_handle* h, int enable) {
   if (!h) return -1;
   h->timing = enable != 0;

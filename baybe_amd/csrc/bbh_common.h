@@ -114,6 +114,7 @@ struct bbh_handle {
   double* d_rstream = nullptr;    // [4 waves][rstream_frags][64]
   int64_t rstream_frags = 0;
   int coop_g0 = 0;
+  int last_form = -1;             // bbh_last_posterior_form
   bool use_w32 = false;           // env BBH_W32=1: one-wave-per-SIMD form where instantiated (A/B; measured slower so far)
   int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
   // pending state

@@ -373,9 +373,11 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     ca.g0 = h->coop_g0;
     const size_t clds = sizeof(double) * (16 * (size_t)h->nb + 2 * 4 * 256 + 128);
     bbh_coop_launch(kdp, a.kind, has_tbl, dim3((unsigned)((N + 15) / 16)), clds, h->stream, ca);
+    h->last_form = 1;
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;
   }
+  if (with_var) h->last_form = 0;
   if (h->wmax == 32 && with_var && !(kdp && a.mean_valu)) {
     h->err = "BBH_W32=1 (experimental one-wave-per-SIMD form): variance passes without pending columns only";
     return -6;

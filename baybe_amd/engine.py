@@ -455,6 +455,10 @@ class HipGP:
         return val.value, gidx.value, row
 
     # ---- instrumentation ------------------------------------------------------------------
+    def posterior_kernel_form(self) -> str:
+        """Which form of the fused posterior kernel the last variance pass ran as."""
+        return {0: "windowed", 1: "cooperative"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
+
     def timing(self, enable: bool):
         self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")
 

@@ -183,6 +183,7 @@ def run(args):
     dt = time.perf_counter() - t0
     fused_ms, fused_launches = gp.timing_read(reset=True)
     gp.timing(False)
+    form = gp.posterior_kernel_form()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_dev else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -245,9 +246,10 @@ def run(args):
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
         "traffic": traffic,
-        "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json; algorithmic = %d; "
-                        "the excess is scratch traffic of 76 spilled VGPRs - the kernel is fp64-pipe bound)" % (rows_local * (8 * d + 16)),
-        "kernel": "bbh_fused_posterior_kernel",
+        "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/traffic.json); "
+                        "algorithmic = %d (read every candidate row once, write mean + variance)" % (rows_local * (8 * d + 16)),
+        "kernel": {"cooperative": "bbh_coop_posterior_kernel", "windowed": "bbh_fused_posterior_kernel"}.get(form, form),
+        "kernel_form": form,
         "avg_launch_ms": avg_ms,
         "launches": fused_launches,
         "flops_per_candidate": flops_per_cand,
