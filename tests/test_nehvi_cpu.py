@@ -121,3 +121,15 @@ def test_native_box_decomposition_equals_the_numpy_form(m, n, S):
     o2, lo2, ll2 = bd.pack_cells_native(obj, ref)
     assert np.array_equal(o1, o2) and np.array_equal(lo1, lo2)
     assert np.allclose(ll1, ll2, rtol=1e-14, atol=1e-15)
+
+
+def test_compute_ref_point_reproduces_the_references_doctest_values():
+    """The only known-answer values the reference holds on this path: the doctest of
+    ``_ExpectedHypervolumeImprovement.compute_ref_point`` (baybe/acquisition/acqfs.py:386-392)."""
+    from baybe_amd.nehvi import compute_ref_point
+    from oracle import nehvi_oracle as no
+
+    for fn in (compute_ref_point, no.compute_ref_point):
+        assert np.allclose(fn([[0, 10], [2, 20]], [True, True], 0.1), [-0.2, 9.0])
+        assert np.allclose(fn([[0, 10], [2, 20]], [True, False], 0.2), [-0.4, 22.0])
+        assert np.allclose(fn(np.array([[0.0, 10.0], [2.0, 20.0]])), [-0.2, 9.0])  # default: maximise everything, factor 0.1
