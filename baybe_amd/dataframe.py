@@ -1,0 +1,133 @@
+"""Search-space row matching for large discrete spaces (last item).
+
+``Campaign.add_measurements`` marks measured rows through ``fuzzy_row_match``
+(``baybe/campaign.py:366-370`` -> ``baybe/utils/dataframe.py:361-460``), which materialises, per parameter, a
+``len(right) x len(left)`` comparison / absolute-difference matrix: at 1e6 search-space rows and 20 parameters that is
+seconds and gigabytes for a handful of measurements, and it is paid on every call.  The semantics, however, are
+column-separable:
+
+* a categorical column matches where the values are equal;
+* a numerical column matches where ``|right - left|`` equals the minimum of that quantity over **all** left rows - i.e.
+  where the left value is (one of) the value(s) of that column nearest to the right value, independently of the other
+  columns;
+* a left row matches if every column matches; the first matching row (left order) is returned per right row, right rows
+  without a match are dropped, several matches raise a warning.
+
+So every left row can be reduced once to a mixed-radix integer key over per-column value codes (cached per search
+space: O(N p) once), and a right row to the key(s) of its nearest / equal codes (two per numerical column only in an
+exact tie); matching is then a sorted-key lookup, O(k p log N) per call.  Same signature and result as the reference
+function; ``FuzzyRowMatcher`` keeps the index for repeated calls against the same left frame.
+"""
+
+from __future__ import annotations
+
+import itertools
+import warnings
+from typing import Sequence
+
+import numpy as np
+import pandas as pd
+
+
+class SearchSpaceMatchWarning(UserWarning):
+    """``baybe.exceptions.SearchSpaceMatchWarning``: several search-space rows match one input row."""
+
+    def __init__(self, message: str, data: pd.DataFrame):
+        super().__init__(message)
+        self.data = data
+
+
+def _split_columns(parameters):
+    cat = [p.name for p in parameters if (not p.is_numerical and p.is_discrete)]
+    num = [p.name for p in parameters if (p.is_numerical and p.is_discrete)]
+    other = {p.name for p in parameters if not p.is_discrete}
+    provided = {p.name for p in parameters}
+    assert set(cat) | set(num) | other == provided, (
+        f"There are parameter types that would be silently ignored: {provided.difference(set(cat) | set(num) | other)}"
+    )
+    return cat, num
+
+
+class FuzzyRowMatcher:
+    """Index over the rows of ``left_df`` for repeated ``fuzzy_row_match`` calls with the same parameters."""
+
+    def __init__(self, left_df: pd.DataFrame, parameters: Sequence):
+        self.cat_cols, self.num_cols = _split_columns(parameters)
+        if diff := (set(self.cat_cols) | set(self.num_cols)).difference(left_df.columns):
+            raise ValueError(
+                f"For fuzzy row matching, all discrete parameters need to have a corresponding column in the left "
+                f"dataframe. Parameters not found: {diff})"
+            )
+        self.index = left_df.index
+        self.levels: dict[str, np.ndarray] = {}
+        radix = 1
+        keys = np.zeros(len(left_df), dtype=np.int64)
+        self.stride: dict[str, int] = {}
+        for col in self.cat_cols + self.num_cols:
+            values = np.asarray(left_df[col], dtype=np.float64) if col in self.num_cols else np.asarray(left_df[col])
+            levels, codes = np.unique(values, return_inverse=True)  # sorted levels: nearest-value search for numbers
+            if radix * max(len(levels), 1) >= 2**62:
+                raise OverflowError("the product of the parameter cardinalities does not fit a 64-bit row key")
+            self.levels[col], self.stride[col] = levels, radix
+            keys += codes.astype(np.int64) * radix
+            radix *= max(len(levels), 1)
+        self._order = np.argsort(keys, kind="stable")  # stable: the first left row of a key stays first
+        self._sorted = keys[self._order]
+
+    def _codes_for(self, col: str, values: np.ndarray) -> list[np.ndarray]:
+        """Per right value the left codes that match it in this column (empty: none)."""
+        levels = self.levels[col]
+        out = []
+        if col in self.num_cols:
+            v = np.asarray(values, dtype=np.float64)
+            if len(levels) == 0:
+                return [np.empty(0, dtype=np.int64) for _ in v]
+            pos = np.clip(np.searchsorted(levels, v), 1, max(len(levels) - 1, 1))
+            for x, p in zip(v, pos):
+                cand = np.unique(np.clip([p - 1, p], 0, len(levels) - 1))
+                diff = np.abs(x - levels[cand])
+                out.append(cand[diff == diff.min()].astype(np.int64))  # both neighbours in an exact tie; NaN: none
+        else:
+            lookup = {lv: i for i, lv in enumerate(levels.tolist())}
+            for x in np.asarray(values).tolist():
+                out.append(np.array([lookup[x]], dtype=np.int64) if x in lookup else np.empty(0, dtype=np.int64))
+        return out
+
+    def match(self, right_df: pd.DataFrame) -> pd.Index:
+        if diff := (set(self.cat_cols) | set(self.num_cols)).difference(right_df.columns):
+            raise ValueError(
+                f"For fuzzy row matching, all discrete parameters need to have a corresponding column in the right "
+                f"dataframe. Parameters not found: {diff})"
+            )
+        cols = self.cat_cols + self.num_cols
+        per_col = [self._codes_for(c, right_df[c].to_numpy()) for c in cols]
+        matched, multiple = [], []
+        for r in range(len(right_df)):
+            options = [per_col[ci][r] for ci in range(len(cols))]
+            first, count = None, 0
+            if all(len(o) for o in options):
+                for combo in itertools.product(*options):  # one combination unless a numerical value sits in an exact tie
+                    key = sum(int(code) * self.stride[c] for code, c in zip(combo, cols))
+                    lo, hi = np.searchsorted(self._sorted, key, "left"), np.searchsorted(self._sorted, key, "right")
+                    if hi > lo:
+                        count += int(hi - lo)
+                        pos = int(self._order[lo])
+                        first = pos if first is None or pos < first else first
+            elif not cols and len(self.index):  # no discrete parameter at all: every left row matches
+                first, count = 0, len(self.index)
+            if first is not None:
+                matched.append(first)
+                if count > 1:
+                    multiple.append(right_df.index[r])
+        if multiple:
+            warnings.warn(SearchSpaceMatchWarning(
+                f"Some input rows have multiple matches with the search space. Matching only first occurrence for these "
+                f"rows. Indices with multiple matches: {multiple}", right_df.loc[multiple]))
+        return pd.Index(self.index[np.asarray(matched, dtype=np.int64)]) if matched else pd.Index([], dtype=self.index.dtype)
+
+
+def fuzzy_row_match(left_df: pd.DataFrame, right_df: pd.DataFrame, parameters: Sequence) -> pd.Index:
+    """Drop-in for ``baybe.utils.dataframe.fuzzy_row_match`` (``utils/dataframe.py:361-460``): the index of the rows of
+    ``left_df`` matched by the rows of ``right_df``.  Builds the row index on every call; keep a ``FuzzyRowMatcher`` per
+    search space to pay for it once."""
+    return FuzzyRowMatcher(left_df, parameters).match(right_df)
