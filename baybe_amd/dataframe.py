@@ -13,9 +13,9 @@ column-separable:
 * a left row matches if every column matches; the first matching row (left order) is returned per right row, right rows
   without a match are dropped, several matches raise a warning.
 
-So every left row can be reduced once to a mixed-radix integer key over per-column value codes (cached per search
-space: O(N p) once), and a right row to the key(s) of its nearest / equal codes (two per numerical column only in an
-exact tie); matching is then a sorted-key lookup, O(k p log N) per call.  Same signature and result as the reference
+So every left row can be reduced once to a 64-bit key over its per-column value codes (cached per search space: O(N p)
+once), and a right row to the key(s) of its nearest / equal codes (two per numerical column only in an exact tie);
+matching is then a sorted-key lookup with an exact check of the codes, O(k p log N) per call.  Same signature and result as the reference
 function; ``FuzzyRowMatcher`` keeps the index for repeated calls against the same left frame.
 """
 
@@ -60,17 +60,19 @@ class FuzzyRowMatcher:
             )
         self.index = left_df.index
         self.levels: dict[str, np.ndarray] = {}
-        radix = 1
-        keys = np.zeros(len(left_df), dtype=np.int64)
-        self.stride: dict[str, int] = {}
-        for col in self.cat_cols + self.num_cols:
+        cols = self.cat_cols + self.num_cols
+        # Per-column value codes of every left row, and a 64-bit multiply-add hash of the code tuple as the row key
+        # (a mixed-radix key would overflow: 11^20 rows-worth of key space for a 20-parameter grid).  Hash collisions can
+        # only add candidates to a key's range - every candidate is checked against the codes - never lose a match.
+        self._codes = np.zeros((len(left_df), len(cols)), dtype=np.int32)
+        self._mult = (np.random.default_rng(0x5EED).integers(1, 2**63, size=len(cols), dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
+        keys = np.zeros(len(left_df), dtype=np.uint64)
+        for ci, col in enumerate(cols):
             values = np.asarray(left_df[col], dtype=np.float64) if col in self.num_cols else np.asarray(left_df[col])
             levels, codes = np.unique(values, return_inverse=True)  # sorted levels: nearest-value search for numbers
-            if radix * max(len(levels), 1) >= 2**62:
-                raise OverflowError("the product of the parameter cardinalities does not fit a 64-bit row key")
-            self.levels[col], self.stride[col] = levels, radix
-            keys += codes.astype(np.int64) * radix
-            radix *= max(len(levels), 1)
+            self.levels[col] = levels
+            self._codes[:, ci] = codes
+            keys += codes.astype(np.uint64) * self._mult[ci]  # wraps modulo 2^64
         self._order = np.argsort(keys, kind="stable")  # stable: the first left row of a key stays first
         self._sorted = keys[self._order]
 
@@ -107,11 +109,17 @@ class FuzzyRowMatcher:
             first, count = None, 0
             if all(len(o) for o in options):
                 for combo in itertools.product(*options):  # one combination unless a numerical value sits in an exact tie
-                    key = sum(int(code) * self.stride[c] for code, c in zip(combo, cols))
+                    code = np.asarray(combo, dtype=np.int32)
+                    key = np.uint64(0)
+                    with np.errstate(over="ignore"):
+                        for cv, mv in zip(code, self._mult):
+                            key = key + np.uint64(cv) * mv
                     lo, hi = np.searchsorted(self._sorted, key, "left"), np.searchsorted(self._sorted, key, "right")
-                    if hi > lo:
-                        count += int(hi - lo)
-                        pos = int(self._order[lo])
+                    rows = self._order[lo:hi]
+                    rows = rows[(self._codes[rows] == code[None, :]).all(axis=1)]  # drop hash collisions
+                    if len(rows):
+                        count += len(rows)
+                        pos = int(rows.min())
                         first = pos if first is None or pos < first else first
             elif not cols and len(self.index):  # no discrete parameter at all: every left row matches
                 first, count = 0, len(self.index)
