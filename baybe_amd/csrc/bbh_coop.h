@@ -43,6 +43,9 @@
 #ifndef BBH_COOP_ABLATE_MEM
 #define BBH_COOP_ABLATE_MEM 0  // timing experiment: every operand load hits the same 4 KB (L1-resident)
 #endif
+#ifndef BBH_COOP_ABLATE_PRO
+#define BBH_COOP_ABLATE_PRO 0  // timing experiments on the per-tile set-up: 1 no alpha fill, 2 no candidate-row loads, 4 no first production, 8 no epilogue
+#endif
 #ifndef BBH_COOP_ABLATE_LOADS
 #define BBH_COOP_ABLATE_LOADS 0  // timing experiment: no operand loads in the main loop at all
 #endif
@@ -190,7 +193,8 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   double* s_alpha = s_mem;
   double* s_kv = s_alpha + 16 * a.nb;
   double* s_red = s_kv + 2 * 4 * 256;
-  for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
+  if (!(BBH_COOP_ABLATE_PRO & 1))
+    for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
   const int64_t tile0 = (int64_t)blockIdx.x * 16;
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
     const int dim = 4 * k + q;
     double v = 0.0;
     if (dim < a.dn) {
-      v = fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
+      v = (BBH_COOP_ABLATE_PRO & 2) ? 0.01 * (double)(dim + cnd) : fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
       nbsum = fma(v, v, nbsum);
     }
     c.cf[k] = v;
@@ -244,12 +248,28 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   const bbh_lds_double* alq = (const bbh_lds_double*)(s_alpha + q);  // alpha[16 tb + 4 r + q]
   const int g0 = ca.g0;
   double accm = 0.0;
+  d4 acc[BBH_COOP_ROUNDS];
+#pragma unroll
+  for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
+  // wave-uniform stream pointer + lane index: scalar base / 32-bit lane offset addressing (no 64-bit VALU pointer
+  // arithmetic).  The first fragments are requested before the first kernel values are computed: their L2 latency
+  // passes under that work (the compiler's own wait for the training fragments below also covers these older loads).
+  const double* rs = ca.rstream + (int64_t)w * ca.frags * 64;
+  d2 ring[BBH_COOP_PAIRS];
+  static_for<0, BBH_COOP_PAIRS>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, (unsigned)l * 16u);
+  });
   {  // the first group's kernel values: wave w produces k-block w, not overlapped with anything
     double tfv[KD], kv0[4];
     d4 dsa, dsb;
-    kvp_load<KD>(c, w, tfv);
-    kvp_dist<KD>(c, tfv, dsa, dsb);
-    kv_all<KVF>(c, w, dsa, dsb, kv0);
+    if constexpr (BBH_COOP_ABLATE_PRO & 4) {
+      for (int r = 0; r < 4; r++) kv0[r] = 0.5 + 0.001 * (double)(l + r);
+    } else {
+      kvp_load<KD>(c, w, tfv);
+      kvp_dist<KD>(c, tfv, dsa, dsb);
+      kv_all<KVF>(c, w, dsa, dsb, kv0);
+    }
     __syncthreads();  // alpha is in LDS
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -257,16 +277,6 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
       accm = fma(kv0[r], alq[16 * w + 4 * r], accm);
     }
   }
-  d4 acc[BBH_COOP_ROUNDS];
-#pragma unroll
-  for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
-  // wave-uniform stream pointer + lane index: scalar base / 32-bit lane offset addressing (no 64-bit VALU pointer arithmetic)
-  const double* rs = ca.rstream + (int64_t)w * ca.frags * 64;
-  d2 ring[BBH_COOP_PAIRS];
-  static_for<0, BBH_COOP_PAIRS>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
-    coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, (unsigned)l * 16u);
-  });
   __syncthreads();  // group g0 is complete in LDS
 
   static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
@@ -285,6 +295,13 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   });
 
   // ---- ||v||^2 over this wave's column blocks, then over the 16 columns of a block (lanes), then over the waves ----
+  if constexpr (BBH_COOP_ABLATE_PRO & 8) {  // no reductions: one value per accumulator row keeps the work alive
+    double keep = accm;
+#pragma unroll
+    for (int s = 0; s < BBH_COOP_ROUNDS; s++) keep += (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
+    if (l == 0 && w == 0) a.var[tile0] = keep;
+    return;
+  }
   double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int s = 0; s < BBH_COOP_ROUNDS; s++)
