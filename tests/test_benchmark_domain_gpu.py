@@ -64,7 +64,7 @@ def test_hartmann_3d_discretized_convergence():
     last = res[res["Iteration"] == 9].groupby("Scenario")["target_CumBest"]
     hip, rnd = last.get_group("HIP Recommender"), last.get_group("Random Recommender")
     # minimisation: CumBest is the lowest value seen; 30 experiments out of 15 625 candidates per run
-    assert (hip < -3.6).all(), hip.tolist()  # within 7 % of the grid optimum in every run
-    assert hip.mean() < rnd.mean() - 0.5, (hip.tolist(), rnd.tolist())
+    assert (hip < grid_best + 0.05).all(), (hip.tolist(), grid_best)  # at (or next to) the grid optimum in every run
+    assert hip.mean() < rnd.mean() - 0.2, (hip.tolist(), rnd.tolist())  # random search: -3.2 / -3.5 after 30 draws
     curve = res[(res["Scenario"] == "HIP Recommender") & (res["Initial_Data"] == 0)]["target_CumBest"].to_numpy()
     assert (np.diff(curve) <= 1e-12).all()  # a convergence curve: monotone
