@@ -98,13 +98,17 @@ def run(args):
     # BENCH_SINGLE_DEVICE=1: dry run of the N > 1 code path on ONE GPU (all ranks on cuda:0, gloo
     # instead of RCCL) — used to test the sharded path where only one device is available.
     single_dev = os.environ.get("BENCH_SINGLE_DEVICE", "0") == "1"
+    # BENCH_FORCE_COLLECTIVE=1: initialise the process group and run the sharded code path (RowShard, all-gather per
+    # step, agreement broadcasts) even with one rank - the only way to drive the RCCL ("nccl") transport on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_COLLECTIVE", "0") == "1"
     if single_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         if single_dev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -141,7 +145,7 @@ def run(args):
     best_f = gp.best_f()
     z = engine.sobol_normal_base_samples(S, 1, 1234)[:, 0]
     Xd = torch.from_numpy(X).cuda()
-    shard = RowShard(total_rows, rank, world) if world > 1 else None
+    shard = RowShard(total_rows, rank, world) if dist_on else None
     if shard is not None and not args.strong:
         shard.start, shard.stop = rank * rows_local, (rank + 1) * rows_local
 
@@ -167,7 +171,7 @@ def run(args):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,7 +188,7 @@ def run(args):
     fused_ms, fused_launches = gp.timing_read(reset=True)
     gp.timing(False)
     form = gp.posterior_kernel_form()
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_dev else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -274,7 +278,7 @@ def run(args):
                         f"fixed-theta, top-{TOPK} to host",
             "global_rows": total_rows,
             "parallelism": f"row-shard x{world}",
-            "collective": "none" if world == 1 else ("rccl (library)" if use_rccl else "torch.distributed " + dist.get_backend()),
+            "collective": "none" if not dist_on else ("rccl (library)" if use_rccl else "torch.distributed " + dist.get_backend()),
         },
         "roofline": roofline,
         "extra": extra,
@@ -315,7 +319,7 @@ def run(args):
         out["extra"]["speedup_vs_cpu_baseline"] = value / cps
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

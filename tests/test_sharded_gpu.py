@@ -230,3 +230,29 @@ def test_library_rccl_entry_points_on_a_single_rank_communicator():
     ev, ei = gp.allgather_topk(s[:3], 0, 5)  # fewer rows than k: padded with (-inf, -1)
     assert ei[3:].tolist() == [-1, -1] and np.isneginf(ev[3:]).all() and set(ei[:3]) == {0, 1, 2}
     gp.close()
+
+
+@pytest.mark.parametrize("collective", ["torch", "rccl"])
+def test_bench_sharded_path_over_rccl_with_one_rank(collective):
+    """The transport the 8-GPU run uses, on the one GPU there is: ``init_process_group("nccl")`` with world size 1 and
+    the sharded code path forced (BENCH_FORCE_COLLECTIVE=1) - agreement broadcasts, the per-step all-gather on device
+    tensors (torch.distributed, or the library's own communicator with BBH_COLLECTIVE=rccl), barrier, max-reduce of the
+    time.  The selection must equal the single-process one."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_SINGLE_DEVICE")}
+    cmd = [sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--rows", "120000", "--cpu-budget", "0",
+           "--greedy", "3"]
+    recs = []
+    for env in (dict(base), dict(base, BENCH_FORCE_COLLECTIVE="1", BBH_COLLECTIVE=collective, MASTER_PORT=str(_free_port()))):
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        recs.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
+    plain, sharded = recs
+    assert plain["config"]["collective"] == "none"
+    assert sharded["config"]["collective"] == ("rccl (library)" if collective == "rccl" else "torch.distributed nccl")
+    assert sharded["extra"]["greedy_q3_indices"] == plain["extra"]["greedy_q3_indices"] and sharded["n_gpus"] == 1
