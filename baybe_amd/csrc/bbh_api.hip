@@ -36,6 +36,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_W32")) h->use_w32 = (e[0] != '0');
   if (const char* e = getenv("BBH_COOP")) h->coop_mode = atoi(e);
   if (const char* e = getenv("BBH_POTRF_REG")) h->potrf_register_form = (e[0] != '0');
+  if (const char* e = getenv("BBH_FIT_OVERLAP")) h->fit_overlap = (e[0] != '0');
   *out = h;
   return 0;
 }
@@ -54,6 +55,12 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   bbh_comm_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
+  if (h->side_stream) {
+    hipStreamSynchronize(h->side_stream);
+    hipStreamDestroy(h->side_stream);
+  }
+  for (auto& e : h->side_events)
+    if (e) hipEventDestroy(e);
   if (h->d_rstream) hipFree(h->d_rstream);
   if (h->d_kvcache) hipFree(h->d_kvcache);
   if (h->d_slab_flags) hipFree(h->d_slab_flags);

@@ -108,6 +108,9 @@ struct bbh_handle {
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
   int num_cu = 256;               // compute units of the device (sizes the slab pool of the kernel-value cache)
   int wmax = 16;                  // column blocks per pass of the fused kernel: 16 (two waves per SIMD) or 32 (one)
+  bool fit_overlap = true;        // env BBH_FIT_OVERLAP=0: the inverse of the factor strictly after the factorisation (A/B)
+  hipStream_t side_stream = nullptr;  // second stream of the fit (rows of L^-1 next to the trailing updates)
+  hipEvent_t side_events[2] = {nullptr, nullptr};
   bool potrf_register_form = false;  // env BBH_POTRF_REG=1: 64x64 diagonal blocks by the one-wave register kernel (A/B)
   int coop_mode = 1;              // env BBH_COOP: 0 never use the cooperative form, 1 where it pays (default), 2 wherever instantiated
   bool coop_ready = false;        // operand slices of the cooperative form are packed for the current factorisation

@@ -419,6 +419,7 @@ extern "C" int bbh_get_standardization(bbh_handle* h, double* ybar, double* ysd)
 }
 
 // K -> L, X = L^-1, r, alpha.  Returns the Cholesky info flag (0 ok) via *info_out.
+// info_out == nullptr: nothing is read back here (the caller fetches d_info together with its own results)
 static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
   hipStream_t s = h->stream;
   const int64_t np = h->np;
@@ -428,6 +429,7 @@ static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
                      (int)h->n, (int)np, h->d_r);
   bbh_matvec(s, h->d_X, np, np, np, h->d_r, h->d_t);        // t = L^-1 r
   bbh_matvec_t(s, h->d_X, np, np, np, h->d_t, h->d_alpha);  // alpha = L^-T t
+  if (!info_out) return 0;
   int info = 0;
   BBH_HIP_TRY(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
@@ -448,14 +450,10 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
   hipStream_t s = h->stream;
   const int64_t np = h->np, n = h->n;
   const int64_t tl = bbh_theta_len(h);
-  int info = 0;
-  rc = bbh_chol_and_alpha(h, 0.0, &info);
+  // One host synchronisation per evaluation: the Cholesky flag is fetched with the results at the end (after a failed
+  // factorisation the remaining kernels run on NaNs, harmlessly, and the outcome is discarded).
+  rc = bbh_chol_and_alpha(h, 0.0, nullptr);
   if (rc) return rc;
-  if (info != 0) {
-    *value_host = -INFINITY;
-    for (int64_t i = 0; i < tl; i++) grad_host[i] = 0.0;
-    return 1;
-  }
   // M = X^T X
   bbh_gemm(s, true, false, np, np, np, 1.0, h->d_X, np, 0, h->d_X, np, 0, 0.0, h->d_M, np, 0, 1);
   const int crit = h->desc.criterion;
@@ -477,8 +475,15 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
   hipLaunchKernelGGL(bbh_grad_reduce_kernel, dim3((unsigned)tl), dim3(256), 0, s, h->d_partial,
                      (int64_t)n * nchunks * 4, (int)tl, h->d_out);
   std::vector<double> out(1 + tl);
+  int info = 0;
   BBH_HIP_TRY(h, hipMemcpyAsync(out.data(), h->d_out, sizeof(double) * (1 + tl), hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  if (info != 0) {
+    *value_host = -INFINITY;
+    for (int64_t i = 0; i < tl; i++) grad_host[i] = 0.0;
+    return 1;
+  }
   *value_host = out[0];
   for (int64_t i = 0; i < tl; i++) grad_host[i] = out[1 + i];
   return 0;
