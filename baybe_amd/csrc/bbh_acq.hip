@@ -212,7 +212,8 @@ __device__ __forceinline__ double bbh_fast_log_pos(double x) {
   return (x < INFINITY) ? r2 : x;  // log(inf) = inf (NaN propagates)
 }
 
-// Register-resident form of the kernel above for q' = Q <= 8 (the usual batch sizes): the packed Cholesky
+// Register-resident form of the kernel above for q' = Q <= 14 (208 VGPRs at Q = 8, 2 waves per SIMD from Q = 9,
+// 1 from Q = 10, no spills up to Q = 14; Q = 15, 16 spill and run no faster than the LDS form): the packed Cholesky
 // factor (Q (Q + 1) / 2 doubles) and the per-sample values live in registers (every index is a
 // compile-time constant), the base samples z [S, Q] in LDS (broadcast reads).  The LDS form needs 69 KB
 // per 64 threads - one wave per two SIMDs - and took 30 ms per greedy step on 1e6 candidates, six times the
@@ -507,6 +508,12 @@ extern "C" int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const d
     BBH_PENDING_Q(6)
     BBH_PENDING_Q(7)
     BBH_PENDING_Q(8)
+    BBH_PENDING_Q(9)
+    BBH_PENDING_Q(10)
+    BBH_PENDING_Q(11)
+    BBH_PENDING_Q(12)
+    BBH_PENDING_Q(13)
+    BBH_PENDING_Q(14)
     default:
       hipLaunchKernelGGL(bbh_qlogei_pending_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, mean_dev,
                          var_dev, cross_dev, N, p, dmp, dcpp, dz, (int)S, best_f, sign, alive_dev, scores_dev);
@@ -989,7 +996,7 @@ __global__ __launch_bounds__(64) void bbh_mc_pending_kernel(int kind, const doub
   scores[i] = sum / (double)S;
 }
 
-// Register-resident form of bbh_mc_pending_kernel for q' = Q <= 8 (see bbh_qlogei_pending_q_kernel): same
+// Register-resident form of bbh_mc_pending_kernel for q' = Q <= 14 (see bbh_qlogei_pending_q_kernel): same
 // arithmetic in the same order, factor and per-point values in registers, base samples in LDS.
 template <int Q>
 __global__ __launch_bounds__(256) void bbh_mc_pending_q_kernel(int kind, const double* __restrict__ mean,
@@ -1207,6 +1214,12 @@ extern "C" int bbh_mc_acq_pending(bbh_handle* h, int32_t kind, const double* mea
     BBH_MC_PENDING_Q(6)
     BBH_MC_PENDING_Q(7)
     BBH_MC_PENDING_Q(8)
+    BBH_MC_PENDING_Q(9)
+    BBH_MC_PENDING_Q(10)
+    BBH_MC_PENDING_Q(11)
+    BBH_MC_PENDING_Q(12)
+    BBH_MC_PENDING_Q(13)
+    BBH_MC_PENDING_Q(14)
     default:
       hipLaunchKernelGGL(bbh_mc_pending_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, kind, mean_dev,
                          var_dev, cross_dev, N, p, dmp, dcpp, dz, dzb, (int)S, best_f, sign, cu, alive_dev, scores_dev);
