@@ -35,6 +35,7 @@ class ModelDesc(C.Structure):
         ("n_tasks", C.c_int32),
         ("use_outputscale", C.c_int32),
         ("criterion", C.c_int32),
+        ("hadamard", C.c_int32),
     ]
 
 

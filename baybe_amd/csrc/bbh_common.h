@@ -51,6 +51,7 @@ struct bbh_handle {
   int dn = 0;         // numerical columns
   int kd = 0;         // k-steps of the augmented distance GEMM: ceil((dn+2)/4)
   int T = 1;          // tasks
+  bool hadamard = false;  // per-task noise and mean (theta tail), see bbh_model_desc
   std::vector<int> numcol;        // numerical column -> comp-rep column
   std::vector<double> lo, hi;     // per numerical column
   double ybar = 0.0, ysd = 1.0;
@@ -198,6 +199,7 @@ void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int
 // ---- model (bbh_model.hip) --------------------------------------------------------------
 int bbh_upload_theta(bbh_handle* h, const double* theta_host);
 void bbh_launch_gram(bbh_handle* h, double jitter);
+int bbh_hadamard_offset(const bbh_handle* h);  // per-task noise block in theta (means follow at + T), -1 = none
 
 // ---- fused posterior (bbh_panel.hip) ----------------------------------------------------
 int bbh_pack_operands(bbh_handle* h);   // trainfrag, rfrag, meanB, tables (after factorize / pending_set)

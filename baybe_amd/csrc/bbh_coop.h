@@ -333,19 +333,20 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
     if (gi < a.N) {
       const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
       const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
-      if (a.mean) a.mean[gi] = a.ybar + a.ysd * (a.mean_const + sm);
-      double pv = a.prior_scale;
+      double pv = a.prior_scale, mc = a.mean_const;
       if constexpr ((KVF & 1) != 0) {
         const int tcm = __shfl(tc, m, 64);  // lane m of wave 0 holds candidate m's task (cnd = m, q = 0)
         pv = a.tasktbl[tcm * a.T + tcm];
+        if (a.taskmean) mc = a.taskmean[tcm];
       }
+      if (a.mean) a.mean[gi] = a.ybar + a.ysd * (mc + sm);
       if (a.var) a.var[gi] = a.ysd * a.ysd * (pv - sv);
     }
   }
 }
 
 // Instantiations (bbh_fused_coop_a.hip: 2, 4, 6 k-steps of the distance GEMM; _b: 8, 12, 16): Matérn-5/2 with and
-// without the task / outputscale table, RBF and Matérn-3/2 without - the set of the windowed pipelined form.
+// without the task / outputscale table, RBF with and without, Matérn-3/2 without.
 // false: no instantiation for this model; grid.x == 0 only asks.
 bool bbh_coop_launch(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_a(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
@@ -353,10 +354,12 @@ bool bbh_coop_launch_b(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hi
 
 #define BBH_COOP_DISPATCH_KD(KDV)                                                                                        \
   if (kd == KDV) {                                                                                                       \
-    const bool m52 = kind == BBH_KERNEL_MATERN52, plain = (kind == BBH_KERNEL_RBF || kind == BBH_KERNEL_MATERN32) && !has_tbl; \
-    if (!m52 && !plain) return false;                                                                                    \
+    const bool m52 = kind == BBH_KERNEL_MATERN52, rbf = kind == BBH_KERNEL_RBF, plain = kind == BBH_KERNEL_MATERN32 && !has_tbl; \
+    if (!m52 && !rbf && !plain) return false;                                                                            \
     if (grid.x == 0) return true;                                                                                        \
-    if (kind == BBH_KERNEL_RBF)                                                                                          \
+    if (rbf && has_tbl) /* multi-task HVARFNER / BOTORCH presets */                                                      \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 3>), grid, dim3(256), lds, s, a);                               \
+    else if (rbf)                                                                                                        \
       hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 2>), grid, dim3(256), lds, s, a);                               \
     else if (kind == BBH_KERNEL_MATERN32)                                                                                \
       hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 4>), grid, dim3(256), lds, s, a);                               \

@@ -32,6 +32,7 @@ struct FusedArgs {
   const double* ofs;
   const int* numcol;
   const double* tasktbl;
+  const double* taskmean;  // [T] per-task constant means (hadamard models), nullptr = mean_const for every task
   const int* taskext;
   double* mean;
   double* var;
@@ -835,7 +836,8 @@ __global__ __launch_bounds__(256, (WMAX > 16 ? 1 : 2)) void bbh_fused_posterior_
     const int64_t gi = tile0 + m;
     double pv = a.prior_scale;
     if (has_tbl) pv = a.tasktbl[tcm * a.T + tcm];
-    mval[r] = a.ybar + a.ysd * (a.mean_const + accm[r]);  // meaningful in the cnd == 0 lanes
+    const double mc = (has_tbl && a.taskmean) ? a.taskmean[tcm] : a.mean_const;
+    mval[r] = a.ybar + a.ysd * (mc + accm[r]);  // meaningful in the cnd == 0 lanes
     vval[r] = s2 * (pv - ss[r]);
     if (gi < a.N) {
       if (cnd == 0) {

@@ -27,7 +27,8 @@ __device__ __forceinline__ double bbh_gfun(int kind, double r2) {
   return r > 0.0 ? exp(-r) / r : 0.0;
 }
 
-// theta layout: [noise, mean, outputscale, ls[dn], B[T*T]]
+// theta layout: [noise, mean, outputscale, ls[dn], B[T*T], (hadamard: noise_t[T], mean_t[T])]
+// hoff = offset of noise_t (mean_t follows at hoff + T), -1 = the scalar slots are in use
 #define TH_NOISE 0
 #define TH_MEAN 1
 #define TH_OS 2
@@ -59,7 +60,7 @@ int bbh_upload_theta(bbh_handle* h, const double* theta_host) {
 __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict__ xnT, const int* __restrict__ task,
                                                        const double* __restrict__ nmask,
                                                        const double* __restrict__ theta, int n, int np, int dn,
-                                                       int kind, int use_os, int T, double jitter,
+                                                       int kind, int use_os, int T, int hoff, double jitter,
                                                        double* __restrict__ K) {
   extern __shared__ double s_invls[];
   for (int j = threadIdx.x; j < dn; j += blockDim.x) s_invls[j] = 1.0 / theta[TH_LS + j];
@@ -79,21 +80,21 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
   double k = bbh_kfun(kind, r2);
   if (use_os) k *= theta[TH_OS];
   if (T > 1) k *= theta[TH_LS + dn + task[a] * T + task[b]];
-  if (a == b) k += theta[TH_NOISE] * nmask[a] + jitter;
+  if (a == b) k += (hoff >= 0 ? theta[hoff + task[a]] : theta[TH_NOISE]) * nmask[a] + jitter;
   K[(int64_t)a * np + b] = k;
 }
 
 void bbh_launch_gram(bbh_handle* h, double jitter) {
   dim3 grid((unsigned)((h->np + 255) / 256), (unsigned)h->np), block(256);
   hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn, h->stream, h->d_xnT, h->d_task, h->d_nmask, h->d_theta,
-                     (int)h->n, (int)h->np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T, jitter,
+                     (int)h->n, (int)h->np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T, bbh_hadamard_offset(h), jitter,
                      h->d_K);
 }
 
-__global__ void bbh_resid_kernel(const double* __restrict__ ystd, const double* __restrict__ theta, int n, int np,
-                                 double* __restrict__ r) {
+__global__ void bbh_resid_kernel(const double* __restrict__ ystd, const double* __restrict__ theta,
+                                 const int* __restrict__ task, int T, int hoff, int n, int np, double* __restrict__ r) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < np) r[i] = (i < n) ? ystd[i] - theta[TH_MEAN] : 0.0;
+  if (i < np) r[i] = (i < n) ? ystd[i] - (hoff >= 0 ? theta[hoff + T + task[i]] : theta[TH_MEAN]) : 0.0;
 }
 
 // LOO helper vectors: d = diag(M), u = 0.5/d + 0.5 alpha^2/d^2, w = alpha/d (0 on padding)
@@ -132,7 +133,8 @@ __device__ __forceinline__ double bbh_block_sum_256(double v, double* sm) {
 __global__ __launch_bounds__(256) void bbh_value_kernel(const double* __restrict__ L, const double* __restrict__ M,
                                                         const double* __restrict__ r,
                                                         const double* __restrict__ alpha,
-                                                        const double* __restrict__ q, int n, int np, int criterion,
+                                                        const double* __restrict__ q, const int* __restrict__ task,
+                                                        int T, int hoff, int n, int np, int criterion,
                                                         double* __restrict__ out) {
   __shared__ double sm[4];
   double v = 0.0, gm = 0.0;
@@ -150,7 +152,15 @@ __global__ __launch_bounds__(256) void bbh_value_kernel(const double* __restrict
   gm = bbh_block_sum_256(gm, sm);
   if (threadIdx.x == 0) {
     out[0] = v - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
-    out[1 + TH_MEAN] = gm;
+    out[1 + TH_MEAN] = hoff >= 0 ? 0.0 : gm;
+  }
+  if (hoff < 0) return;
+  for (int t = 0; t < T; t++) {  // per-task constant means: d/dc_t = the same sum over the task's points
+    double gt = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256)
+      if (task[i] == t) gt += (criterion == BBH_CRITERION_MLL) ? alpha[i] : q[i];
+    gt = bbh_block_sum_256(gt, sm);
+    if (threadIdx.x == 0) out[1 + hoff + T + t] = gt;
   }
 }
 
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void bbh_value_kernel(const double* __restrict
 __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     const double* __restrict__ xnT, const int* __restrict__ task, const double* __restrict__ nmask,
     const double* __restrict__ theta, const double* __restrict__ M, const double* __restrict__ Q, const double* __restrict__ alpha,
-    const double* __restrict__ q, int n, int np, int dn, int kind, int use_os, int T, int criterion, int nslots,
+    const double* __restrict__ q, int n, int np, int dn, int kind, int use_os, int T, int hoff, int criterion, int nslots,
     double* __restrict__ partial) {
   const int a = blockIdx.x;
   const int b = blockIdx.y * 256 + threadIdx.x;
@@ -177,13 +187,13 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   else
     G = -Q[(int64_t)a * np + bb] + 0.5 * (alpha[a] * q[bb] + alpha[bb] * q[a]);
   if (!act) G = 0.0;
+  const int ta = (T > 1) ? task[a] : 0, tb = (T > 1) ? task[bb] : 0;
   double r2 = 0.0;
   for (int j = 0; j < dn; j++) {
     const double df = (xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb]) / theta[TH_LS + j];
     r2 += df * df;
   }
   const double os = use_os ? theta[TH_OS] : 1.0;
-  const int ta = (T > 1) ? task[a] : 0, tb = (T > 1) ? task[bb] : 0;
   const double Bab = (T > 1) ? theta[TH_LS + dn + ta * T + tb] : 1.0;
   const double kb = bbh_kfun(kind, r2);
   const double Gg = G * bbh_gfun(kind, r2) * os * Bab;
@@ -193,7 +203,14 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     double v = (a == bb) ? G * nmask[a] : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) prow[TH_NOISE] = v;
+    if (lane == 0) {
+      prow[TH_NOISE] = hoff >= 0 ? 0.0 : v;
+      if (hoff >= 0)  // per-task noise: the diagonal term of row a belongs to the task of a (wave-uniform)
+        for (int t = 0; t < T; t++) {
+          prow[hoff + t] = (t == ta) ? v : 0.0;
+          prow[hoff + T + t] = 0.0;  // mean slots: written by the value kernel
+        }
+    }
   }
   {
     double v = use_os ? G * kb * Bab : 0.0;
@@ -225,20 +242,25 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
 
 // out[1 + slot] = sum over partial rows (fixed order -> deterministic); mean slot is skipped
 __global__ __launch_bounds__(256) void bbh_grad_reduce_kernel(const double* __restrict__ partial, int64_t rows,
-                                                              int nslots, double* __restrict__ out) {
+                                                              int nslots, int mean_lo, int mean_hi,
+                                                              double* __restrict__ out) {
   __shared__ double sm[4];
   const int slot = blockIdx.x;
+  if (slot == TH_MEAN || (slot >= mean_lo && slot < mean_hi)) return;  // written by the value kernel
   double v = 0.0;
   for (int64_t r = threadIdx.x; r < rows; r += 256) v += partial[r * nslots + slot];
   v = bbh_block_sum_256(v, sm);
-  if (threadIdx.x == 0 && slot != TH_MEAN) out[1 + slot] = v;
+  if (threadIdx.x == 0) out[1 + slot] = v;
 }
 
 // -----------------------------------------------------------------------------------------
 extern "C" int64_t bbh_theta_len(bbh_handle* h) {
   if (!h || !h->have_model) return -1;
-  return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0);
+  return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0) + (h->hadamard ? 2 * (int64_t)h->T : 0);
 }
+
+// offset of the per-task noise block in theta (the per-task means follow), -1 without one
+int bbh_hadamard_offset(const bbh_handle* h) { return h->hadamard ? 3 + h->dn + h->T * h->T : -1; }
 
 static void bbh_free_model(bbh_handle* h) {
   void* ptrs[] = {h->d_xnT,   h->d_task,    h->d_ystd,      h->d_theta, h->d_K,     h->d_X,       h->d_M,
@@ -289,6 +311,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   h->np = bbh_round_up(n, BBH_PAD);
   h->nb = h->np / BBH_TB;
   h->T = desc->n_tasks;
+  h->hadamard = (desc->hadamard != 0 && desc->n_tasks > 1);
   const int d = desc->d;
   const int tc = (desc->n_tasks > 1 || desc->task_col >= 0) ? desc->task_col : -1;
   h->numcol.clear();
@@ -426,7 +449,7 @@ static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
   bbh_launch_gram(h, jitter);
   bbh_potrf_trtri(h);
   hipLaunchKernelGGL(bbh_resid_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, h->d_ystd, h->d_theta,
-                     (int)h->n, (int)np, h->d_r);
+                     h->d_task, h->T, bbh_hadamard_offset(h), (int)h->n, (int)np, h->d_r);
   bbh_matvec(s, h->d_X, np, np, np, h->d_r, h->d_t);        // t = L^-1 r
   bbh_matvec_t(s, h->d_X, np, np, np, h->d_t, h->d_alpha);  // alpha = L^-T t
   if (!info_out) return 0;
@@ -466,14 +489,16 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
     bbh_gemm(s, false, false, np, np, np, 1.0, h->d_Q2, np, 0, h->d_M, np, 0, 0.0, h->d_Q, np, 0, 1);
   }
   hipMemsetAsync(h->d_out, 0, sizeof(double) * (1 + tl), s);
-  hipLaunchKernelGGL(bbh_value_kernel, dim3(1), dim3(256), 0, s, h->d_K, h->d_M, h->d_r, h->d_alpha, h->d_q, (int)n,
-                     (int)np, crit, h->d_out);
+  hipLaunchKernelGGL(bbh_value_kernel, dim3(1), dim3(256), 0, s, h->d_K, h->d_M, h->d_r, h->d_alpha, h->d_q, h->d_task,
+                     h->T, bbh_hadamard_offset(h), (int)n, (int)np, crit, h->d_out);
   const int nchunks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bbh_grad_pair_kernel, dim3((unsigned)n, (unsigned)nchunks), dim3(256), 0, s, h->d_xnT, h->d_task,
                      h->d_nmask, h->d_theta, h->d_M, h->d_Q, h->d_alpha, h->d_q, (int)n, (int)np, h->dn, h->desc.kernel_kind,
-                     h->desc.use_outputscale, h->T, crit, (int)tl, h->d_partial);
+                     h->desc.use_outputscale, h->T, bbh_hadamard_offset(h), crit, (int)tl, h->d_partial);
+  const int hoff = bbh_hadamard_offset(h);
   hipLaunchKernelGGL(bbh_grad_reduce_kernel, dim3((unsigned)tl), dim3(256), 0, s, h->d_partial,
-                     (int64_t)n * nchunks * 4, (int)tl, h->d_out);
+                     (int64_t)n * nchunks * 4, (int)tl, hoff >= 0 ? hoff + h->T : -1, hoff >= 0 ? hoff + 2 * h->T : -1,
+                     h->d_out);
   std::vector<double> out(1 + tl);
   int info = 0;
   BBH_HIP_TRY(h, hipMemcpyAsync(out.data(), h->d_out, sizeof(double) * (1 + tl), hipMemcpyDeviceToHost, s));

@@ -270,6 +270,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   a.ofs = h->d_sclofs + h->dn;
   a.numcol = h->d_numcol;
   a.tasktbl = h->d_tasktbl;
+  a.taskmean = h->hadamard ? h->d_theta + bbh_hadamard_offset(h) + h->T : nullptr;
   a.taskext = h->d_taskext;
   a.mean = mean_dev;
   a.var = var_dev;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __rest
                                                             const double* __restrict__ alpha,
                                                             const double* __restrict__ X, int64_t ldx, int64_t Nc,
                                                             int64_t np, const double* __restrict__ theta, int dn,
-                                                            int use_os, int T, int task_col, double ybar, double ysd,
+                                                            int use_os, int T, int task_col, int hoff, double ybar, double ysd,
                                                             double* __restrict__ mean, double* __restrict__ var) {
   const int lane = threadIdx.x & 63;
   const int64_t cand = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -454,13 +455,14 @@ __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __rest
     sv += __shfl_down(sv, o, 64);
   }
   if (lane == 0) {
-    double pv = use_os ? theta[2] : 1.0;
+    double pv = use_os ? theta[2] : 1.0, mc = theta[1];
     if (T > 1) {
       int tcand = (int)X[cand * ldx + task_col];
       tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
       pv *= theta[3 + dn + tcand * T + tcand];
+      if (hoff >= 0) mc = theta[hoff + T + tcand];
     }
-    if (mean) mean[cand] = ybar + ysd * (theta[1] + sm);
+    if (mean) mean[cand] = ybar + ysd * (mc + sm);
     if (var) var[cand] = ysd * ysd * (pv - sv);
   }
 }
@@ -497,6 +499,7 @@ int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ld
     if (rc) return rc;
     hipLaunchKernelGGL(bbh_rowreduce_kernel, dim3((unsigned)((Nc + 3) / 4)), dim3(256), 0, h->stream, Kst, V, h->d_alpha,
                        X_dev + s0 * ldx, ldx, Nc, np, h->d_theta, h->dn, h->desc.use_outputscale, h->T, h->desc.task_col,
+                       bbh_hadamard_offset(h),
                        h->ybar, h->ysd, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr);
   }
   BBH_HIP_TRY(h, hipGetLastError());
@@ -579,7 +582,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
   for (int64_t i = 0; i < p; i++) {
     double m = 0.0;
     for (int64_t k = 0; k < np; k++) m += hK[i * np + k] * hal[k];
-    h->pend_mean[i] = h->ybar + h->ysd * (th[1] + m);
+    h->pend_mean[i] = h->ybar + h->ysd * ((h->hadamard ? th[bbh_hadamard_offset(h) + T + pt[i]] : th[1]) + m);
     for (int64_t j = 0; j < p; j++) {
       double r2 = 0.0;
       for (int c = 0; c < dn; c++) {
@@ -677,10 +680,12 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedAr
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int64_t gi = tile0 + q + 4 * r;
+    const int tcm = __shfl(tc, q + 4 * r, 64);  // lane m (< 16) holds candidate m's task
+    const double mc = (HAS_TBL && a.taskmean) ? a.taskmean[tcm] : a.mean_const;
     if (gi < a.N) {
 #pragma unroll
       for (int cb = 0; cb < 8; cb++)
-        tmat[gi * ldt + col0 + 16 * cb + cnd] = a.ybar + a.ysd * (a.mean_const + acc[cb][r]);
+        tmat[gi * ldt + col0 + 16 * cb + cnd] = a.ybar + a.ysd * (mc + acc[cb][r]);
     }
   }
 }
@@ -694,11 +699,12 @@ __global__ void bbh_pack_colfrag_kernel(const double* __restrict__ A, int64_t sp
 
 // Yc[i][s] = (Y[i][s] - ybar) / ysd - c for real rows and columns, 0 on the padding
 __global__ void bbh_prep_columns_kernel(const double* __restrict__ Y, int64_t n, int64_t S, int64_t np, int64_t spad,
-                                        double ybar, double ysd, double c, double* __restrict__ out) {
+                                        double ybar, double ysd, double c, const double* __restrict__ taskmean,
+                                        const int* __restrict__ task, double* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= np * spad) return;
   const int64_t i = e / spad, s = e % spad;
-  out[e] = (i < n && s < S) ? (Y[i * S + s] - ybar) / ysd - c : 0.0;
+  out[e] = (i < n && s < S) ? (Y[i * S + s] - ybar) / ysd - (taskmean ? taskmean[task[i]] : c) : 0.0;
 }
 
 extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t S) {
@@ -720,7 +726,7 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
   double* A = T1 + np * spad;
   BBH_HIP_TRY(h, hipMemcpyAsync(dY, Y_host, sizeof(double) * n * S, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(bbh_prep_columns_kernel, dim3((unsigned)((np * spad + 255) / 256)), dim3(256), 0, s, dY, n, S, np, spad,
-                     h->ybar, h->ysd, h->theta[1], Yc);
+                     h->ybar, h->ysd, h->theta[1], h->hadamard ? h->d_theta + bbh_hadamard_offset(h) + h->T : nullptr, h->d_task, Yc);
   bbh_gemm(s, false, false, np, spad, np, 1.0, h->d_X, np, 0, Yc, spad, 0, 0.0, T1, spad, 0, 1);  // L^-1 Yc
   bbh_gemm(s, true, false, np, spad, np, 1.0, h->d_X, np, 0, T1, spad, 0, 0.0, A, spad, 0, 1);    // L^-T (.)
   const int64_t nks = np / 4, groups = spad / 128;
@@ -750,6 +756,7 @@ static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev
   a.ofs = h->d_sclofs + h->dn;
   a.numcol = h->d_numcol;
   a.tasktbl = h->d_tasktbl;
+  a.taskmean = h->hadamard ? h->d_theta + bbh_hadamard_offset(h) + h->T : nullptr;
   a.taskext = h->d_taskext;
   a.mean = nullptr;
   a.var = nullptr;
@@ -895,7 +902,13 @@ extern "C" int bbh_posterior_joint(bbh_handle* h, const double* Xq_host, int64_t
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
   const double s2 = h->ysd * h->ysd;
   for (int64_t i = 0; i < q; i++) {
-    mean_host[i] = h->ybar + h->ysd * (h->theta[1] + hm[i]);
+    double mc = h->theta[1];
+    if (h->hadamard) {
+      int t = (int)Xq_host[i * d + h->desc.task_col];
+      t = t < 0 ? 0 : (t >= h->T ? h->T - 1 : t);
+      mc = h->theta[bbh_hadamard_offset(h) + h->T + t];
+    }
+    mean_host[i] = h->ybar + h->ysd * (mc + hm[i]);
     for (int64_t j = 0; j < q; j++) cov_host[i * q + j] = s2 * 0.5 * (hc[i * qpad + j] + hc[j * qpad + i]);
   }
   return 0;

@@ -159,6 +159,7 @@ class HipGP:
             int(spec.n_tasks),
             1 if spec.use_outputscale else 0,
             _lib.CRITERIA[spec.criterion],
+            1 if (getattr(spec, "hadamard", False) and spec.n_tasks > 1) else 0,
         )
         lo = np.ascontiguousarray(spec.lo, dtype=np.float64)
         hi = np.ascontiguousarray(spec.hi, dtype=np.float64)

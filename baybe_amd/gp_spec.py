@@ -53,6 +53,10 @@ class GPSpec:
     outputscale_prior: tuple | None = None
     outputscale_init: float | None = None
     criterion: str = "mll"
+    # multi-task forms of the HVARFNER / BOTORCH presets (presets/hvarfner.py:72-137, presets/botorch.py:80-92):
+    hadamard: bool = False  # one noise variance and one constant mean per task (components/_gpytorch.py:15-75)
+    task_unit_scale: bool = False  # botorch PositiveIndexKernel default: B / B[target, target], target task 0
+    task_prior: tuple | None = None  # ("beta", a, b) on the lower-triangle task correlations (BOTORCH preset)
 
     @property
     def dn(self) -> int:
@@ -107,7 +111,12 @@ def from_preset(preset: str, d: int, lo, hi, task_idx: int | None = None, n_task
       LogNormal(sqrt 2 + log(d)/2, sqrt 3) lengthscale prior with l >= 0.025 (no transform), noise
       LogNormal(-4, 1) with sigma^2 >= 1e-4, both started at the prior mode, plain MLL
       (presets/hvarfner.py:60-71, :118-122; botorch ``get_covar_module_with_dim_scaled_prior``).
-      Their multi-task forms use a per-task mean and a multi-task likelihood and are not on this path.
+      Their multi-task forms (presets/hvarfner.py:72-137, presets/botorch.py:80-92) keep that base kernel inside the ICM
+      product with botorch's ``PositiveIndexKernel(num_tasks=T, rank=T)`` at ITS defaults (covariance scaled to 1 at
+      task 0, unlike BayBE's own wrapper which passes ``unit_scale_for_target=False``; BOTORCH adds a Beta(2.5, 1.5)
+      prior on the task correlations), one constant mean per task (``HadamardConstantMean``) and one noise variance per
+      task (``HadamardGaussianLikelihood``, LogNormal(-4, 1), sigma_t^2 >= 1e-4 without transform, started at the
+      mode) - ``GPSpec.hadamard`` - and are fitted by plain MLL.
 
     Kernels built from BayBE kernel objects use gpytorch's ``Positive()`` (softplus) constraints and the
     likelihoods of EDBO/EDBO_SMOOTHED gpytorch's default ``GreaterThan(1e-4)`` with a softplus transform.
@@ -121,14 +130,15 @@ def from_preset(preset: str, d: int, lo, hi, task_idx: int | None = None, n_task
     spec = GPSpec.baybe_default(d, lo, hi, task_idx=task_idx, n_tasks=n_tasks)
     dn = spec.dn
     if name in ("HVARFNER", "BOTORCH"):
-        if n_tasks > 1:
-            raise NotImplementedError(f"the multi-task form of the {name} preset is not on the HIP path")
         mu, sd = math.sqrt(2.0) + 0.5 * math.log(dn), math.sqrt(3.0)
         spec.kernel = "rbf"
         spec.ls_constraint, spec.ls_lower = "box", 2.5e-2
         spec.ls_prior, spec.ls_init = ("lognormal", mu, sd), math.exp(mu - sd * sd)
         spec.noise_prior, spec.noise_init = ("lognormal", -4.0, 1.0), math.exp(-4.0 - 1.0)
         spec.criterion = "mll"
+        if n_tasks > 1:
+            spec.hadamard, spec.task_unit_scale = True, True
+            spec.task_prior = ("beta", 2.5, 1.5) if name == "BOTORCH" else None
         return spec
     spec.use_outputscale = True
     spec.ls_constraint = "softplus"
@@ -171,16 +181,22 @@ class GPParams:
     """Natural hyper-parameters (normalised inputs, standardised targets)."""
 
     lengthscale: np.ndarray
-    noise: float
-    mean: float = 0.0
+    noise: "float | np.ndarray"  # [T] for hadamard models
+    mean: "float | np.ndarray" = 0.0  # [T] for hadamard models
     outputscale: float = 1.0
     task_W: np.ndarray | None = None
     task_v: np.ndarray | None = None
+    task_unit_scale: bool = False
 
-    def task_B(self):
+    def task_B_unscaled(self):
         if self.task_W is None:
             return None
         return self.task_W @ self.task_W.T + np.diag(self.task_v)
+
+    def task_B(self):
+        """The task covariance the kernel multiplies with (scaled to 1 at task 0 for ``task_unit_scale``)."""
+        B = self.task_B_unscaled()
+        return B if (B is None or not self.task_unit_scale) else B / B[0, 0]
 
 
 def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
@@ -200,6 +216,9 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
         T = spec.n_tasks
         p.task_W = np.full((T, T), task_init / math.sqrt(T))
         p.task_v = np.full(T, float(softplus(0.0)))
+        p.task_unit_scale = bool(spec.task_unit_scale)
+        if spec.hadamard:
+            p.noise, p.mean = np.full(T, nz0), np.zeros(T)
     return p
 
 
@@ -223,24 +242,31 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
 
     p = initial_params(spec)
     p.lengthscale = np.maximum(draw(spec.ls_prior, spec.dn, p.lengthscale[0]), spec.ls_lower if spec.ls_constraint == "box" else 1e-6)
-    p.noise = float(max(draw(spec.noise_prior, 1, p.noise)[0], spec.noise_lower))
+    if spec.hadamard:
+        p.noise = np.maximum(draw(spec.noise_prior, spec.n_tasks, p.noise[0]), spec.noise_lower)
+    else:
+        p.noise = float(max(draw(spec.noise_prior, 1, p.noise)[0], spec.noise_lower))
     if spec.use_outputscale:
         p.outputscale = float(max(draw(spec.outputscale_prior, 1, p.outputscale)[0], 1e-6))
     return p
 
 
-# ---- natural parameters <-> the device theta vector [noise, mean, outputscale, ls.., B..] ------
+# ---- natural parameters <-> the device theta vector [noise, mean, outputscale, ls.., B.., (noise_t.., mean_t..)] ------
 def theta_from_params(spec: GPSpec, p: GPParams) -> np.ndarray:
-    parts = [np.array([p.noise, p.mean, p.outputscale]), np.asarray(p.lengthscale, dtype=np.float64)]
+    nz, mu = np.atleast_1d(np.asarray(p.noise, dtype=np.float64)), np.atleast_1d(np.asarray(p.mean, dtype=np.float64))
+    parts = [np.array([nz[0], mu[0], p.outputscale]), np.asarray(p.lengthscale, dtype=np.float64)]
     if spec.n_tasks > 1:
         parts.append(p.task_B().reshape(-1))
+    if spec.hadamard:  # the scalar slots [0], [1] are ignored by the device then (include/baybe_hip.h)
+        parts += [nz, mu]
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
 
 
 # ---- raw optimiser vector (order of mll.named_parameters(): noise, mean, kernel parameters) ----
 def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
-    nz = np.array([p.noise]) if spec.noise_constraint == "box" else inv_softplus(np.array([p.noise - spec.noise_lower]))
-    parts = [nz, np.array([p.mean])]
+    nz = np.atleast_1d(np.asarray(p.noise, dtype=np.float64))
+    nz = nz if spec.noise_constraint == "box" else inv_softplus(nz - spec.noise_lower)
+    parts = [nz, np.atleast_1d(np.asarray(p.mean, dtype=np.float64))]
     if spec.use_outputscale:
         parts.append(inv_softplus(np.array([p.outputscale])))
     parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
@@ -253,9 +279,12 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
 def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     raw = np.asarray(raw, dtype=np.float64)
     i = 0
-    noise = float(raw[i]) if spec.noise_constraint == "box" else spec.noise_lower + float(softplus(raw[i]))
-    i += 1
-    mean = float(raw[i]); i += 1
+    m = spec.n_tasks if spec.hadamard else 1  # noise / mean entries (named_parameters order: all noises, then all means)
+    noise = raw[i : i + m].copy() if spec.noise_constraint == "box" else spec.noise_lower + softplus(raw[i : i + m])
+    i += m
+    mean = raw[i : i + m].copy(); i += m
+    if not spec.hadamard:
+        noise, mean = float(noise[0]), float(mean[0])
     os_ = 1.0
     if spec.use_outputscale:
         os_ = float(softplus(raw[i])); i += 1
@@ -266,12 +295,13 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
         T = spec.n_tasks
         W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
         v = softplus(raw[i : i + T]); i += T
-    return GPParams(ls, noise, mean, os_, W, v)
+    return GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale))
 
 
 def raw_bounds(spec: GPSpec):
     """Only constraints with ``transform=None`` become L-BFGS-B bounds (botorch fit)."""
-    b = [((spec.noise_lower, None) if spec.noise_constraint == "box" else (None, None)), (None, None)]
+    m = spec.n_tasks if spec.hadamard else 1
+    b = [((spec.noise_lower, None) if spec.noise_constraint == "box" else (None, None))] * m + [(None, None)] * m
     if spec.use_outputscale:
         b.append((None, None))
     b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
@@ -297,24 +327,54 @@ def _prior_logp_and_grad(prior, x):
     raise ValueError(f"unknown prior kind {kind!r}")
 
 
+def _task_correlation_prior(prior, B):
+    """log p and d log p / dB (lower-triangle + diagonal entries, upper zero) of a Beta(a, b) prior on the task
+    correlations rho_ij = B_ij / sqrt(B_ii B_jj), i > j (botorch ``PositiveIndexKernel(task_prior=...)``)."""
+    T = B.shape[0]
+    G = np.zeros((T, T))
+    if prior is None:
+        return 0.0, G
+    if prior[0] != "beta":
+        raise ValueError(f"unknown task prior {prior[0]!r}")
+    _, a, b = prior
+    lp = 0.0
+    for i in range(T):
+        for j in range(i):
+            den = math.sqrt(B[i, i] * B[j, j])
+            rho = B[i, j] / den
+            lp += (a - 1.0) * math.log(rho) + (b - 1.0) * math.log1p(-rho) - (gammaln(a) + gammaln(b) - gammaln(a + b))
+            dl = (a - 1.0) / rho - (b - 1.0) / (1.0 - rho)
+            G[i, j] += dl / den
+            G[i, i] -= dl * rho / (2.0 * B[i, i])
+            G[j, j] -= dl * rho / (2.0 * B[j, j])
+    return float(lp), G
+
+
 def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float, grad_theta: np.ndarray):
     """-(data term + log priors)/n and its gradient w.r.t. the raw vector, given the device's
     data term ``value`` and its gradient in theta layout (gpytorch: add priors, divide by n)."""
     p = unpack_raw(spec, raw)
     dn = spec.dn
-    g_noise, g_mean, g_os = grad_theta[0], grad_theta[1], grad_theta[2]
+    T = spec.n_tasks
+    m = T if spec.hadamard else 1
+    if spec.hadamard:
+        h0 = 3 + dn + T * T
+        g_noise, g_mean = grad_theta[h0 : h0 + T], grad_theta[h0 + T : h0 + 2 * T]
+    else:
+        g_noise, g_mean = grad_theta[0:1], grad_theta[1:2]
+    g_os = grad_theta[2]
     g_ls = grad_theta[3 : 3 + dn]
     lp_ls, glp_ls = _prior_logp_and_grad(spec.ls_prior, p.lengthscale)
-    lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.array([p.noise]))
+    lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.atleast_1d(p.noise))
     lp_os, glp_os = 0.0, np.zeros(1)
     if spec.use_outputscale:
         lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
     total = value + lp_ls + lp_nz + lp_os
-    g_nz = g_noise + glp_nz[0]
+    g_nz = g_noise + glp_nz
     if spec.noise_constraint != "box":
-        g_nz = g_nz * float(sigmoid(raw[0]))
-    g = [np.array([g_nz]), np.array([g_mean])]
-    i = 2
+        g_nz = g_nz * sigmoid(raw[0:m])
+    g = [np.asarray(g_nz, dtype=np.float64), np.asarray(g_mean, dtype=np.float64)]
+    i = 2 * m
     if spec.use_outputscale:
         g.append(np.array([(g_os + glp_os[0]) * float(sigmoid(raw[i]))]))
         i += 1
@@ -323,9 +383,15 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         gl = gl * sigmoid(raw[i : i + dn])
     g.append(gl)
     i += dn
-    if spec.n_tasks > 1:
-        T = spec.n_tasks
-        S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)
+    if T > 1:
+        S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)  # dL/dB of the (scaled) table the device multiplies with
+        Bu = p.task_B_unscaled()
+        if spec.task_unit_scale:  # B = Bu / Bu[0, 0]
+            S = S / Bu[0, 0]
+            S[0, 0] -= float((S * Bu).sum()) / Bu[0, 0]
+        lp_t, G_t = _task_correlation_prior(spec.task_prior, Bu)
+        total += lp_t
+        S = S + G_t
         gW = (S + S.T) @ p.task_W
         g.append((gW * sigmoid(raw[i : i + T * T]).reshape(T, T)).reshape(-1))
         i += T * T

@@ -70,6 +70,9 @@ typedef struct bbh_model_desc {
   int32_t n_tasks;         /* 1 = single task                                         */
   int32_t use_outputscale; /* 1 = ScaleKernel wrapper (user kernels)                   */
   int32_t criterion;       /* enum bbh_criterion                                      */
+  int32_t hadamard;        /* 1 (n_tasks > 1 only) = one noise variance and one constant mean PER TASK:
+                              HadamardGaussianLikelihood + HadamardConstantMean of the multi-task HVARFNER /
+                              BOTORCH presets (surrogates/gaussian_process/components/_gpytorch.py:15-75)     */
 } bbh_model_desc;
 
 /*
@@ -80,6 +83,8 @@ typedef struct bbh_model_desc {
  *   [3 .. 3+dn)    ARD lengthscales of the dn = d - (task_col>=0) numerical columns,
  *                  in column order (normalised input scale)
  *   [3+dn .. +T*T) task covariance B[t][t'] row-major (only when n_tasks > 1)
+ *   [.. +T) [.. +T) per-task noise variances, then per-task constant means (only with desc.hadamard;
+ *                  slots [0] and [1] are then ignored and their gradients are 0)
  * Gradients are returned in the same layout (for B: dL/dB[t][t'], accumulated
  * over ordered pairs, i.e. the matrix S with dL = sum_tt' S[t][t'] dB[t][t']).
  * Constraint transforms (softplus) and prior terms are O(d) scalar work and stay

@@ -14,6 +14,12 @@ parameters in ``mll.named_parameters()`` order; every piece of arithmetic comes 
   ``MultivariateNormal(c 1, K + s2 I).log_prob(y)``;
 * LeaveOneOutPseudoLikelihood (several tasks, ``presets/baybe.py:277-281``): ``Normal(mu_-i, sd_-i).log_prob(y_i)``
   with the leave-one-out moments from ``torch.cholesky_inverse``;
+* multi-task HVARFNER / BOTORCH presets (``presets/hvarfner.py:72-137``, ``presets/botorch.py:80-92``,
+  ``components/_gpytorch.py:15-75``; ``spec.task_model == "per_task"``): ``HadamardGaussianLikelihood`` = one noise
+  variance per task picked by the row's task index, ``HadamardConstantMean`` = one constant per task, botorch's
+  ``PositiveIndexKernel`` at its own defaults = the task covariance divided by its target-task entry
+  (``spec.index_kernel_scaling == "target"``, target task 0) and, for BOTORCH, ``torch.distributions.Beta(2.5, 1.5)``
+  on the lower-triangle task correlations;
 * ``(log-likelihood + sum of prior log-densities) / n``, negated; the **gradient is autograd's**.
 
 The product's host code (``baybe_amd/gp_spec.py``: hand-written chain rules and prior derivatives around the
@@ -27,7 +33,7 @@ from dataclasses import dataclass
 
 import numpy as np
 import torch
-from torch.distributions import Gamma, LogNormal, MultivariateNormal, Normal
+from torch.distributions import Beta, Gamma, LogNormal, MultivariateNormal, Normal
 from torch.nn import functional as F
 
 F64 = torch.float64
@@ -68,9 +74,13 @@ def parameter_layout(spec) -> list[RawParameter]:
     box_noise = spec.noise_constraint == "box"
     box_ls = spec.ls_constraint == "box"
     base = "covar_module.kernels.0" if T > 1 else "covar_module"
+    per_task = getattr(spec, "task_model", "shared") == "per_task"
     out = [
-        RawParameter("likelihood.noise_covar.raw_noise", (1,), spec.noise_lower, not box_noise, _prior(spec.noise_prior)),
-        RawParameter("mean_module.raw_constant", (), None, False, None),
+        RawParameter("likelihood.noise_covar.raw_noise", (T if per_task else 1,), spec.noise_lower, not box_noise,
+                     _prior(spec.noise_prior)),
+        # MultitaskMean keeps T ConstantMean modules (base_means.0 ... base_means.T-1); one vector stands for them here
+        RawParameter("mean_module.multitask_mean.base_means.raw_constant", (T,), None, False, None) if per_task
+        else RawParameter("mean_module.raw_constant", (), None, False, None),
     ]
     if spec.use_outputscale:
         out.append(RawParameter(f"{base}.raw_outputscale", (), 0.0, True, _prior(spec.outputscale_prior)))
@@ -136,17 +146,30 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     if spec.use_outputscale:
         K = K * nat["outputscale"]
     if spec.n_tasks > 1:
-        W, v = nat["covar_factor"], nat["var"]
-        B = W @ W.T + torch.diag(v)
         t = Xn[:, spec.task_idx].to(torch.long)
-        K = K * B[t][:, t]
+        K = K * task_covariance(spec, nat)[t][:, t]
     return K
+
+
+def task_covariance(spec, nat: dict) -> torch.Tensor:
+    """The index kernel's T x T matrix: ``covar_factor covar_factor^T + diag(var)``, divided by its entry at the
+    target task (index 0) when the kernel is botorch's ``PositiveIndexKernel`` with ``unit_scale_for_target`` left on."""
+    W, v = nat["covar_factor"], nat["var"]
+    B = W @ W.T + torch.diag(v)
+    if getattr(spec, "index_kernel_scaling", "none") == "target":
+        B = B / B[0, 0]
+    return B
 
 
 def log_likelihood(spec, nat: dict, Xn: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     n = y.shape[0]
-    Ky = train_covariance(spec, nat, Xn) + nat["noise"].reshape(()) * torch.eye(n, dtype=F64)
-    mean = nat["constant"].reshape(()) * torch.ones(n, dtype=F64)
+    if getattr(spec, "task_model", "shared") == "per_task":
+        t = Xn[:, spec.task_idx].to(torch.long)
+        Ky = train_covariance(spec, nat, Xn) + torch.diag(nat["noise"][t])
+        mean = nat["constant"][t]
+    else:
+        Ky = train_covariance(spec, nat, Xn) + nat["noise"].reshape(()) * torch.eye(n, dtype=F64)
+        mean = nat["constant"].reshape(()) * torch.ones(n, dtype=F64)
     if spec.criterion == "mll":
         return MultivariateNormal(mean, covariance_matrix=Ky).log_prob(y)
     if spec.criterion == "loo":
@@ -162,6 +185,16 @@ def log_prior(spec, nat: dict) -> torch.Tensor:
     for prm in parameter_layout(spec):
         if prm.prior is not None:
             total = total + prm.prior.log_prob(nat[prm.name.rsplit(".raw_", 1)[1]]).sum()
+    corr_prior = getattr(spec, "correlation_prior", None)
+    if corr_prior is not None and spec.n_tasks > 1:
+        family, c1, c0 = corr_prior
+        if family != "beta":
+            raise ValueError(f"no torch distribution for task prior family {family!r}")
+        B = task_covariance(spec, nat)
+        sd = torch.sqrt(torch.diagonal(B))
+        rows, cols = torch.tril_indices(spec.n_tasks, spec.n_tasks, offset=-1)
+        corr = (B / (sd[:, None] * sd[None, :]))[rows, cols]
+        total = total + Beta(torch.tensor(c1, dtype=F64), torch.tensor(c0, dtype=F64)).log_prob(corr).sum()
     return total
 
 

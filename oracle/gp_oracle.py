@@ -100,6 +100,10 @@ class GPSpec:
     noise: Hyper = field(default_factory=lambda: Hyper(lower=MIN_INFERRED_NOISE_LEVEL))
     outputscale: Hyper = field(default_factory=Hyper)
     criterion: str = "mll"  # "mll" (ExactMarginalLogLikelihood) | "loo" (LeaveOneOutPseudoLikelihood)
+    # multi-task HVARFNER / BOTORCH presets (presets/hvarfner.py:72-137, presets/botorch.py:80-92):
+    task_model: str = "shared"  # "per_task": HadamardGaussianLikelihood + HadamardConstantMean (one noise, one mean per task)
+    index_kernel_scaling: str = "none"  # "target": botorch PositiveIndexKernel default, covariance / its [0, 0] entry
+    correlation_prior: tuple | None = None  # ("beta", 2.5, 1.5): BetaPrior on the lower-triangle task correlations
 
     @property
     def dn(self) -> int:
@@ -143,19 +147,31 @@ class GPParams:
     """Natural (constrained) hyper-parameters of the standardised / normalised GP."""
 
     lengthscale: np.ndarray  # [dn]
-    noise: float  # sigma^2
-    mean: float = 0.0  # ConstantMean
+    noise: "float | np.ndarray"  # sigma^2 ([T] for task_model == "per_task")
+    mean: "float | np.ndarray" = 0.0  # ConstantMean ([T] for task_model == "per_task")
     outputscale: float = 1.0
     task_W: "np.ndarray | None" = None  # PositiveIndexKernel covar_factor [T, rank = T]
     task_v: "np.ndarray | None" = None  # PositiveIndexKernel var [T]
+    target_scaled: bool = False  # index_kernel_scaling == "target"
 
     def task_B(self) -> np.ndarray | None:
-        return None if self.task_W is None else self.task_W @ self.task_W.T + np.diag(self.task_v)
+        if self.task_W is None:
+            return None
+        full = self.task_W @ self.task_W.T + np.diag(self.task_v)
+        return full / full[0, 0] if self.target_scaled else full
+
+    def noise_of(self, tasks: np.ndarray) -> np.ndarray:
+        """Noise variance of every row given its task index (the scalar for single-noise models)."""
+        return np.broadcast_to(self.noise, tasks.shape) if np.ndim(self.noise) == 0 else np.asarray(self.noise)[tasks]
+
+    def mean_of(self, tasks: np.ndarray) -> np.ndarray:
+        return np.broadcast_to(self.mean, tasks.shape) if np.ndim(self.mean) == 0 else np.asarray(self.mean)[tasks]
 
     def copy(self) -> "GPParams":
         dup = lambda a: None if a is None else np.array(a, dtype=np.float64, copy=True)  # noqa: E731
-        return GPParams(dup(self.lengthscale), float(self.noise), float(self.mean), float(self.outputscale),
-                        dup(self.task_W), dup(self.task_v))
+        scal = lambda a: float(a) if np.ndim(a) == 0 else dup(a)  # noqa: E731
+        return GPParams(dup(self.lengthscale), scal(self.noise), scal(self.mean), float(self.outputscale),
+                        dup(self.task_W), dup(self.task_v), self.target_scaled)
 
 
 def softplus(x):
@@ -169,13 +185,15 @@ def initial_params(spec, task_init=1.0):
     Task factors: gpytorch draws raw W / v randomly; the oracle (and the HIP path) start deterministically at
     W = task_init / sqrt(T), v = softplus(0) — documented deviation, unpinned."""
     T = int(spec.n_tasks)
+    per_task = spec.task_model == "per_task"
     return GPParams(
         lengthscale=np.full(spec.dn, spec.lengthscale.start()),
-        noise=spec.noise.start(),
-        mean=0.0,
+        noise=np.full(T, spec.noise.start()) if per_task else spec.noise.start(),
+        mean=np.zeros(T) if per_task else 0.0,
         outputscale=spec.outputscale.start() if spec.use_outputscale else 1.0,
         task_W=np.full((T, T), task_init / math.sqrt(T)) if T > 1 else None,
         task_v=np.full(T, math.log(2.0)) if T > 1 else None,
+        target_scaled=spec.index_kernel_scaling == "target",
     )
 
 
@@ -257,6 +275,11 @@ def cross_cov(spec: GPSpec, p: GPParams, XAn: np.ndarray, XBn: np.ndarray) -> np
     return K
 
 
+def task_rows(spec: GPSpec, Xn: np.ndarray) -> np.ndarray:
+    """Task index of every row (zeros without a task column)."""
+    return np.zeros(Xn.shape[0], dtype=np.int64) if spec.task_idx is None else Xn[:, spec.task_idx].astype(np.int64)
+
+
 def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
     """k(x,x) for each row (1 * outputscale * B[t,t])."""
     v = np.full(Xn.shape[0], p.outputscale if spec.use_outputscale else 1.0)
@@ -274,8 +297,8 @@ def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
 class DataTerm:
     value: float  # log-likelihood (mll) or LOO sum incl. the -n/2 log(2pi) constant
     g_ls: np.ndarray
-    g_noise: float
-    g_mean: float
+    g_noise: "float | np.ndarray"  # [T] for per-task noise
+    g_mean: "float | np.ndarray"  # [T] for per-task means
     g_outputscale: float
     g_task_B: np.ndarray | None  # dL/dB[t,t'] (symmetric accumulation S)
 
@@ -291,17 +314,18 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
            w = alpha/d,  d = diag(M).
     """
     n = Xn.shape[0]
+    trow = task_rows(spec, Xn)
     Kf = cross_cov(spec, p, Xn, Xn)
-    Ky = Kf + p.noise * np.eye(n)
+    Ky = Kf + np.diag(p.noise_of(trow))
     L = sla.cholesky(Ky, lower=True)
-    r = ystd - p.mean
+    r = ystd - p.mean_of(trow)
     alpha = sla.cho_solve((L, True), r)
     Linv = sla.solve_triangular(L, np.eye(n), lower=True)
     M = Linv.T @ Linv
     if spec.criterion == "mll":
         value = -0.5 * float(r @ alpha) - float(np.log(np.diag(L)).sum()) - 0.5 * n * math.log(2 * math.pi)
         G = 0.5 * (np.outer(alpha, alpha) - M)
-        g_mean = float(alpha.sum())
+        g_mean_rows = alpha
     elif spec.criterion == "loo":
         dg = np.diag(M)
         value = float((0.5 * np.log(dg) - 0.5 * alpha**2 / dg).sum()) - 0.5 * n * math.log(2 * math.pi)
@@ -310,7 +334,7 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
         Mw = M @ w
         G = -(M * u[None, :]) @ M + np.outer(alpha, Mw)
         G = 0.5 * (G + G.T)
-        g_mean = float(w @ M.sum(axis=1))
+        g_mean_rows = M @ w
     else:
         raise ValueError(spec.criterion)
 
@@ -330,7 +354,11 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     for j in range(spec.dn):
         diff = Xs[:, j : j + 1] - Xs[None, :, j]
         g_ls[j] = float((GW * diff * diff).sum()) / p.lengthscale[j] ** 3
-    g_noise = float(np.trace(G))
+    if spec.task_model == "per_task":  # one slot per task: the rows of that task contribute
+        g_noise = np.array([float(np.diag(G)[trow == k].sum()) for k in range(spec.n_tasks)])
+        g_mean = np.array([float(g_mean_rows[trow == k].sum()) for k in range(spec.n_tasks)])
+    else:
+        g_noise, g_mean = float(np.trace(G)), float(g_mean_rows.sum())
     g_os = float((G * Kf).sum()) / p.outputscale if spec.use_outputscale else 0.0
     g_B = None
     if spec.task_idx is not None:
@@ -346,7 +374,7 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
 # All of it is oracle/fit_objective.py (torch.distributions + autograd); these wrappers only translate between
 # GPParams and the gpytorch-named parameter dictionary.
 def _natural_dict(spec: GPSpec, p: GPParams) -> dict:
-    nat = {"noise": [p.noise], "constant": p.mean, "lengthscale": p.lengthscale}
+    nat = {"noise": np.atleast_1d(p.noise), "constant": p.mean, "lengthscale": p.lengthscale}
     if spec.use_outputscale:
         nat["outputscale"] = p.outputscale
     if spec.n_tasks > 1:
@@ -368,11 +396,12 @@ def unpack_raw(spec, raw):
     nat = {k: v.detach().numpy() for k, v in fo.split_raw(spec, torch.as_tensor(np.asarray(raw, dtype=np.float64))).items()}
     return GPParams(
         lengthscale=nat["lengthscale"].reshape(-1).copy(),
-        noise=float(nat["noise"].reshape(-1)[0]),
-        mean=float(nat["constant"]),
+        noise=nat["noise"].reshape(-1).copy() if spec.task_model == "per_task" else float(nat["noise"].reshape(-1)[0]),
+        mean=nat["constant"].reshape(-1).copy() if spec.task_model == "per_task" else float(nat["constant"]),
         outputscale=float(nat["outputscale"]) if spec.use_outputscale else 1.0,
         task_W=nat["covar_factor"].copy() if spec.n_tasks > 1 else None,
         task_v=nat["var"].copy() if spec.n_tasks > 1 else None,
+        target_scaled=spec.index_kernel_scaling == "target",
     )
 
 
@@ -438,7 +467,8 @@ class GPModel:
         self.Xn = normalize_inputs(self.spec, self.X_train)
         self.ystd, self.ybar, self.ysd = standardize_targets(self.y_train)
         n = self.Xn.shape[0]
-        Ky = cross_cov(self.spec, self.params, self.Xn, self.Xn) + self.params.noise * np.eye(n)
+        trow = task_rows(self.spec, self.Xn)
+        Ky = cross_cov(self.spec, self.params, self.Xn, self.Xn) + np.diag(self.params.noise_of(trow))
         # gpytorch psd_safe_cholesky: retry with jitter 1e-8 * 10^i [UPSTREAM A7]
         jit = 0.0
         for attempt in range(4):
@@ -450,13 +480,13 @@ class GPModel:
         else:
             raise sla.LinAlgError("train covariance not PD even with jitter")
         self.jitter = jit
-        self.alpha = sla.cho_solve((self.L, True), self.ystd - self.params.mean)
+        self.alpha = sla.cho_solve((self.L, True), self.ystd - self.params.mean_of(trow))
 
     # posterior of standardised GP at normalised inputs
     def _std_posterior(self, Xc: np.ndarray, joint: bool):
         Xcn = normalize_inputs(self.spec, np.atleast_2d(Xc))
         Ks = cross_cov(self.spec, self.params, Xcn, self.Xn)  # [N, n]
-        mu = self.params.mean + Ks @ self.alpha
+        mu = self.params.mean_of(task_rows(self.spec, Xcn)) + Ks @ self.alpha
         V = sla.solve_triangular(self.L, Ks.T, lower=True)  # [n, N]
         if joint:
             Kss = cross_cov(self.spec, self.params, Xcn, Xcn)

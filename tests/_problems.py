@@ -53,4 +53,7 @@ def oracle_spec(spec):
                              spec.ls_prior, spec.ls_init),
         noise=go.Hyper(spec.noise_lower, spec.noise_constraint != "box", spec.noise_prior, spec.noise_init),
         outputscale=go.Hyper(0.0, True, spec.outputscale_prior, spec.outputscale_init),
-        criterion=spec.criterion)
+        criterion=spec.criterion,
+        task_model="per_task" if spec.hadamard else "shared",
+        index_kernel_scaling="target" if spec.task_unit_scale else "none",
+        correlation_prior=spec.task_prior)

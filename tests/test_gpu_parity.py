@@ -39,7 +39,8 @@ def _oparams(p):
     from oracle import gp_oracle as go
 
     return go.GPParams(np.array(p.lengthscale, dtype=float), p.noise, p.mean, p.outputscale,
-                       None if p.task_W is None else p.task_W.copy(), None if p.task_v is None else p.task_v.copy())
+                       None if p.task_W is None else p.task_W.copy(), None if p.task_v is None else p.task_v.copy(),
+                       bool(getattr(p, "task_unit_scale", False)))
 
 
 def _np(t):

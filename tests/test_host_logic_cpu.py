@@ -107,8 +107,13 @@ def test_preset_tables_follow_the_reference():
     assert gp_spec.from_preset("BOTORCH", 10, lo[:10], hi[:10]).ls_prior == hv.ls_prior
     tl = gp_spec.from_preset("CHEN", 5, lo[:5], hi[:5], task_idx=4, n_tasks=3)
     assert tl.criterion == "loo" and tl.dn == 4
-    with pytest.raises(NotImplementedError):
-        gp_spec.from_preset("HVARFNER", 5, lo[:5], hi[:5], task_idx=4, n_tasks=2)
+    # multi-task forms (presets/hvarfner.py:72-137, presets/botorch.py:80-92): per-task noise + mean, plain MLL,
+    # botorch's own PositiveIndexKernel defaults (scaled to the target task), BetaPrior(2.5, 1.5) for BOTORCH only
+    mh = gp_spec.from_preset("HVARFNER", 5, lo[:5], hi[:5], task_idx=4, n_tasks=2)
+    assert mh.hadamard and mh.task_unit_scale and mh.task_prior is None and mh.criterion == "mll" and mh.kernel == "rbf"
+    assert mh.ls_prior == ("lognormal", pytest.approx(math.sqrt(2) + 0.5 * math.log(4)), pytest.approx(math.sqrt(3)))
+    mb = gp_spec.from_preset("BOTORCH", 5, lo[:5], hi[:5], task_idx=4, n_tasks=2)
+    assert mb.hadamard and mb.task_prior == ("beta", 2.5, 1.5)
     with pytest.raises(ValueError):
         gp_spec.from_preset("NOPE", 5, lo[:5], hi[:5])
 
@@ -141,6 +146,42 @@ def test_preset_raw_parameterisation_round_trip_and_oracle_gradient(preset):
         e[i] = 1e-5
         fd = (go.fit_objective(ospec, raw + e, Xn, ys)[0] - go.fit_objective(ospec, raw - e, Xn, ys)[0]) / 2e-5
         assert math.isclose(fd, g0[i], rel_tol=1e-3, abs_tol=1e-5)
+
+
+@pytest.mark.parametrize("preset", ["HVARFNER", "BOTORCH"])
+def test_multitask_botorch_presets_host_objective_equals_the_autograd_oracle(preset):
+    """Per-task noise / mean slots, the target-scaled task covariance and the Beta prior on the task correlations:
+    the host's chain rules around a data term against the oracle's torch.distributions + autograd objective."""
+    d, n, T = 5, 40, 3
+    X, Xt, y = make_tl_problem(60, d - 1, n, T=T, seed=4)
+    spec = gp_spec.from_preset(preset, d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=T)
+    ospec = _ospec(spec)
+    p = gp_spec.initial_params(spec)
+    assert np.shape(p.noise) == (T,) and np.shape(p.mean) == (T,)
+    raw = gp_spec.pack_raw(spec, p)
+    assert len(raw) == 2 * T + spec.dn + T * T + T == len(gp_spec.raw_bounds(spec))
+    assert gp_spec.raw_bounds(spec) == go.raw_bounds(ospec)
+    assert np.allclose(go.pack_raw(ospec, go.initial_params(ospec)), raw)
+    rng = np.random.default_rng(5)
+    raw = raw + 0.1 * rng.standard_normal(raw.shape)
+    raw[:T] = np.abs(raw[:T]) + 2e-4  # noises stay inside their box
+    q = gp_spec.unpack_raw(spec, raw)
+    assert np.isclose(q.task_B()[0, 0], 1.0) and not np.isclose(q.task_B_unscaled()[0, 0], 1.0)
+    theta = gp_spec.theta_from_params(spec, q)
+    h0 = 3 + spec.dn + T * T
+    assert len(theta) == h0 + 2 * T and np.allclose(theta[h0:h0 + T], q.noise) and np.allclose(theta[h0 + T:], q.mean)
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    oq = go.unpack_raw(ospec, raw)
+    assert np.allclose(oq.task_B(), q.task_B()) and np.allclose(oq.noise, q.noise)
+    dt = go.data_term(ospec, oq, Xn, ys)
+    grad_theta = np.concatenate([[0.0, 0.0, dt.g_outputscale], dt.g_ls, dt.g_task_B.reshape(-1), dt.g_noise, dt.g_mean])
+    f1, g1 = gp_spec.objective_from_data_term(spec, raw, len(y), dt.value, grad_theta)
+    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+    assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    # the prior term is really there for BOTORCH (and only there)
+    plain = gp_spec.from_preset("HVARFNER", d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=T)
+    fp, _ = gp_spec.objective_from_data_term(plain, raw, len(y), dt.value, grad_theta)
+    assert (preset == "BOTORCH") == (abs(fp - f1) > 1e-6)
 
 
 # ---- backtesting driver: lookup semantics (simulation/lookup.py:19-150), no device needed ---------------

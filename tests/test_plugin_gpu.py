@@ -182,6 +182,51 @@ def test_transfer_learning_campaign_recommends():
     assert rec._surrogate_model.engine.spec.criterion == "loo"
 
 
+@pytest.mark.parametrize("preset", ["HVARFNER", "BOTORCH"])
+def test_transfer_learning_with_the_botorch_presets(preset):
+    """``GaussianProcessSurrogate.from_preset("BOTORCH")`` on a TaskParameter space (presets/botorch.py:80-92,
+    presets/hvarfner.py:72-137; the reference pins this against ``MultiTaskGP`` in tests/test_gp.py:203-225): RBF x
+    index kernel, one noise and one mean per task, plain MLL - through the surrogate, against the oracle's fit."""
+    from _problems import oracle_spec
+    from baybe_amd import gp_spec
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate
+    from oracle import gp_oracle as go
+
+    rng = np.random.default_rng(9)
+    vals = np.arange(6) / 5.0
+    params = [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals), NumericalDiscreteParameter("x2", vals),
+              TaskParameter("task", ["A", "B"], active_values=["A"])]
+    space = SearchSpace.from_product(params)
+    exp = space.discrete.exp_rep
+    rows = []
+    for t, shift in (("A", 0.0), ("B", 0.3)):
+        sub = exp.iloc[rng.choice(len(exp), 14, replace=False)].copy()
+        sub["task"] = t
+        m = _measure(sub, rng)
+        m["yield"] += shift
+        rows.append(m)
+    meas = pd.concat(rows, ignore_index=True)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    rec = HipBotorchRecommender(surrogate_model=HipGaussianProcessSurrogate(preset=preset))
+    got = rec.recommend(2, space, obj, meas)
+    assert len(got) == 2 and (got["task"] == "A").all()
+    eng = rec._surrogate_model.engine
+    assert eng.spec.hadamard and eng.spec.criterion == "mll" and eng.spec.kernel == "rbf"
+    assert (eng.spec.task_prior is not None) == (preset == "BOTORCH")
+    Xt = space.transform(meas).to_numpy(dtype=float)
+    y = meas["yield"].to_numpy(dtype=float)
+    ospec = oracle_spec(eng.spec)
+    fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+    fi = rec._surrogate_model._fit_info
+    assert np.isclose(fi.fun, fo.fun, rtol=1e-6), (fi.fun, fo.fun)
+    cand = space.transform(exp[exp["task"] == "A"]).to_numpy(dtype=float)
+    om = go.GPModel(ospec, fo.params, Xt, y)
+    mo, vo = om.posterior(cand)
+    m, v = eng.posterior(cand)
+    assert np.allclose(m.cpu().numpy(), mo, rtol=2e-3, atol=2e-3) and np.allclose(v.cpu().numpy(), vo, rtol=2e-2, atol=1e-6)
+
+
 def test_user_kernel_specifications_fit_like_the_oracle():
     """tests/conftest.py:704-747 uses GP(Matern-2.5, Gamma(3, 1)); tests/test_iterations.py:365-371
     iterates kernels.  User kernels get Positive() constraints and no preset priors."""
