@@ -36,6 +36,10 @@ class ModelDesc(C.Structure):
         ("use_outputscale", C.c_int32),
         ("criterion", C.c_int32),
         ("hadamard", C.c_int32),
+        ("n_factors", C.c_int32),
+        ("combine", C.c_int32),
+        ("factor_kind", C.c_int32 * 4),
+        ("factor_scaled", C.c_int32 * 4),
     ]
 
 

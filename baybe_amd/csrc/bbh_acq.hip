@@ -677,6 +677,21 @@ extern "C" int bbh_score_qlogei(bbh_handle* h, const double* X_dev, int64_t N, i
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  if (h->F > 1) {  // composite kernels: materialised-K* posterior, then the stand-alone scoring kernel
+    double *tm = mean_dev, *tv = var_dev, *scratch = nullptr;
+    if (!tm || !tv) {
+      BBH_HIP_TRY(h, hipMalloc((void**)&scratch, sizeof(double) * 2 * (size_t)N));
+      tm = tm ? tm : scratch;
+      tv = tv ? tv : scratch + N;
+    }
+    int rc2 = bbh_launch_fused(h, X_dev, N, ldx, tm, tv, nullptr, true);
+    if (!rc2) rc2 = bbh_qlogei_q1(h, tm, tv, N, z_host, S, best_f, sign, alive_dev, scores_dev);
+    if (scratch) {
+      hipStreamSynchronize(h->stream);
+      hipFree(scratch);
+    }
+    return rc2;
+  }
   int rc = bbh_upload_z(h, z_host, (size_t)S);
   if (rc) return rc;
   h->fuse_qz = h->d_z;

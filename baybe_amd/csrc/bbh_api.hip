@@ -182,16 +182,22 @@ extern "C" int bbh_train_posterior_mean(bbh_handle* h, double* mean_host) {
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   const int64_t n = h->n, d = h->desc.d;
-  int rc = bbh_ensure_ws(h, sizeof(double) * (size_t)(n * d + n));
-  if (rc) return rc;
-  double* dX = h->d_ws;
+  int rc = 0;
+  double* own = nullptr;  // composite kernels: the posterior path uses the workspace itself
+  if (h->F > 1)
+    BBH_HIP_TRY(h, hipMalloc((void**)&own, sizeof(double) * (size_t)(n * d + n)));
+  else if ((rc = bbh_ensure_ws(h, sizeof(double) * (size_t)(n * d + n))))
+    return rc;
+  double* dX = own ? own : h->d_ws;
   double* dm = dX + n * d;
-  BBH_HIP_TRY(h, hipMemcpyAsync(dX, h->xraw_host.data(), sizeof(double) * n * d, hipMemcpyHostToDevice, h->stream));
+  hipError_t e = hipMemcpyAsync(dX, h->xraw_host.data(), sizeof(double) * n * d, hipMemcpyHostToDevice, h->stream);
   // pending columns do not affect column 0 (the mean), but keep the call side-effect free
-  rc = bbh_launch_fused(h, dX, n, d, dm, nullptr, nullptr, false);
+  if (e == hipSuccess) rc = bbh_launch_fused(h, dX, n, d, dm, nullptr, nullptr, false);
+  if (e == hipSuccess && !rc) e = hipMemcpyAsync(mean_host, dm, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (own) hipFree(own);
   if (rc) return rc;
-  BBH_HIP_TRY(h, hipMemcpyAsync(mean_host, dm, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  BBH_HIP_TRY(h, e);
   return 0;
 }
 

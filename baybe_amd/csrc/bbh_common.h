@@ -36,6 +36,35 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     }                                                                                     \
   } while (0)
 
+// How the elementwise kernels (Gram matrix, gradient pairs, K*, K_qq) assemble one kernel value from theta; by value.
+#define BBH_MAX_FACTORS 4
+struct bbh_kern_spec {
+  int F;                        // factors; 1 = the plain single-kernel model
+  int combine;                  // 0 product, 1 sum
+  int kind[BBH_MAX_FACTORS];    // enum bbh_kernel_kind
+  int ls_off[BBH_MAX_FACTORS];  // theta offset of the factor's dn lengthscales
+  int fos_off;                  // theta offset of the F per-factor outputscales (-1: F == 1)
+  int use_os;                   // outer outputscale theta[2]
+};
+// base kernel value and g(r) = -(dk/dr)/r (dk/dl_j = g Delta_j^2 / l_j^3) as functions of the scaled squared distance
+__device__ __forceinline__ double bbh_kbase(int kind, double r2) {
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
+  return exp(-r);
+}
+// composite value from the per-factor squared distances: (prod | sum)_f os_f k_f(r2_f), without the outer scale
+__device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta, const double* r2) {
+  if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0]);
+  double acc = ks.combine ? 0.0 : 1.0;
+  for (int f = 0; f < ks.F; f++) {
+    const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f]);
+    acc = ks.combine ? acc + u : acc * u;
+  }
+  return acc;
+}
+
 struct bbh_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -52,6 +81,7 @@ struct bbh_handle {
   int kd = 0;         // k-steps of the augmented distance GEMM: ceil((dn+2)/4)
   int T = 1;          // tasks
   bool hadamard = false;  // per-task noise and mean (theta tail), see bbh_model_desc
+  int F = 1;              // kernel factors (composite kernels: 2..4), see bbh_model_desc
   std::vector<int> numcol;        // numerical column -> comp-rep column
   std::vector<double> lo, hi;     // per numerical column
   double ybar = 0.0, ysd = 1.0;
@@ -65,6 +95,9 @@ struct bbh_handle {
   double* d_xnT = nullptr;     // [dn, np]  normalised training inputs, transposed
   int* d_task = nullptr;       // [np]      task ids (0 for padding)
   double* d_nmask = nullptr;   // [np]      noise mask (1 = noisy observation, 0 = latent value / padding)
+  double* d_pendT = nullptr;   // [dn, 16]  normalised pending points, transposed (composite-kernel path)
+  double* d_colA = nullptr;    // [np, spad] alpha columns of bbh_set_mean_columns (composite-kernel path)
+  int64_t colA_elems = 0;
   std::vector<double> nmask_host;
   double* d_ystd = nullptr;    // [np]
   double* d_theta = nullptr;   // [theta_len]
@@ -199,7 +232,11 @@ void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int
 // ---- model (bbh_model.hip) --------------------------------------------------------------
 int bbh_upload_theta(bbh_handle* h, const double* theta_host);
 void bbh_launch_gram(bbh_handle* h, double jitter);
-int bbh_hadamard_offset(const bbh_handle* h);  // per-task noise block in theta (means follow at + T), -1 = none
+bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h);
+int bbh_hadamard_offset(const bbh_handle* h);
+double bbh_prior_base(const bbh_handle* h);  // k(x, x) without the task factor
+int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
+                           double* cross_dev);  // composite kernels: every posterior output through the materialised K*  // per-task noise block in theta (means follow at + T), -1 = none
 
 // ---- fused posterior (bbh_panel.hip) ----------------------------------------------------
 int bbh_pack_operands(bbh_handle* h);   // trainfrag, rfrag, meanB, tables (after factorize / pending_set)

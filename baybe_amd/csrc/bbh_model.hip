@@ -60,10 +60,10 @@ int bbh_upload_theta(bbh_handle* h, const double* theta_host) {
 __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict__ xnT, const int* __restrict__ task,
                                                        const double* __restrict__ nmask,
                                                        const double* __restrict__ theta, int n, int np, int dn,
-                                                       int kind, int use_os, int T, int hoff, double jitter,
+                                                       const bbh_kern_spec ks, int T, int hoff, double jitter,
                                                        double* __restrict__ K) {
-  extern __shared__ double s_invls[];
-  for (int j = threadIdx.x; j < dn; j += blockDim.x) s_invls[j] = 1.0 / theta[TH_LS + j];
+  extern __shared__ double s_invls[];  // [F][dn]
+  for (int e = threadIdx.x; e < ks.F * dn; e += blockDim.x) s_invls[e] = 1.0 / theta[ks.ls_off[e / dn] + e % dn];
   __syncthreads();
   const int a = blockIdx.y;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,13 +72,16 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
     K[(int64_t)a * np + b] = (a == b) ? 1.0 : 0.0;
     return;
   }
-  double r2 = 0.0;
+  double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
-    const double df = (xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + b]) * s_invls[j];
-    r2 += df * df;
+    const double dx = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + b];
+    for (int f = 0; f < ks.F; f++) {
+      const double df = dx * s_invls[f * dn + j];
+      r2[f] += df * df;
+    }
   }
-  double k = bbh_kfun(kind, r2);
-  if (use_os) k *= theta[TH_OS];
+  double k = bbh_kcomp(ks, theta, r2);
+  if (ks.use_os) k *= theta[TH_OS];
   if (T > 1) k *= theta[TH_LS + dn + task[a] * T + task[b]];
   if (a == b) k += (hoff >= 0 ? theta[hoff + task[a]] : theta[TH_NOISE]) * nmask[a] + jitter;
   K[(int64_t)a * np + b] = k;
@@ -86,8 +89,8 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
 
 void bbh_launch_gram(bbh_handle* h, double jitter) {
   dim3 grid((unsigned)((h->np + 255) / 256), (unsigned)h->np), block(256);
-  hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn, h->stream, h->d_xnT, h->d_task, h->d_nmask, h->d_theta,
-                     (int)h->n, (int)h->np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T, bbh_hadamard_offset(h), jitter,
+  hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn * h->F, h->stream, h->d_xnT, h->d_task, h->d_nmask,
+                     h->d_theta, (int)h->n, (int)h->np, h->dn, bbh_kern_spec_of(h), h->T, bbh_hadamard_offset(h), jitter,
                      h->d_K);
 }
 
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void bbh_value_kernel(const double* __restrict
 __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     const double* __restrict__ xnT, const int* __restrict__ task, const double* __restrict__ nmask,
     const double* __restrict__ theta, const double* __restrict__ M, const double* __restrict__ Q, const double* __restrict__ alpha,
-    const double* __restrict__ q, int n, int np, int dn, int kind, int use_os, int T, int hoff, int criterion, int nslots,
+    const double* __restrict__ q, int n, int np, int dn, const bbh_kern_spec ks, int T, int hoff, int criterion, int nslots,
     double* __restrict__ partial) {
   const int a = blockIdx.x;
   const int b = blockIdx.y * 256 + threadIdx.x;
@@ -188,17 +191,30 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     G = -Q[(int64_t)a * np + bb] + 0.5 * (alpha[a] * q[bb] + alpha[bb] * q[a]);
   if (!act) G = 0.0;
   const int ta = (T > 1) ? task[a] : 0, tb = (T > 1) ? task[bb] : 0;
-  double r2 = 0.0;
+  double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
-    const double df = (xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb]) / theta[TH_LS + j];
-    r2 += df * df;
+    const double dx = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
+    for (int f = 0; f < ks.F; f++) {
+      const double df = dx / theta[ks.ls_off[f] + j];
+      r2[f] += df * df;
+    }
   }
-  const double os = use_os ? theta[TH_OS] : 1.0;
+  const double os = ks.use_os ? theta[TH_OS] : 1.0;
   const double Bab = (T > 1) ? theta[TH_LS + dn + ta * T + tb] : 1.0;
-  const double kb = bbh_kfun(kind, r2);
-  const double Gg = G * bbh_gfun(kind, r2) * os * Bab;
+  // per factor: value u_f = os_f k_f, and the weight W_f of its derivative in the composite:
+  //   product: d/dk_f = os_f prod_{g != f} u_g,   sum: d/dk_f = os_f
+  double kf[BBH_MAX_FACTORS], wf[BBH_MAX_FACTORS];
+  for (int f = 0; f < ks.F; f++) kf[f] = bbh_kfun(ks.kind[f], r2[f]);
+  for (int f = 0; f < ks.F; f++) {
+    double w = 1.0;
+    if (ks.F > 1 && !ks.combine)
+      for (int g = 0; g < ks.F; g++)
+        if (g != f) w *= theta[ks.fos_off + g] * kf[g];
+    wf[f] = w;  // without the factor's own outputscale
+  }
+  const double kb = bbh_kcomp(ks, theta, r2);
   double* prow = partial + ((int64_t)(a * gridDim.y + blockIdx.y) * 4 + wave) * nslots;
-  // slot layout = gradient layout of theta: [noise, mean(unused), outputscale, ls.., B..]
+  // slot layout = gradient layout of theta: [noise, mean(unused), outputscale, ls.., B.., (noise_t, mean_t), (ls_f.., os_f..)]
   {
     double v = (a == bb) ? G * nmask[a] : 0.0;
 #pragma unroll
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     }
   }
   {
-    double v = use_os ? G * kb * Bab : 0.0;
+    double v = ks.use_os ? G * kb * Bab : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (lane == 0) {
@@ -221,13 +237,23 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
       prow[TH_MEAN] = 0.0;
     }
   }
-  for (int j = 0; j < dn; j++) {
-    const double l = theta[TH_LS + j];
-    const double df = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
-    double v = Gg * df * df / (l * l * l);
+  for (int f = 0; f < ks.F; f++) {
+    const double fos = ks.F > 1 ? theta[ks.fos_off + f] : 1.0;
+    const double Gg = G * bbh_gfun(ks.kind[f], r2[f]) * os * Bab * wf[f] * fos;
+    for (int j = 0; j < dn; j++) {
+      const double l = theta[ks.ls_off[f] + j];
+      const double df = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
+      double v = Gg * df * df / (l * l * l);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) prow[TH_LS + j] = v;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) prow[ks.ls_off[f] + j] = v;
+    }
+    if (ks.F > 1) {  // d/d os_f = W_f k_f
+      double v = G * os * Bab * wf[f] * kf[f];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) prow[ks.fos_off + f] = v;
+    }
   }
   if (T > 1) {
     const double gk = G * kb * os;
@@ -254,9 +280,29 @@ __global__ __launch_bounds__(256) void bbh_grad_reduce_kernel(const double* __re
 }
 
 // -----------------------------------------------------------------------------------------
+static int64_t bbh_theta_len_of(const bbh_handle* h) {
+  return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0) + (h->hadamard ? 2 * (int64_t)h->T : 0) +
+         (h->F > 1 ? (int64_t)(h->F - 1) * h->dn + h->F : 0);
+}
+
 extern "C" int64_t bbh_theta_len(bbh_handle* h) {
   if (!h || !h->have_model) return -1;
-  return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0) + (h->hadamard ? 2 * (int64_t)h->T : 0);
+  return bbh_theta_len_of(h);
+}
+
+// how the elementwise kernels find the factors of the kernel in theta
+bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h) {
+  bbh_kern_spec ks{};
+  ks.F = h->F;
+  ks.combine = h->desc.combine;
+  ks.use_os = h->desc.use_outputscale;
+  const int base = 3 + h->dn + (h->T > 1 ? h->T * h->T : 0) + (h->hadamard ? 2 * h->T : 0);
+  for (int f = 0; f < BBH_MAX_FACTORS; f++) {
+    ks.kind[f] = (f == 0 || h->F <= 1) ? h->desc.kernel_kind : h->desc.factor_kind[f];
+    ks.ls_off[f] = (f == 0 || f >= h->F) ? 3 : base + (f - 1) * h->dn;
+  }
+  ks.fos_off = h->F > 1 ? base + (h->F - 1) * h->dn : -1;
+  return ks;
 }
 
 // offset of the per-task noise block in theta (the per-task means follow), -1 without one
@@ -266,7 +312,7 @@ static void bbh_free_model(bbh_handle* h) {
   void* ptrs[] = {h->d_xnT,   h->d_task,    h->d_ystd,      h->d_theta, h->d_K,     h->d_X,       h->d_M,
                   h->d_Q,     h->d_Q2,      h->d_D,         h->d_tmp,   h->d_r,     h->d_t,       h->d_alpha,
                   h->d_u,     h->d_w,       h->d_q,         h->d_partial, h->d_out, h->d_info,    h->d_trainfrag,
-                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag};
+                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag, h->d_pendT, h->d_colA};
   for (void* p : ptrs)
     if (p) hipFree(p);
   h->d_xnT = h->d_ystd = h->d_theta = h->d_K = h->d_X = h->d_M = h->d_Q = h->d_Q2 = h->d_D = h->d_tmp = nullptr;
@@ -275,6 +321,8 @@ static void bbh_free_model(bbh_handle* h) {
   h->d_task = h->d_info = h->d_numcol = h->d_taskext = h->d_pass_w = nullptr;
   h->d_pass_off = nullptr;
   h->d_nmask = nullptr;
+  h->d_pendT = h->d_colA = nullptr;
+  h->colA_elems = 0;
   h->d_colfrag = nullptr;
   h->colfrag_elems = 0;
   h->ncols = 0;
@@ -304,6 +352,15 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->err = "bbh_set_model: invalid model description";
     return -1;
   }
+  if (desc->n_factors > 1) {
+    bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1) &&
+              desc->factor_kind[0] == desc->kernel_kind;
+    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= 3;
+    if (!ok) {
+      h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1, factor_kind[0] == kernel_kind)";
+      return -1;
+    }
+  }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   bbh_free_model(h);
   h->desc = *desc;
@@ -312,6 +369,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   h->nb = h->np / BBH_TB;
   h->T = desc->n_tasks;
   h->hadamard = (desc->hadamard != 0 && desc->n_tasks > 1);
+  h->F = desc->n_factors > 1 ? desc->n_factors : 1;
   const int d = desc->d;
   const int tc = (desc->n_tasks > 1 || desc->task_col >= 0) ? desc->task_col : -1;
   h->numcol.clear();
@@ -388,7 +446,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   for (int j = 0; j < h->dn; j++) h->xcenter[j] /= (double)n;
 
   const int64_t np = h->np;
-  const int64_t tl = 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0);
+  const int64_t tl = bbh_theta_len_of(h);
   std::vector<double> xnT((size_t)h->dn * np, 0.0), ypad(np, 0.0);
   std::vector<int> tpad(np, 0);
   h->nmask_host.assign(np, 0.0);
@@ -422,6 +480,8 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   BBH_ALLOC(h->d_out, 1 + tl);
   BBH_ALLOC(h->d_info, 1);
   BBH_ALLOC(h->d_beta, np * BBH_MEANCOLS);
+  BBH_ALLOC(h->d_pendT, (int64_t)h->dn * 16);
+  BBH_HIP_TRY(h, hipMemset(h->d_pendT, 0, sizeof(double) * h->dn * 16));
   BBH_HIP_TRY(h, hipMemcpy(h->d_xnT, xnT.data(), sizeof(double) * xnT.size(), hipMemcpyHostToDevice));
   BBH_HIP_TRY(h, hipMemcpy(h->d_task, tpad.data(), sizeof(int) * np, hipMemcpyHostToDevice));
   BBH_HIP_TRY(h, hipMemcpy(h->d_nmask, h->nmask_host.data(), sizeof(double) * np, hipMemcpyHostToDevice));
@@ -493,8 +553,8 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
                      h->T, bbh_hadamard_offset(h), (int)n, (int)np, crit, h->d_out);
   const int nchunks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bbh_grad_pair_kernel, dim3((unsigned)n, (unsigned)nchunks), dim3(256), 0, s, h->d_xnT, h->d_task,
-                     h->d_nmask, h->d_theta, h->d_M, h->d_Q, h->d_alpha, h->d_q, (int)n, (int)np, h->dn, h->desc.kernel_kind,
-                     h->desc.use_outputscale, h->T, bbh_hadamard_offset(h), crit, (int)tl, h->d_partial);
+                     h->d_nmask, h->d_theta, h->d_M, h->d_Q, h->d_alpha, h->d_q, (int)n, (int)np, h->dn, bbh_kern_spec_of(h),
+                     h->T, bbh_hadamard_offset(h), crit, (int)tl, h->d_partial);
   const int hoff = bbh_hadamard_offset(h);
   hipLaunchKernelGGL(bbh_grad_reduce_kernel, dim3((unsigned)tl), dim3(256), 0, s, h->d_partial,
                      (int64_t)n * nchunks * 4, (int)tl, hoff >= 0 ? hoff + h->T : -1, hoff >= 0 ? hoff + 2 * h->T : -1,

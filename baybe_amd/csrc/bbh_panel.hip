@@ -259,6 +259,8 @@ int bbh_pack_operands(bbh_handle* h) {
 int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                      double* cross_dev, bool with_var) {
   if (N <= 0) return 0;
+  if (h->F > 1)  // composite kernels: materialised-K* path (the fused qLogEI epilogue is applied by the caller)
+    return bbh_launch_unfused_ext(h, X_dev, N, ldx, mean_dev, with_var ? var_dev : nullptr, cross_dev);
   FusedArgs a;
   a.X = X_dev;
   a.N = N;
@@ -409,36 +411,41 @@ __global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict
                                                         const double* __restrict__ xnT, const int* __restrict__ task,
                                                         const double* __restrict__ theta, const int* __restrict__ numcol,
                                                         const double* __restrict__ lo, const double* __restrict__ hi,
-                                                        int n, int64_t np, int dn, int kind, int use_os, int T,
-                                                        int task_col, double* __restrict__ Kst) {
+                                                        int n, int64_t np, int dn, const bbh_kern_spec ks, int T,
+                                                        int task_col, int64_t ldk, double* __restrict__ Kst) {
+  // xnT [dn, np] / task [np]: the points of the columns (training rows, or the pending points with np = 16);
+  // Kst[cand * ldk + i], i < np
   const int64_t cand = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= np) return;
   double v = 0.0;
   if (cand < Nc && i < n) {
     const double* xr = X + cand * ldx;
-    double r2 = 0.0;
+    double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
     for (int j = 0; j < dn; j++) {
       const double xc = (xr[numcol[j]] - lo[j]) / (hi[j] - lo[j]);
-      const double df = (xc - xnT[(int64_t)j * np + i]) / theta[3 + j];
-      r2 += df * df;
+      const double dx = xc - xnT[(int64_t)j * np + i];
+      for (int f = 0; f < ks.F; f++) {
+        const double df = dx / theta[ks.ls_off[f] + j];
+        r2[f] += df * df;
+      }
     }
-    v = bbh_kfun_p(kind, r2);
-    if (use_os) v *= theta[2];
+    v = bbh_kcomp(ks, theta, r2);
+    if (ks.use_os) v *= theta[2];
     if (T > 1) {
       int tcand = (int)xr[task_col];
       tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
       v *= theta[3 + dn + tcand * T + task[i]];
     }
   }
-  Kst[cand * np + i] = v;
+  Kst[cand * ldk + i] = v;
 }
 
 __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __restrict__ Kst, const double* __restrict__ V,
                                                             const double* __restrict__ alpha,
                                                             const double* __restrict__ X, int64_t ldx, int64_t Nc,
                                                             int64_t np, const double* __restrict__ theta, int dn,
-                                                            int use_os, int T, int task_col, int hoff, double ybar, double ysd,
+                                                            double prior_base, int T, int task_col, int hoff, double ybar, double ysd,
                                                             double* __restrict__ mean, double* __restrict__ var) {
   const int lane = threadIdx.x & 63;
   const int64_t cand = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __rest
     sv += __shfl_down(sv, o, 64);
   }
   if (lane == 0) {
-    double pv = use_os ? theta[2] : 1.0, mc = theta[1];
+    double pv = prior_base, mc = theta[1];  // k(x, x) without the task factor
     if (T > 1) {
       int tcand = (int)X[cand * ldx + task_col];
       tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
@@ -474,10 +481,116 @@ static int bbh_unfused_chunk(bbh_handle* h, const double* X_dev, int64_t Nc, int
   const int64_t Ncpad = bbh_round_up(Nc, 64);
   dim3 grid((unsigned)((np + 255) / 256), (unsigned)Ncpad), block(256);
   hipLaunchKernelGGL(bbh_kstar_kernel, grid, block, 0, h->stream, X_dev, Nc, ldx, h->d_xnT, h->d_task, h->d_theta,
-                     h->d_numcol, d_lo, d_hi, (int)h->n, np, h->dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T,
-                     h->desc.task_col, Kst);
+                     h->d_numcol, d_lo, d_hi, (int)h->n, np, h->dn, bbh_kern_spec_of(h), h->T, h->desc.task_col, np, Kst);
   if (V) bbh_gemm(h->stream, false, true, Ncpad, np, np, 1.0, Kst, np, 0, h->d_X, np, 0, 0.0, V, np, 0, 1);
   BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// k(x, x) without the task factor: outputscale * (prod_f | sum_f) os_f
+double bbh_prior_base(const bbh_handle* h) {
+  const double* th = h->theta.data();
+  double v = h->desc.use_outputscale ? th[2] : 1.0;
+  if (h->F > 1) {
+    const bbh_kern_spec ks = bbh_kern_spec_of(h);
+    double acc = ks.combine ? 0.0 : 1.0;
+    for (int f = 0; f < ks.F; f++) acc = ks.combine ? acc + th[ks.fos_off + f] : acc * th[ks.fos_off + f];
+    v *= acc;
+  }
+  return v;
+}
+
+// ---- composite kernels: the whole posterior through the materialised K* ------------------------------------------
+// The fused kernels are specialised for one stationary factor (one distance GEMM, one staged kernel-value evaluation).
+// Products / sums of factors (bbh_model_desc.n_factors > 1) take this path for every posterior-shaped call:
+//   Kext = [K(X*, X) | K(X*, P)]  [Nc, np + 16]   (bbh_kstar_kernel twice: training columns, pending columns)
+//   O    = Kext meanB             [Nc, 1 + p]      column 0: mean sum, columns 1..p: posterior cross-covariances (epilogue)
+//   V    = K(X*, X) L^-T          [Nc, np]         variance = prior - |v|^2
+// in chunks of 16384 candidates; ~2 np^2 flops per candidate on the generic GEMM plus 16 np bytes of K* traffic.
+__global__ __launch_bounds__(256) void bbh_ext_epilogue_kernel(const double* __restrict__ V, const double* __restrict__ Kext,
+                                                               int64_t ldk, const double* __restrict__ Bm,
+                                                               const double* __restrict__ X, int64_t ldx, int64_t Nc,
+                                                               int64_t np, const double* __restrict__ theta, int dn,
+                                                               double prior_base, int T, int task_col, int hoff, double ybar,
+                                                               double ysd, int p, double* __restrict__ mean,
+                                                               double* __restrict__ var, double* __restrict__ cross) {
+  // one wave per candidate: O[c] = sum_i Kext[i] Bm[i][c] for the mean column c = 0 and the pending columns 1..p
+  const int lane = threadIdx.x & 63;
+  const int64_t cand = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cand >= Nc) return;
+  double sv = 0.0, o[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) o[c] = 0.0;
+  const int ncol = cross ? 1 + p : 1;
+  for (int64_t i = lane; i < ldk; i += 64) {
+    const double k = Kext[cand * ldk + i];
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      if (c < ncol) o[c] = fma(k, Bm[i * 16 + c], o[c]);
+  }
+  if (V && var)
+    for (int64_t i = lane; i < np; i += 64) {
+      const double v = V[cand * np + i];
+      sv = fma(v, v, sv);
+    }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    sv += __shfl_down(sv, sh, 64);
+#pragma unroll
+    for (int c = 0; c < 16; c++) o[c] += __shfl_down(o[c], sh, 64);
+  }
+  if (lane == 0) {
+    double pv = prior_base, mc = theta[1];
+    if (T > 1) {
+      int tcand = (int)X[cand * ldx + task_col];
+      tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
+      pv *= theta[3 + dn + tcand * T + tcand];
+      if (hoff >= 0) mc = theta[hoff + T + tcand];
+    }
+    if (mean) mean[cand] = ybar + ysd * (mc + o[0]);
+    if (var) var[cand] = ysd * ysd * (pv - sv);
+    if (cross)
+#pragma unroll
+      for (int c = 1; c < 16; c++)
+        if (c <= p) cross[cand * p + (c - 1)] = ysd * ysd * o[c];
+  }
+}
+
+int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
+                           double* cross_dev) {
+  if (N <= 0) return 0;
+  const int64_t np = h->np, ldk = np + 16;
+  const int64_t chunk = 16384;
+  const size_t need = sizeof(double) * ((size_t)chunk * ldk + (size_t)chunk * np + 2 * h->dn);
+  int rc = bbh_ensure_ws(h, need);
+  if (rc) return rc;
+  double* Kext = h->d_ws;
+  double* V = Kext + chunk * ldk;
+  double* d_lo = V + chunk * np;
+  double* d_hi = d_lo + h->dn;
+  hipStream_t s = h->stream;
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
+  const bbh_kern_spec ks = bbh_kern_spec_of(h);
+  for (int64_t s0 = 0; s0 < N; s0 += chunk) {
+    const int64_t Nc = (N - s0 < chunk) ? N - s0 : chunk;
+    const int64_t Ncpad = bbh_round_up(Nc, 64);
+    const double* Xc = X_dev + s0 * ldx;
+    hipLaunchKernelGGL(bbh_kstar_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)Ncpad), dim3(256), 0, s, Xc, Nc, ldx,
+                       h->d_xnT, h->d_task, h->d_theta, h->d_numcol, d_lo, d_hi, (int)h->n, np, h->dn, ks, h->T,
+                       h->desc.task_col, ldk, Kext);
+    // pending columns (zero when there are none: p = 0 points -> every entry is written as 0)
+    hipLaunchKernelGGL(bbh_kstar_kernel, dim3(1, (unsigned)Ncpad), dim3(256), 0, s, Xc, Nc, ldx, h->d_pendT, h->d_taskext + np,
+                       h->d_theta, h->d_numcol, d_lo, d_hi, h->p, (int64_t)16, h->dn, ks, h->T, h->desc.task_col, ldk,
+                       Kext + np);
+    if (var_dev) bbh_gemm(s, false, true, Ncpad, np, np, 1.0, Kext, ldk, 0, h->d_X, np, 0, 0.0, V, np, 0, 1);
+    hipLaunchKernelGGL(bbh_ext_epilogue_kernel, dim3((unsigned)((Nc + 3) / 4)), dim3(256), 0, s, var_dev ? V : nullptr, Kext, ldk,
+                       h->d_meanB, Xc, ldx, Nc, np, h->d_theta, h->dn, bbh_prior_base(h), h->T, h->desc.task_col, bbh_hadamard_offset(h),
+                       h->ybar, h->ysd, h->p, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr,
+                       cross_dev ? cross_dev + s0 * h->p : nullptr);
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  h->last_form = 2;
   return 0;
 }
 
@@ -498,7 +611,7 @@ int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ld
     rc = bbh_unfused_chunk(h, X_dev + s0 * ldx, Nc, ldx, Kst, V, d_lo, d_hi);
     if (rc) return rc;
     hipLaunchKernelGGL(bbh_rowreduce_kernel, dim3((unsigned)((Nc + 3) / 4)), dim3(256), 0, h->stream, Kst, V, h->d_alpha,
-                       X_dev + s0 * ldx, ldx, Nc, np, h->d_theta, h->dn, h->desc.use_outputscale, h->T, h->desc.task_col,
+                       X_dev + s0 * ldx, ldx, Nc, np, h->d_theta, h->dn, bbh_prior_base(h), h->T, h->desc.task_col,
                        bbh_hadamard_offset(h),
                        h->ybar, h->ysd, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr);
   }
@@ -536,6 +649,10 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
       pt[j] = t < 0 ? 0 : (t >= T ? T - 1 : t);
     }
   }
+  std::vector<double> pnT((size_t)dn * 16, 0.0);
+  for (int64_t j = 0; j < p; j++)
+    for (int c = 0; c < dn; c++) pnT[c * 16 + j] = pn[j * dn + c];
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_pendT, pnT.data(), sizeof(double) * pnT.size(), hipMemcpyHostToDevice, s));
   std::vector<double> tf;
   host_pack_trainfrag(h, pn.data(), p, nb, nb + 1, tf);
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag + nb * h->kd * 64, tf.data(), sizeof(double) * tf.size(),
@@ -577,6 +694,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
   const double* th = h->theta.data();
   const double os = h->desc.use_outputscale ? th[2] : 1.0;
+  const bbh_kern_spec ks = bbh_kern_spec_of(h);
   h->pend_mean.assign(p, 0.0);
   h->pend_cov.assign((size_t)p * p, 0.0);
   for (int64_t i = 0; i < p; i++) {
@@ -584,12 +702,17 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
     for (int64_t k = 0; k < np; k++) m += hK[i * np + k] * hal[k];
     h->pend_mean[i] = h->ybar + h->ysd * ((h->hadamard ? th[bbh_hadamard_offset(h) + T + pt[i]] : th[1]) + m);
     for (int64_t j = 0; j < p; j++) {
-      double r2 = 0.0;
-      for (int c = 0; c < dn; c++) {
-        const double df = (pn[i * dn + c] - pn[j * dn + c]) / th[3 + c];
-        r2 += df * df;
+      double kc = ks.combine && ks.F > 1 ? 0.0 : 1.0;
+      for (int f = 0; f < ks.F; f++) {
+        double r2 = 0.0;
+        for (int c = 0; c < dn; c++) {
+          const double df = (pn[i * dn + c] - pn[j * dn + c]) / th[ks.ls_off[f] + c];
+          r2 += df * df;
+        }
+        const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * host_kfun(ks.kind[f], r2);
+        kc = (ks.combine && ks.F > 1) ? kc + u : kc * u;
       }
-      double kpp = os * host_kfun(h->desc.kernel_kind, r2);
+      double kpp = os * kc;
       if (T > 1) kpp *= th[3 + dn + pt[i] * T + pt[j]];
       double dot = 0.0;
       for (int64_t k = 0; k < np; k++) dot += hT[i * np + k] * hT[j * np + k];
@@ -739,6 +862,15 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
   }
   hipLaunchKernelGGL(bbh_pack_colfrag_kernel, dim3((unsigned)nks, 8, (unsigned)groups), dim3(64), 0, s, A, spad, nks,
                      h->d_colfrag);
+  if (h->F > 1) {  // composite kernels contract K* with the plain matrix (bbh_posterior_columns)
+    if (!h->d_colA || h->colA_elems < np * spad) {
+      if (h->d_colA) hipFree(h->d_colA);
+      h->d_colA = nullptr;
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_colA, sizeof(double) * np * spad));
+      h->colA_elems = np * spad;
+    }
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_colA, A, sizeof(double) * np * spad, hipMemcpyDeviceToDevice, s));
+  }
   BBH_HIP_TRY(h, hipGetLastError());
   BBH_HIP_TRY(h, hipStreamSynchronize(s));  // the workspace may be reused by the next call
   h->ncols = S;
@@ -791,6 +923,50 @@ static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev
   a.nblk = (N + 63) / 64;
 }
 
+// tmat[i][c] = ybar + ysd * (mean_const(task of i) + P[i][c]) for the real columns of a padded product P [Nc, spad]
+__global__ void bbh_columns_affine_kernel(const double* __restrict__ P, int64_t spad, int64_t Nc, int64_t S,
+                                          const double* __restrict__ X, int64_t ldx, const double* __restrict__ theta,
+                                          int T, int task_col, int hoff, double ybar, double ysd, double* __restrict__ tmat) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Nc * S) return;
+  const int64_t i = e / S, c = e % S;
+  double mc = theta[1];
+  if (hoff >= 0) {
+    int t = (int)X[i * ldx + task_col];
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    mc = theta[hoff + T + t];
+  }
+  tmat[i * S + c] = ybar + ysd * (mc + P[i * spad + c]);
+}
+
+// composite kernels: conditional means under the alternative target columns as K* A on the generic GEMM
+static int bbh_columns_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
+  const int64_t np = h->np, S = h->ncols, spad = bbh_round_up(S, 128);
+  const int64_t chunk = 8192;
+  const size_t need = sizeof(double) * ((size_t)chunk * np + (size_t)chunk * spad + 2 * h->dn);
+  int rc = bbh_ensure_ws(h, need);
+  if (rc) return rc;
+  double* Kst = h->d_ws;
+  double* P = Kst + chunk * np;
+  double* d_lo = P + chunk * spad;
+  double* d_hi = d_lo + h->dn;
+  hipStream_t s = h->stream;
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
+  for (int64_t s0 = 0; s0 < N; s0 += chunk) {
+    const int64_t Nc = (N - s0 < chunk) ? N - s0 : chunk;
+    const int64_t Ncpad = bbh_round_up(Nc, 64);
+    rc = bbh_unfused_chunk(h, X_dev + s0 * ldx, Nc, ldx, Kst, nullptr, d_lo, d_hi);
+    if (rc) return rc;
+    bbh_gemm(s, false, false, Ncpad, spad, np, 1.0, Kst, np, 0, h->d_colA, spad, 0, 0.0, P, spad, 0, 1);
+    hipLaunchKernelGGL(bbh_columns_affine_kernel, dim3((unsigned)((Nc * S + 255) / 256)), dim3(256), 0, s, P, spad, Nc, S,
+                       X_dev + s0 * ldx, ldx, h->d_theta, h->T, h->desc.task_col, bbh_hadamard_offset(h), h->ybar, h->ysd,
+                       tmat_dev + s0 * S);
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
   if (!h) return -1;
   if (!h->factorized || h->ncols < 1 || !h->d_colfrag || !tmat_dev || N < 0 || (N > 0 && !X_dev) || ldx < h->desc.d) {
@@ -799,6 +975,7 @@ extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  if (h->F > 1) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev);
   FusedArgs a;
   bbh_fill_fused_args(h, a, X_dev, N, ldx);
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
@@ -842,20 +1019,23 @@ extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t
 __global__ __launch_bounds__(256) void bbh_kqq_kernel(const double* __restrict__ Xq, int64_t q, int64_t qpad, int64_t ldx,
                                                       const double* __restrict__ theta, const int* __restrict__ numcol,
                                                       const double* __restrict__ lo, const double* __restrict__ hi, int dn,
-                                                      int kind, int use_os, int T, int task_col, double* __restrict__ Kqq) {
+                                                      const bbh_kern_spec ks, int T, int task_col, double* __restrict__ Kqq) {
   const int64_t a = blockIdx.y;
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= qpad) return;
   double v = 0.0;
   if (a < q && b < q) {
-    double r2 = 0.0;
+    double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
     for (int j = 0; j < dn; j++) {
       const double rng = hi[j] - lo[j];
-      const double df = ((Xq[a * ldx + numcol[j]] - lo[j]) / rng - (Xq[b * ldx + numcol[j]] - lo[j]) / rng) / theta[3 + j];
-      r2 += df * df;
+      const double dx = (Xq[a * ldx + numcol[j]] - lo[j]) / rng - (Xq[b * ldx + numcol[j]] - lo[j]) / rng;
+      for (int f = 0; f < ks.F; f++) {
+        const double df = dx / theta[ks.ls_off[f] + j];
+        r2[f] += df * df;
+      }
     }
-    v = bbh_kfun_p(kind, r2);
-    if (use_os) v *= theta[2];
+    v = bbh_kcomp(ks, theta, r2);
+    if (ks.use_os) v *= theta[2];
     if (T > 1) {
       int ta = (int)Xq[a * ldx + task_col], tb = (int)Xq[b * ldx + task_col];
       ta = ta < 0 ? 0 : (ta >= T ? T - 1 : ta);
@@ -892,8 +1072,7 @@ extern "C" int bbh_posterior_joint(bbh_handle* h, const double* Xq_host, int64_t
   rc = bbh_unfused_chunk(h, dX, q, d, Kst, Tm, d_lo, d_hi);
   if (rc) return rc;
   hipLaunchKernelGGL(bbh_kqq_kernel, dim3((unsigned)((qpad + 255) / 256), (unsigned)qpad), dim3(256), 0, s, dX, q, qpad, d,
-                     h->d_theta, h->d_numcol, d_lo, d_hi, (int)dn, h->desc.kernel_kind, h->desc.use_outputscale, h->T,
-                     h->desc.task_col, Kqq);
+                     h->d_theta, h->d_numcol, d_lo, d_hi, (int)dn, bbh_kern_spec_of(h), h->T, h->desc.task_col, Kqq);
   bbh_gemm(s, false, true, qpad, qpad, np, -1.0, Tm, np, 0, Tm, np, 0, 1.0, Kqq, qpad, 0, 1);  // Kqq - Tm Tm^T
   bbh_matvec(s, Kst, np, qpad, np, h->d_alpha, dm);
   std::vector<double> hc((size_t)qpad * qpad), hm(qpad);

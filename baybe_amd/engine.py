@@ -161,6 +161,13 @@ class HipGP:
             _lib.CRITERIA[spec.criterion],
             1 if (getattr(spec, "hadamard", False) and spec.n_tasks > 1) else 0,
         )
+        factors = getattr(spec, "factors", None)
+        if factors:  # composite kernel: ProductKernel / AdditiveKernel of stationary factors
+            desc.n_factors = len(factors)
+            desc.combine = {"product": 0, "sum": 1}[spec.combine]
+            for k, f in enumerate(factors):
+                desc.factor_kind[k] = _lib.KERNEL_KINDS[f.kernel]
+                desc.factor_scaled[k] = 1 if f.scaled else 0
         lo = np.ascontiguousarray(spec.lo, dtype=np.float64)
         hi = np.ascontiguousarray(spec.hi, dtype=np.float64)
         if lo.shape[0] != spec.d or hi.shape[0] != spec.d:
@@ -458,7 +465,7 @@ class HipGP:
     # ---- instrumentation ------------------------------------------------------------------
     def posterior_kernel_form(self) -> str:
         """Which form of the fused posterior kernel the last variance pass ran as."""
-        return {0: "windowed", 1: "cooperative"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
+        return {0: "windowed", 1: "cooperative", 2: "materialised"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
 
     def timing(self, enable: bool):
         self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")

@@ -32,6 +32,22 @@ def sigmoid(x):
 
 
 @dataclass
+class KernelFactor:
+    """One stationary factor of a composite kernel (``baybe/kernels/composite.py:60-91``): ARD over all numerical
+    columns with its own lengthscales, optionally inside its own ``ScaleKernel``.  User kernels: gpytorch's
+    ``Positive()`` (softplus) constraints, priors only where given (``baybe/kernels/base.py:113-194``)."""
+
+    kernel: str = "matern52"
+    ls_constraint: str = "softplus"
+    ls_lower: float = 0.0
+    ls_prior: tuple | None = None
+    ls_init: float | None = None
+    scaled: bool = False
+    outputscale_prior: tuple | None = None
+    outputscale_init: float | None = None
+
+
+@dataclass
 class GPSpec:
     """Architecture, priors and constraints of one single-output GP."""
 
@@ -57,6 +73,26 @@ class GPSpec:
     hadamard: bool = False  # one noise variance and one constant mean per task (components/_gpytorch.py:15-75)
     task_unit_scale: bool = False  # botorch PositiveIndexKernel default: B / B[target, target], target task 0
     task_prior: tuple | None = None  # ("beta", a, b) on the lower-triangle task correlations (BOTORCH preset)
+    # composite kernels: 2..4 factors combined as a product or a sum; factors[0] IS (kernel, ls_*) above
+    factors: "list[KernelFactor] | None" = None
+    combine: str = "product"  # "product" (ProductKernel) | "sum" (AdditiveKernel)
+
+    @property
+    def n_factors(self) -> int:
+        return len(self.factors) if self.factors else 1
+
+    def set_factors(self, factors, combine: str = "product"):
+        """Make this a composite-kernel model; the first factor takes over the single-kernel fields."""
+        factors = list(factors)
+        if not 2 <= len(factors) <= 4:
+            raise ValueError("composite kernels have 2..4 factors on the HIP path")
+        if combine not in ("product", "sum"):
+            raise ValueError(combine)
+        f0 = factors[0]
+        self.kernel, self.ls_constraint, self.ls_prior, self.ls_init = f0.kernel, f0.ls_constraint, f0.ls_prior, f0.ls_init
+        self.ls_lower = f0.ls_lower if f0.ls_constraint == "box" else self.ls_lower
+        self.factors, self.combine = factors, combine
+        return self
 
     @property
     def dn(self) -> int:
@@ -187,6 +223,8 @@ class GPParams:
     task_W: np.ndarray | None = None
     task_v: np.ndarray | None = None
     task_unit_scale: bool = False
+    factor_ls: "list[np.ndarray] | None" = None  # lengthscales of the factors 1.. of a composite kernel
+    factor_os: "np.ndarray | None" = None  # [F] per-factor outputscales (1 for unscaled factors)
 
     def task_B_unscaled(self):
         if self.task_W is None:
@@ -219,6 +257,11 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
         p.task_unit_scale = bool(spec.task_unit_scale)
         if spec.hadamard:
             p.noise, p.mean = np.full(T, nz0), np.zeros(T)
+    if spec.factors:
+        sp0 = float(softplus(0.0))
+        p.factor_ls = [np.full(spec.dn, f.ls_init if f.ls_init is not None else sp0) for f in spec.factors[1:]]
+        p.factor_os = np.array([(f.outputscale_init if f.outputscale_init is not None else sp0) if f.scaled else 1.0
+                                for f in spec.factors], dtype=np.float64)
     return p
 
 
@@ -248,6 +291,12 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
         p.noise = float(max(draw(spec.noise_prior, 1, p.noise)[0], spec.noise_lower))
     if spec.use_outputscale:
         p.outputscale = float(max(draw(spec.outputscale_prior, 1, p.outputscale)[0], 1e-6))
+    if spec.factors:
+        for k, f in enumerate(spec.factors[1:]):
+            p.factor_ls[k] = np.maximum(draw(f.ls_prior, spec.dn, p.factor_ls[k][0]), f.ls_lower if f.ls_constraint == "box" else 1e-6)
+        for k, f in enumerate(spec.factors):
+            if f.scaled:
+                p.factor_os[k] = float(max(draw(f.outputscale_prior, 1, p.factor_os[k])[0], 1e-6))
     return p
 
 
@@ -259,6 +308,8 @@ def theta_from_params(spec: GPSpec, p: GPParams) -> np.ndarray:
         parts.append(p.task_B().reshape(-1))
     if spec.hadamard:  # the scalar slots [0], [1] are ignored by the device then (include/baybe_hip.h)
         parts += [nz, mu]
+    if spec.factors:
+        parts += [np.asarray(l, dtype=np.float64) for l in p.factor_ls] + [np.asarray(p.factor_os, dtype=np.float64)]
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
 
 
@@ -269,7 +320,13 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
     parts = [nz, np.atleast_1d(np.asarray(p.mean, dtype=np.float64))]
     if spec.use_outputscale:
         parts.append(inv_softplus(np.array([p.outputscale])))
+    if spec.factors and spec.factors[0].scaled:
+        parts.append(inv_softplus(np.array([p.factor_os[0]])))
     parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
+    for k, f in enumerate((spec.factors or [])[1:]):
+        if f.scaled:
+            parts.append(inv_softplus(np.array([p.factor_os[k + 1]])))
+        parts.append(p.factor_ls[k] if f.ls_constraint == "box" else inv_softplus(p.factor_ls[k]))
     if spec.n_tasks > 1:
         parts.append(inv_softplus(p.task_W).reshape(-1))
         parts.append(inv_softplus(p.task_v))
@@ -288,14 +345,23 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     os_ = 1.0
     if spec.use_outputscale:
         os_ = float(softplus(raw[i])); i += 1
+    fos = np.ones(spec.n_factors) if spec.factors else None
+    if spec.factors and spec.factors[0].scaled:
+        fos[0] = float(softplus(raw[i])); i += 1
     ls_raw = raw[i : i + spec.dn]; i += spec.dn
     ls = ls_raw.copy() if spec.ls_constraint == "box" else softplus(ls_raw)
+    fls = [] if spec.factors else None
+    for k, f in enumerate((spec.factors or [])[1:]):
+        if f.scaled:
+            fos[k + 1] = float(softplus(raw[i])); i += 1
+        r = raw[i : i + spec.dn]; i += spec.dn
+        fls.append(r.copy() if f.ls_constraint == "box" else softplus(r))
     W = v = None
     if spec.n_tasks > 1:
         T = spec.n_tasks
         W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
         v = softplus(raw[i : i + T]); i += T
-    return GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale))
+    return GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos)
 
 
 def raw_bounds(spec: GPSpec):
@@ -304,7 +370,13 @@ def raw_bounds(spec: GPSpec):
     b = [((spec.noise_lower, None) if spec.noise_constraint == "box" else (None, None))] * m + [(None, None)] * m
     if spec.use_outputscale:
         b.append((None, None))
+    if spec.factors and spec.factors[0].scaled:
+        b.append((None, None))
     b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
+    for f in (spec.factors or [])[1:]:
+        if f.scaled:
+            b.append((None, None))
+        b += [((f.ls_lower, None) if f.ls_constraint == "box" else (None, None))] * spec.dn
     if spec.n_tasks > 1:
         b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
     return b
@@ -378,11 +450,34 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
     if spec.use_outputscale:
         g.append(np.array([(g_os + glp_os[0]) * float(sigmoid(raw[i]))]))
         i += 1
+    F = spec.n_factors
+    base = 3 + dn + (T * T if T > 1 else 0) + (2 * T if spec.hadamard else 0)  # extra lengthscale blocks, then os_f [F]
+    fos_off = base + (F - 1) * dn
+
+    def scale_slot(k, f, i):  # a factor's own ScaleKernel: prior + softplus chain
+        lp, glp = _prior_logp_and_grad(f.outputscale_prior, np.array([p.factor_os[k]]))
+        g.append(np.array([(grad_theta[fos_off + k] + glp[0]) * float(sigmoid(raw[i]))]))
+        return lp
+
+    if spec.factors and spec.factors[0].scaled:
+        total += scale_slot(0, spec.factors[0], i)
+        i += 1
     gl = g_ls + glp_ls
     if spec.ls_constraint != "box":
         gl = gl * sigmoid(raw[i : i + dn])
     g.append(gl)
     i += dn
+    for k, f in enumerate((spec.factors or [])[1:]):
+        if f.scaled:
+            total += scale_slot(k + 1, f, i)
+            i += 1
+        lp_f, glp_f = _prior_logp_and_grad(f.ls_prior, p.factor_ls[k])
+        total += lp_f
+        gf = grad_theta[base + k * dn : base + (k + 1) * dn] + glp_f
+        if f.ls_constraint != "box":
+            gf = gf * sigmoid(raw[i : i + dn])
+        g.append(gf)
+        i += dn
     if T > 1:
         S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)  # dL/dB of the (scaled) table the device multiplies with
         Bu = p.task_B_unscaled()

@@ -2,7 +2,8 @@
 (mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
 ``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
 device: Matérn(0.5|1.5|2.5) / RBF base kernels with ARD over all numerical columns, optionally
-wrapped in a ScaleKernel).
+wrapped in a ScaleKernel, and ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``) of two to
+four such factors, each optionally in its own ScaleKernel, the whole optionally in an outer ScaleKernel).
 
 ``apply_kernel_spec`` is duck-typed on class names and attribute names, so BayBE's own kernel
 objects can be passed unchanged.  As in ``Kernel.to_gpytorch`` (``baybe/kernels/base.py:113-194``)
@@ -52,6 +53,20 @@ class ScaleKernel:
     outputscale_trainable: bool = field(default=True, validator=instance_of(bool))
 
 
+@define(frozen=True)
+class ProductKernel:
+    """``baybe.kernels.composite.ProductKernel``: the product of the base kernels (each over all numerical columns)."""
+
+    base_kernels: tuple = field(converter=tuple)
+
+
+@define(frozen=True)
+class AdditiveKernel:
+    """``baybe.kernels.composite.AdditiveKernel``: the sum of the base kernels."""
+
+    base_kernels: tuple = field(converter=tuple)
+
+
 def _prior_tuple(prior):
     if prior is None:
         return None
@@ -76,6 +91,36 @@ def apply_kernel_spec(spec, kernel):
         name = type(kernel).__name__
     else:
         spec.use_outputscale = False
+    if name in ("ProductKernel", "AdditiveKernel"):
+        from baybe_amd.gp_spec import KernelFactor
+
+        members = tuple(kernel.base_kernels)
+        if not 2 <= len(members) <= 4:
+            raise IncompatibilityError(f"'{name}' with {len(members)} base kernels: the HIP path evaluates 2 to 4 factors.")
+        factors = []
+        for member in members:
+            mname, scaled, os_prior, os_init = type(member).__name__, False, None, None
+            if mname == "ScaleKernel":
+                if not getattr(member, "outputscale_trainable", True):
+                    raise IncompatibilityError("Frozen outputscales are not available on the HIP path.")
+                scaled, os_prior = True, _prior_tuple(getattr(member, "outputscale_prior", None))
+                os_init = getattr(member, "outputscale_initial_value", None)
+                member = member.base_kernel
+                mname = type(member).__name__
+            if mname == "MaternKernel":
+                kind = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(member.nu)]
+            elif mname == "RBFKernel":
+                kind = "rbf"
+            else:
+                raise IncompatibilityError(
+                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF factors, each "
+                    f"optionally in a ScaleKernel, are)."
+                )
+            if getattr(member, "parameter_names", None):
+                raise IncompatibilityError("Kernels restricted to a parameter subset are not available on the HIP path.")
+            factors.append(KernelFactor(kind, "softplus", 0.0, _prior_tuple(getattr(member, "lengthscale_prior", None)),
+                                        getattr(member, "lengthscale_initial_value", None), scaled, os_prior, os_init))
+        return spec.set_factors(factors, "product" if name == "ProductKernel" else "sum")
     if name == "MaternKernel":
         spec.kernel = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(kernel.nu)]
     elif name == "RBFKernel":

@@ -73,6 +73,15 @@ typedef struct bbh_model_desc {
   int32_t hadamard;        /* 1 (n_tasks > 1 only) = one noise variance and one constant mean PER TASK:
                               HadamardGaussianLikelihood + HadamardConstantMean of the multi-task HVARFNER /
                               BOTORCH presets (surrogates/gaussian_process/components/_gpytorch.py:15-75)     */
+  /* Composite kernels (baybe/kernels/composite.py:60-91): n_factors in 2..4 stationary factors, each with its own ARD
+   * lengthscales over the numerical columns, combined as a ProductKernel (combine 0) or an AdditiveKernel (combine 1);
+   * factor f may sit in its own ScaleKernel (factor_scaled[f]).  n_factors 0 / 1 = the single kernel_kind above;
+   * factor_kind[0] must equal kernel_kind otherwise.  Evaluated through the materialised-K* posterior path (the fused
+   * kernels are specialised for one factor). */
+  int32_t n_factors;
+  int32_t combine;
+  int32_t factor_kind[4];
+  int32_t factor_scaled[4];
 } bbh_model_desc;
 
 /*
@@ -85,6 +94,9 @@ typedef struct bbh_model_desc {
  *   [3+dn .. +T*T) task covariance B[t][t'] row-major (only when n_tasks > 1)
  *   [.. +T) [.. +T) per-task noise variances, then per-task constant means (only with desc.hadamard;
  *                  slots [0] and [1] are then ignored and their gradients are 0)
+ *   [.. +(F-1)*dn)  lengthscales of the factors 1 .. F-1 of a composite kernel (factor 0 uses [3 .. 3+dn))
+ *   [.. +F)         per-factor outputscales (1 for an unscaled factor; its gradient slot is still filled)
+ *                  k = outputscale * (prod_f | sum_f) os_f k_f(r_f) * B[t][t']
  * Gradients are returned in the same layout (for B: dL/dB[t][t'], accumulated
  * over ordered pairs, i.e. the matrix S with dL = sum_tt' S[t][t'] dB[t][t']).
  * Constraint transforms (softplus) and prior terms are O(d) scalar work and stay

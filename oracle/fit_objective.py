@@ -20,6 +20,9 @@ parameters in ``mll.named_parameters()`` order; every piece of arithmetic comes 
   ``PositiveIndexKernel`` at its own defaults = the task covariance divided by its target-task entry
   (``spec.index_kernel_scaling == "target"``, target task 0) and, for BOTORCH, ``torch.distributions.Beta(2.5, 1.5)``
   on the lower-triangle task correlations;
+* user ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``: ``reduce(mul | add, gpytorch
+  kernels)``): ``spec.members`` lists the base kernels (each ARD over all numerical columns, optionally inside its own
+  ``ScaleKernel``); their Gram matrices are multiplied / added elementwise;
 * ``(log-likelihood + sum of prior log-densities) / n``, negated; the **gradient is autograd's**.
 
 The product's host code (``baybe_amd/gp_spec.py``: hand-written chain rules and prior derivatives around the
@@ -48,10 +51,17 @@ class RawParameter:
     lower: float | None  # GreaterThan(lower) / Positive() (lower = 0); None = unconstrained (the mean constant)
     transformed: bool  # True: natural = lower + softplus(raw); False: natural = raw and `lower` is an optimiser bound
     prior: torch.distributions.Distribution | None
+    member: int | None = None  # index inside a ProductKernel / AdditiveKernel (several parameters share a leaf name there)
 
     @property
     def size(self) -> int:
         return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def key(self) -> str:
+        """Name under which the natural value is filed: gpytorch's leaf name, plus the member index in a composite."""
+        leaf = self.name.rsplit(".raw_", 1)[1]
+        return leaf if self.member is None else f"{leaf}.{self.member}"
 
 
 def _prior(desc):
@@ -85,8 +95,18 @@ def parameter_layout(spec) -> list[RawParameter]:
     if spec.use_outputscale:
         out.append(RawParameter(f"{base}.raw_outputscale", (), 0.0, True, _prior(spec.outputscale_prior)))
         base += ".base_kernel"
-    out.append(RawParameter(f"{base}.raw_lengthscale", (1, spec.dn), spec.ls_lower if box_ls else 0.0, not box_ls,
-                            _prior(spec.ls_prior)))
+    members = getattr(spec, "members", None)
+    if members:  # ProductKernel / AdditiveKernel: .kernels.0, .kernels.1, ... each possibly a ScaleKernel
+        for m, term in enumerate(members):
+            leaf = f"{base}.kernels.{m}"
+            if term.outputscale is not None:
+                out.append(RawParameter(f"{leaf}.raw_outputscale", (), 0.0, True, _prior(term.outputscale.prior), m))
+                leaf += ".base_kernel"
+            h = term.lengthscale
+            out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, spec.dn), h.lower, h.transformed, _prior(h.prior), m))
+    else:
+        out.append(RawParameter(f"{base}.raw_lengthscale", (1, spec.dn), spec.ls_lower if box_ls else 0.0, not box_ls,
+                                _prior(spec.ls_prior)))
     if T > 1:
         out.append(RawParameter("covar_module.kernels.1.raw_covar_factor", (T, T), 0.0, True, None))
         out.append(RawParameter("covar_module.kernels.1.raw_var", (T,), 0.0, True, None))
@@ -107,7 +127,7 @@ def split_raw(spec, raw: torch.Tensor) -> dict:
     for prm in parameter_layout(spec):
         chunk = raw[i : i + prm.size].reshape(prm.shape)
         i += prm.size
-        out[prm.name.rsplit(".raw_", 1)[1]] = (prm.lower + F.softplus(chunk)) if prm.transformed else chunk
+        out[prm.key] = (prm.lower + F.softplus(chunk)) if prm.transformed else chunk
     if i != raw.numel():
         raise ValueError(f"raw vector has {raw.numel()} entries, the model has {i}")
     return out
@@ -117,7 +137,7 @@ def natural_to_raw(spec, natural: dict) -> np.ndarray:
     """Inverse of ``split_raw`` (``softplus^-1(y) = y + log(-expm1(-y))``) for start points given naturally."""
     parts = []
     for prm in parameter_layout(spec):
-        v = torch.as_tensor(natural[prm.name.rsplit(".raw_", 1)[1]], dtype=F64).reshape(-1)
+        v = torch.as_tensor(natural[prm.key], dtype=F64).reshape(-1)
         if prm.transformed:
             y = v - prm.lower
             v = y + torch.log(-torch.expm1(-y))
@@ -140,9 +160,23 @@ def _base_kernel(kernel: str, r2: torch.Tensor) -> torch.Tensor:
 
 def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     """K(X, X) without noise on the normalised inputs: stationary ARD kernel (x outputscale) (x B[t, t'])."""
-    Xs = Xn[:, torch.as_tensor(np.asarray(spec.num_idx))] / nat["lengthscale"].reshape(1, -1)
-    diff = Xs[:, None, :] - Xs[None, :, :]
-    K = _base_kernel(spec.kernel, (diff * diff).sum(-1))
+    Xnum = Xn[:, torch.as_tensor(np.asarray(spec.num_idx))]
+
+    def gram(kind, lengthscale):
+        Xs = Xnum / lengthscale.reshape(1, -1)
+        diff = Xs[:, None, :] - Xs[None, :, :]
+        return _base_kernel(kind, (diff * diff).sum(-1))
+
+    members = getattr(spec, "members", None)
+    if members:
+        K = None
+        for m, term in enumerate(members):
+            Km = gram(term.kernel, nat[f"lengthscale.{m}"])
+            if term.outputscale is not None:
+                Km = Km * nat[f"outputscale.{m}"]
+            K = Km if K is None else (K * Km if spec.composition == "product" else K + Km)
+    else:
+        K = gram(spec.kernel, nat["lengthscale"])
     if spec.use_outputscale:
         K = K * nat["outputscale"]
     if spec.n_tasks > 1:
@@ -184,7 +218,7 @@ def log_prior(spec, nat: dict) -> torch.Tensor:
     total = torch.zeros((), dtype=F64)
     for prm in parameter_layout(spec):
         if prm.prior is not None:
-            total = total + prm.prior.log_prob(nat[prm.name.rsplit(".raw_", 1)[1]]).sum()
+            total = total + prm.prior.log_prob(nat[prm.key]).sum()
     corr_prior = getattr(spec, "correlation_prior", None)
     if corr_prior is not None and spec.n_tasks > 1:
         family, c1, c0 = corr_prior

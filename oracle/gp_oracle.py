@@ -85,6 +85,16 @@ class Hyper:
 
 
 @dataclass
+class KernelTerm:
+    """One base kernel of a user ``ProductKernel`` / ``AdditiveKernel`` (baybe/kernels/composite.py:60-91): a stationary
+    ARD kernel over all numerical columns; ``outputscale`` is set when the term sits in its own ``ScaleKernel``."""
+
+    kernel: str = "matern52"
+    lengthscale: Hyper = field(default_factory=Hyper)
+    outputscale: "Hyper | None" = None
+
+
+@dataclass
 class GPSpec:
     """Architecture + priors + constraints of one single-output GP (``baybe_default`` = presets/baybe.py)."""
 
@@ -104,6 +114,8 @@ class GPSpec:
     task_model: str = "shared"  # "per_task": HadamardGaussianLikelihood + HadamardConstantMean (one noise, one mean per task)
     index_kernel_scaling: str = "none"  # "target": botorch PositiveIndexKernel default, covariance / its [0, 0] entry
     correlation_prior: tuple | None = None  # ("beta", 2.5, 1.5): BetaPrior on the lower-triangle task correlations
+    members: "list[KernelTerm] | None" = None  # base kernels of a ProductKernel / AdditiveKernel (replaces `kernel`)
+    composition: str = "product"  # "product" | "sum"
 
     @property
     def dn(self) -> int:
@@ -153,6 +165,8 @@ class GPParams:
     task_W: "np.ndarray | None" = None  # PositiveIndexKernel covar_factor [T, rank = T]
     task_v: "np.ndarray | None" = None  # PositiveIndexKernel var [T]
     target_scaled: bool = False  # index_kernel_scaling == "target"
+    member_ls: "list[np.ndarray] | None" = None  # per base kernel of a composite: lengthscales [dn] (ALL members)
+    member_scale: "np.ndarray | None" = None  # per base kernel: its own outputscale (1 where it has none)
 
     def task_B(self) -> np.ndarray | None:
         if self.task_W is None:
@@ -171,7 +185,8 @@ class GPParams:
         dup = lambda a: None if a is None else np.array(a, dtype=np.float64, copy=True)  # noqa: E731
         scal = lambda a: float(a) if np.ndim(a) == 0 else dup(a)  # noqa: E731
         return GPParams(dup(self.lengthscale), scal(self.noise), scal(self.mean), float(self.outputscale),
-                        dup(self.task_W), dup(self.task_v), self.target_scaled)
+                        dup(self.task_W), dup(self.task_v), self.target_scaled,
+                        None if self.member_ls is None else [dup(a) for a in self.member_ls], dup(self.member_scale))
 
 
 def softplus(x):
@@ -194,6 +209,9 @@ def initial_params(spec, task_init=1.0):
         task_W=np.full((T, T), task_init / math.sqrt(T)) if T > 1 else None,
         task_v=np.full(T, math.log(2.0)) if T > 1 else None,
         target_scaled=spec.index_kernel_scaling == "target",
+        member_ls=[np.full(spec.dn, t.lengthscale.start()) for t in spec.members] if spec.members else None,
+        member_scale=np.array([1.0 if t.outputscale is None else t.outputscale.start() for t in spec.members])
+        if spec.members else None,
     )
 
 
@@ -261,10 +279,27 @@ def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
     raise ValueError(kernel)
 
 
+def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> list[np.ndarray]:
+    """Scaled Gram matrix of every base kernel of a composite (numerical columns only)."""
+    return [p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A, B, p.member_ls[m]))
+            for m, t in enumerate(spec.members)]
+
+
+def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """The kernel over the numerical columns without outer outputscale / task factor: the single stationary kernel, or
+    the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
+    if not spec.members:
+        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A, B, p.lengthscale))
+    grams = member_grams(spec, p, A, B)
+    out = grams[0].copy()
+    for Km in grams[1:]:
+        out = out * Km if spec.composition == "product" else out + Km
+    return out
+
+
 def cross_cov(spec: GPSpec, p: GPParams, XAn: np.ndarray, XBn: np.ndarray) -> np.ndarray:
     """K(XA, XB) on *normalised* inputs, incl. outputscale and task factor."""
-    r2 = _scaled_sqdist(XAn[:, spec.num_idx], XBn[:, spec.num_idx], p.lengthscale)
-    K = base_kernel_from_r2(spec.kernel, r2)
+    K = stationary_part(spec, p, XAn[:, spec.num_idx], XBn[:, spec.num_idx])
     if spec.use_outputscale:
         K = K * p.outputscale
     if spec.task_idx is not None:
@@ -283,6 +318,8 @@ def task_rows(spec: GPSpec, Xn: np.ndarray) -> np.ndarray:
 def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
     """k(x,x) for each row (1 * outputscale * B[t,t])."""
     v = np.full(Xn.shape[0], p.outputscale if spec.use_outputscale else 1.0)
+    if spec.members:  # k_m(x, x) = 1 for every stationary member
+        v = v * (np.prod(p.member_scale) if spec.composition == "product" else np.sum(p.member_scale))
     if spec.task_idx is not None:
         B = p.task_B()
         t = Xn[:, spec.task_idx].astype(np.int64)
@@ -301,6 +338,8 @@ class DataTerm:
     g_mean: "float | np.ndarray"  # [T] for per-task means
     g_outputscale: float
     g_task_B: np.ndarray | None  # dL/dB[t,t'] (symmetric accumulation S)
+    g_member_ls: "list[np.ndarray] | None" = None  # composite kernels: per base kernel
+    g_member_scale: "np.ndarray | None" = None
 
 
 def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> DataTerm:
@@ -340,6 +379,8 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
 
     # kernel-parameter gradients through G
     Xs = Xn[:, spec.num_idx]
+    if spec.members:
+        return _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow)
     r2 = _scaled_sqdist(Xs, Xs, p.lengthscale)
     gfac = base_kernel_gfac_from_r2(spec.kernel, r2)
     scale = np.full((n, n), p.outputscale if spec.use_outputscale else 1.0)
@@ -370,11 +411,56 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     return DataTerm(value, g_ls, g_noise, g_mean, g_os, g_B)
 
 
+def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> DataTerm:
+    """dL/d(member lengthscales, member scales, outer scale, task table, noise, mean) for a product / sum of members.
+    With S = stationary part, K = os * S * B:  dK/dtheta_m = os * B * dS/dtheta_m, and
+      product: dS/dtheta_m = (S / S_m) dS_m/dtheta_m = prod_{g != m} S_g * dS_m/dtheta_m;   sum: dS/dtheta_m = dS_m/dtheta_m."""
+    n = Xn.shape[0]
+    os = p.outputscale if spec.use_outputscale else 1.0
+    Bsel = np.ones((n, n))
+    if spec.task_idx is not None:
+        Bsel = p.task_B()[np.ix_(trow, trow)]
+    grams = member_grams(spec, p, Xs, Xs)
+    g_ls, g_sc = [], np.zeros(len(spec.members))
+    for m, t in enumerate(spec.members):
+        others = np.ones((n, n))
+        if spec.composition == "product":
+            for k, Kk in enumerate(grams):
+                if k != m:
+                    others = others * Kk
+        r2 = _scaled_sqdist(Xs, Xs, p.member_ls[m])
+        front = G * os * Bsel * others * p.member_scale[m] * base_kernel_gfac_from_r2(t.kernel, r2)
+        gl = np.empty(spec.dn)
+        for j in range(spec.dn):
+            diff = Xs[:, j : j + 1] - Xs[None, :, j]
+            gl[j] = float((front * diff * diff).sum()) / p.member_ls[m][j] ** 3
+        g_ls.append(gl)
+        g_sc[m] = float((G * os * Bsel * others * base_kernel_from_r2(t.kernel, r2)).sum())
+    S = stationary_part(spec, p, Xs, Xs)
+    g_os = float((G * S * Bsel).sum()) if spec.use_outputscale else 0.0
+    g_B = None
+    if spec.task_idx is not None:
+        onehot = np.zeros((n, spec.n_tasks))
+        onehot[np.arange(n), trow] = 1.0
+        g_B = onehot.T @ (G * S * os) @ onehot
+    if spec.task_model == "per_task":
+        g_noise = np.array([float(np.diag(G)[trow == k].sum()) for k in range(spec.n_tasks)])
+        g_mean = np.array([float(g_mean_rows[trow == k].sum()) for k in range(spec.n_tasks)])
+    else:
+        g_noise, g_mean = float(np.trace(G)), float(g_mean_rows.sum())
+    return DataTerm(value, g_ls[0], g_noise, g_mean, g_os, g_B, g_ls, g_sc)
+
+
 # ---- the optimiser's view: raw vector <-> natural parameters, objective, bounds -----------------------
 # All of it is oracle/fit_objective.py (torch.distributions + autograd); these wrappers only translate between
 # GPParams and the gpytorch-named parameter dictionary.
 def _natural_dict(spec: GPSpec, p: GPParams) -> dict:
     nat = {"noise": np.atleast_1d(p.noise), "constant": p.mean, "lengthscale": p.lengthscale}
+    if spec.members:
+        for m, t in enumerate(spec.members):
+            nat[f"lengthscale.{m}"] = p.member_ls[m]
+            if t.outputscale is not None:
+                nat[f"outputscale.{m}"] = p.member_scale[m]
     if spec.use_outputscale:
         nat["outputscale"] = p.outputscale
     if spec.n_tasks > 1:
@@ -394,8 +480,13 @@ def unpack_raw(spec, raw):
     from oracle import fit_objective as fo
 
     nat = {k: v.detach().numpy() for k, v in fo.split_raw(spec, torch.as_tensor(np.asarray(raw, dtype=np.float64))).items()}
+    mls = [nat[f"lengthscale.{m}"].reshape(-1).copy() for m in range(len(spec.members))] if spec.members else None
+    msc = np.array([float(nat[f"outputscale.{m}"]) if t.outputscale is not None else 1.0
+                    for m, t in enumerate(spec.members)]) if spec.members else None
     return GPParams(
-        lengthscale=nat["lengthscale"].reshape(-1).copy(),
+        lengthscale=mls[0] if spec.members else nat["lengthscale"].reshape(-1).copy(),
+        member_ls=mls,
+        member_scale=msc,
         noise=nat["noise"].reshape(-1).copy() if spec.task_model == "per_task" else float(nat["noise"].reshape(-1)[0]),
         mean=nat["constant"].reshape(-1).copy() if spec.task_model == "per_task" else float(nat["constant"]),
         outputscale=float(nat["outputscale"]) if spec.use_outputscale else 1.0,

@@ -56,4 +56,9 @@ def oracle_spec(spec):
         criterion=spec.criterion,
         task_model="per_task" if spec.hadamard else "shared",
         index_kernel_scaling="target" if spec.task_unit_scale else "none",
-        correlation_prior=spec.task_prior)
+        correlation_prior=spec.task_prior,
+        members=[go.KernelTerm(f.kernel,
+                               go.Hyper(f.ls_lower if f.ls_constraint == "box" else 0.0, f.ls_constraint != "box", f.ls_prior, f.ls_init),
+                               go.Hyper(0.0, True, f.outputscale_prior, f.outputscale_init) if f.scaled else None)
+                 for f in spec.factors] if spec.factors else None,
+        composition=spec.combine)

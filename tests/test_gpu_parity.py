@@ -40,7 +40,9 @@ def _oparams(p):
 
     return go.GPParams(np.array(p.lengthscale, dtype=float), p.noise, p.mean, p.outputscale,
                        None if p.task_W is None else p.task_W.copy(), None if p.task_v is None else p.task_v.copy(),
-                       bool(getattr(p, "task_unit_scale", False)))
+                       bool(getattr(p, "task_unit_scale", False)),
+                       None if p.factor_ls is None else [np.array(p.lengthscale, dtype=float)] + [np.array(a, dtype=float) for a in p.factor_ls],
+                       None if p.factor_os is None else np.array(p.factor_os, dtype=float))
 
 
 def _np(t):

@@ -184,6 +184,42 @@ def test_multitask_botorch_presets_host_objective_equals_the_autograd_oracle(pre
     assert (preset == "BOTORCH") == (abs(fp - f1) > 1e-6)
 
 
+def test_composite_kernel_parameterisation_against_the_autograd_oracle():
+    """ProductKernel / AdditiveKernel (baybe/kernels/composite.py:60-91): raw vector layout, bounds, theta layout and the
+    host's chain rules (per-factor lengthscale / outputscale slots) against oracle/fit_objective.py."""
+    from baybe_amd.kernels import (AdditiveKernel, GammaPrior, LogNormalPrior, MaternKernel, ProductKernel, RBFKernel, ScaleKernel,
+                                   apply_kernel_spec)
+    from baybe_amd.exceptions import IncompatibilityError
+
+    d, n = 4, 30
+    rng = np.random.default_rng(0)
+    X, Xt, y = make_problem(100, d, n, seed=2)
+    for kern in (ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(RBFKernel(), GammaPrior(2, 0.5))]),
+                 ScaleKernel(AdditiveKernel([ScaleKernel(MaternKernel(1.5)), ScaleKernel(RBFKernel(LogNormalPrior(0, 1))),
+                                             MaternKernel(0.5)]), GammaPrior(2, 0.15))):
+        spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern)
+        ospec = _ospec(spec)
+        F = spec.n_factors
+        raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+        assert np.allclose(go.pack_raw(ospec, go.initial_params(ospec)), raw) and gp_spec.raw_bounds(spec) == go.raw_bounds(ospec)
+        raw = raw + 0.2 * rng.standard_normal(raw.shape)
+        q = gp_spec.unpack_raw(spec, raw)
+        assert np.allclose(gp_spec.pack_raw(spec, q), raw)
+        theta = gp_spec.theta_from_params(spec, q)
+        assert len(theta) == 3 + F * d + F and np.allclose(theta[-F:], q.factor_os)
+        Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+        dt = go.data_term(ospec, go.unpack_raw(ospec, raw), Xn, ys)
+        grad_theta = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale]] + dt.g_member_ls + [dt.g_member_scale])
+        f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
+        f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+        assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    with pytest.raises(IncompatibilityError):  # nested composites are not flattened
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
+                          ProductKernel([MaternKernel(2.5), AdditiveKernel([RBFKernel(), MaternKernel(1.5)])]))
+    with pytest.raises(IncompatibilityError):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), ProductKernel([RBFKernel()] * 5))
+
+
 # ---- backtesting driver: lookup semantics (simulation/lookup.py:19-150), no device needed ---------------
 def test_lookup_dataframe_callable_and_impute_modes():
     import pandas as pd

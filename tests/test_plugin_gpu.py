@@ -263,6 +263,45 @@ def test_user_kernel_specifications_fit_like_the_oracle():
         assert np.allclose(st["yield_mean"], mo, rtol=1e-8, atol=1e-10) and np.allclose(st["yield_var"], vo, rtol=1e-7)
 
 
+def test_user_product_and_additive_kernels_through_the_surrogate():
+    """baybe/kernels/composite.py:60-91: ``ProductKernel`` / ``AdditiveKernel`` given to the surrogate as kernel - fitted on
+    the device like the oracle fits them, posterior statistics and a recommendation off the same model."""
+    from _problems import oracle_spec
+    from baybe_amd import gp_spec
+    from baybe_amd.kernels import AdditiveKernel, GammaPrior, MaternKernel, ProductKernel, RBFKernel, ScaleKernel, apply_kernel_spec
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate
+    from oracle import gp_oracle as go
+
+    rng = np.random.default_rng(16)
+    space = _space3()
+    exp = space.discrete.exp_rep
+    meas = _measure(exp.iloc[rng.choice(len(exp), 30, replace=False)], rng)
+    obj = SingleTargetObjective(NumericalTarget("yield"))
+    Xt = space.transform(meas).to_numpy(dtype=float)
+    y = meas["yield"].to_numpy(dtype=float)
+    for kern in (ScaleKernel(ProductKernel([MaternKernel(nu=2.5, lengthscale_prior=GammaPrior(3, 1)),
+                                            RBFKernel(lengthscale_prior=GammaPrior(3, 1), lengthscale_initial_value=2.0)]),
+                             outputscale_prior=GammaPrior(2, 0.15)),
+                 AdditiveKernel([ScaleKernel(MaternKernel(nu=1.5, lengthscale_prior=GammaPrior(3, 1)), outputscale_prior=GammaPrior(2, 0.5)),
+                                 ScaleKernel(RBFKernel(lengthscale_prior=GammaPrior(3, 0.5)), outputscale_prior=GammaPrior(2, 0.5))])):
+        sur = HipGaussianProcessSurrogate(kernel=kern)
+        sur.fit(space, obj, meas)
+        spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3)), kern)
+        assert sur.engine.spec.n_factors == 2 and sur.engine.spec.combine == spec.combine
+        ospec = oracle_spec(spec)
+        fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+        fi = sur._fit_info
+        # products / sums have ridges (a factor's lengthscale against another's, scales against each other): two L-BFGS-B
+        # runs whose gradients differ in the last bits stop a few 1e-6 apart on them
+        assert np.isclose(fi.fun, fo.fun, rtol=2e-5), (kern, fi.fun, fo.fun)
+        mo, vo = go.GPModel(ospec, fo.params, Xt, y).posterior(space.transform(exp.iloc[:100]).to_numpy(dtype=float))
+        st = sur.posterior_stats(exp.iloc[:100], ("mean", "var"))
+        assert np.allclose(st["yield_mean"], mo, rtol=5e-3, atol=5e-3) and np.allclose(st["yield_var"], vo, rtol=5e-2, atol=1e-6)
+        got = HipBotorchRecommender(surrogate_model=HipGaussianProcessSurrogate(kernel=kern)).recommend(3, space, obj, meas)
+        assert len(got) == 3 and not got.duplicated().any()
+
+
 def test_batch_constraint_subsets_pick_the_best_joint_batch():
     """recommend_discrete_with_subsets (botorch/discrete.py:21-75): one greedy batch per subset of
     a batch constraint, the one with the highest joint acquisition value is returned."""
