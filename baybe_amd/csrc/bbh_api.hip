@@ -28,6 +28,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && v > 0) h->lds_per_block = (size_t)v;
   }
   if (const char* e = getenv("BBH_PENDING_LDS")) h->pending_lds_form = (e[0] != '0');
+  if (const char* e = getenv("BBH_FIT_GRAPH")) h->fit_graph_mode = (e[0] != '0');
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
   if (const char* e = getenv("BBH_KV_LDS")) h->kv_lds_blocks = atoi(e);
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');
@@ -55,6 +56,10 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   bbh_comm_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
+  if (h->fit_stream) {
+    hipStreamSynchronize(h->fit_stream);
+    hipStreamDestroy(h->fit_stream);
+  }
   if (h->side_stream) {
     hipStreamSynchronize(h->side_stream);
     hipStreamDestroy(h->side_stream);

@@ -144,6 +144,11 @@ struct bbh_handle {
   int wmax = 16;                  // column blocks per pass of the fused kernel: 16 (two waves per SIMD) or 32 (one)
   bool fit_overlap = true;        // env BBH_FIT_OVERLAP=0: the inverse of the factor strictly after the factorisation (A/B)
   hipStream_t side_stream = nullptr;  // second stream of the fit (rows of L^-1 next to the trailing updates)
+  hipStream_t fit_stream = nullptr;   // stream the captured evaluation graph is replayed on
+  hipGraphExec_t fit_exec = nullptr;  // one evaluation of the fit objective, captured per model (bbh_fit_value_grad)
+  bool fit_graph_mode = false, fit_graph_failed = false;  // env BBH_FIT_GRAPH=1: replay the captured graph (slower, see bbh_model.hip)
+  double *pin_theta = nullptr, *pin_out = nullptr;  // pinned staging of the evaluation (theta in, value + gradient out)
+  int* pin_info = nullptr;
   hipEvent_t side_events[2] = {nullptr, nullptr};
   bool potrf_register_form = false;  // env BBH_POTRF_REG=1: 64x64 diagonal blocks by the one-wave register kernel (A/B)
   int coop_mode = 1;              // env BBH_COOP: 0 never use the cooperative form, 1 where it pays (default), 2 wherever instantiated
@@ -224,6 +229,7 @@ void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int
               int64_t strideB, double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 // In-place blocked Cholesky of the np x np matrix K (lower), with X = L^-1; info!=0 on failure.
 void bbh_potrf_trtri(bbh_handle* h);
+void bbh_ensure_side_stream(bbh_handle* h);  // creates the fit's second stream and its events (not during a capture)
 void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,
                 const double* x, double* y);   // y = A x   (row-major A)
 void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,

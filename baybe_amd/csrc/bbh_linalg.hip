@@ -333,6 +333,13 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
   }
 }
 
+void bbh_ensure_side_stream(bbh_handle* h) {
+  if (!h->fit_overlap || h->side_stream) return;
+  if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) h->side_stream = nullptr;
+  for (auto& e : h->side_events)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+}
+
 void bbh_potrf_trtri(bbh_handle* h) {
   hipStream_t s = h->stream;
   const int64_t np = h->np, nbk = np / 64;
@@ -346,11 +353,7 @@ void bbh_potrf_trtri(bbh_handle* h) {
   // - none of which the trailing update of step I touches.  Sequentially (sub-diagonal by sub-diagonal, after the
   // factorisation) these 14 small GEMM launches were 25 % of a fit evaluation at n = 512.
   const bool overlap = h->fit_overlap;
-  if (overlap && !h->side_stream) {
-    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) h->side_stream = nullptr;
-    for (auto& e : h->side_events)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-  }
+  bbh_ensure_side_stream(h);
   hipStream_t s2 = (overlap && h->side_stream && h->side_events[0] && h->side_events[1]) ? h->side_stream : s;
   for (int64_t J = 0; J < nbk; J++) {
     if (h->potrf_register_form)  // env BBH_POTRF_REG=1: the one-wave register form (A/B)

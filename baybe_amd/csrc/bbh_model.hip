@@ -6,7 +6,11 @@
 //   ICM task covariance     baybe/surrogates/gaussian_process/components/kernel.py:298-337
 //   MLL / LOO criterion     baybe/surrogates/gaussian_process/components/fit_criterion.py:31-41
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include "bbh_common.h"
 
@@ -323,6 +327,14 @@ static void bbh_free_model(bbh_handle* h) {
   h->d_nmask = nullptr;
   h->d_pendT = h->d_colA = nullptr;
   h->colA_elems = 0;
+  if (h->fit_exec) hipGraphExecDestroy(h->fit_exec);
+  h->fit_exec = nullptr;
+  h->fit_graph_failed = false;
+  if (h->pin_theta) hipHostFree(h->pin_theta);
+  if (h->pin_out) hipHostFree(h->pin_out);
+  if (h->pin_info) hipHostFree(h->pin_info);
+  h->pin_theta = h->pin_out = nullptr;
+  h->pin_info = nullptr;
   h->d_colfrag = nullptr;
   h->colfrag_elems = 0;
   h->ncols = 0;
@@ -520,22 +532,16 @@ static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
   return 0;
 }
 
-extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, double* value_host, double* grad_host) {
-  if (!h) return -1;
-  if (!h->have_model || !theta_host || !value_host || !grad_host) {
-    h->err = "bbh_fit_value_grad: no model / bad arguments";
-    return -1;
-  }
-  BBH_HIP_TRY(h, hipSetDevice(h->device));
-  int rc = bbh_upload_theta(h, theta_host);
-  if (rc) return rc;
-  h->factorized = false;
+// Everything one evaluation of the fit objective puts on h->stream: theta from the pinned staging buffer, Gram matrix,
+// factorisation, inverse, the criterion's value and gradient slots, results into the pinned result buffers.
+static int bbh_fit_enqueue(bbh_handle* h) {
   hipStream_t s = h->stream;
   const int64_t np = h->np, n = h->n;
-  const int64_t tl = bbh_theta_len(h);
+  const int64_t tl = bbh_theta_len_of(h);
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_theta, h->pin_theta, sizeof(double) * tl, hipMemcpyHostToDevice, s));
   // One host synchronisation per evaluation: the Cholesky flag is fetched with the results at the end (after a failed
   // factorisation the remaining kernels run on NaNs, harmlessly, and the outcome is discarded).
-  rc = bbh_chol_and_alpha(h, 0.0, nullptr);
+  int rc = bbh_chol_and_alpha(h, 0.0, nullptr);
   if (rc) return rc;
   // M = X^T X
   bbh_gemm(s, true, false, np, np, np, 1.0, h->d_X, np, 0, h->d_X, np, 0, 0.0, h->d_M, np, 0, 1);
@@ -559,18 +565,91 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
   hipLaunchKernelGGL(bbh_grad_reduce_kernel, dim3((unsigned)tl), dim3(256), 0, s, h->d_partial,
                      (int64_t)n * nchunks * 4, (int)tl, hoff >= 0 ? hoff + h->T : -1, hoff >= 0 ? hoff + 2 * h->T : -1,
                      h->d_out);
-  std::vector<double> out(1 + tl);
-  int info = 0;
-  BBH_HIP_TRY(h, hipMemcpyAsync(out.data(), h->d_out, sizeof(double) * (1 + tl), hipMemcpyDeviceToHost, s));
-  BBH_HIP_TRY(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->d_out, sizeof(double) * (1 + tl), hipMemcpyDeviceToHost, s));
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->pin_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+// The evaluation is ~60 short launches (45 kernels of 5 - 30 us, memsets, event edges between the two streams).  Enqueued
+// one by one the host spends 586 us in launch calls per evaluation at n = 512 and then waits 10 us for the device
+// (BBH_FIT_TRACE=1), which looks launch-bound - but the device's own dependency chain is as long: captured once per model
+// into a hipGraph (both streams; the side stream joins the capture through its event edges; theta and the results
+// travel through pinned staging buffers) and replayed, the same evaluation takes 147 us of hipGraphLaunch + 503 us on
+// the device = 0.66 ms against 0.59 ms launch by launch, where device execution overlaps the enqueueing.  The chain
+// (8 x [diagonal block 28 us -> panel 9 us -> trailing update 12 us] + inverse product, gradient) is what a faster fit
+// has to shorten; the graph path stays available for that work (BBH_FIT_GRAPH=1) and is off by default.
+static int bbh_fit_graph_build(bbh_handle* h) {
+  bbh_ensure_side_stream(h);
+  if (!h->fit_stream && hipStreamCreateWithFlags(&h->fit_stream, hipStreamNonBlocking) != hipSuccess) {
+    h->fit_stream = nullptr;
+    return -1;
+  }
+  hipStream_t saved = h->stream;
+  h->stream = h->fit_stream;
+  int rc = -1;
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(h->fit_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    rc = bbh_fit_enqueue(h);
+    const hipError_t e = hipStreamEndCapture(h->fit_stream, &graph);
+    if (e != hipSuccess || !graph) rc = -1;
+  }
+  h->stream = saved;
+  if (rc == 0 && hipGraphInstantiate(&h->fit_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    h->fit_exec = nullptr;
+    rc = -1;
+  }
+  if (graph) hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  return rc;
+}
+
+extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, double* value_host, double* grad_host) {
+  if (!h) return -1;
+  if (!h->have_model || !theta_host || !value_host || !grad_host) {
+    h->err = "bbh_fit_value_grad: no model / bad arguments";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int64_t tl = bbh_theta_len(h);
+  for (int64_t i = 0; i < tl; i++)
+    if (!(theta_host[i] == theta_host[i])) {
+      h->err = "theta contains NaN";
+      return -3;
+    }
+  h->theta.assign(theta_host, theta_host + tl);
+  h->factorized = false;
+  if (!h->pin_theta) {  // pinned staging: theta in, [value, gradient] and the Cholesky flag out
+    BBH_HIP_TRY(h, hipHostMalloc((void**)&h->pin_theta, sizeof(double) * tl, hipHostMallocDefault));
+    BBH_HIP_TRY(h, hipHostMalloc((void**)&h->pin_out, sizeof(double) * (1 + tl), hipHostMallocDefault));
+    BBH_HIP_TRY(h, hipHostMalloc((void**)&h->pin_info, sizeof(int), hipHostMallocDefault));
+  }
+  memcpy(h->pin_theta, theta_host, sizeof(double) * tl);
+  if (h->fit_graph_mode && !h->fit_exec && !h->fit_graph_failed && bbh_fit_graph_build(h) != 0) h->fit_graph_failed = true;
+  hipStream_t s = h->stream;
+  if (h->fit_exec) {
+    BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier work on the handle's stream (normally idle here)
+    s = h->fit_stream;
+    BBH_HIP_TRY(h, hipGraphLaunch(h->fit_exec, s));
+  } else {
+    int rc = bbh_fit_enqueue(h);
+    if (rc) return rc;
+  }
+  const auto t_enq = std::chrono::steady_clock::now();
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
-  if (info != 0) {
+  if (getenv("BBH_FIT_TRACE")) {  // host time spent enqueueing vs waiting for the device
+    const auto t_end = std::chrono::steady_clock::now();
+    fprintf(stderr, "bbh_fit_value_grad (%s): enqueue %.1f us, wait %.1f us\n", h->fit_exec ? "graph" : "launches",
+            std::chrono::duration<double, std::micro>(t_enq - t_begin).count(),
+            std::chrono::duration<double, std::micro>(t_end - t_enq).count());
+  }
+  if (*h->pin_info != 0) {
     *value_host = -INFINITY;
     for (int64_t i = 0; i < tl; i++) grad_host[i] = 0.0;
     return 1;
   }
-  *value_host = out[0];
-  for (int64_t i = 0; i < tl; i++) grad_host[i] = out[1 + i];
+  *value_host = h->pin_out[0];
+  for (int64_t i = 0; i < tl; i++) grad_host[i] = h->pin_out[1 + i];
   return 0;
 }
 
