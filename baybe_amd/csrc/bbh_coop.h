@@ -193,21 +193,36 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   double* s_alpha = s_mem;
   double* s_kv = s_alpha + 16 * a.nb;
   double* s_red = s_kv + 2 * 4 * 256;
-  if (!(BBH_COOP_ABLATE_PRO & 1))
-    for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
   const int64_t tile0 = (int64_t)blockIdx.x * 16;
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
 
   WaveCtx c;
   // candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2]; every wave builds the tile's fragments itself
+  // Loads first, all of them unconditional (clamped index) and independent: written as `if (dim < dn) v = fma(xr[numcol[dim]],
+  // ...)` every k-step became its own divergent block - column index, wait, row value, wait - twelve dependent memory round
+  // trips per tile before the first kernel value could be computed.
   double nbsum = 0.0;
+  int xcol[KD];
+  double xval[KD], xscl[KD], xofs[KD];
+#pragma unroll
+  for (int k = 0; k < KD; k++) xcol[k] = a.numcol[(4 * k + q < a.dn) ? 4 * k + q : a.dn - 1];
+#pragma unroll
+  for (int k = 0; k < KD; k++) {
+    const int dimc = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
+    xval[k] = xr[xcol[k]];
+    xscl[k] = a.scl[dimc];
+    xofs[k] = a.ofs[dimc];
+  }
+  // alpha -> LDS: requested after the candidate-row loads, so that its round trip passes under theirs
+  if (!(BBH_COOP_ABLATE_PRO & 1))
+    for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
 #pragma unroll
   for (int k = 0; k < KD; k++) {
     const int dim = 4 * k + q;
     double v = 0.0;
     if (dim < a.dn) {
-      v = (BBH_COOP_ABLATE_PRO & 2) ? 0.01 * (double)(dim + cnd) : fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
+      v = (BBH_COOP_ABLATE_PRO & 2) ? 0.01 * (double)(dim + cnd) : fma(xval[k], xscl[k], xofs[k]);
       nbsum = fma(v, v, nbsum);
     }
     c.cf[k] = v;

@@ -661,15 +661,32 @@ __global__ __launch_bounds__(256, (WMAX > 16 ? 1 : 2)) void bbh_fused_posterior_
   double* candw = s_cand + (int64_t)w * a.kd * 64;
 
   // ---- candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2] -------------------
+  // (loads in independent groups of four k-steps with clamped indices: as `if (dim < dn) v = fma(xr[numcol[dim]], ...)`
+  // every k-step was its own divergent block with two dependent memory round trips)
   double nbsum = 0.0;
-  for (int k = 0; k < a.kd; k++) {
-    const int dim = 4 * k + q;
-    double v = 0.0;
-    if (dim < a.dn) {
-      v = fma(xr[a.numcol[dim]], a.scl[dim], a.ofs[dim]);
-      nbsum = fma(v, v, nbsum);
+  for (int k0 = 0; k0 < a.kd; k0 += 4) {
+    int xcol[4];
+    double xval[4], xscl[4], xofs[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) xcol[u] = a.numcol[(4 * (k0 + u) + q < a.dn) ? 4 * (k0 + u) + q : a.dn - 1];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int dimc = (4 * (k0 + u) + q < a.dn) ? 4 * (k0 + u) + q : a.dn - 1;
+      xval[u] = xr[xcol[u]];
+      xscl[u] = a.scl[dimc];
+      xofs[u] = a.ofs[dimc];
     }
-    candw[k * 64 + l] = v;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u < a.kd) {
+        double v = 0.0;
+        if (4 * (k0 + u) + q < a.dn) {
+          v = fma(xval[u], xscl[u], xofs[u]);
+          nbsum = fma(v, v, nbsum);
+        }
+        candw[(k0 + u) * 64 + l] = v;
+      }
+    }
   }
   nbsum += __shfl_xor(nbsum, 16, 64);
   nbsum += __shfl_xor(nbsum, 32, 64);
