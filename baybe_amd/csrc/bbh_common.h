@@ -151,6 +151,7 @@ struct bbh_handle {
   int* pin_info = nullptr;
   hipEvent_t side_events[2] = {nullptr, nullptr};
   bool potrf_register_form = false;  // env BBH_POTRF_REG=1: 64x64 diagonal blocks by the one-wave register kernel (A/B)
+  int coop_nt = 0;                // env BBH_COOP_NT: candidate tiles per workgroup of the cooperative form (2: two tiles where instantiated; default one)
   int coop_mode = 1;              // env BBH_COOP: 0 never use the cooperative form, 1 where it pays (default), 2 wherever instantiated
   bool coop_ready = false;        // operand slices of the cooperative form are packed for the current factorisation
   double* d_rstream = nullptr;    // [4 waves][rstream_frags][64]

@@ -25,6 +25,7 @@
 #include "bbh_fused.h"
 
 #define BBH_COOP_ROUNDS 8  // 8 rounds x 4 column blocks x 16 = 512 training points
+#define BBH_COOP_KV_TILE (2 * 4 * 256)  // doubles of kernel-value buffer per candidate tile: [2 buffers][4 k-blocks][4 x 64]
 #ifndef BBH_COOP_WAVES
 #define BBH_COOP_WAVES 2  // waves per SIMD the register budget is set for (workgroups per CU)
 #endif
@@ -91,23 +92,28 @@ struct CoopArgs {
 // fragments of the groups before G (in the full 8-round numbering)
 __host__ __device__ constexpr int coop_frags_before(int G) { return 16 * (G * BBH_COOP_ROUNDS - (G * (G - 1)) / 2); }
 
-template <int G, int KD, int KVF, bool PRODUCE>
-__device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, const double* tfn, const bbh_lds_double* kv_cur,
+// NT = candidate tiles (of 16) per workgroup.  NT = 2: every operand fragment that comes back from memory feeds two
+// MFMAs (one per tile), which halves the vector-memory traffic per MFMA, at the price of a second set of accumulators
+// (2 x 64 registers: 256 VGPRs in all, no spills).  Measured: not faster than NT = 1 (4.72 vs 4.68 ms) - see bbh_panel.hip.
+template <int G, int KD, int KVF, bool PRODUCE, int NT>
+__device__ __forceinline__ void coop_group(const WaveCtx (&c)[NT], const double* rs, const double* tfn, const bbh_lds_double* kv_cur,
                                            bbh_lds_double* kv_mine_next, const bbh_lds_double* alpha_next, int tbn, int cw,
-                                           d4 (&acc)[BBH_COOP_ROUNDS], d2 (&ring)[BBH_COOP_PAIRS], double& accm) {
+                                           d4 (&acc)[NT][BBH_COOP_ROUNDS], d2 (&ring)[BBH_COOP_PAIRS], double (&accm)[NT]) {
   // rs: this wave's operand slice at the start of the group (wave-uniform); tfn: training fragments of k-block tbn
-  // (wave-uniform); the lane's slot inside a fragment (pair) is added by the load
+  // (wave-uniform); the lane's slot inside a fragment (pair) is added by the load.  kv_cur / kv_mine_next: tile 0's
+  // buffers, tile t's follow at t * BBH_COOP_KV_TILE doubles.
   constexpr int NP = BBH_COOP_PAIRS;        // ring: NP register pairs = 2 NP fragments in flight
   constexpr int CNT = BBH_COOP_ROUNDS - G;  // ring fragments per (k-block, k-step): slots G .. 7
   constexpr int FULL = CNT - 1;             // of which always multiplied
   constexpr int TOT = 16 * CNT;             // fragments of this group (even: pairs never straddle groups)
   constexpr int REM = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(G + 1);  // fragments after this group
-  constexpr int HOSTS = 12 * FULL;  // MFMAs of k-blocks 1..3 that carry the micro-steps of the production
-  const unsigned lane8 = (unsigned)c.l * 8u, lane16 = (unsigned)c.l * 16u;
+  constexpr int HOSTS = 12 * FULL;  // MFMA slots of k-blocks 1..3 that carry the micro-steps of the production
+  constexpr int STEPS = NT * BBH_KV_STEPS;  // micro-steps of this wave's production: tile 0's, then tile 1's
+  const unsigned lane8 = (unsigned)c[0].l * 8u, lane16 = (unsigned)c[0].l * 16u;
   double tfv[KD];
-  d4 dsa, dsb;
+  d4 dsa[NT], dsb[NT];
   KvState<BBH_KV_NU> P;
-  double kv[4], kvx[4], kvn[4], alv[4];
+  double kv[NT][4], kvx[NT][4], kvn[NT][4], alv[4];
   if constexpr (PRODUCE) {
     static_for<0, KD>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
@@ -115,13 +121,17 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
     });
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) kv[r] = kv_cur[r * 64];
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) kv[t][r] = kv_cur[t * BBH_COOP_KV_TILE + r * 64];
   __builtin_amdgcn_sched_barrier(0);
   static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     if constexpr (i < 3) {  // the next k-block's values are requested one block ahead
 #pragma unroll
-      for (int r = 0; r < 4; r++) kvx[r] = kv_cur[(i + 1) * 256 + r * 64];
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) kvx[t][r] = kv_cur[t * BBH_COOP_KV_TILE + (i + 1) * 256 + r * 64];
     } else if constexpr (PRODUCE) {
 #pragma unroll
       for (int r = 0; r < 4; r++) alv[r] = alpha_next[4 * r];
@@ -139,17 +149,23 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
           coop_vmwait2<BEHIND + ((PRODUCE && pr < NP) ? KD : 0)>(ring[pr % NP]);
         }
 #if BBH_COOP_ABLATE_CHAIN  // timing experiment (wrong results): every MFMA goes to the accumulator (f mod 8)
-        if constexpr (s == 0) {
-          if (cw >= i) acc[f % 8] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[f % 8]);
-        } else {
-          acc[f % 8] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[f % 8]);
-        }
+        static_for<0, NT>([&](auto tc_) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc_)::value;
+          if constexpr (s == 0) {
+            if (cw >= i) acc[t][f % 8] = mfma_f64(kv[t][r], ring[pr % NP][f % 2], acc[t][f % 8]);
+          } else {
+            acc[t][f % 8] = mfma_f64(kv[t][r], ring[pr % NP][f % 2], acc[t][f % 8]);
+          }
+        });
 #else
-        if constexpr (s == 0) {  // diagonal slot: column block 4 G + cw, zero (and skipped) for k-blocks above it
-          if (cw >= i) acc[G] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[G]);
-        } else {
-          acc[G + s] = mfma_f64(kv[r], ring[pr % NP][f % 2], acc[G + s]);
-        }
+        static_for<0, NT>([&](auto tc_) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc_)::value;
+          if constexpr (s == 0) {  // diagonal slot: column block 4 G + cw, zero (and skipped) for k-blocks above it
+            if (cw >= i) acc[t][G] = mfma_f64(kv[t][r], ring[pr % NP][f % 2], acc[t][G]);
+          } else {
+            acc[t][G + s] = mfma_f64(kv[t][r], ring[pr % NP][f % 2], acc[t][G + s]);
+          }
+        });
 #endif
         if constexpr (f % 2 == 1 && 2 * (pr + NP) < TOT + REM && !BBH_COOP_ABLATE_LOADS) {  // both halves are consumed
           constexpr int np = pr + NP;  // pair to request, relative to the group start; 4 pairs per 4 KB window
@@ -157,8 +173,9 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
         }
         if constexpr (PRODUCE && i >= 1 && s >= 1 && !BBH_COOP_ABLATE_KV) {
           constexpr int m = ((i - 1) * 4 + r) * FULL + (s - 1);
-          static_for<(m * BBH_KV_STEPS) / HOSTS, ((m + 1) * BBH_KV_STEPS) / HOSTS>([&](auto st) __attribute__((always_inline)) {
-            kv_micro<KVF, BBH_KV_NU, decltype(st)::value>(P, c, tbn, 0, dsa, dsb, kvn);
+          static_for<(m * STEPS) / HOSTS, ((m + 1) * STEPS) / HOSTS>([&](auto st) __attribute__((always_inline)) {
+            constexpr int tile = decltype(st)::value / BBH_KV_STEPS, micro = decltype(st)::value % BBH_KV_STEPS;
+            kv_micro<KVF, BBH_KV_NU, micro>(P, c[tile], tbn, 0, dsa[tile], dsb[tile], kvn[tile]);
           });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -166,51 +183,65 @@ __device__ __forceinline__ void coop_group(const WaveCtx& c, const double* rs, c
       if constexpr (PRODUCE && i == 0 && r == 3) {
         coop_vmwait<NP>(tfv[KD - 1]);  // the NP pair loads in flight are all younger than the training fragments
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!BBH_COOP_ABLATE_KV) kvp_dist<KD>(c, tfv, dsa, dsb);
+        if constexpr (!BBH_COOP_ABLATE_KV) {
+          static_for<0, NT>([&](auto tc_) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc_)::value;
+            kvp_dist<KD>(c[t], tfv, dsa[t], dsb[t]);
+          });
+        }
       }
     });
     if constexpr (i < 3) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) kv[r] = kvx[r];
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) kv[t][r] = kvx[t][r];
     }
   });
   if constexpr (PRODUCE) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if constexpr (BBH_COOP_ABLATE_KV) kvn[r] = tfv[r];
-      kv_mine_next[r * 64] = kvn[r];
-      accm = fma(kvn[r], alv[r], accm);
-    }
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if constexpr (BBH_COOP_ABLATE_KV) kvn[t][r] = tfv[r];
+        kv_mine_next[t * BBH_COOP_KV_TILE + r * 64] = kvn[t][r];
+        accm[t] = fma(kvn[t][r], alv[r], accm[t]);
+      }
   }
 }
 
-template <int KD, int KVF>
+template <int KD, int KVF, int NT>
 __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel(const CoopArgs ca) {
   const FusedArgs& a = ca.f;
-  extern __shared__ __attribute__((aligned(16))) double s_mem[];  // alpha [16 nb] | kv [2][4][256] | red [4][16] x 2
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];  // alpha [16 nb] | kv [NT][2][4][256] | red [NT][2][4][16]
   const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cnd = l & 15, q = l >> 4;
   double* s_alpha = s_mem;
   double* s_kv = s_alpha + 16 * a.nb;
-  double* s_red = s_kv + 2 * 4 * 256;
-  const int64_t tile0 = (int64_t)blockIdx.x * 16;
-  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
-  const double* xr = a.X + row * a.ldx;
+  double* s_red = s_kv + NT * BBH_COOP_KV_TILE;
+  const int64_t tile0 = (int64_t)blockIdx.x * (16 * NT);
 
-  WaveCtx c;
-  // candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2]; every wave builds the tile's fragments itself
+  WaveCtx c[NT];
+  int tcs[NT];
+  // candidate fragments: b = x * scl + ofs, augmented with [1, |b|^2]; every wave builds the tiles' fragments itself.
   // Loads first, all of them unconditional (clamped index) and independent: written as `if (dim < dn) v = fma(xr[numcol[dim]],
   // ...)` every k-step became its own divergent block - column index, wait, row value, wait - twelve dependent memory round
   // trips per tile before the first kernel value could be computed.
-  double nbsum = 0.0;
   int xcol[KD];
-  double xval[KD], xscl[KD], xofs[KD];
+  double xval[NT][KD], xscl[KD], xofs[KD];
+  const double* xr[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int64_t row = (tile0 + 16 * t + cnd < a.N) ? tile0 + 16 * t + cnd : a.N - 1;
+    xr[t] = a.X + row * a.ldx;
+  }
 #pragma unroll
   for (int k = 0; k < KD; k++) xcol[k] = a.numcol[(4 * k + q < a.dn) ? 4 * k + q : a.dn - 1];
 #pragma unroll
   for (int k = 0; k < KD; k++) {
     const int dimc = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
-    xval[k] = xr[xcol[k]];
+#pragma unroll
+    for (int t = 0; t < NT; t++) xval[t][k] = xr[t][xcol[k]];
     xscl[k] = a.scl[dimc];
     xofs[k] = a.ofs[dimc];
   }
@@ -218,54 +249,63 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   if (!(BBH_COOP_ABLATE_PRO & 1))
     for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
 #pragma unroll
-  for (int k = 0; k < KD; k++) {
-    const int dim = 4 * k + q;
-    double v = 0.0;
-    if (dim < a.dn) {
-      v = (BBH_COOP_ABLATE_PRO & 2) ? 0.01 * (double)(dim + cnd) : fma(xval[k], xscl[k], xofs[k]);
-      nbsum = fma(v, v, nbsum);
-    }
-    c.cf[k] = v;
-  }
-  nbsum += __shfl_xor(nbsum, 16, 64);
-  nbsum += __shfl_xor(nbsum, 32, 64);
+  for (int t = 0; t < NT; t++) {
+    double nbsum = 0.0;
 #pragma unroll
-  for (int k = 0; k < KD; k++) {
-    if (4 * k + q == a.dn) c.cf[k] = 1.0;
-    if (4 * k + q == a.dn + 1) c.cf[k] = nbsum;
-  }
-  int tc = 0;
-  if constexpr ((KVF & 1) != 0) {  // task / outputscale table: the candidate's own task selects the table row
-    if (a.task_col >= 0) {
-      tc = (int)xr[a.task_col];
-      tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+    for (int k = 0; k < KD; k++) {
+      const int dim = 4 * k + q;
+      double v = 0.0;
+      if (dim < a.dn) {
+        v = (BBH_COOP_ABLATE_PRO & 2) ? 0.01 * (double)(dim + cnd) : fma(xval[t][k], xscl[k], xofs[k]);
+        nbsum = fma(v, v, nbsum);
+      }
+      c[t].cf[k] = v;
     }
+    nbsum += __shfl_xor(nbsum, 16, 64);
+    nbsum += __shfl_xor(nbsum, 32, 64);
+#pragma unroll
+    for (int k = 0; k < KD; k++) {
+      if (4 * k + q == a.dn) c[t].cf[k] = 1.0;
+      if (4 * k + q == a.dn + 1) c[t].cf[k] = nbsum;
+    }
+    int tc = 0;
+    if constexpr ((KVF & 1) != 0) {  // task / outputscale table: the candidate's own task selects the table row
+      if (a.task_col >= 0) {
+        tc = (int)xr[t][a.task_col];
+        tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+      }
+    }
+    tcs[t] = tc;
+    c[t].tf = a.trainfrag + l;
+    c[t].candl = nullptr;
+    c[t].mb = nullptr;
+    c[t].tbl = a.tasktbl;
+    c[t].taskext = a.taskext;
+    c[t].kvc = nullptr;
+    c[t].kvl = (bbh_lds_double*)nullptr;
+    c[t].nl = 0;
+    c[t].ncache = 0;
+    c[t].al = (const bbh_lds_double*)nullptr;
+    c[t].kd = KD;
+    c[t].kind = a.kind;
+    c[t].T = a.T;
+    c[t].tc = tc;
+    c[t].q = q;
+    c[t].l = l;
+    c[t].dn = a.dn;
   }
-  c.tf = a.trainfrag + l;
-  c.candl = nullptr;
-  c.mb = nullptr;
-  c.tbl = a.tasktbl;
-  c.taskext = a.taskext;
-  c.kvc = nullptr;
-  c.kvl = (bbh_lds_double*)nullptr;
-  c.nl = 0;
-  c.ncache = 0;
-  c.al = (const bbh_lds_double*)nullptr;
-  c.kd = KD;
-  c.kind = a.kind;
-  c.T = a.T;
-  c.tc = tc;
-  c.q = q;
-  c.l = l;
-  c.dn = a.dn;
 
-  bbh_lds_double* kvb = (bbh_lds_double*)(s_kv + l);           // [buffer][k-block of the group][4 values x 64 lanes]
+  bbh_lds_double* kvb = (bbh_lds_double*)(s_kv + l);  // [tile][buffer][k-block of the group][4 values x 64 lanes]
   const bbh_lds_double* alq = (const bbh_lds_double*)(s_alpha + q);  // alpha[16 tb + 4 r + q]
   const int g0 = ca.g0;
-  double accm = 0.0;
-  d4 acc[BBH_COOP_ROUNDS];
+  double accm[NT];
+  d4 acc[NT][BBH_COOP_ROUNDS];
 #pragma unroll
-  for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < NT; t++) {
+    accm[t] = 0.0;
+#pragma unroll
+    for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[t][s] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
   // wave-uniform stream pointer + lane index: scalar base / 32-bit lane offset addressing (no 64-bit VALU pointer
   // arithmetic).  The first fragments are requested before the first kernel values are computed: their L2 latency
   // passes under that work (the compiler's own wait for the training fragments below also covers these older loads).
@@ -276,21 +316,27 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
     coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, (unsigned)l * 16u);
   });
   {  // the first group's kernel values: wave w produces k-block w, not overlapped with anything
-    double tfv[KD], kv0[4];
-    d4 dsa, dsb;
+    double tfv[KD], kv0[NT][4];
     if constexpr (BBH_COOP_ABLATE_PRO & 4) {
-      for (int r = 0; r < 4; r++) kv0[r] = 0.5 + 0.001 * (double)(l + r);
+      for (int t = 0; t < NT; t++)
+        for (int r = 0; r < 4; r++) kv0[t][r] = 0.5 + 0.001 * (double)(l + r);
     } else {
-      kvp_load<KD>(c, w, tfv);
-      kvp_dist<KD>(c, tfv, dsa, dsb);
-      kv_all<KVF>(c, w, dsa, dsb, kv0);
+      kvp_load<KD>(c[0], w, tfv);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        d4 dsa, dsb;
+        kvp_dist<KD>(c[t], tfv, dsa, dsb);
+        kv_all<KVF>(c[t], w, dsa, dsb, kv0[t]);
+      }
     }
     __syncthreads();  // alpha is in LDS
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      kvb[((g0 & 1) * 4 + w) * 256 + r * 64] = kv0[r];
-      accm = fma(kv0[r], alq[16 * w + 4 * r], accm);
-    }
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        kvb[t * BBH_COOP_KV_TILE + ((g0 & 1) * 4 + w) * 256 + r * 64] = kv0[t][r];
+        accm[t] = fma(kv0[t][r], alq[16 * w + 4 * r], accm[t]);
+      }
   }
   __syncthreads();  // group g0 is complete in LDS
 
@@ -300,8 +346,8 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
       const int cw = (G & 1) ? 3 - w : w;
       const int tbn = 4 * (G + 1 - g0) + w;  // real k-block this wave produces for the next group
       constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
-      coop_group<G, KD, KVF, PRODUCE>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, kvb + (G & 1) * 4 * 256,
-                                      kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn, cw, acc, ring, accm);
+      coop_group<G, KD, KVF, PRODUCE, NT>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, kvb + (G & 1) * 4 * 256,
+                                          kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn, cw, acc, ring, accm);
       rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
 #if !BBH_COOP_ABLATE_BARRIER  // (timing experiment only: wrong results without the barrier)
       if constexpr (PRODUCE) __syncthreads();
@@ -311,49 +357,63 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
 
   // ---- ||v||^2 over this wave's column blocks, then over the 16 columns of a block (lanes), then over the waves ----
   if constexpr (BBH_COOP_ABLATE_PRO & 8) {  // no reductions: one value per accumulator row keeps the work alive
-    double keep = accm;
+    double keep = 0.0;
 #pragma unroll
-    for (int s = 0; s < BBH_COOP_ROUNDS; s++) keep += (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
+    for (int t = 0; t < NT; t++) {
+      keep += accm[t];
+#pragma unroll
+      for (int s = 0; s < BBH_COOP_ROUNDS; s++) keep += (acc[t][s][0] + acc[t][s][1]) + (acc[t][s][2] + acc[t][s][3]);
+    }
     if (l == 0 && w == 0) a.var[tile0] = keep;
     return;
   }
-  double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < BBH_COOP_ROUNDS; s++)
+  for (int t = 0; t < NT; t++) {
+    double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; r++) ss[r] = fma(acc[s][r], acc[s][r], ss[r]);
+    for (int s = 0; s < BBH_COOP_ROUNDS; s++)
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    double v = ss[r];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    ss[r] = v;  // candidate q + 4 r
+      for (int r = 0; r < 4; r++) ss[r] = fma(acc[t][s][r], acc[t][s][r], ss[r]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      double v = ss[r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      ss[r] = v;  // candidate q + 4 r
+    }
+    double mp = accm[t];  // lane (q, cnd): a quarter of this wave's share of candidate cnd's mean
+    mp += __shfl_xor(mp, 16, 64);
+    mp += __shfl_xor(mp, 32, 64);
+    double* red_v = s_red + t * 128;  // [4 waves][16 candidates]
+    double* red_m = red_v + 64;
+    if (cnd == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) red_v[w * 16 + q + 4 * r] = ss[r];
+    }
+    if (q == 0) red_m[w * 16 + cnd] = mp;
   }
-  double mp = accm;  // lane (q, cnd): a quarter of this wave's share of candidate cnd's mean
-  mp += __shfl_xor(mp, 16, 64);
-  mp += __shfl_xor(mp, 32, 64);
-  double* red_v = s_red;        // [4 waves][16 candidates]
-  double* red_m = s_red + 64;
-  if (cnd == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) red_v[w * 16 + q + 4 * r] = ss[r];
-  }
-  if (q == 0) red_m[w * 16 + cnd] = mp;
   __syncthreads();
-  if (threadIdx.x < 16) {
-    const int m = threadIdx.x;
-    const int64_t gi = tile0 + m;
-    if (gi < a.N) {
-      const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
-      const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
-      double pv = a.prior_scale, mc = a.mean_const;
-      if constexpr ((KVF & 1) != 0) {
-        const int tcm = __shfl(tc, m, 64);  // lane m of wave 0 holds candidate m's task (cnd = m, q = 0)
-        pv = a.tasktbl[tcm * a.T + tcm];
-        if (a.taskmean) mc = a.taskmean[tcm];
+  if (threadIdx.x < 16 * NT) {  // wave 0: lane m + 16 t finishes candidate m of tile t
+    const int m = threadIdx.x & 15, t = threadIdx.x >> 4;
+    const int64_t gi = tile0 + 16 * t + m;
+    const double* red_v = s_red + t * 128;
+    const double* red_m = red_v + 64;
+    const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
+    const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
+    double pv = a.prior_scale, mc = a.mean_const;
+    if constexpr ((KVF & 1) != 0) {
+      // lane m of wave 0 holds candidate m's task of every tile (cnd = m, q = 0)
+      int tcm = __shfl(tcs[0], m, 64);
+      if constexpr (NT > 1) {
+        const int tcm1 = __shfl(tcs[NT - 1], m, 64);
+        tcm = t ? tcm1 : tcm;
       }
+      pv = a.tasktbl[tcm * a.T + tcm];
+      if (a.taskmean) mc = a.taskmean[tcm];
+    }
+    if (gi < a.N) {
       if (a.mean) a.mean[gi] = a.ybar + a.ysd * (mc + sm);
       if (a.var) a.var[gi] = a.ysd * a.ysd * (pv - sv);
     }
@@ -366,21 +426,23 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
 bool bbh_coop_launch(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_a(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_b(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
+// two candidate tiles per workgroup (grid = ceil(N / 32) workgroups): Matérn-5/2, 6 k-steps
+bool bbh_coop_launch_w2(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 
-#define BBH_COOP_DISPATCH_KD(KDV)                                                                                        \
+#define BBH_COOP_DISPATCH_KD(KDV, NTV)                                                                                        \
   if (kd == KDV) {                                                                                                       \
     const bool m52 = kind == BBH_KERNEL_MATERN52, rbf = kind == BBH_KERNEL_RBF, plain = kind == BBH_KERNEL_MATERN32 && !has_tbl; \
     if (!m52 && !rbf && !plain) return false;                                                                            \
     if (grid.x == 0) return true;                                                                                        \
     if (rbf && has_tbl) /* multi-task HVARFNER / BOTORCH presets */                                                      \
-      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 3>), grid, dim3(256), lds, s, a);                               \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 3, NTV>), grid, dim3(256), lds, s, a);                               \
     else if (rbf)                                                                                                        \
-      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 2>), grid, dim3(256), lds, s, a);                               \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 2, NTV>), grid, dim3(256), lds, s, a);                               \
     else if (kind == BBH_KERNEL_MATERN32)                                                                                \
-      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 4>), grid, dim3(256), lds, s, a);                               \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 4, NTV>), grid, dim3(256), lds, s, a);                               \
     else if (has_tbl)                                                                                                    \
-      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 1>), grid, dim3(256), lds, s, a);                               \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 1, NTV>), grid, dim3(256), lds, s, a);                               \
     else                                                                                                                 \
-      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 0>), grid, dim3(256), lds, s, a);                               \
+      hipLaunchKernelGGL((bbh_coop_posterior_kernel<KDV, 0, NTV>), grid, dim3(256), lds, s, a);                               \
     return true;                                                                                                         \
   }

@@ -3,9 +3,9 @@
 #include "bbh_coop.h"
 
 bool bbh_coop_launch_a(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a) {
-  BBH_COOP_DISPATCH_KD(2)
-  BBH_COOP_DISPATCH_KD(4)
-  BBH_COOP_DISPATCH_KD(6)
+  BBH_COOP_DISPATCH_KD(2, 1)
+  BBH_COOP_DISPATCH_KD(4, 1)
+  BBH_COOP_DISPATCH_KD(6, 1)
   return false;
 }
 

@@ -374,8 +374,18 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     ca.rstream = h->d_rstream;
     ca.frags = h->rstream_frags;
     ca.g0 = h->coop_g0;
-    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + 2 * 4 * 256 + 128);
-    bbh_coop_launch(kdp, a.kind, has_tbl, dim3((unsigned)((N + 15) / 16)), clds, h->stream, ca);
+    // Two candidate tiles per workgroup (env BBH_COOP_NT=2, where instantiated): every operand fragment feeds two MFMAs,
+    // i.e. half the vector-memory traffic per MFMA, 256 VGPRs, no spills - and no faster: 4.72 vs 4.68 ms on the bench
+    // shape (profiles/r02_libs_nt2.log).  What the MFMA pipe loses is per candidate (kernel values on the shared fp64
+    // pipe, per-tile set-up), not per operand fragment; the one-tile form stays the default.
+    const bool two = h->coop_nt == 2 && bbh_coop_launch_w2(kdp, a.kind, has_tbl, dim3(0), 0, nullptr, ca);
+    const int nt = two ? 2 : 1;
+    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + nt * (2 * 4 * 256 + 128));
+    const dim3 cgrid((unsigned)((N + 16 * nt - 1) / (16 * nt)));
+    if (two)
+      bbh_coop_launch_w2(kdp, a.kind, has_tbl, cgrid, clds, h->stream, ca);
+    else
+      bbh_coop_launch(kdp, a.kind, has_tbl, cgrid, clds, h->stream, ca);
     h->last_form = 1;
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;

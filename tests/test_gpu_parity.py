@@ -206,6 +206,31 @@ def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n, kernel):
         assert np.array_equal(out[name][1], out["no_cache"][1])
 
 
+def test_two_tile_cooperative_form_matches_the_one_tile_form(monkeypatch):
+    """BBH_COOP_NT=2: two candidate tiles per workgroup share every operand fragment (bbh_coop.h, NT = 2); same
+    per-candidate arithmetic in the same order as the one-tile form, so the results are identical - ragged last tile,
+    odd tile count and a single row included."""
+    import torch
+
+    from baybe_amd import engine, gp_spec
+
+    d, n = 20, 512
+    X, Xt, y = make_problem(5000 + 17, d, n, seed=31)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    out = {}
+    for nt in ("1", "2"):
+        monkeypatch.setenv("BBH_COOP_NT", nt)
+        g = engine.HipGP(0)
+        g.set_model(spec, Xt, y)
+        g.factorize(gp_spec.GPParams(np.full(d, ls), nz, 0.1))
+        out[nt] = [tuple(t.clone() for t in g.posterior(X[:rows])) for rows in (len(X), 33, 1)]
+        assert g.posterior_kernel_form() == "cooperative"
+        g.close()
+    for (m1, v1), (m2, v2) in zip(out["1"], out["2"]):
+        assert torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
 @pytest.mark.parametrize("N,d,n", [(1, 4, 300), (63, 6, 257), (65, 3, 320), (1000, 7, 513), (130, 20, 777),
                                    (4097, 14, 272), (17, 30, 1041)])
 def test_multi_pass_edges_fused_matches_unfused(gp, N, d, n):
