@@ -13,6 +13,25 @@ if stats:
     with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
         csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(rows)
 
+# per-launch durations of the dominant kernel from the kernel trace, in launch order, and their average over the
+# launches of bench.py's timed region (after the pre-warm and warm-up passes, before the greedy extra) - the number the
+# HIP-event average of bench.py must agree with; the stats file's own average also contains the clock-ramp launches
+trace = glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    PRE, WARM, STEPS = 8, 3, 20  # bench.py: extra["pre_warm_steps"], --warmup, --steps of scripts/profile_bench.sh
+    rows = [r for r in csv.DictReader(open(trace[0])) if "coop_posterior_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    timed = dur[PRE + WARM : PRE + WARM + STEPS]
+    with open(os.path.join(dst, f"{tag}_bench_posterior_launches.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["launch", "region", "duration_ms"])
+        for i, t in enumerate(dur):
+            region = "pre-warm" if i < PRE else "warm-up" if i < PRE + WARM else "timed" if i < PRE + WARM + STEPS else "greedy extra"
+            w.writerow([i, region, f"{t:.4f}"])
+        if timed:
+            w.writerow(["timed-region average", len(timed), f"{sum(timed) / len(timed):.4f}"])
+
 acc = defaultdict(list)
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
