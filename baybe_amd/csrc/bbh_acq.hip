@@ -677,7 +677,7 @@ extern "C" int bbh_score_qlogei(bbh_handle* h, const double* X_dev, int64_t N, i
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
-  if (h->F > 1) {  // composite kernels: materialised-K* posterior, then the stand-alone scoring kernel
+  if (bbh_materialised_only(h)) {  // no fused form: materialised-K* posterior, then the stand-alone scoring kernel
     double *tm = mean_dev, *tv = var_dev, *scratch = nullptr;
     if (!tm || !tv) {
       BBH_HIP_TRY(h, hipMalloc((void**)&scratch, sizeof(double) * 2 * (size_t)N));

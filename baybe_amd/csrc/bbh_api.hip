@@ -190,7 +190,7 @@ extern "C" int bbh_train_posterior_mean(bbh_handle* h, double* mean_host) {
   const int64_t n = h->n, d = h->desc.d;
   int rc = 0;
   double* own = nullptr;  // composite kernels: the posterior path uses the workspace itself
-  if (h->F > 1)
+  if (bbh_materialised_only(h))
     BBH_HIP_TRY(h, hipMalloc((void**)&own, sizeof(double) * (size_t)(n * d + n)));
   else if ((rc = bbh_ensure_ws(h, sizeof(double) * (size_t)(n * d + n))))
     return rc;

@@ -45,10 +45,37 @@ struct bbh_kern_spec {
   int ls_off[BBH_MAX_FACTORS];  // theta offset of the factor's dn lengthscales
   int fos_off;                  // theta offset of the F per-factor outputscales (-1: F == 1)
   int use_os;                   // outer outputscale theta[2]
+  int jb;                       // floor(dn / 2) + 1 (piecewise-polynomial kernels)
 };
-// base kernel value and g(r) = -(dk/dr)/r (dk/dl_j = g Delta_j^2 / l_j^3) as functions of the scaled squared distance
-__device__ __forceinline__ double bbh_kbase(int kind, double r2) {
+// gpytorch PiecewisePolynomialKernel: k = (1 - r)_+^(j + q) P_q(r) with j = jb + q, jb = floor(dn / 2) + 1, and
+// g = -(dk/dr)/r = (1 - r)_+^(j + q - 1) Q_q(r) in closed form (no cancellation at r -> 0 for q >= 1)
+__host__ __device__ inline double bbh_powi(double x, int n) {
+  double acc = 1.0;
+  for (int i = 0; i < n; i++) acc *= x;
+  return acc;
+}
+__host__ __device__ inline double bbh_piecewise(int q, int jb, double r2, bool want_g) {
+  const double r = sqrt(r2 > 1e-30 ? r2 : 1e-30);  // gpytorch's distance: sqrt(clamp_min(r^2, 1e-30))
+  if (!(r < 1.0)) return 0.0;
+  const double j = (double)(jb + q), u = 1.0 - r;
+  if (!want_g) {
+    double P = 1.0;
+    if (q == 1) P = fma(j + 1.0, r, 1.0);
+    if (q == 2) P = fma(fma((j * j + 4.0 * j + 3.0) / 3.0, r, j + 2.0), r, 1.0);
+    if (q == 3)
+      P = fma(fma(fma((j * j * j + 9.0 * j * j + 23.0 * j + 15.0) / 15.0, r, (6.0 * j * j + 36.0 * j + 45.0) / 15.0), r, j + 3.0), r, 1.0);
+    return bbh_powi(u, jb + 2 * q) * P;
+  }
+  const double m = bbh_powi(u, jb + 2 * q - 1);
+  if (q == 0) return r2 > 1e-30 ? j * m / r : 0.0;  // not differentiable at r = 0 (as Matern-1/2)
+  if (q == 1) return (j + 1.0) * (j + 2.0) * m;
+  if (q == 2) return (j + 3.0) * (j + 4.0) * fma(j + 1.0, r, 1.0) / 3.0 * m;
+  return (j + 5.0) * (j + 6.0) * fma(fma(j * j + 4.0 * j + 3.0, r, 3.0 * j + 6.0), r, 3.0) / 15.0 * m;
+}
+// base kernel value as a function of the scaled squared distance (jb: only the piecewise-polynomial family needs it)
+__host__ __device__ inline double bbh_kbase(int kind, double r2, int jb) {
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);
   const double r = sqrt(r2);
   if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
   if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
@@ -56,10 +83,10 @@ __device__ __forceinline__ double bbh_kbase(int kind, double r2) {
 }
 // composite value from the per-factor squared distances: (prod | sum)_f os_f k_f(r2_f), without the outer scale
 __device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta, const double* r2) {
-  if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0]);
+  if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0], ks.jb);
   double acc = ks.combine ? 0.0 : 1.0;
   for (int f = 0; f < ks.F; f++) {
-    const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f]);
+    const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb);
     acc = ks.combine ? acc + u : acc * u;
   }
   return acc;
@@ -241,7 +268,8 @@ int bbh_upload_theta(bbh_handle* h, const double* theta_host);
 void bbh_launch_gram(bbh_handle* h, double jitter);
 bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h);
 int bbh_hadamard_offset(const bbh_handle* h);
-double bbh_prior_base(const bbh_handle* h);  // k(x, x) without the task factor
+double bbh_prior_base(const bbh_handle* h);
+bool bbh_materialised_only(const bbh_handle* h);  // composite / piecewise-polynomial models: no fused kernel form  // k(x, x) without the task factor
 int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                            double* cross_dev);  // composite kernels: every posterior output through the materialised K*  // per-task noise block in theta (means follow at + T), -1 = none
 

@@ -15,16 +15,10 @@
 #include "bbh_common.h"
 
 // ---- stationary kernels as functions of the scaled squared distance -----------------------
-__device__ __forceinline__ double bbh_kfun(int kind, double r2) {
-  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
-  const double r = sqrt(r2);
-  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
-  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
-  return exp(-r);
-}
 // g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3
-__device__ __forceinline__ double bbh_gfun(int kind, double r2) {
+__device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb) {
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, true);
   const double r = sqrt(r2);
   if (kind == BBH_KERNEL_MATERN52) return (5.0 / 3.0) * (1.0 + BBH_SQRT5 * r) * exp(-BBH_SQRT5 * r);
   if (kind == BBH_KERNEL_MATERN32) return 3.0 * exp(-BBH_SQRT3 * r);
@@ -208,7 +202,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   // per factor: value u_f = os_f k_f, and the weight W_f of its derivative in the composite:
   //   product: d/dk_f = os_f prod_{g != f} u_g,   sum: d/dk_f = os_f
   double kf[BBH_MAX_FACTORS], wf[BBH_MAX_FACTORS];
-  for (int f = 0; f < ks.F; f++) kf[f] = bbh_kfun(ks.kind[f], r2[f]);
+  for (int f = 0; f < ks.F; f++) kf[f] = bbh_kbase(ks.kind[f], r2[f], ks.jb);
   for (int f = 0; f < ks.F; f++) {
     double w = 1.0;
     if (ks.F > 1 && !ks.combine)
@@ -243,7 +237,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   }
   for (int f = 0; f < ks.F; f++) {
     const double fos = ks.F > 1 ? theta[ks.fos_off + f] : 1.0;
-    const double Gg = G * bbh_gfun(ks.kind[f], r2[f]) * os * Bab * wf[f] * fos;
+    const double Gg = G * bbh_gfun(ks.kind[f], r2[f], ks.jb) * os * Bab * wf[f] * fos;
     for (int j = 0; j < dn; j++) {
       const double l = theta[ks.ls_off[f] + j];
       const double df = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
@@ -300,6 +294,7 @@ bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h) {
   ks.F = h->F;
   ks.combine = h->desc.combine;
   ks.use_os = h->desc.use_outputscale;
+  ks.jb = h->dn / 2 + 1;
   const int base = 3 + h->dn + (h->T > 1 ? h->T * h->T : 0) + (h->hadamard ? 2 * h->T : 0);
   for (int f = 0; f < BBH_MAX_FACTORS; f++) {
     ks.kind[f] = (f == 0 || h->F <= 1) ? h->desc.kernel_kind : h->desc.factor_kind[f];
@@ -358,7 +353,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->err = "bbh_set_model: bad arguments";
     return -1;
   }
-  if (desc->kernel_kind < 0 || desc->kernel_kind > 3 || desc->d < 1 || desc->n_tasks < 1 ||
+  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_PIECEWISE3 || desc->d < 1 || desc->n_tasks < 1 ||
       (desc->n_tasks > 1 && (desc->task_col < 0 || desc->task_col >= desc->d)) ||
       (desc->criterion != BBH_CRITERION_MLL && desc->criterion != BBH_CRITERION_LOO)) {
     h->err = "bbh_set_model: invalid model description";
@@ -367,7 +362,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   if (desc->n_factors > 1) {
     bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1) &&
               desc->factor_kind[0] == desc->kernel_kind;
-    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= 3;
+    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_PIECEWISE3;
     if (!ok) {
       h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1, factor_kind[0] == kernel_kind)";
       return -1;

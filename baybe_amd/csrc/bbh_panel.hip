@@ -92,14 +92,6 @@ __global__ void bbh_set_beta_kernel(const double* __restrict__ betaT, int64_t ld
   }
 }
 
-static double host_kfun(int kind, double r2) {
-  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
-  const double r = sqrt(r2);
-  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
-  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
-  return exp(-r);
-}
-
 // Host-side layout of the augmented training fragments for blocks [tb0, tb1):
 //   frag[tb][k][l] = Aaug[16 tb + (l & 15)][4 k + (l >> 4)]
 // pts: normalised numerical coordinates [cnt, dn] of the real points in this range (row 0 is
@@ -259,7 +251,7 @@ int bbh_pack_operands(bbh_handle* h) {
 int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                      double* cross_dev, bool with_var) {
   if (N <= 0) return 0;
-  if (h->F > 1)  // composite kernels: materialised-K* path (the fused qLogEI epilogue is applied by the caller)
+  if (bbh_materialised_only(h))  // composite / piecewise kernels: materialised-K* path (fused qLogEI: applied by the caller)
     return bbh_launch_unfused_ext(h, X_dev, N, ldx, mean_dev, with_var ? var_dev : nullptr, cross_dev);
   FusedArgs a;
   a.X = X_dev;
@@ -368,7 +360,11 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   // 16-block window would be needed (n > 256: 4.70 vs 5.17 ms on the bench shape), level at n = 256, a few per cent behind
   // below; for small candidate sets its four waves per tile cut the latency to a third (0.016 vs 0.052 ms for 1000 rows).
   const bool coop_pays = h->coop_mode == 2 || h->nb > 16 || N <= 16384;
-  if (h->coop_ready && coop_pays && kdp && with_var && a.mean_valu && !a.qz) {
+  // (its own instantiation set: also RBF with a task table - the multi-task HVARFNER / BOTORCH presets - which the
+  // windowed pipelined form does not have)
+  const int kdc = (h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
+  const bool coop_mean_valu = h->p == 0 && !cross_dev && h->use_mean_valu && h->nb <= 256;
+  if (h->coop_ready && coop_pays && kdc && with_var && coop_mean_valu && !a.qz) {
     CoopArgs ca;
     ca.f = a;
     ca.rstream = h->d_rstream;
@@ -378,14 +374,14 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     // i.e. half the vector-memory traffic per MFMA, 256 VGPRs, no spills - and no faster: 4.72 vs 4.68 ms on the bench
     // shape (profiles/r02_libs_nt2.log).  What the MFMA pipe loses is per candidate (kernel values on the shared fp64
     // pipe, per-tile set-up), not per operand fragment; the one-tile form stays the default.
-    const bool two = h->coop_nt == 2 && bbh_coop_launch_w2(kdp, a.kind, has_tbl, dim3(0), 0, nullptr, ca);
+    const bool two = h->coop_nt == 2 && bbh_coop_launch_w2(kdc, a.kind, has_tbl, dim3(0), 0, nullptr, ca);
     const int nt = two ? 2 : 1;
     const size_t clds = sizeof(double) * (16 * (size_t)h->nb + nt * (2 * 4 * 256 + 128));
     const dim3 cgrid((unsigned)((N + 16 * nt - 1) / (16 * nt)));
     if (two)
-      bbh_coop_launch_w2(kdp, a.kind, has_tbl, cgrid, clds, h->stream, ca);
+      bbh_coop_launch_w2(kdc, a.kind, has_tbl, cgrid, clds, h->stream, ca);
     else
-      bbh_coop_launch(kdp, a.kind, has_tbl, cgrid, clds, h->stream, ca);
+      bbh_coop_launch(kdc, a.kind, has_tbl, cgrid, clds, h->stream, ca);
     h->last_form = 1;
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;
@@ -496,6 +492,9 @@ static int bbh_unfused_chunk(bbh_handle* h, const double* X_dev, int64_t Nc, int
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
 }
+
+// models the fused kernels are not instantiated for: composite kernels, the piecewise-polynomial family
+bool bbh_materialised_only(const bbh_handle* h) { return h->F > 1 || h->desc.kernel_kind > BBH_KERNEL_RBF; }
 
 // k(x, x) without the task factor: outputscale * (prod_f | sum_f) os_f
 double bbh_prior_base(const bbh_handle* h) {
@@ -719,7 +718,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
           const double df = (pn[i * dn + c] - pn[j * dn + c]) / th[ks.ls_off[f] + c];
           r2 += df * df;
         }
-        const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * host_kfun(ks.kind[f], r2);
+        const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb);
         kc = (ks.combine && ks.F > 1) ? kc + u : kc * u;
       }
       double kpp = os * kc;
@@ -889,7 +888,7 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
   }
   hipLaunchKernelGGL(bbh_pack_colfrag_kernel, dim3((unsigned)nks, 8, (unsigned)groups), dim3(64), 0, s, A, spad, nks,
                      h->d_colfrag);
-  if (h->F > 1) {  // composite kernels contract K* with the plain matrix (bbh_posterior_columns)
+  if (bbh_materialised_only(h)) {  // these models contract K* with the plain matrix (bbh_posterior_columns)
     if (!h->d_colA || h->colA_elems < np * spad) {
       if (h->d_colA) hipFree(h->d_colA);
       h->d_colA = nullptr;
@@ -1002,7 +1001,7 @@ extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
-  if (h->F > 1) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev);
+  if (bbh_materialised_only(h)) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev);
   FusedArgs a;
   bbh_fill_fused_args(h, a, X_dev, N, ldx);
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;

@@ -1,7 +1,7 @@
 """Declarative kernel / prior specifications accepted by ``HipGaussianProcessSurrogate``
 (mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
 ``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
-device: Matérn(0.5|1.5|2.5) / RBF base kernels with ARD over all numerical columns, optionally
+device: Matérn(0.5|1.5|2.5) / RBF / PiecewisePolynomial(q) base kernels with ARD over all numerical columns, optionally
 wrapped in a ScaleKernel, and ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``) of two to
 four such factors, each optionally in its own ScaleKernel, the whole optionally in an outer ScaleKernel).
 
@@ -46,6 +46,15 @@ class RBFKernel:
 
 
 @define(frozen=True)
+class PiecewisePolynomialKernel:
+    """``baybe.kernels.basic.PiecewisePolynomialKernel`` (basic.py:114-131): compact support, smoothness q."""
+
+    q: int = field(default=2, validator=in_([0, 1, 2, 3]))
+    lengthscale_prior = field(default=None)
+    lengthscale_initial_value: float | None = field(default=None)
+
+
+@define(frozen=True)
 class ScaleKernel:
     base_kernel = field()
     outputscale_prior = field(default=None)
@@ -78,6 +87,18 @@ def _prior_tuple(prior):
     raise IncompatibilityError(f"Prior '{name}' is not available on the HIP path (Gamma / LogNormal are).")
 
 
+def _basic_kind(kernel) -> str | None:
+    """Device kernel kind of a basic stationary kernel object, None if it is not one of them."""
+    name = type(kernel).__name__
+    if name == "MaternKernel":
+        return {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(kernel.nu)]
+    if name == "RBFKernel":
+        return "rbf"
+    if name == "PiecewisePolynomialKernel":
+        return f"piecewise{int(kernel.q)}"
+    return None
+
+
 def apply_kernel_spec(spec, kernel):
     """Configure a ``GPSpec`` from a (BayBE or mirror) kernel specification object."""
     name = type(kernel).__name__
@@ -107,28 +128,24 @@ def apply_kernel_spec(spec, kernel):
                 os_init = getattr(member, "outputscale_initial_value", None)
                 member = member.base_kernel
                 mname = type(member).__name__
-            if mname == "MaternKernel":
-                kind = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(member.nu)]
-            elif mname == "RBFKernel":
-                kind = "rbf"
-            else:
+            kind = _basic_kind(member)
+            if kind is None:
                 raise IncompatibilityError(
-                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF factors, each "
-                    f"optionally in a ScaleKernel, are)."
+                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / PiecewisePolynomial "
+                    f"factors, each optionally in a ScaleKernel, are)."
                 )
             if getattr(member, "parameter_names", None):
                 raise IncompatibilityError("Kernels restricted to a parameter subset are not available on the HIP path.")
             factors.append(KernelFactor(kind, "softplus", 0.0, _prior_tuple(getattr(member, "lengthscale_prior", None)),
                                         getattr(member, "lengthscale_initial_value", None), scaled, os_prior, os_init))
         return spec.set_factors(factors, "product" if name == "ProductKernel" else "sum")
-    if name == "MaternKernel":
-        spec.kernel = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}[float(kernel.nu)]
-    elif name == "RBFKernel":
-        spec.kernel = "rbf"
-    else:
+    kind = _basic_kind(kernel)
+    if kind is None:
         raise IncompatibilityError(
-            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF, optionally in a ScaleKernel, are)."
+            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / PiecewisePolynomial, optionally in a "
+            f"ScaleKernel, and Product / Additive kernels of them are)."
         )
+    spec.kernel = kind
     if getattr(kernel, "parameter_names", None):
         raise IncompatibilityError("Kernels restricted to a parameter subset are not available on the HIP path.")
     spec.ls_constraint = "softplus"

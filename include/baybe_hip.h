@@ -54,7 +54,13 @@ enum bbh_kernel_kind {
   BBH_KERNEL_MATERN12 = 0,
   BBH_KERNEL_MATERN32 = 1,
   BBH_KERNEL_MATERN52 = 2, /* BayBE default: presets/baybe.py:100-107 */
-  BBH_KERNEL_RBF = 3
+  BBH_KERNEL_RBF = 3,
+  /* gpytorch PiecewisePolynomialKernel(q), baybe/kernels/basic.py:114-131: (1 - r)_+^(j + q) P_q(r), j = floor(dn / 2) + q + 1.
+   * Compact support; evaluated through the materialised-K* posterior path (like composite kernels). */
+  BBH_KERNEL_PIECEWISE0 = 4,
+  BBH_KERNEL_PIECEWISE1 = 5,
+  BBH_KERNEL_PIECEWISE2 = 6,
+  BBH_KERNEL_PIECEWISE3 = 7
 };
 
 enum bbh_criterion {

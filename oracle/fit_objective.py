@@ -145,7 +145,17 @@ def natural_to_raw(spec, natural: dict) -> np.ndarray:
     return torch.cat(parts).numpy().copy()
 
 
-def _base_kernel(kernel: str, r2: torch.Tensor) -> torch.Tensor:
+def _base_kernel(kernel: str, r2: torch.Tensor, dims: int) -> torch.Tensor:
+    if kernel.startswith("piecewise"):  # gpytorch PiecewisePolynomialKernel(q): fmax(r, j, q) * get_cov(r, j, q)
+        q = int(kernel[-1])
+        r = torch.sqrt(torch.clamp_min(r2, 1e-30))
+        j = math.floor(dims / 2.0) + q + 1
+        cov = {0: lambda: torch.ones_like(r),
+               1: lambda: (j + 1) * r + 1,
+               2: lambda: 1 + (j + 2) * r + ((j**2 + 4 * j + 3) / 3.0) * r**2,
+               3: lambda: 1 + (j + 3) * r + ((6 * j**2 + 36 * j + 45) / 15.0) * r**2
+                          + ((j**3 + 9 * j**2 + 23 * j + 15) / 15.0) * r**3}[q]()
+        return torch.clamp_min(1 - r, 0.0).pow(j + q) * cov
     if kernel == "rbf":
         return torch.exp(-0.5 * r2)
     r = torch.sqrt(torch.clamp_min(r2, 1e-30))  # gpytorch clamps before the root as well
@@ -165,7 +175,7 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     def gram(kind, lengthscale):
         Xs = Xnum / lengthscale.reshape(1, -1)
         diff = Xs[:, None, :] - Xs[None, :, :]
-        return _base_kernel(kind, (diff * diff).sum(-1))
+        return _base_kernel(kind, (diff * diff).sum(-1), Xnum.shape[1])
 
     members = getattr(spec, "members", None)
     if members:

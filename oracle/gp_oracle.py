@@ -55,7 +55,7 @@ FAT_ALPHA_MAX = 2.0  # [UPSTREAM] botorch.utils.safe_math.fatmax alpha
 MIN_INFERRED_NOISE_LEVEL = 0.0001  # [UPSTREAM] botorch.models.utils.gpytorch_modules.MIN_INFERRED_NOISE_LEVEL
 MAX_BATCH_SIZE = 2048  # [UPSTREAM] optimize_acqf_discrete(max_batch_size=2048)
 
-KERNELS = ("matern12", "matern32", "matern52", "rbf")
+KERNELS = ("matern12", "matern32", "matern52", "rbf", "piecewise0", "piecewise1", "piecewise2", "piecewise3")
 
 
 # --------------------------------------------------------------------------------------
@@ -249,8 +249,28 @@ def _scaled_sqdist(XA: np.ndarray, XB: np.ndarray, ls: np.ndarray) -> np.ndarray
     return d2
 
 
-def base_kernel_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
-    """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2."""
+def _piecewise_terms(q: int, dims: int, r: np.ndarray):
+    """gpytorch PiecewisePolynomialKernel [UPSTREAM, piecewise_polynomial_kernel.py]: exponent j = floor(D / 2) + q + 1 and
+    the polynomial ``get_cov(r, j, q)`` with its derivative."""
+    j = math.floor(dims / 2.0) + q + 1
+    if q == 0:
+        return j, np.ones_like(r), np.zeros_like(r)
+    if q == 1:
+        return j, (j + 1) * r + 1, np.full_like(r, j + 1.0)
+    if q == 2:
+        c2 = (j**2 + 4 * j + 3) / 3.0
+        return j, 1 + (j + 2) * r + c2 * r**2, (j + 2) + 2 * c2 * r
+    c2, c3 = (6 * j**2 + 36 * j + 45) / 15.0, (j**3 + 9 * j**2 + 23 * j + 15) / 15.0
+    return j, 1 + (j + 3) * r + c2 * r**2 + c3 * r**3, (j + 3) + 2 * c2 * r + 3 * c3 * r**2
+
+
+def base_kernel_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None) -> np.ndarray:
+    """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2 (``dims``: input dimension, piecewise family)."""
+    if kernel.startswith("piecewise"):
+        q = int(kernel[-1])
+        r = np.sqrt(np.maximum(r2, 1e-30))
+        j, poly, _ = _piecewise_terms(q, dims, r)
+        return np.maximum(0.0, 1.0 - r) ** (j + q) * poly
     if kernel == "rbf":
         return np.exp(-0.5 * r2)
     r = np.sqrt(r2)
@@ -263,8 +283,16 @@ def base_kernel_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
     raise ValueError(kernel)
 
 
-def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
+def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None) -> np.ndarray:
     """g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3."""
+    if kernel.startswith("piecewise"):  # product rule on max(0, 1 - r)^(j + q) * poly(r); plain quotient by r
+        q = int(kernel[-1])
+        r = np.sqrt(np.maximum(r2, 1e-30))
+        j, poly, dpoly = _piecewise_terms(q, dims, r)
+        base = np.maximum(0.0, 1.0 - r)
+        dk = -(j + q) * base ** (j + q - 1) * poly + base ** (j + q) * dpoly
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(r2 > 1e-30, -dk / r, 0.0 if q == 0 else -_second_derivative_at_zero(q, j))
     if kernel == "rbf":
         return np.exp(-0.5 * r2)
     r = np.sqrt(r2)
@@ -279,9 +307,18 @@ def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray) -> np.ndarray:
     raise ValueError(kernel)
 
 
+def _second_derivative_at_zero(q: int, j: int) -> float:
+    """k''(0) of the piecewise-polynomial kernel (the limit of k'(r) / r for q >= 1, where k'(0) = 0)."""
+    p = j + q
+    c1 = {1: j + 1.0, 2: j + 2.0, 3: j + 3.0}[q]
+    c2 = {1: 0.0, 2: (j**2 + 4 * j + 3) / 3.0, 3: (6 * j**2 + 36 * j + 45) / 15.0}[q]
+    # k = (1 - r)^p (1 + c1 r + c2 r^2 + ...):  k'' (0) = p (p - 1) - 2 p c1 + 2 c2
+    return p * (p - 1) - 2 * p * c1 + 2 * c2
+
+
 def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> list[np.ndarray]:
     """Scaled Gram matrix of every base kernel of a composite (numerical columns only)."""
-    return [p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A, B, p.member_ls[m]))
+    return [p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A, B, p.member_ls[m]), A.shape[1])
             for m, t in enumerate(spec.members)]
 
 
@@ -289,7 +326,7 @@ def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> 
     """The kernel over the numerical columns without outer outputscale / task factor: the single stationary kernel, or
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
     if not spec.members:
-        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A, B, p.lengthscale))
+        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A, B, p.lengthscale), A.shape[1])
     grams = member_grams(spec, p, A, B)
     out = grams[0].copy()
     for Km in grams[1:]:
@@ -382,7 +419,7 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     if spec.members:
         return _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow)
     r2 = _scaled_sqdist(Xs, Xs, p.lengthscale)
-    gfac = base_kernel_gfac_from_r2(spec.kernel, r2)
+    gfac = base_kernel_gfac_from_r2(spec.kernel, r2, spec.dn)
     scale = np.full((n, n), p.outputscale if spec.use_outputscale else 1.0)
     Bsel = None
     if spec.task_idx is not None:
@@ -403,7 +440,7 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     g_os = float((G * Kf).sum()) / p.outputscale if spec.use_outputscale else 0.0
     g_B = None
     if spec.task_idx is not None:
-        kb = base_kernel_from_r2(spec.kernel, r2) * (p.outputscale if spec.use_outputscale else 1.0)
+        kb = base_kernel_from_r2(spec.kernel, r2, spec.dn) * (p.outputscale if spec.use_outputscale else 1.0)
         T = spec.n_tasks
         onehot = np.zeros((n, T))
         onehot[np.arange(n), t] = 1.0
@@ -429,13 +466,13 @@ def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> Da
                 if k != m:
                     others = others * Kk
         r2 = _scaled_sqdist(Xs, Xs, p.member_ls[m])
-        front = G * os * Bsel * others * p.member_scale[m] * base_kernel_gfac_from_r2(t.kernel, r2)
+        front = G * os * Bsel * others * p.member_scale[m] * base_kernel_gfac_from_r2(t.kernel, r2, spec.dn)
         gl = np.empty(spec.dn)
         for j in range(spec.dn):
             diff = Xs[:, j : j + 1] - Xs[None, :, j]
             gl[j] = float((front * diff * diff).sum()) / p.member_ls[m][j] ** 3
         g_ls.append(gl)
-        g_sc[m] = float((G * os * Bsel * others * base_kernel_from_r2(t.kernel, r2)).sum())
+        g_sc[m] = float((G * os * Bsel * others * base_kernel_from_r2(t.kernel, r2, spec.dn)).sum())
     S = stationary_part(spec, p, Xs, Xs)
     g_os = float((G * S * Bsel).sum()) if spec.use_outputscale else 0.0
     g_B = None

@@ -213,6 +213,23 @@ def test_composite_kernel_parameterisation_against_the_autograd_oracle():
         f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
         f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
         assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    # PiecewisePolynomialKernel(q): the oracle's two statements of it (numpy value + product-rule derivative; torch value +
+    # autograd) agree, alone and as a factor
+    from baybe_amd.kernels import PiecewisePolynomialKernel
+    for q in range(4):
+        for kern in (ScaleKernel(PiecewisePolynomialKernel(q, GammaPrior(3, 1), 2.0)),
+                     ProductKernel([PiecewisePolynomialKernel(q, None, 3.0), RBFKernel()])):
+            spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern)
+            ospec = _ospec(spec)
+            raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+            raw = raw + 0.1 * rng.standard_normal(raw.shape)
+            raw[0] = abs(raw[0]) + 1e-3
+            Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+            dt = go.data_term(ospec, go.unpack_raw(ospec, raw), Xn, ys)
+            grad_theta = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale]] + (dt.g_member_ls + [dt.g_member_scale] if spec.factors else [dt.g_ls]))
+            f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
+            f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+            assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
     with pytest.raises(IncompatibilityError):  # nested composites are not flattened
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
                           ProductKernel([MaternKernel(2.5), AdditiveKernel([RBFKernel(), MaternKernel(1.5)])]))
