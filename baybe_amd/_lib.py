@@ -44,7 +44,7 @@ class ModelDesc(C.Structure):
 
 
 KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3,
-                "piecewise0": 4, "piecewise1": 5, "piecewise2": 6, "piecewise3": 7}  # enum bbh_kernel_kind
+                "piecewise0": 4, "piecewise1": 5, "piecewise2": 6, "piecewise3": 7, "rq": 8}  # enum bbh_kernel_kind
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15
 MAX_OBJECTIVES = 4

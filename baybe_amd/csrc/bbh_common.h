@@ -46,6 +46,7 @@ struct bbh_kern_spec {
   int fos_off;                  // theta offset of the F per-factor outputscales (-1: F == 1)
   int use_os;                   // outer outputscale theta[2]
   int jb;                       // floor(dn / 2) + 1 (piecewise-polynomial kernels)
+  int alpha_off;                // theta offset of the F alpha parameters (-1: no RQ factor)
 };
 // gpytorch PiecewisePolynomialKernel: k = (1 - r)_+^(j + q) P_q(r) with j = jb + q, jb = floor(dn / 2) + 1, and
 // g = -(dk/dr)/r = (1 - r)_+^(j + q - 1) Q_q(r) in closed form (no cancellation at r -> 0 for q >= 1)
@@ -72,10 +73,12 @@ __host__ __device__ inline double bbh_piecewise(int q, int jb, double r2, bool w
   if (q == 2) return (j + 3.0) * (j + 4.0) * fma(j + 1.0, r, 1.0) / 3.0 * m;
   return (j + 5.0) * (j + 6.0) * fma(fma(j * j + 4.0 * j + 3.0, r, 3.0 * j + 6.0), r, 3.0) / 15.0 * m;
 }
-// base kernel value as a function of the scaled squared distance (jb: only the piecewise-polynomial family needs it)
-__host__ __device__ inline double bbh_kbase(int kind, double r2, int jb) {
+// base kernel value as a function of the scaled squared distance (jb: only the piecewise-polynomial family needs it;
+// alpha: only the RQ kernel)
+__host__ __device__ inline double bbh_kbase(int kind, double r2, int jb, double alpha = 1.0) {
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
-  if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);
+  if (kind == BBH_KERNEL_RQ) return exp(-alpha * log1p(r2 / (2.0 * alpha)));
+  if (kind >= BBH_KERNEL_PIECEWISE0 && kind <= BBH_KERNEL_PIECEWISE3) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);
   const double r = sqrt(r2);
   if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
   if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
@@ -83,10 +86,10 @@ __host__ __device__ inline double bbh_kbase(int kind, double r2, int jb) {
 }
 // composite value from the per-factor squared distances: (prod | sum)_f os_f k_f(r2_f), without the outer scale
 __device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta, const double* r2) {
-  if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0], ks.jb);
+  if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off] : 1.0);
   double acc = ks.combine ? 0.0 : 1.0;
   for (int f = 0; f < ks.F; f++) {
-    const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb);
+    const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0);
     acc = ks.combine ? acc + u : acc * u;
   }
   return acc;

@@ -16,8 +16,9 @@
 
 // ---- stationary kernels as functions of the scaled squared distance -----------------------
 // g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3
-__device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb) {
+__device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double alpha) {
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  if (kind == BBH_KERNEL_RQ) return exp(-(alpha + 1.0) * log1p(r2 / (2.0 * alpha)));  // (1 + u)^-(alpha + 1), u = r^2 / (2 alpha)
   if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, true);
   const double r = sqrt(r2);
   if (kind == BBH_KERNEL_MATERN52) return (5.0 / 3.0) * (1.0 + BBH_SQRT5 * r) * exp(-BBH_SQRT5 * r);
@@ -202,7 +203,9 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   // per factor: value u_f = os_f k_f, and the weight W_f of its derivative in the composite:
   //   product: d/dk_f = os_f prod_{g != f} u_g,   sum: d/dk_f = os_f
   double kf[BBH_MAX_FACTORS], wf[BBH_MAX_FACTORS];
-  for (int f = 0; f < ks.F; f++) kf[f] = bbh_kbase(ks.kind[f], r2[f], ks.jb);
+  double al[BBH_MAX_FACTORS];
+  for (int f = 0; f < ks.F; f++) al[f] = ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0;
+  for (int f = 0; f < ks.F; f++) kf[f] = bbh_kbase(ks.kind[f], r2[f], ks.jb, al[f]);
   for (int f = 0; f < ks.F; f++) {
     double w = 1.0;
     if (ks.F > 1 && !ks.combine)
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   }
   for (int f = 0; f < ks.F; f++) {
     const double fos = ks.F > 1 ? theta[ks.fos_off + f] : 1.0;
-    const double Gg = G * bbh_gfun(ks.kind[f], r2[f], ks.jb) * os * Bab * wf[f] * fos;
+    const double Gg = G * bbh_gfun(ks.kind[f], r2[f], ks.jb, al[f]) * os * Bab * wf[f] * fos;
     for (int j = 0; j < dn; j++) {
       const double l = theta[ks.ls_off[f] + j];
       const double df = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
@@ -251,6 +254,16 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
       if (lane == 0) prow[ks.fos_off + f] = v;
+    }
+    if (ks.alpha_off >= 0) {  // RQ: dk/dalpha = k (u / (1 + u) - log(1 + u)), u = r^2 / (2 alpha); 0 for the other kinds
+      double v = 0.0;
+      if (ks.kind[f] == BBH_KERNEL_RQ) {
+        const double u = r2[f] / (2.0 * al[f]);
+        v = G * os * Bab * wf[f] * fos * kf[f] * (u / (1.0 + u) - log1p(u));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) prow[ks.alpha_off + f] = v;
     }
   }
   if (T > 1) {
@@ -278,9 +291,17 @@ __global__ __launch_bounds__(256) void bbh_grad_reduce_kernel(const double* __re
 }
 
 // -----------------------------------------------------------------------------------------
+// any factor (or the single kernel) a rational-quadratic kernel: theta carries F alpha slots at its end
+static bool bbh_has_rq(const bbh_handle* h) {
+  if (h->F <= 1) return h->desc.kernel_kind == BBH_KERNEL_RQ;
+  for (int f = 0; f < h->F; f++)
+    if (h->desc.factor_kind[f] == BBH_KERNEL_RQ) return true;
+  return false;
+}
+
 static int64_t bbh_theta_len_of(const bbh_handle* h) {
   return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0) + (h->hadamard ? 2 * (int64_t)h->T : 0) +
-         (h->F > 1 ? (int64_t)(h->F - 1) * h->dn + h->F : 0);
+         (h->F > 1 ? (int64_t)(h->F - 1) * h->dn + h->F : 0) + (bbh_has_rq(h) ? h->F : 0);
 }
 
 extern "C" int64_t bbh_theta_len(bbh_handle* h) {
@@ -301,6 +322,7 @@ bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h) {
     ks.ls_off[f] = (f == 0 || f >= h->F) ? 3 : base + (f - 1) * h->dn;
   }
   ks.fos_off = h->F > 1 ? base + (h->F - 1) * h->dn : -1;
+  ks.alpha_off = bbh_has_rq(h) ? base + (h->F > 1 ? (h->F - 1) * h->dn + h->F : 0) : -1;
   return ks;
 }
 
@@ -353,7 +375,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->err = "bbh_set_model: bad arguments";
     return -1;
   }
-  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_PIECEWISE3 || desc->d < 1 || desc->n_tasks < 1 ||
+  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_RQ || desc->d < 1 || desc->n_tasks < 1 ||
       (desc->n_tasks > 1 && (desc->task_col < 0 || desc->task_col >= desc->d)) ||
       (desc->criterion != BBH_CRITERION_MLL && desc->criterion != BBH_CRITERION_LOO)) {
     h->err = "bbh_set_model: invalid model description";
@@ -362,7 +384,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   if (desc->n_factors > 1) {
     bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1) &&
               desc->factor_kind[0] == desc->kernel_kind;
-    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_PIECEWISE3;
+    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_RQ;
     if (!ok) {
       h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1, factor_kind[0] == kernel_kind)";
       return -1;

@@ -718,7 +718,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
           const double df = (pn[i * dn + c] - pn[j * dn + c]) / th[ks.ls_off[f] + c];
           r2 += df * df;
         }
-        const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb);
+        const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb, ks.alpha_off >= 0 ? th[ks.alpha_off + f] : 1.0);
         kc = (ks.combine && ks.F > 1) ? kc + u : kc * u;
       }
       double kpp = os * kc;

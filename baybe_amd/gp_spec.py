@@ -81,6 +81,16 @@ class GPSpec:
     def n_factors(self) -> int:
         return len(self.factors) if self.factors else 1
 
+    @property
+    def factor_kinds(self) -> list:
+        return [f.kernel for f in self.factors] if self.factors else [self.kernel]
+
+    @property
+    def has_rq(self) -> bool:
+        """A rational-quadratic kernel somewhere: theta ends with one alpha per factor (gpytorch ``RQKernel.raw_alpha``:
+        ``Positive()``, raw 0, no prior - BayBE's ``RQKernel`` exposes neither, kernels/basic.py:202-216)."""
+        return "rq" in self.factor_kinds
+
     def set_factors(self, factors, combine: str = "product"):
         """Make this a composite-kernel model; the first factor takes over the single-kernel fields."""
         factors = list(factors)
@@ -225,6 +235,7 @@ class GPParams:
     task_unit_scale: bool = False
     factor_ls: "list[np.ndarray] | None" = None  # lengthscales of the factors 1.. of a composite kernel
     factor_os: "np.ndarray | None" = None  # [F] per-factor outputscales (1 for unscaled factors)
+    alpha: "np.ndarray | None" = None  # [F] RQ alpha per factor (1 for the other kinds); None without an RQ kernel
 
     def task_B_unscaled(self):
         if self.task_W is None:
@@ -262,6 +273,8 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
         p.factor_ls = [np.full(spec.dn, f.ls_init if f.ls_init is not None else sp0) for f in spec.factors[1:]]
         p.factor_os = np.array([(f.outputscale_init if f.outputscale_init is not None else sp0) if f.scaled else 1.0
                                 for f in spec.factors], dtype=np.float64)
+    if spec.has_rq:
+        p.alpha = np.array([float(softplus(0.0)) if k == "rq" else 1.0 for k in spec.factor_kinds])
     return p
 
 
@@ -310,6 +323,8 @@ def theta_from_params(spec: GPSpec, p: GPParams) -> np.ndarray:
         parts += [nz, mu]
     if spec.factors:
         parts += [np.asarray(l, dtype=np.float64) for l in p.factor_ls] + [np.asarray(p.factor_os, dtype=np.float64)]
+    if spec.has_rq:
+        parts.append(np.asarray(p.alpha, dtype=np.float64))
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
 
 
@@ -323,10 +338,15 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
     if spec.factors and spec.factors[0].scaled:
         parts.append(inv_softplus(np.array([p.factor_os[0]])))
     parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
+    kinds = spec.factor_kinds
+    if kinds[0] == "rq":
+        parts.append(inv_softplus(np.array([p.alpha[0]])))
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             parts.append(inv_softplus(np.array([p.factor_os[k + 1]])))
         parts.append(p.factor_ls[k] if f.ls_constraint == "box" else inv_softplus(p.factor_ls[k]))
+        if f.kernel == "rq":
+            parts.append(inv_softplus(np.array([p.alpha[k + 1]])))
     if spec.n_tasks > 1:
         parts.append(inv_softplus(p.task_W).reshape(-1))
         parts.append(inv_softplus(p.task_v))
@@ -350,18 +370,24 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
         fos[0] = float(softplus(raw[i])); i += 1
     ls_raw = raw[i : i + spec.dn]; i += spec.dn
     ls = ls_raw.copy() if spec.ls_constraint == "box" else softplus(ls_raw)
+    kinds = spec.factor_kinds
+    alpha = np.ones(len(kinds)) if spec.has_rq else None
+    if kinds[0] == "rq":
+        alpha[0] = float(softplus(raw[i])); i += 1
     fls = [] if spec.factors else None
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             fos[k + 1] = float(softplus(raw[i])); i += 1
         r = raw[i : i + spec.dn]; i += spec.dn
         fls.append(r.copy() if f.ls_constraint == "box" else softplus(r))
+        if f.kernel == "rq":
+            alpha[k + 1] = float(softplus(raw[i])); i += 1
     W = v = None
     if spec.n_tasks > 1:
         T = spec.n_tasks
         W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
         v = softplus(raw[i : i + T]); i += T
-    return GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos)
+    return GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos, alpha)
 
 
 def raw_bounds(spec: GPSpec):
@@ -373,10 +399,14 @@ def raw_bounds(spec: GPSpec):
     if spec.factors and spec.factors[0].scaled:
         b.append((None, None))
     b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
+    if spec.factor_kinds[0] == "rq":
+        b.append((None, None))
     for f in (spec.factors or [])[1:]:
         if f.scaled:
             b.append((None, None))
         b += [((f.ls_lower, None) if f.ls_constraint == "box" else (None, None))] * spec.dn
+        if f.kernel == "rq":
+            b.append((None, None))
     if spec.n_tasks > 1:
         b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
     return b
@@ -453,6 +483,7 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
     F = spec.n_factors
     base = 3 + dn + (T * T if T > 1 else 0) + (2 * T if spec.hadamard else 0)  # extra lengthscale blocks, then os_f [F]
     fos_off = base + (F - 1) * dn
+    alpha_off = base + ((F - 1) * dn + F if F > 1 else 0)  # one alpha per factor, present when any factor is an RQ kernel
 
     def scale_slot(k, f, i):  # a factor's own ScaleKernel: prior + softplus chain
         lp, glp = _prior_logp_and_grad(f.outputscale_prior, np.array([p.factor_os[k]]))
@@ -467,6 +498,9 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         gl = gl * sigmoid(raw[i : i + dn])
     g.append(gl)
     i += dn
+    if spec.factor_kinds[0] == "rq":  # softplus chain, no prior
+        g.append(np.array([grad_theta[alpha_off] * float(sigmoid(raw[i]))]))
+        i += 1
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             total += scale_slot(k + 1, f, i)
@@ -478,6 +512,9 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
             gf = gf * sigmoid(raw[i : i + dn])
         g.append(gf)
         i += dn
+        if f.kernel == "rq":
+            g.append(np.array([grad_theta[alpha_off + k + 1] * float(sigmoid(raw[i]))]))
+            i += 1
     if T > 1:
         S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)  # dL/dB of the (scaled) table the device multiplies with
         Bu = p.task_B_unscaled()

@@ -1,7 +1,7 @@
 """Declarative kernel / prior specifications accepted by ``HipGaussianProcessSurrogate``
 (mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
 ``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
-device: Matérn(0.5|1.5|2.5) / RBF / PiecewisePolynomial(q) base kernels with ARD over all numerical columns, optionally
+device: Matérn(0.5|1.5|2.5) / RBF / RQ / PiecewisePolynomial(q) base kernels with ARD over all numerical columns, optionally
 wrapped in a ScaleKernel, and ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``) of two to
 four such factors, each optionally in its own ScaleKernel, the whole optionally in an outer ScaleKernel).
 
@@ -55,6 +55,14 @@ class PiecewisePolynomialKernel:
 
 
 @define(frozen=True)
+class RQKernel:
+    """``baybe.kernels.basic.RQKernel`` (basic.py:202-216): rational quadratic; alpha is gpytorch's own parameter."""
+
+    lengthscale_prior = field(default=None)
+    lengthscale_initial_value: float | None = field(default=None)
+
+
+@define(frozen=True)
 class ScaleKernel:
     base_kernel = field()
     outputscale_prior = field(default=None)
@@ -96,6 +104,8 @@ def _basic_kind(kernel) -> str | None:
         return "rbf"
     if name == "PiecewisePolynomialKernel":
         return f"piecewise{int(kernel.q)}"
+    if name == "RQKernel":
+        return "rq"
     return None
 
 
@@ -131,7 +141,7 @@ def apply_kernel_spec(spec, kernel):
             kind = _basic_kind(member)
             if kind is None:
                 raise IncompatibilityError(
-                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / PiecewisePolynomial "
+                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial "
                     f"factors, each optionally in a ScaleKernel, are)."
                 )
             if getattr(member, "parameter_names", None):
@@ -142,7 +152,7 @@ def apply_kernel_spec(spec, kernel):
     kind = _basic_kind(kernel)
     if kind is None:
         raise IncompatibilityError(
-            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / PiecewisePolynomial, optionally in a "
+            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial, optionally in a "
             f"ScaleKernel, and Product / Additive kernels of them are)."
         )
     spec.kernel = kind

@@ -60,7 +60,10 @@ enum bbh_kernel_kind {
   BBH_KERNEL_PIECEWISE0 = 4,
   BBH_KERNEL_PIECEWISE1 = 5,
   BBH_KERNEL_PIECEWISE2 = 6,
-  BBH_KERNEL_PIECEWISE3 = 7
+  BBH_KERNEL_PIECEWISE3 = 7,
+  /* gpytorch RQKernel, baybe/kernels/basic.py:202-216: (1 + r^2 / (2 alpha))^-alpha with a learnable alpha per kernel
+   * (theta: one slot per factor at the very end, present when any factor is an RQ kernel). */
+  BBH_KERNEL_RQ = 8
 };
 
 enum bbh_criterion {
@@ -103,6 +106,7 @@ typedef struct bbh_model_desc {
  *   [.. +(F-1)*dn)  lengthscales of the factors 1 .. F-1 of a composite kernel (factor 0 uses [3 .. 3+dn))
  *   [.. +F)         per-factor outputscales (1 for an unscaled factor; its gradient slot is still filled)
  *                  k = outputscale * (prod_f | sum_f) os_f k_f(r_f) * B[t][t']
+ *   [.. +F)         alpha of every factor (only when at least one factor is BBH_KERNEL_RQ; 1 for the other factors)
  * Gradients are returned in the same layout (for B: dL/dB[t][t'], accumulated
  * over ordered pairs, i.e. the matrix S with dL = sum_tt' S[t][t'] dB[t][t']).
  * Constraint transforms (softplus) and prior terms are O(d) scalar work and stay

@@ -104,9 +104,13 @@ def parameter_layout(spec) -> list[RawParameter]:
                 leaf += ".base_kernel"
             h = term.lengthscale
             out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, spec.dn), h.lower, h.transformed, _prior(h.prior), m))
+            if term.kernel == "rq":  # gpytorch RQKernel registers raw_alpha (Positive(), no prior) after the lengthscale
+                out.append(RawParameter(f"{leaf}.raw_alpha", (1,), 0.0, True, None, m))
     else:
         out.append(RawParameter(f"{base}.raw_lengthscale", (1, spec.dn), spec.ls_lower if box_ls else 0.0, not box_ls,
                                 _prior(spec.ls_prior)))
+        if spec.kernel == "rq":
+            out.append(RawParameter(f"{base}.raw_alpha", (1,), 0.0, True, None))
     if T > 1:
         out.append(RawParameter("covar_module.kernels.1.raw_covar_factor", (T, T), 0.0, True, None))
         out.append(RawParameter("covar_module.kernels.1.raw_var", (T,), 0.0, True, None))
@@ -145,7 +149,9 @@ def natural_to_raw(spec, natural: dict) -> np.ndarray:
     return torch.cat(parts).numpy().copy()
 
 
-def _base_kernel(kernel: str, r2: torch.Tensor, dims: int) -> torch.Tensor:
+def _base_kernel(kernel: str, r2: torch.Tensor, dims: int, alpha=None) -> torch.Tensor:
+    if kernel == "rq":  # gpytorch RQKernel.postprocess_rq: (1 + dist / (2 alpha)).pow(-alpha) on the squared distance
+        return (1 + r2 / (2 * alpha)).pow(-alpha)
     if kernel.startswith("piecewise"):  # gpytorch PiecewisePolynomialKernel(q): fmax(r, j, q) * get_cov(r, j, q)
         q = int(kernel[-1])
         r = torch.sqrt(torch.clamp_min(r2, 1e-30))
@@ -172,21 +178,21 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     """K(X, X) without noise on the normalised inputs: stationary ARD kernel (x outputscale) (x B[t, t'])."""
     Xnum = Xn[:, torch.as_tensor(np.asarray(spec.num_idx))]
 
-    def gram(kind, lengthscale):
+    def gram(kind, lengthscale, alpha=None):
         Xs = Xnum / lengthscale.reshape(1, -1)
         diff = Xs[:, None, :] - Xs[None, :, :]
-        return _base_kernel(kind, (diff * diff).sum(-1), Xnum.shape[1])
+        return _base_kernel(kind, (diff * diff).sum(-1), Xnum.shape[1], alpha)
 
     members = getattr(spec, "members", None)
     if members:
         K = None
         for m, term in enumerate(members):
-            Km = gram(term.kernel, nat[f"lengthscale.{m}"])
+            Km = gram(term.kernel, nat[f"lengthscale.{m}"], nat.get(f"alpha.{m}"))
             if term.outputscale is not None:
                 Km = Km * nat[f"outputscale.{m}"]
             K = Km if K is None else (K * Km if spec.composition == "product" else K + Km)
     else:
-        K = gram(spec.kernel, nat["lengthscale"])
+        K = gram(spec.kernel, nat["lengthscale"], nat.get("alpha"))
     if spec.use_outputscale:
         K = K * nat["outputscale"]
     if spec.n_tasks > 1:

@@ -55,7 +55,7 @@ FAT_ALPHA_MAX = 2.0  # [UPSTREAM] botorch.utils.safe_math.fatmax alpha
 MIN_INFERRED_NOISE_LEVEL = 0.0001  # [UPSTREAM] botorch.models.utils.gpytorch_modules.MIN_INFERRED_NOISE_LEVEL
 MAX_BATCH_SIZE = 2048  # [UPSTREAM] optimize_acqf_discrete(max_batch_size=2048)
 
-KERNELS = ("matern12", "matern32", "matern52", "rbf", "piecewise0", "piecewise1", "piecewise2", "piecewise3")
+KERNELS = ("matern12", "matern32", "matern52", "rbf", "piecewise0", "piecewise1", "piecewise2", "piecewise3", "rq")
 
 
 # --------------------------------------------------------------------------------------
@@ -167,6 +167,7 @@ class GPParams:
     target_scaled: bool = False  # index_kernel_scaling == "target"
     member_ls: "list[np.ndarray] | None" = None  # per base kernel of a composite: lengthscales [dn] (ALL members)
     member_scale: "np.ndarray | None" = None  # per base kernel: its own outputscale (1 where it has none)
+    rq_alpha: "np.ndarray | None" = None  # RQ kernels: alpha per base kernel ([1] for a single kernel; 1 for other kinds)
 
     def task_B(self) -> np.ndarray | None:
         if self.task_W is None:
@@ -186,11 +187,17 @@ class GPParams:
         scal = lambda a: float(a) if np.ndim(a) == 0 else dup(a)  # noqa: E731
         return GPParams(dup(self.lengthscale), scal(self.noise), scal(self.mean), float(self.outputscale),
                         dup(self.task_W), dup(self.task_v), self.target_scaled,
-                        None if self.member_ls is None else [dup(a) for a in self.member_ls], dup(self.member_scale))
+                        None if self.member_ls is None else [dup(a) for a in self.member_ls], dup(self.member_scale),
+                        dup(self.rq_alpha))
 
 
 def softplus(x):
     return np.logaddexp(0.0, np.asarray(x, dtype=np.float64))
+
+
+def kernel_names(spec) -> list:
+    """Names of the base kernels of the model: the members of a composite, or the single kernel."""
+    return [t.kernel for t in spec.members] if spec.members else [spec.kernel]
 
 
 def initial_params(spec, task_init=1.0):
@@ -212,6 +219,7 @@ def initial_params(spec, task_init=1.0):
         member_ls=[np.full(spec.dn, t.lengthscale.start()) for t in spec.members] if spec.members else None,
         member_scale=np.array([1.0 if t.outputscale is None else t.outputscale.start() for t in spec.members])
         if spec.members else None,
+        rq_alpha=np.array([math.log(2.0) if k == "rq" else 1.0 for k in kernel_names(spec)]) if "rq" in kernel_names(spec) else None,
     )
 
 
@@ -264,8 +272,11 @@ def _piecewise_terms(q: int, dims: int, r: np.ndarray):
     return j, 1 + (j + 3) * r + c2 * r**2 + c3 * r**3, (j + 3) + 2 * c2 * r + 3 * c3 * r**2
 
 
-def base_kernel_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None) -> np.ndarray:
-    """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2 (``dims``: input dimension, piecewise family)."""
+def base_kernel_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None, alpha: float | None = None) -> np.ndarray:
+    """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2 (``dims``: input dimension, piecewise family;
+    ``alpha``: RQ kernel, ``(1 + r^2 / (2 alpha))^-alpha``)."""
+    if kernel == "rq":
+        return (1.0 + r2 / (2.0 * alpha)) ** (-alpha)
     if kernel.startswith("piecewise"):
         q = int(kernel[-1])
         r = np.sqrt(np.maximum(r2, 1e-30))
@@ -283,8 +294,16 @@ def base_kernel_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None) ->
     raise ValueError(kernel)
 
 
-def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None) -> np.ndarray:
+def rq_alpha_derivative(r2: np.ndarray, alpha: float) -> np.ndarray:
+    """d/dalpha (1 + u)^-alpha with u = r^2 / (2 alpha):  k (u / (1 + u) - log(1 + u))."""
+    u = r2 / (2.0 * alpha)
+    return (1.0 + u) ** (-alpha) * (u / (1.0 + u) - np.log1p(u))
+
+
+def base_kernel_gfac_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None, alpha: float | None = None) -> np.ndarray:
     """g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3."""
+    if kernel == "rq":  # dk/dr = -r (1 + u)^-(alpha + 1)
+        return (1.0 + r2 / (2.0 * alpha)) ** (-alpha - 1.0)
     if kernel.startswith("piecewise"):  # product rule on max(0, 1 - r)^(j + q) * poly(r); plain quotient by r
         q = int(kernel[-1])
         r = np.sqrt(np.maximum(r2, 1e-30))
@@ -316,9 +335,13 @@ def _second_derivative_at_zero(q: int, j: int) -> float:
     return p * (p - 1) - 2 * p * c1 + 2 * c2
 
 
+def _alpha_of(p: GPParams, m: int):
+    return None if p.rq_alpha is None else float(p.rq_alpha[m])
+
+
 def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> list[np.ndarray]:
     """Scaled Gram matrix of every base kernel of a composite (numerical columns only)."""
-    return [p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A, B, p.member_ls[m]), A.shape[1])
+    return [p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A, B, p.member_ls[m]), A.shape[1], _alpha_of(p, m))
             for m, t in enumerate(spec.members)]
 
 
@@ -326,7 +349,7 @@ def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> 
     """The kernel over the numerical columns without outer outputscale / task factor: the single stationary kernel, or
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
     if not spec.members:
-        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A, B, p.lengthscale), A.shape[1])
+        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A, B, p.lengthscale), A.shape[1], _alpha_of(p, 0))
     grams = member_grams(spec, p, A, B)
     out = grams[0].copy()
     for Km in grams[1:]:
@@ -377,6 +400,7 @@ class DataTerm:
     g_task_B: np.ndarray | None  # dL/dB[t,t'] (symmetric accumulation S)
     g_member_ls: "list[np.ndarray] | None" = None  # composite kernels: per base kernel
     g_member_scale: "np.ndarray | None" = None
+    g_alpha: "np.ndarray | None" = None  # RQ kernels: one entry per base kernel (0 for the other kinds)
 
 
 def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> DataTerm:
@@ -419,7 +443,7 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     if spec.members:
         return _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow)
     r2 = _scaled_sqdist(Xs, Xs, p.lengthscale)
-    gfac = base_kernel_gfac_from_r2(spec.kernel, r2, spec.dn)
+    gfac = base_kernel_gfac_from_r2(spec.kernel, r2, spec.dn, _alpha_of(p, 0))
     scale = np.full((n, n), p.outputscale if spec.use_outputscale else 1.0)
     Bsel = None
     if spec.task_idx is not None:
@@ -440,12 +464,15 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     g_os = float((G * Kf).sum()) / p.outputscale if spec.use_outputscale else 0.0
     g_B = None
     if spec.task_idx is not None:
-        kb = base_kernel_from_r2(spec.kernel, r2, spec.dn) * (p.outputscale if spec.use_outputscale else 1.0)
+        kb = base_kernel_from_r2(spec.kernel, r2, spec.dn, _alpha_of(p, 0)) * (p.outputscale if spec.use_outputscale else 1.0)
         T = spec.n_tasks
         onehot = np.zeros((n, T))
         onehot[np.arange(n), t] = 1.0
         g_B = onehot.T @ (G * kb) @ onehot
-    return DataTerm(value, g_ls, g_noise, g_mean, g_os, g_B)
+    g_alpha = None
+    if spec.kernel == "rq":
+        g_alpha = np.array([float((G * scale * rq_alpha_derivative(r2, float(p.rq_alpha[0]))).sum())])
+    return DataTerm(value, g_ls, g_noise, g_mean, g_os, g_B, g_alpha=g_alpha)
 
 
 def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> DataTerm:
@@ -458,7 +485,7 @@ def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> Da
     if spec.task_idx is not None:
         Bsel = p.task_B()[np.ix_(trow, trow)]
     grams = member_grams(spec, p, Xs, Xs)
-    g_ls, g_sc = [], np.zeros(len(spec.members))
+    g_ls, g_sc, g_al = [], np.zeros(len(spec.members)), np.zeros(len(spec.members))
     for m, t in enumerate(spec.members):
         others = np.ones((n, n))
         if spec.composition == "product":
@@ -466,13 +493,15 @@ def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> Da
                 if k != m:
                     others = others * Kk
         r2 = _scaled_sqdist(Xs, Xs, p.member_ls[m])
-        front = G * os * Bsel * others * p.member_scale[m] * base_kernel_gfac_from_r2(t.kernel, r2, spec.dn)
+        front = G * os * Bsel * others * p.member_scale[m] * base_kernel_gfac_from_r2(t.kernel, r2, spec.dn, _alpha_of(p, m))
         gl = np.empty(spec.dn)
         for j in range(spec.dn):
             diff = Xs[:, j : j + 1] - Xs[None, :, j]
             gl[j] = float((front * diff * diff).sum()) / p.member_ls[m][j] ** 3
         g_ls.append(gl)
-        g_sc[m] = float((G * os * Bsel * others * base_kernel_from_r2(t.kernel, r2, spec.dn)).sum())
+        g_sc[m] = float((G * os * Bsel * others * base_kernel_from_r2(t.kernel, r2, spec.dn, _alpha_of(p, m))).sum())
+        if t.kernel == "rq":
+            g_al[m] = float((G * os * Bsel * others * p.member_scale[m] * rq_alpha_derivative(r2, float(p.rq_alpha[m]))).sum())
     S = stationary_part(spec, p, Xs, Xs)
     g_os = float((G * S * Bsel).sum()) if spec.use_outputscale else 0.0
     g_B = None
@@ -485,7 +514,7 @@ def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> Da
         g_mean = np.array([float(g_mean_rows[trow == k].sum()) for k in range(spec.n_tasks)])
     else:
         g_noise, g_mean = float(np.trace(G)), float(g_mean_rows.sum())
-    return DataTerm(value, g_ls[0], g_noise, g_mean, g_os, g_B, g_ls, g_sc)
+    return DataTerm(value, g_ls[0], g_noise, g_mean, g_os, g_B, g_ls, g_sc, g_al if p.rq_alpha is not None else None)
 
 
 # ---- the optimiser's view: raw vector <-> natural parameters, objective, bounds -----------------------
@@ -498,6 +527,10 @@ def _natural_dict(spec: GPSpec, p: GPParams) -> dict:
             nat[f"lengthscale.{m}"] = p.member_ls[m]
             if t.outputscale is not None:
                 nat[f"outputscale.{m}"] = p.member_scale[m]
+            if t.kernel == "rq":
+                nat[f"alpha.{m}"] = [p.rq_alpha[m]]
+    elif spec.kernel == "rq":
+        nat["alpha"] = [p.rq_alpha[0]]
     if spec.use_outputscale:
         nat["outputscale"] = p.outputscale
     if spec.n_tasks > 1:
@@ -520,7 +553,14 @@ def unpack_raw(spec, raw):
     mls = [nat[f"lengthscale.{m}"].reshape(-1).copy() for m in range(len(spec.members))] if spec.members else None
     msc = np.array([float(nat[f"outputscale.{m}"]) if t.outputscale is not None else 1.0
                     for m, t in enumerate(spec.members)]) if spec.members else None
+    names = kernel_names(spec)
+    if "rq" in names:
+        key = (lambda m: f"alpha.{m}") if spec.members else (lambda m: "alpha")
+        alphas = np.array([float(nat[key(m)].reshape(-1)[0]) if k == "rq" else 1.0 for m, k in enumerate(names)])
+    else:
+        alphas = None
     return GPParams(
+        rq_alpha=alphas,
         lengthscale=mls[0] if spec.members else nat["lengthscale"].reshape(-1).copy(),
         member_ls=mls,
         member_scale=msc,

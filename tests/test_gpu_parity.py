@@ -42,7 +42,8 @@ def _oparams(p):
                        None if p.task_W is None else p.task_W.copy(), None if p.task_v is None else p.task_v.copy(),
                        bool(getattr(p, "task_unit_scale", False)),
                        None if p.factor_ls is None else [np.array(p.lengthscale, dtype=float)] + [np.array(a, dtype=float) for a in p.factor_ls],
-                       None if p.factor_os is None else np.array(p.factor_os, dtype=float))
+                       None if p.factor_os is None else np.array(p.factor_os, dtype=float),
+                       None if getattr(p, "alpha", None) is None else np.array(p.alpha, dtype=float))
 
 
 def _np(t):
@@ -675,3 +676,55 @@ def test_piecewise_polynomial_kernels(gp, q):
         fo = go.fit_hyperparameters(ospec, Xn, ys)
         assert math.isclose(fi.fun, fo.fun, rel_tol=1e-6)
         assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=2e-2)
+
+
+@pytest.mark.parametrize("name", ["scaled_rq", "rq_x_matern", "rq_plus_rbf"])
+def test_rational_quadratic_kernels(gp, name):
+    """``RQKernel`` (baybe/kernels/basic.py:202-216; gpytorch: (1 + r^2 / (2 alpha))^-alpha with a learnable alpha, one theta
+    slot per factor): value, lengthscale and alpha derivatives on the device against the oracle, materialised-K* posterior,
+    greedy batch, device fit - alone and as a factor of a product / sum."""
+    from baybe_amd import gp_spec
+    from baybe_amd.kernels import AdditiveKernel, GammaPrior, MaternKernel, ProductKernel, RBFKernel, RQKernel, ScaleKernel, apply_kernel_spec
+    from oracle import gp_oracle as go
+
+    kern = {"scaled_rq": ScaleKernel(RQKernel(GammaPrior(3.0, 1.0), 0.8), GammaPrior(2.0, 0.5)),
+            "rq_x_matern": ProductKernel([RQKernel(None, 1.2), ScaleKernel(MaternKernel(2.5))]),
+            "rq_plus_rbf": AdditiveKernel([ScaleKernel(RQKernel()), ScaleKernel(RBFKernel(GammaPrior(3.0, 2.0)))])}[name]
+    d = 5
+    X, Xt, y = make_problem(2000, d, 60, seed=50)
+    spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern)
+    assert spec.has_rq
+    ospec = _ospec(spec)
+    rng = np.random.default_rng(3)
+    p = gp_spec.initial_params(spec)
+    p.lengthscale = p.lengthscale * (0.6 + 0.8 * rng.random(d))
+    p.alpha = np.where(np.array(spec.factor_kinds) == "rq", 0.4 + 2.0 * rng.random(len(p.alpha)), 1.0)
+    p.noise, p.mean = 0.03, 0.05
+    gp.set_model(spec, Xt, y)
+    val, g = gp.data_term(p)
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    dt = go.data_term(ospec, _oparams(p), Xn, ys)
+    if spec.factors:
+        gref = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale]] + dt.g_member_ls + [dt.g_member_scale, dt.g_alpha])
+    else:
+        gref = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls, dt.g_alpha])
+    assert len(g) == len(gref)
+    assert math.isclose(val, dt.value, rel_tol=1e-11)
+    assert np.allclose(g, gref, rtol=1e-9, atol=1e-10 * np.abs(gref).max())
+    gp.factorize(p)
+    om = go.GPModel(ospec, _oparams(p), Xt, y)
+    mo, vo = om.posterior(X)
+    for unfused in (False, True):
+        m, v = gp.posterior(X, unfused=unfused)
+        assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL, atol=1e-14)
+    cand = np.ascontiguousarray(X[:600])
+    res = gp.greedy_qlogei(cand, 3, seed=9)
+    ref = go.optimize_acqf_discrete_qlogei(om, cand, 3, seed=9)
+    assert list(res.indices) == list(ref.indices) and np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL)
+    if name == "scaled_rq":
+        fi = gp.fit()
+        fo = go.fit_hyperparameters(ospec, Xn, ys)
+        assert math.isclose(fi.fun, fo.fun, rel_tol=2e-5)  # alpha against the lengthscales: a shallow valley
+        m, v = gp.posterior(X)
+        mf, vf = go.GPModel(ospec, fo.params, Xt, y).posterior(X)
+        assert np.max(np.abs(_np(m) - mf)) < 0.02 * np.std(y)

@@ -230,6 +230,26 @@ def test_composite_kernel_parameterisation_against_the_autograd_oracle():
             f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
             f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
             assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    # RQKernel: alpha slots (softplus chain, no prior) alone, scaled and inside composites
+    from baybe_amd.kernels import RQKernel
+    for kern in (RQKernel(GammaPrior(3, 1)), ScaleKernel(RQKernel(None, 0.7), GammaPrior(2, 0.5)),
+                 ProductKernel([MaternKernel(2.5), ScaleKernel(RQKernel())]), AdditiveKernel([RQKernel(), RQKernel(None, 2.0), RBFKernel()])):
+        spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern)
+        ospec = _ospec(spec)
+        raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+        assert np.allclose(go.pack_raw(ospec, go.initial_params(ospec)), raw) and gp_spec.raw_bounds(spec) == go.raw_bounds(ospec)
+        raw = raw + 0.2 * rng.standard_normal(raw.shape)
+        raw[0] = abs(raw[0]) + 1e-3
+        q = gp_spec.unpack_raw(spec, raw)
+        assert np.allclose(gp_spec.pack_raw(spec, q), raw) and len(q.alpha) == spec.n_factors
+        Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+        dt = go.data_term(ospec, go.unpack_raw(ospec, raw), Xn, ys)
+        head = [[dt.g_noise, dt.g_mean, dt.g_outputscale]]
+        grad_theta = np.concatenate(head + (dt.g_member_ls + [dt.g_member_scale] if spec.factors else [dt.g_ls]) + [dt.g_alpha])
+        assert len(grad_theta) == len(gp_spec.theta_from_params(spec, q))
+        f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
+        f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+        assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
     with pytest.raises(IncompatibilityError):  # nested composites are not flattened
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
                           ProductKernel([MaternKernel(2.5), AdditiveKernel([RBFKernel(), MaternKernel(1.5)])]))
