@@ -75,7 +75,9 @@ __host__ __device__ inline double bbh_piecewise(int q, int jb, double r2, bool w
 }
 // base kernel value as a function of the scaled squared distance (jb: only the piecewise-polynomial family needs it;
 // alpha: only the RQ kernel)
-__host__ __device__ inline double bbh_kbase(int kind, double r2, int jb, double alpha = 1.0) {
+// (not inlined: nine kinds with their libm calls, called once per factor and entry - inlined into the unrolled K* kernel it
+// made 23 000 instructions, far beyond the instruction cache)
+__host__ __device__ __attribute__((noinline)) inline double bbh_kbase(int kind, double r2, int jb, double alpha = 1.0) {
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
   if (kind == BBH_KERNEL_RQ) return exp(-alpha * log1p(r2 / (2.0 * alpha)));
   if (kind >= BBH_KERNEL_PIECEWISE0 && kind <= BBH_KERNEL_PIECEWISE3) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);
@@ -84,14 +86,19 @@ __host__ __device__ inline double bbh_kbase(int kind, double r2, int jb, double 
   if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
   return exp(-r);
 }
-// composite value from the per-factor squared distances: (prod | sum)_f os_f k_f(r2_f), without the outer scale
-__device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta, const double* r2) {
+// composite value from the per-factor squared distances: (prod | sum)_f os_f k_f(r2_f), without the outer scale.
+// (Reference to a fixed-size array and compile-time indices: with a pointer and a run-time loop bound the callers' r2
+// arrays went to scratch memory, and the K* kernel ran at 5 TFLOP/s.)
+__device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta,
+                                            const double (&r2)[BBH_MAX_FACTORS]) {
   if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off] : 1.0);
   double acc = ks.combine ? 0.0 : 1.0;
-  for (int f = 0; f < ks.F; f++) {
-    const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0);
-    acc = ks.combine ? acc + u : acc * u;
-  }
+#pragma unroll
+  for (int f = 0; f < BBH_MAX_FACTORS; f++)
+    if (f < ks.F) {
+      const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0);
+      acc = ks.combine ? acc + u : acc * u;
+    }
   return acc;
 }
 

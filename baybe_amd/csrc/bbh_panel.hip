@@ -413,6 +413,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
 
 // ---- unfused verification path ------------------------------------------------------------------
 // K(X*, X) materialised with direct-difference distances, then V = K* L^-T through bbh_gemm.
+#define BBH_KSTAR_CB 8  // candidates per workgroup
 __global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict__ X, int64_t Nc, int64_t ldx,
                                                         const double* __restrict__ xnT, const int* __restrict__ task,
                                                         const double* __restrict__ theta, const int* __restrict__ numcol,
@@ -420,31 +421,58 @@ __global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict
                                                         int n, int64_t np, int dn, const bbh_kern_spec ks, int T,
                                                         int task_col, int64_t ldk, double* __restrict__ Kst) {
   // xnT [dn, np] / task [np]: the points of the columns (training rows, or the pending points with np = 16);
-  // Kst[cand * ldk + i], i < np
-  const int64_t cand = blockIdx.y;
+  // Kst[cand * ldk + i], i < np.  A workgroup takes BBH_KSTAR_CB candidates x 256 columns: the candidates' normalised
+  // coordinates and the reciprocal lengthscales of every factor are staged in LDS once, every thread reads its column's
+  // coordinates once for all of them (as one thread per entry with two fp64 divisions per dimension and factor this kernel
+  // was 67 % of a composite-kernel posterior pass).
+  extern __shared__ double s_ks[];  // invls [F][dn] | xc [CB][dn]
+  double* s_il = s_ks;
+  double* s_xc = s_ks + ks.F * dn;
+  const int64_t cand0 = (int64_t)blockIdx.y * BBH_KSTAR_CB;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int e = threadIdx.x; e < ks.F * dn; e += 256) s_il[e] = 1.0 / theta[ks.ls_off[e / dn] + e % dn];
+  for (int e = threadIdx.x; e < BBH_KSTAR_CB * dn; e += 256) {
+    const int64_t cand = cand0 + e / dn;
+    const int j = e % dn;
+    s_xc[e] = cand < Nc ? (X[cand * ldx + numcol[j]] - lo[j]) / (hi[j] - lo[j]) : 0.0;
+  }
+  __syncthreads();
   if (i >= np) return;
-  double v = 0.0;
-  if (cand < Nc && i < n) {
-    const double* xr = X + cand * ldx;
-    double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
+  double r2[BBH_KSTAR_CB][BBH_MAX_FACTORS];
+#pragma unroll
+  for (int c = 0; c < BBH_KSTAR_CB; c++)
+#pragma unroll
+    for (int f = 0; f < BBH_MAX_FACTORS; f++) r2[c][f] = 0.0;
+  if (i < n)
     for (int j = 0; j < dn; j++) {
-      const double xc = (xr[numcol[j]] - lo[j]) / (hi[j] - lo[j]);
-      const double dx = xc - xnT[(int64_t)j * np + i];
-      for (int f = 0; f < ks.F; f++) {
-        const double df = dx / theta[ks.ls_off[f] + j];
-        r2[f] += df * df;
+      const double x = xnT[(int64_t)j * np + i];
+#pragma unroll
+      for (int c = 0; c < BBH_KSTAR_CB; c++) {
+        const double dx = s_xc[c * dn + j] - x;
+#pragma unroll
+        for (int f = 0; f < BBH_MAX_FACTORS; f++)
+          if (f < ks.F) {
+            const double df = dx * s_il[f * dn + j];
+            r2[c][f] = fma(df, df, r2[c][f]);
+          }
       }
     }
-    v = bbh_kcomp(ks, theta, r2);
-    if (ks.use_os) v *= theta[2];
-    if (T > 1) {
-      int tcand = (int)xr[task_col];
-      tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
-      v *= theta[3 + dn + tcand * T + task[i]];
+  const int ti = (T > 1 && i < n) ? task[i] : 0;
+#pragma unroll
+  for (int c = 0; c < BBH_KSTAR_CB; c++) {
+    const int64_t cand = cand0 + c;
+    double v = 0.0;
+    if (cand < Nc && i < n) {
+      v = bbh_kcomp(ks, theta, r2[c]);
+      if (ks.use_os) v *= theta[2];
+      if (T > 1) {
+        int tcand = (int)X[cand * ldx + task_col];
+        tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
+        v *= theta[3 + dn + tcand * T + ti];
+      }
     }
+    Kst[cand * ldk + i] = v;  // rows up to the padded candidate count exist
   }
-  Kst[cand * ldk + i] = v;
 }
 
 __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __restrict__ Kst, const double* __restrict__ V,
@@ -485,8 +513,8 @@ static int bbh_unfused_chunk(bbh_handle* h, const double* X_dev, int64_t Nc, int
                              const double* d_lo, const double* d_hi) {
   const int64_t np = h->np;
   const int64_t Ncpad = bbh_round_up(Nc, 64);
-  dim3 grid((unsigned)((np + 255) / 256), (unsigned)Ncpad), block(256);
-  hipLaunchKernelGGL(bbh_kstar_kernel, grid, block, 0, h->stream, X_dev, Nc, ldx, h->d_xnT, h->d_task, h->d_theta,
+  dim3 grid((unsigned)((np + 255) / 256), (unsigned)(Ncpad / BBH_KSTAR_CB)), block(256);
+  hipLaunchKernelGGL(bbh_kstar_kernel, grid, block, sizeof(double) * h->dn * (BBH_KSTAR_CB + h->F), h->stream, X_dev, Nc, ldx, h->d_xnT, h->d_task, h->d_theta,
                      h->d_numcol, d_lo, d_hi, (int)h->n, np, h->dn, bbh_kern_spec_of(h), h->T, h->desc.task_col, np, Kst);
   if (V) bbh_gemm(h->stream, false, true, Ncpad, np, np, 1.0, Kst, np, 0, h->d_X, np, 0, 0.0, V, np, 0, 1);
   BBH_HIP_TRY(h, hipGetLastError());
@@ -581,15 +609,16 @@ int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_
   BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
   BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
   const bbh_kern_spec ks = bbh_kern_spec_of(h);
+  const size_t klds = sizeof(double) * h->dn * (BBH_KSTAR_CB + h->F);
   for (int64_t s0 = 0; s0 < N; s0 += chunk) {
     const int64_t Nc = (N - s0 < chunk) ? N - s0 : chunk;
     const int64_t Ncpad = bbh_round_up(Nc, 64);
     const double* Xc = X_dev + s0 * ldx;
-    hipLaunchKernelGGL(bbh_kstar_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)Ncpad), dim3(256), 0, s, Xc, Nc, ldx,
+    hipLaunchKernelGGL(bbh_kstar_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)(Ncpad / BBH_KSTAR_CB)), dim3(256), klds, s, Xc, Nc, ldx,
                        h->d_xnT, h->d_task, h->d_theta, h->d_numcol, d_lo, d_hi, (int)h->n, np, h->dn, ks, h->T,
                        h->desc.task_col, ldk, Kext);
     // pending columns (zero when there are none: p = 0 points -> every entry is written as 0)
-    hipLaunchKernelGGL(bbh_kstar_kernel, dim3(1, (unsigned)Ncpad), dim3(256), 0, s, Xc, Nc, ldx, h->d_pendT, h->d_taskext + np,
+    hipLaunchKernelGGL(bbh_kstar_kernel, dim3(1, (unsigned)(Ncpad / BBH_KSTAR_CB)), dim3(256), klds, s, Xc, Nc, ldx, h->d_pendT, h->d_taskext + np,
                        h->d_theta, h->d_numcol, d_lo, d_hi, h->p, (int64_t)16, h->dn, ks, h->T, h->desc.task_col, ldk,
                        Kext + np);
     if (var_dev) bbh_gemm(s, false, true, Ncpad, np, np, 1.0, Kext, ldk, 0, h->d_X, np, 0, 0.0, V, np, 0, 1);
