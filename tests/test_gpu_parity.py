@@ -539,8 +539,8 @@ def test_multitask_botorch_presets_data_term_posterior_and_fit(gp, preset, n_per
     assert np.allclose(pm, om.posterior(X[[3, 11]])[0], rtol=MEAN_RTOL, atol=1e-12)
     gp.set_pending(None)
     assert np.allclose(gp.train_posterior_mean(), om.posterior(Xt)[0], rtol=MEAN_RTOL, atol=1e-12)
-    if n_per_task > 100:
-        return  # the fit below is covered at the small sizes
+    if n_per_task > 100 or preset == "HVARFNER":
+        return  # the fit below runs for BOTORCH at the small size (HVARFNER's: tests/test_plugin_gpu.py, through the surrogate)
     # The target-scaled index kernel leaves the overall scale of (covar_factor, var) without any effect on the model: the
     # objective has an exactly flat direction, L-BFGS-B runs 500 - 700 iterations along a near-flat valley and two runs whose
     # gradients differ in the last bits stop a few 1e-6 apart.  Compared: the value reached, the identifiable quantities,
