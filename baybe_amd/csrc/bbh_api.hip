@@ -29,6 +29,8 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   }
   if (const char* e = getenv("BBH_PENDING_LDS")) h->pending_lds_form = (e[0] != '0');
   if (const char* e = getenv("BBH_FIT_GRAPH")) h->fit_graph_mode = (e[0] != '0');
+  if (const char* e = getenv("BBH_POTRF_TILES")) h->potrf_tiles = (e[0] != '0');
+  if (const char* e = getenv("BBH_TILE_SPIN")) h->tile_spin_limit = atoi(e);
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
   if (const char* e = getenv("BBH_KV_LDS")) h->kv_lds_blocks = atoi(e);
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');
@@ -68,6 +70,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   for (auto& e : h->side_events)
     if (e) hipEventDestroy(e);
   if (h->d_rstream) hipFree(h->d_rstream);
+  if (h->d_tileflags) hipFree(h->d_tileflags);
   if (h->d_kvcache) hipFree(h->d_kvcache);
   if (h->d_slab_flags) hipFree(h->d_slab_flags);
   if (h->d_z) hipFree(h->d_z);

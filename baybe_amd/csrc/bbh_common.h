@@ -141,6 +141,7 @@ struct bbh_handle {
   double* d_K = nullptr;       // [np, np]  K + s2 I  -> L (lower, in place)
   double* d_X = nullptr;       // [np, np]  L^-1
   double* d_M = nullptr;       // [np, np]  (K + s2 I)^-1
+  double* d_Mpart = nullptr;   // [4, np, np] split-K partial products of X^T X (256 <= np <= 1024)
   double* d_Q = nullptr;       // [np, np]  scratch (LOO: M diag(u) M; Msc)
   double* d_Q2 = nullptr;      // [np, np]  scratch
   double* d_D = nullptr;       // [np/64, 64, 64] inverses of the diagonal Cholesky blocks
@@ -182,6 +183,10 @@ struct bbh_handle {
   bool fit_overlap = true;        // env BBH_FIT_OVERLAP=0: the inverse of the factor strictly after the factorisation (A/B)
   hipStream_t side_stream = nullptr;  // second stream of the fit (rows of L^-1 next to the trailing updates)
   hipStream_t fit_stream = nullptr;   // stream the captured evaluation graph is replayed on
+  bool potrf_tiles = true, tiles_ready = false;  // env BBH_POTRF_TILES=0: per-step launches instead of the one-launch tile-dataflow factorisation (np <= 1024)
+  int tile_spin_limit = 1 << 20, tile_spin_limit_set = -1;  // env BBH_TILE_SPIN: polls (~1 us each) before a waiting tile gives up
+  int* d_tileflags = nullptr;         // [2][16][16] publish flags of the L- and X-tiles (epoch-stamped)
+  int tile_epoch = 0;
   hipGraphExec_t fit_exec = nullptr;  // one evaluation of the fit objective, captured per model (bbh_fit_value_grad)
   bool fit_graph_mode = false, fit_graph_failed = false;  // env BBH_FIT_GRAPH=1: replay the captured graph (slower, see bbh_model.hip)
   double *pin_theta = nullptr, *pin_out = nullptr;  // pinned staging of the evaluation (theta in, value + gradient out)

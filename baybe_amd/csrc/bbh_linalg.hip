@@ -224,20 +224,19 @@ __device__ __forceinline__ d4 pd_mul_nn(const double (*a)[PD_LD], int ar, int ac
   return c;
 }
 
-__global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_t lda, int64_t J, double* D, double* X,
-                                                               int64_t ldx, int* info) {
-  __shared__ double a[64][PD_LD];  // the block: A -> L (lower), upper part zeroed at the end
-  __shared__ double x[64][PD_LD];  // L^-1 (lower)
-  __shared__ double s[64][PD_LD];  // products awaiting a second multiplication (inverse assembly)
+// Factor and invert the 64 x 64 SPD block held in LDS array a (in place: lower factor L, strict upper zeroed) into x =
+// L^-1 (lower); s is scratch.  256 threads, all LDS arrays [64][PD_LD]; x must be zero on entry.  row0: global index of
+// the block's first row (failure reports row0 + pivot + 1 through *info).
+__device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[PD_LD], double (*s)[PD_LD], int64_t row0, int* info,
+                                                int* early_flag = nullptr, int epoch = 0) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  double* Ajj = A + (J * 64) * lda + J * 64;
-  for (int e = t; e < 4096; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    a[i][j] = Ajj[(int64_t)i * lda + j];
-    x[i][j] = 0.0;
-  }
-  __syncthreads();
   for (int jb = 0; jb < 4; jb++) {
+    // (tile-dataflow caller: stores issued before this call have landed by now - publish them without a stall)
+    if (jb == 1 && early_flag) {
+      __threadfence();
+      __syncthreads();  // every thread's stores are fenced before the flag goes up
+      if (t == 0) __atomic_store_n(early_flag, epoch, __ATOMIC_RELEASE);
+    }
     const int o = 16 * jb;
     if (w == 0) {  // diagonal sub-block: lane i < 16 holds row i; pivots travel by v_readlane
       double row[16];
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
           row[k] = fma(-row[j], lkj, row[k]);  // meaningful for i >= k
         }
       }
-      if (l == 0 && bad) atomicCAS(info, 0, (int)(J * 64 + o + bad));
+      if (l == 0 && bad) atomicCAS(info, 0, (int)(row0 + o + bad));
       if (l < 16) {
 #pragma unroll
         for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
@@ -322,6 +321,22 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
     }
   }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_t lda, int64_t J, double* D, double* X,
+                                                               int64_t ldx, int* info) {
+  __shared__ double a[64][PD_LD];  // the block: A -> L (lower), upper part zeroed at the end
+  __shared__ double x[64][PD_LD];  // L^-1 (lower)
+  __shared__ double s[64][PD_LD];  // products awaiting a second multiplication (inverse assembly)
+  const int t = threadIdx.x;
+  double* Ajj = A + (J * 64) * lda + J * 64;
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    a[i][j] = Ajj[(int64_t)i * lda + j];
+    x[i][j] = 0.0;
+  }
+  __syncthreads();
+  pd_factor_block(a, x, s, J * 64, info);
   double* Xjj = X + (J * 64) * ldx + J * 64;
   double* Dj = D + J * 4096;
   for (int e = t; e < 4096; e += 256) {
@@ -333,6 +348,184 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
   }
 }
 
+// =====================================================================================================================
+// The whole factorisation L = chol(A), X = L^-1 of an np x np matrix (np <= 1024) in ONE launch: tile dataflow.
+// One workgroup per 64 x 64 tile, all resident at once (<= 256 workgroups, one per CU: 101 KB of LDS each):
+//   L-tile (I, K), K <= I-2: a = A_IK;  for J < K: a -= L_IJ L_KJ^T as soon as both are published;  then wait for D_K,
+//                           L_IK = a D_K^T, publish.
+//   row head I:             the tiles (I, I-1) and (I, I) together: the same updates for both, then L_{I,I-1} = a_left
+//                           D_{I-1}^T, a_diag -= L_{I,I-1} L_{I,I-1}^T, factor + invert (pd_factor_block), publish D_I.
+//   X-tile (I, J), I > J:   acc = sum_{K = J}^{I-1} L_IK X_KJ as the operands appear (X_JJ = D_J), then X_IJ = -D_I acc.
+// "Published" = tile written, __threadfence(), flag[tile] = epoch (release); consumers poll the flag (acquire) with a
+// bounded number of polls - if the workgroups are ever not co-resident (another kernel holding CUs) the launch gives up
+// (*info = -7) instead of hanging and the caller falls back to the launch-per-step path.  The dependency chain is
+// nbk x (factor + one 64^3 panel product + one 64^3 update) inside one kernel instead of 8 x 3 dependent launches.
+// =====================================================================================================================
+__device__ int pd_spin_limit;  // polls before a waiting workgroup gives up (set per launch)
+__device__ __forceinline__ bool pd_wait(const int* flag, int epoch, int* info) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1, it = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) {
+      if (++it > pd_spin_limit || __atomic_load_n(info, __ATOMIC_RELAXED) == -7) {
+        __atomic_store_n(info, -7, __ATOMIC_RELAXED);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  __threadfence();  // acquire side for every thread's tile loads
+  __syncthreads();  // (s_ok is reused by the next wait)
+  return ok;
+}
+__device__ __forceinline__ void pd_publish(int* flag, int epoch) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __atomic_store_n(flag, epoch, __ATOMIC_RELEASE);
+}
+// (16-byte accesses: tile rows start 16-byte aligned in global memory - ld is a multiple of 64 - and in LDS, pitch 528 B)
+typedef double pd_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pd_load_tile(double (*dst)[PD_LD], const double* src, int64_t ld) {
+#pragma unroll
+  for (int e = threadIdx.x; e < 2048; e += 256)
+    *(pd_d2*)&dst[e >> 5][2 * (e & 31)] = *(const pd_d2*)(src + (int64_t)(e >> 5) * ld + 2 * (e & 31));
+}
+__device__ __forceinline__ void pd_store_tile(double* dst, int64_t ld, const double (*src)[PD_LD], double scale) {
+#pragma unroll
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    pd_d2 v = *(const pd_d2*)&src[e >> 5][2 * (e & 31)];
+    v *= scale;
+    *(pd_d2*)(dst + (int64_t)(e >> 5) * ld + 2 * (e & 31)) = v;
+  }
+}
+// c (+)= sign * a b^T (NT) or a b (NN), 64 x 64 x 64, the 16 output sub-blocks dealt to the four waves
+template <bool NT, bool ACCUM>
+__device__ __forceinline__ void pd_gemm64(double (*c)[PD_LD], const double (*a)[PD_LD], const double (*b)[PD_LD], double sign) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int sb = w; sb < 16; sb += 4) {
+    const int mb = sb >> 2, nb = sb & 3;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+      if (NT) {
+        const d4 p = pd_mul_nt(a, 16 * mb, 16 * kb, b, 16 * nb, 16 * kb, l);
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] += p[r];
+      } else {
+        acc = pd_mul_nn(a, 16 * mb, 16 * kb, b, 16 * kb, 16 * nb, l, acc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      double* out = &c[16 * mb + (l >> 4) + 4 * r][16 * nb + (l & 15)];
+      *out = ACCUM ? *out + sign * acc[r] : sign * acc[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t lda, int nbk, double* D, double* X, int64_t ldx,
+                                                              int* flagsL, int* flagsX, int epoch, int* info) {
+  extern __shared__ __attribute__((aligned(16))) double s_tiles[];
+  double(*a)[PD_LD] = (double(*)[PD_LD])s_tiles;
+  double(*b)[PD_LD] = (double(*)[PD_LD])(s_tiles + 64 * PD_LD);
+  double(*c)[PD_LD] = (double(*)[PD_LD])(s_tiles + 2 * 64 * PD_LD);
+  double(*al)[PD_LD] = (double(*)[PD_LD])(s_tiles + 3 * 64 * PD_LD);  // row heads: the tile left of the diagonal one
+  const int nOther = (nbk - 1) * (nbk - 2) / 2;
+  int id = blockIdx.x;
+  if (id < nbk) {
+    // ---- row head I: the diagonal tile (I, I) AND its left neighbour (I, I-1) in one workgroup, so that the critical
+    // chain D_{I-1} -> L_{I,I-1} -> update of (I, I) -> factor -> D_I never leaves LDS in between
+    const int I = id;
+    double* Aii = A + (int64_t)(I * 64) * lda + I * 64;
+    double* Ail = Aii - 64;
+    pd_load_tile(a, Aii, lda);
+    if (I > 0) pd_load_tile(al, Ail, lda);
+    __syncthreads();
+    for (int J = 0; J + 1 < I; J++) {
+      if (!pd_wait(&flagsL[I * nbk + J], epoch, info) || !pd_wait(&flagsL[(I - 1) * nbk + J], epoch, info)) return;
+      pd_load_tile(b, A + (int64_t)(I * 64) * lda + J * 64, lda);
+      pd_load_tile(c, A + (int64_t)((I - 1) * 64) * lda + J * 64, lda);
+      __syncthreads();
+      pd_gemm64<true, true>(a, b, b, -1.0);
+      pd_gemm64<true, true>(al, b, c, -1.0);
+      __syncthreads();
+    }
+    if (I > 0) {
+      if (!pd_wait(&flagsL[(I - 1) * nbk + (I - 1)], epoch, info)) return;
+      pd_load_tile(b, D + (int64_t)(I - 1) * 4096, 64);
+      __syncthreads();
+      pd_gemm64<true, false>(c, al, b, 1.0);  // L_{I,I-1} = A_{I,I-1} D_{I-1}^T
+      __syncthreads();
+      pd_store_tile(Ail, lda, c, 1.0);        // (published from inside the factorisation, once the stores have landed)
+      pd_gemm64<true, true>(a, c, c, -1.0);
+      __syncthreads();
+    }
+    for (int e = threadIdx.x; e < 4096; e += 256) b[e >> 6][e & 63] = 0.0;
+    __syncthreads();
+    pd_factor_block(a, b, al, (int64_t)I * 64, info, I > 0 ? &flagsL[I * nbk + (I - 1)] : nullptr, epoch);
+    pd_store_tile(D + (int64_t)I * 4096, 64, b, 1.0);
+    pd_publish(&flagsL[I * nbk + I], epoch);  // D_I first: the next row head waits for it
+    pd_store_tile(Aii, lda, a, 1.0);
+    pd_store_tile(X + (int64_t)(I * 64) * ldx + I * 64, ldx, b, 1.0);
+    return;
+  }
+  id -= nbk;
+  if (id < nOther) {  // ---- L-tile (I, K), K <= I - 2
+    int I = 2;
+    while ((I - 1) * I / 2 <= id) I++;   // tiles of the rows 2 .. I-1 number (I-1)(I-2)/2
+    const int K = id - (I - 1) * (I - 2) / 2;
+    double* Aik = A + (int64_t)(I * 64) * lda + K * 64;
+    pd_load_tile(a, Aik, lda);
+    __syncthreads();
+    for (int J = 0; J < K; J++) {
+      if (!pd_wait(&flagsL[I * nbk + J], epoch, info) || !pd_wait(&flagsL[K * nbk + J], epoch, info)) return;
+      pd_load_tile(b, A + (int64_t)(I * 64) * lda + J * 64, lda);
+      pd_load_tile(c, A + (int64_t)(K * 64) * lda + J * 64, lda);
+      __syncthreads();
+      pd_gemm64<true, true>(a, b, c, -1.0);
+      __syncthreads();
+    }
+    if (!pd_wait(&flagsL[K * nbk + K], epoch, info)) return;
+    pd_load_tile(b, D + (int64_t)K * 4096, 64);
+    __syncthreads();
+    pd_gemm64<true, false>(c, a, b, 1.0);  // L_IK = A_IK D_K^T
+    __syncthreads();
+    pd_store_tile(Aik, lda, c, 1.0);
+    pd_publish(&flagsL[I * nbk + K], epoch);
+    return;
+  }
+  id -= nOther;
+  // ---- X-tile (I, J), I > J: enumeration of the strict lower triangle
+  int I = 1;
+  while (I * (I + 1) / 2 <= id) I++;
+  const int J = id - I * (I - 1) / 2;
+  for (int e = threadIdx.x; e < 4096; e += 256) a[e >> 6][e & 63] = 0.0;
+  __syncthreads();
+  for (int K = J; K < I; K++) {
+    if (!pd_wait(&flagsL[I * nbk + K], epoch, info)) return;
+    if (!pd_wait(K == J ? &flagsL[J * nbk + J] : &flagsX[K * nbk + J], epoch, info)) return;
+    pd_load_tile(b, A + (int64_t)(I * 64) * lda + K * 64, lda);
+    if (K == J)
+      pd_load_tile(c, D + (int64_t)J * 4096, 64);
+    else
+      pd_load_tile(c, X + (int64_t)(K * 64) * ldx + J * 64, ldx);
+    __syncthreads();
+    pd_gemm64<false, true>(a, b, c, 1.0);  // acc += L_IK X_KJ
+    __syncthreads();
+  }
+  if (!pd_wait(&flagsL[I * nbk + I], epoch, info)) return;
+  pd_load_tile(b, D + (int64_t)I * 4096, 64);
+  __syncthreads();
+  pd_gemm64<false, false>(c, b, a, -1.0);  // X_IJ = -D_I acc
+  __syncthreads();
+  pd_store_tile(X + (int64_t)(I * 64) * ldx + J * 64, ldx, c, 1.0);
+  pd_publish(&flagsX[I * nbk + J], epoch);
+}
+
 void bbh_ensure_side_stream(bbh_handle* h) {
   if (!h->fit_overlap || h->side_stream) return;
   if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) h->side_stream = nullptr;
@@ -340,7 +533,42 @@ void bbh_ensure_side_stream(bbh_handle* h) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
 }
 
+// one launch for the whole factorisation + inverse (np <= 1024): see bbh_potrf_tiles_kernel
+static bool bbh_potrf_tiles(bbh_handle* h) {
+  const int64_t np = h->np;
+  const int nbk = (int)(np / 64);
+  if (!h->potrf_tiles || nbk > 16) return false;
+  static const size_t lds = sizeof(double) * 4 * 64 * PD_LD;
+  if (!h->tiles_ready) {
+    if (hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipMalloc((void**)&h->d_tileflags, sizeof(int) * 2 * 16 * 16) != hipSuccess ||
+        hipMemset(h->d_tileflags, 0, sizeof(int) * 2 * 16 * 16) != hipSuccess) {
+      (void)hipGetLastError();
+      h->potrf_tiles = false;
+      return false;
+    }
+    h->tiles_ready = true;
+  }
+  if (h->tile_spin_limit != h->tile_spin_limit_set) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pd_spin_limit), &h->tile_spin_limit, sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      h->potrf_tiles = false;
+      return false;
+    }
+    h->tile_spin_limit_set = h->tile_spin_limit;
+  }
+  hipStream_t s = h->stream;
+  hipMemsetAsync(h->d_X, 0, sizeof(double) * np * np, s);  // the upper tiles of L^-1 (XᵀX reads the full matrix)
+  hipMemsetAsync(h->d_info, 0, sizeof(int), s);
+  const int epoch = ++h->tile_epoch;
+  const int ntiles = nbk + (nbk - 1) * (nbk - 2) / 2 + nbk * (nbk - 1) / 2;  // row heads, other L-tiles, X-tiles
+  hipLaunchKernelGGL(bbh_potrf_tiles_kernel, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np,
+                     h->d_tileflags, h->d_tileflags + 256, epoch, h->d_info);
+  return true;
+}
+
 void bbh_potrf_trtri(bbh_handle* h) {
+  if (bbh_potrf_tiles(h)) return;
   hipStream_t s = h->stream;
   const int64_t np = h->np, nbk = np / 64;
   hipMemsetAsync(h->d_X, 0, sizeof(double) * np * np, s);

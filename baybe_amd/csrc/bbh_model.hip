@@ -114,6 +114,12 @@ __global__ void bbh_loo_vec_kernel(const double* __restrict__ M, const double* _
   w[i] = a / d;
 }
 
+// out = p0 + p1 + p2 + p3 (partial products of the split-K X^T X), fixed order
+__global__ void bbh_sum4_kernel(const double* __restrict__ P, int64_t n, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = (P[e] + P[n + e]) + (P[2 * n + e] + P[3 * n + e]);
+}
+
 // Msc[a][b] = M[a][b] * u[b]
 __global__ void bbh_colscale_kernel(const double* __restrict__ M, const double* __restrict__ u, int np,
                                     double* __restrict__ out) {
@@ -333,7 +339,7 @@ static void bbh_free_model(bbh_handle* h) {
   void* ptrs[] = {h->d_xnT,   h->d_task,    h->d_ystd,      h->d_theta, h->d_K,     h->d_X,       h->d_M,
                   h->d_Q,     h->d_Q2,      h->d_D,         h->d_tmp,   h->d_r,     h->d_t,       h->d_alpha,
                   h->d_u,     h->d_w,       h->d_q,         h->d_partial, h->d_out, h->d_info,    h->d_trainfrag,
-                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag, h->d_pendT, h->d_colA};
+                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag, h->d_pendT, h->d_colA, h->d_Mpart};
   for (void* p : ptrs)
     if (p) hipFree(p);
   h->d_xnT = h->d_ystd = h->d_theta = h->d_K = h->d_X = h->d_M = h->d_Q = h->d_Q2 = h->d_D = h->d_tmp = nullptr;
@@ -342,7 +348,7 @@ static void bbh_free_model(bbh_handle* h) {
   h->d_task = h->d_info = h->d_numcol = h->d_taskext = h->d_pass_w = nullptr;
   h->d_pass_off = nullptr;
   h->d_nmask = nullptr;
-  h->d_pendT = h->d_colA = nullptr;
+  h->d_pendT = h->d_colA = h->d_Mpart = nullptr;
   h->colA_elems = 0;
   if (h->fit_exec) hipGraphExecDestroy(h->fit_exec);
   h->fit_exec = nullptr;
@@ -509,6 +515,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   BBH_ALLOC(h->d_out, 1 + tl);
   BBH_ALLOC(h->d_info, 1);
   BBH_ALLOC(h->d_beta, np * BBH_MEANCOLS);
+  if (np >= 256 && np <= 1024) BBH_ALLOC(h->d_Mpart, 4 * np * np);
   BBH_ALLOC(h->d_pendT, (int64_t)h->dn * 16);
   BBH_HIP_TRY(h, hipMemset(h->d_pendT, 0, sizeof(double) * h->dn * 16));
   BBH_HIP_TRY(h, hipMemcpy(h->d_xnT, xnT.data(), sizeof(double) * xnT.size(), hipMemcpyHostToDevice));
@@ -545,6 +552,10 @@ static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
   int info = 0;
   BBH_HIP_TRY(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  if (info == -7 && h->potrf_tiles) {  // tile-dataflow launch gave up: redo with the per-step path
+    h->potrf_tiles = false;
+    return bbh_chol_and_alpha(h, jitter, info_out);
+  }
   *info_out = info;
   return 0;
 }
@@ -560,8 +571,16 @@ static int bbh_fit_enqueue(bbh_handle* h) {
   // factorisation the remaining kernels run on NaNs, harmlessly, and the outcome is discarded).
   int rc = bbh_chol_and_alpha(h, 0.0, nullptr);
   if (rc) return rc;
-  // M = X^T X
-  bbh_gemm(s, true, false, np, np, np, 1.0, h->d_X, np, 0, h->d_X, np, 0, 0.0, h->d_M, np, 0, 1);
+  // M = X^T X.  One 64 x 64 output tile per workgroup means np / 64 squared workgroups walking all of K: 35 us at np = 512
+  // on a quarter of the CUs.  Up to np = 1024 the product is split four ways along K (batched launch into four partial
+  // matrices) and summed in a fixed order.
+  if (h->d_Mpart) {
+    bbh_gemm(s, true, false, np, np, np / 4, 1.0, h->d_X, np, (np / 4) * np, h->d_X, np, (np / 4) * np, 0.0, h->d_Mpart, np,
+             np * np, 4);
+    hipLaunchKernelGGL(bbh_sum4_kernel, dim3((unsigned)((np * np + 255) / 256)), dim3(256), 0, s, h->d_Mpart, np * np, h->d_M);
+  } else {
+    bbh_gemm(s, true, false, np, np, np, 1.0, h->d_X, np, 0, h->d_X, np, 0, 0.0, h->d_M, np, 0, 1);
+  }
   const int crit = h->desc.criterion;
   if (crit == BBH_CRITERION_LOO) {
     hipLaunchKernelGGL(bbh_loo_vec_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, h->d_M, h->d_alpha,
@@ -659,6 +678,14 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
     fprintf(stderr, "bbh_fit_value_grad (%s): enqueue %.1f us, wait %.1f us\n", h->fit_exec ? "graph" : "launches",
             std::chrono::duration<double, std::micro>(t_enq - t_begin).count(),
             std::chrono::duration<double, std::micro>(t_end - t_enq).count());
+  }
+  if (*h->pin_info == -7 && h->potrf_tiles) {  // the tile-dataflow launch gave up (workgroups not co-resident): per-step path
+    h->potrf_tiles = false;
+    if (h->fit_exec) {
+      hipGraphExecDestroy(h->fit_exec);
+      h->fit_exec = nullptr;
+    }
+    return bbh_fit_value_grad(h, theta_host, value_host, grad_host);
   }
   if (*h->pin_info != 0) {
     *value_host = -INFINITY;

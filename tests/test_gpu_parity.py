@@ -728,3 +728,35 @@ def test_rational_quadratic_kernels(gp, name):
         m, v = gp.posterior(X)
         mf, vf = go.GPModel(ospec, fo.params, Xt, y).posterior(X)
         assert np.max(np.abs(_np(m) - mf)) < 0.02 * np.std(y)
+
+
+def test_tile_dataflow_factorisation_and_its_fallback(monkeypatch):
+    """The one-launch tile-dataflow Cholesky + inverse (bbh_potrf_tiles_kernel, np <= 1024) against the per-step launches
+    (BBH_POTRF_TILES=0): same data term / gradient / posterior to rounding; and with a poll budget of zero the waiting tiles
+    give up at once, the launch reports -7 and the handle falls back to the per-step path with the same results."""
+    from baybe_amd import engine, gp_spec
+
+    d, n = 8, 300
+    X, Xt, y = make_problem(3000, d, n, seed=61)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    p = gp_spec.GPParams(np.full(d, ls), nz, 0.1)
+    out = {}
+    for mode, env in (("tiles", {"BBH_POTRF_TILES": "1"}), ("steps", {"BBH_POTRF_TILES": "0"}),
+                      ("fallback", {"BBH_POTRF_TILES": "1", "BBH_TILE_SPIN": "0"})):
+        for k in ("BBH_POTRF_TILES", "BBH_TILE_SPIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = engine.HipGP(0)
+        g.set_model(spec, Xt, y)
+        val, grad = g.data_term(p)
+        g.factorize(p)
+        m, v = g.posterior(X)
+        out[mode] = (val, grad, m.cpu().numpy(), v.cpu().numpy())
+        g.close()
+    for mode in ("steps", "fallback"):
+        assert math.isclose(out["tiles"][0], out[mode][0], rel_tol=1e-12)
+        assert np.allclose(out["tiles"][1], out[mode][1], rtol=1e-9, atol=1e-11 * np.abs(out["tiles"][1]).max())
+        assert np.allclose(out["tiles"][2], out[mode][2], rtol=1e-10, atol=1e-12) and np.allclose(out["tiles"][3], out[mode][3], rtol=1e-8)
+    assert out["steps"][0] == out["fallback"][0]  # the fallback IS the per-step path
