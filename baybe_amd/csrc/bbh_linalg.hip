@@ -402,15 +402,33 @@ __device__ __forceinline__ void pd_store_tile(double* dst, int64_t ld, const dou
     *(pd_d2*)(dst + (int64_t)(e >> 5) * ld + 2 * (e & 31)) = v;
   }
 }
-// c (+)= sign * a b^T (NT) or a b (NN), 64 x 64 x 64, the 16 output sub-blocks dealt to the four waves
-template <bool NT, bool ACCUM>
+// c (+)= sign * a b^T (NT) or a b (NN), 64 x 64 x 64, the 16 output sub-blocks dealt to the four waves.  SKIP names
+// structural zeros / don't-cares at 16 x 16 sub-block granularity:
+//   PD_B_LOWER (NT): b is lower triangular, b[n][k] = 0 for k > n      -> k-blocks kb <= nb only
+//   PD_A_LOWER (NN): a is lower triangular, a[m][k] = 0 for k > m      -> k-blocks kb <= mb only
+//   PD_OUT_LOWER:    only the lower sub-blocks of c (mb >= nb) are read afterwards (symmetric update of a diagonal tile)
+enum { PD_FULL = 0, PD_B_LOWER = 1, PD_A_LOWER = 2, PD_OUT_LOWER = 3 };
+template <bool NT, bool ACCUM, int SKIP>
 __device__ __forceinline__ void pd_gemm64(double (*c)[PD_LD], const double (*a)[PD_LD], const double (*b)[PD_LD], double sign) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int sb = w; sb < 16; sb += 4) {
-    const int mb = sb >> 2, nb = sb & 3;
+  // sub-blocks are dealt so that every wave gets the same number of k-blocks: lower-only output - the ten lower sub-blocks
+  // in turn; triangular b - one sub-block of every block column; triangular a - one of every block row
+  constexpr int NSB = SKIP == PD_OUT_LOWER ? 10 : 16;
+  for (int sb = w; sb < NSB; sb += 4) {
+    int mb, nb;
+    if (SKIP == PD_OUT_LOWER) {
+      nb = sb < 4 ? 0 : sb < 7 ? 1 : sb < 9 ? 2 : 3;
+      mb = sb - (nb == 0 ? 0 : nb == 1 ? 3 : nb == 2 ? 5 : 6);
+    } else if (SKIP == PD_A_LOWER) {
+      mb = sb >> 2, nb = sb & 3;
+    } else {
+      mb = sb & 3, nb = sb >> 2;
+    }
     d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
+      if (SKIP == PD_B_LOWER && kb > nb) continue;
+      if (SKIP == PD_A_LOWER && kb > mb) continue;
       if (NT) {
         const d4 p = pd_mul_nt(a, 16 * mb, 16 * kb, b, 16 * nb, 16 * kb, l);
 #pragma unroll
@@ -450,18 +468,18 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       pd_load_tile(b, A + (int64_t)(I * 64) * lda + J * 64, lda);
       pd_load_tile(c, A + (int64_t)((I - 1) * 64) * lda + J * 64, lda);
       __syncthreads();
-      pd_gemm64<true, true>(a, b, b, -1.0);
-      pd_gemm64<true, true>(al, b, c, -1.0);
+      pd_gemm64<true, true, PD_OUT_LOWER>(a, b, b, -1.0);
+      pd_gemm64<true, true, PD_FULL>(al, b, c, -1.0);
       __syncthreads();
     }
     if (I > 0) {
       if (!pd_wait(&flagsL[(I - 1) * nbk + (I - 1)], epoch, info)) return;
       pd_load_tile(b, D + (int64_t)(I - 1) * 4096, 64);
       __syncthreads();
-      pd_gemm64<true, false>(c, al, b, 1.0);  // L_{I,I-1} = A_{I,I-1} D_{I-1}^T
+      pd_gemm64<true, false, PD_B_LOWER>(c, al, b, 1.0);  // L_{I,I-1} = A_{I,I-1} D_{I-1}^T
       __syncthreads();
       pd_store_tile(Ail, lda, c, 1.0);        // (published from inside the factorisation, once the stores have landed)
-      pd_gemm64<true, true>(a, c, c, -1.0);
+      pd_gemm64<true, true, PD_OUT_LOWER>(a, c, c, -1.0);
       __syncthreads();
     }
     for (int e = threadIdx.x; e < 4096; e += 256) b[e >> 6][e & 63] = 0.0;
@@ -486,13 +504,13 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       pd_load_tile(b, A + (int64_t)(I * 64) * lda + J * 64, lda);
       pd_load_tile(c, A + (int64_t)(K * 64) * lda + J * 64, lda);
       __syncthreads();
-      pd_gemm64<true, true>(a, b, c, -1.0);
+      pd_gemm64<true, true, PD_FULL>(a, b, c, -1.0);
       __syncthreads();
     }
     if (!pd_wait(&flagsL[K * nbk + K], epoch, info)) return;
     pd_load_tile(b, D + (int64_t)K * 4096, 64);
     __syncthreads();
-    pd_gemm64<true, false>(c, a, b, 1.0);  // L_IK = A_IK D_K^T
+    pd_gemm64<true, false, PD_B_LOWER>(c, a, b, 1.0);  // L_IK = A_IK D_K^T
     __syncthreads();
     pd_store_tile(Aik, lda, c, 1.0);
     pd_publish(&flagsL[I * nbk + K], epoch);
@@ -514,13 +532,13 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
     else
       pd_load_tile(c, X + (int64_t)(K * 64) * ldx + J * 64, ldx);
     __syncthreads();
-    pd_gemm64<false, true>(a, b, c, 1.0);  // acc += L_IK X_KJ
+    pd_gemm64<false, true, PD_FULL>(a, b, c, 1.0);  // acc += L_IK X_KJ
     __syncthreads();
   }
   if (!pd_wait(&flagsL[I * nbk + I], epoch, info)) return;
   pd_load_tile(b, D + (int64_t)I * 4096, 64);
   __syncthreads();
-  pd_gemm64<false, false>(c, b, a, -1.0);  // X_IJ = -D_I acc
+  pd_gemm64<false, false, PD_A_LOWER>(c, b, a, -1.0);  // X_IJ = -D_I acc
   __syncthreads();
   pd_store_tile(X + (int64_t)(I * 64) * ldx + J * 64, ldx, c, 1.0);
   pd_publish(&flagsX[I * nbk + J], epoch);

@@ -216,7 +216,7 @@ class HipGP:
             val, g = self.data_term(p)
             if val is None:
                 return float("inf"), np.zeros_like(raw)
-            return objective_from_data_term(spec, raw, n, val, g)
+            return objective_from_data_term(spec, raw, n, val, g, params=p)
 
         last_msg = ""
         for attempt in range(max_attempts):

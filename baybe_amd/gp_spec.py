@@ -452,10 +452,10 @@ def _task_correlation_prior(prior, B):
     return float(lp), G
 
 
-def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float, grad_theta: np.ndarray):
+def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float, grad_theta: np.ndarray, params=None):
     """-(data term + log priors)/n and its gradient w.r.t. the raw vector, given the device's
     data term ``value`` and its gradient in theta layout (gpytorch: add priors, divide by n)."""
-    p = unpack_raw(spec, raw)
+    p = params if params is not None else unpack_raw(spec, raw)  # (the caller's unpacked copy, if it has one)
     dn = spec.dn
     T = spec.n_tasks
     m = T if spec.hadamard else 1
