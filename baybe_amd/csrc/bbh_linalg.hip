@@ -7,6 +7,8 @@
 // These replace what linear_operator/LAPACK do under gpytorch's ExactMarginalLogLikelihood
 // (reference call site baybe/surrogates/gaussian_process/core.py:340-341).  All matrices are
 // padded to multiples of 64 with an identity block, so no kernel needs edge handling.
+#include <type_traits>
+
 #include "bbh_common.h"
 
 #define GBK 16
@@ -224,6 +226,35 @@ __device__ __forceinline__ d4 pd_mul_nn(const double (*a)[PD_LD], int ar, int ac
   return c;
 }
 
+// Row broadcasts for the 16 x 16 diagonal sub-blocks: the 16 lanes of a DPP row hold the 16 rows of the sub-block, and
+// gfx90a+ has `row_newbcast:n` (lane n of every row to all its lanes) on the 64-bit v_mov and v_fmac.  One instruction
+// instead of two v_readlane_b32 + an SGPR operand: the readlane form of this code was 796 readlanes and 272 hazard nops in
+// 2 500 instructions and spilled SGPRs into VGPR lanes.  The `s_nop 1` in front of every DPP instruction covers the "VALU
+// write -> DPP read" hazard (2 wait states) whatever the compiler places before the statement.
+#ifndef BBH_DIAG_DPP
+#define BBH_DIAG_DPP 1
+#endif
+template <int LANE>
+__device__ __forceinline__ double pd_bcast(double v) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+  return r;
+}
+// acc += bcast_LANE(src) * (-mul)
+template <int LANE>
+__device__ __forceinline__ void pd_fmac_bcast_neg(double& acc, double src, double mul) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(mul), "n"(LANE));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void pd_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pd_static_for<I + 1, N>(f);
+  }
+}
+
 // Factor and invert the 64 x 64 SPD block held in LDS array a (in place: lower factor L, strict upper zeroed) into x =
 // L^-1 (lower); s is scratch.  256 threads, all LDS arrays [64][PD_LD]; x must be zero on entry.  row0: global index of
 // the block's first row (failure reports row0 + pivot + 1 through *info).
@@ -245,6 +276,38 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
       for (int k = 0; k < 16; k++) row[k] = a[o + i][o + k];
       int bad = 0;
       double rd[16];
+      double xc[16];
+#if BBH_DIAG_DPP
+      pd_static_for<0, 16>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const double djj = pd_bcast<j>(row[j]);
+        bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
+        double rs = __builtin_amdgcn_rsq(djj);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rd[j] = rs;  // the same in every lane: 1 / l_jj
+        row[j] = (i == j) ? djj * rs : row[j] * rs;
+        pd_static_for<j + 1, 16>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          pd_fmac_bcast_neg<k>(row[k], row[j], row[j]);  // row[k] -= l_kj * row[j]   (meaningful for i >= k)
+        });
+      });
+      if (l == 0 && bad) atomicCAS(info, 0, (int)(row0 + o + bad));
+      if (l < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
+      }
+      // inverse of the 16 x 16 factor: lane c < 16 owns column c (forward substitution, l_rk = lane r of row[k])
+      pd_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        double acc = (r == i) ? 1.0 : 0.0;
+        pd_static_for<0, r>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          pd_fmac_bcast_neg<r>(acc, row[k], xc[k]);
+        });
+        xc[r] = (r >= i) ? acc * rd[r] : 0.0;
+      });
+#else
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const double djj = bbh_readlane_f64(row[j], j);
@@ -266,7 +329,6 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
         for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
       }
       // inverse of the 16 x 16 factor: lane c < 16 owns column c (forward substitution, L rows by readlane)
-      double xc[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         double acc = (r == i) ? 1.0 : 0.0;
@@ -274,6 +336,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
         for (int k = 0; k < r; k++) acc = fma(-bbh_readlane_f64(row[k], r), xc[k], acc);  // l_rk = row r, entry k
         xc[r] = (r >= i) ? acc * rd[r] : 0.0;
       }
+#endif
       if (l < 16) {
 #pragma unroll
         for (int r = 0; r < 16; r++) x[o + r][o + i] = xc[r];
