@@ -240,12 +240,18 @@ __device__ __forceinline__ double pd_bcast(double v) {
   asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
   return r;
 }
-// acc += bcast_LANE(src) * (-mul)
-template <int LANE>
+// acc += bcast_LANE(src) * (-mul).  GUARD: src may have been written by the instruction just before (first member of an
+// update series: the scaled pivot column); the others read a register that has been at rest for many instructions.
+template <int LANE, bool GUARD>
 __device__ __forceinline__ void pd_fmac_bcast_neg(double& acc, double src, double mul) {
-  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-               : "+v"(acc)
-               : "v"(src), "v"(mul), "n"(LANE));
+  if constexpr (GUARD)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(src), "v"(mul), "n"(LANE));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(src), "v"(mul), "n"(LANE));
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void pd_static_for(F&& f) {
@@ -289,7 +295,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
         row[j] = (i == j) ? djj * rs : row[j] * rs;
         pd_static_for<j + 1, 16>([&](auto kc) __attribute__((always_inline)) {
           constexpr int k = decltype(kc)::value;
-          pd_fmac_bcast_neg<k>(row[k], row[j], row[j]);  // row[k] -= l_kj * row[j]   (meaningful for i >= k)
+          pd_fmac_bcast_neg<k, k == j + 1>(row[k], row[j], row[j]);  // row[k] -= l_kj * row[j]   (meaningful for i >= k)
         });
       });
       if (l == 0 && bad) atomicCAS(info, 0, (int)(row0 + o + bad));
@@ -303,7 +309,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
         double acc = (r == i) ? 1.0 : 0.0;
         pd_static_for<0, r>([&](auto kc) __attribute__((always_inline)) {
           constexpr int k = decltype(kc)::value;
-          pd_fmac_bcast_neg<r>(acc, row[k], xc[k]);
+          pd_fmac_bcast_neg<r, false>(acc, row[k], xc[k]);
         });
         xc[r] = (r >= i) ? acc * rd[r] : 0.0;
       });
