@@ -15,4 +15,13 @@ reference's property tests (sign symmetry, pending-point exclusion, linear-data
 boundary optimum) plus independent derivations (finite differences, dense
 linear algebra identities).  See ``oracle/gp_oracle.py`` for per-function
 citations.
+
+One part IS pinned against an implementation by other people: the GP core -
+stationary ARD kernels (Matern-1/2, -3/2, -5/2, RBF, rational quadratic, scaled
+products and sums), the log marginal likelihood with its gradient, and the exact
+Cholesky posterior (mean, variance, joint covariance) - agrees with scikit-learn's
+``GaussianProcessRegressor`` to rounding (``tests/test_oracle_vs_sklearn_cpu.py``;
+scikit-learn is importable here).  Everything BoTorch-specific (prior constants,
+constraint transforms, LOO, fat-tailed qLogEI / qLogNEHVI, Sobol base samples,
+greedy semantics, index kernels) stays unpinned.
 """

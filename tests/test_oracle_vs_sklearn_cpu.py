@@ -1,0 +1,124 @@
+"""An EXTERNAL pin for the GP core of the oracle: scikit-learn's ``GaussianProcessRegressor`` (an implementation written by
+other people, importable here, unlike gpytorch / botorch) evaluates the same stationary ARD kernels, the same log marginal
+likelihood with its gradient, and the same exact-Cholesky posterior.  The oracle (``oracle/gp_oracle.py``) must agree with
+it to rounding on all three - kernel formulas (Matern-1/2, -3/2, -5/2, RBF, rational quadratic, products and sums with
+scales), likelihood value and gradient, posterior mean / variance / joint covariance.
+
+What this does NOT pin: everything BoTorch-specific (priors and their constants, constraint transforms, the LOO criterion,
+fat-tailed qLogEI / qLogNEHVI, Sobol base samples, greedy semantics, the index kernel) - those parts of the oracle remain
+"parity unpinned" (DESIGN.md §2)."""
+
+import math
+
+import numpy as np
+import pytest
+
+sk = pytest.importorskip("sklearn.gaussian_process")
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, RationalQuadratic, WhiteKernel  # noqa: E402
+
+from oracle import gp_oracle as go  # noqa: E402
+
+
+def _problem(n=40, N=300, d=4, seed=0):
+    rng = np.random.default_rng(seed)
+    Xt, X = rng.random((n, d)), rng.random((N, d))
+    y = np.sin(3 * Xt[:, 0]) + Xt[:, 1] ** 2 - 0.5 * Xt[:, 2] + 0.05 * rng.standard_normal(n)
+    return Xt, X, y
+
+
+def _single(kernel, d):
+    return go.GPSpec(d=d, num_idx=np.arange(d), lo=np.zeros(d), hi=np.ones(d), kernel=kernel, use_outputscale=True,
+                     lengthscale=go.Hyper(0.0, True, None, 0.5), noise=go.Hyper(1e-4, True, None, 0.05),
+                     outputscale=go.Hyper(0.0, True, None, 1.0))
+
+
+CASES = {
+    "matern12": lambda ls: Matern(length_scale=ls, nu=0.5),
+    "matern32": lambda ls: Matern(length_scale=ls, nu=1.5),
+    "matern52": lambda ls: Matern(length_scale=ls, nu=2.5),
+    "rbf": lambda ls: RBF(length_scale=ls),
+}
+
+
+@pytest.mark.parametrize("kernel", sorted(CASES))
+def test_kernel_likelihood_gradient_and_posterior_against_scikit_learn(kernel):
+    d = 4
+    Xt, X, y = _problem(d=d)
+    rng = np.random.default_rng(1)
+    ls = 0.3 + rng.random(d)
+    os_, noise, mean = 1.7, 0.03, 0.2
+    spec = _single(kernel, d)
+    p = go.GPParams(lengthscale=ls, noise=noise, mean=mean, outputscale=os_)
+    Xn = go.normalize_inputs(spec, Xt)  # identity here (bounds [0, 1])
+    ystd, ybar, ysd = go.standardize_targets(y)
+
+    # --- kernel values
+    k_sk = ConstantKernel(os_) * CASES[kernel](ls)
+    assert np.allclose(go.cross_cov(spec, p, go.normalize_inputs(spec, X), Xn), k_sk(X, Xt), rtol=1e-12, atol=1e-14)
+
+    # --- log marginal likelihood and its gradient (scikit-learn differentiates w.r.t. log-parameters)
+    full = k_sk + WhiteKernel(noise)
+    gpr = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None, normalize_y=False).fit(Xn, ystd - mean)
+    lml, grad_log = gpr.log_marginal_likelihood(full.theta, eval_gradient=True)
+    dt = go.data_term(spec, p, Xn, ystd)
+    assert math.isclose(dt.value, lml, rel_tol=1e-10)
+    # theta order of the sklearn kernel: [log constant, log length scales..., log noise]
+    ours = np.concatenate([[dt.g_outputscale * os_], dt.g_ls * ls, [dt.g_noise * noise]])
+    assert np.allclose(ours, grad_log, rtol=1e-7, atol=1e-9 * np.abs(grad_log).max())
+    # the constant mean: d/dc of the likelihood = sum(alpha); check against a central difference of sklearn's value
+    e = 1e-5
+    up = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xn, ystd - (mean + e)).log_marginal_likelihood(full.theta)
+    dn = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xn, ystd - (mean - e)).log_marginal_likelihood(full.theta)
+    assert math.isclose(dt.g_mean, (up - dn) / (2 * e), rel_tol=1e-5, abs_tol=1e-6)
+
+    # --- posterior of the latent function (sklearn's predict includes the WhiteKernel in the prior variance: subtract it)
+    model = go.GPModel(spec, p, Xt, y)
+    mu, var = model.posterior(X)
+    m_sk, s_sk = gpr.predict(X, return_std=True)
+    assert np.allclose(mu, ybar + ysd * (mean + m_sk), rtol=1e-9, atol=1e-11)
+    assert np.allclose(var, ysd**2 * (s_sk**2 - noise), rtol=1e-6, atol=1e-10)
+    mj, cj = model.posterior_joint(X[:6])
+    _, c_sk = gpr.predict(X[:6], return_cov=True)
+    assert np.allclose(cj, ysd**2 * (c_sk - noise * np.eye(6)), rtol=1e-6, atol=1e-10)
+
+
+def test_rational_quadratic_products_and_sums_against_scikit_learn():
+    """RationalQuadratic is isotropic in scikit-learn: equal lengthscales.  Products / sums of scaled kernels as BayBE's
+    ProductKernel / AdditiveKernel build them."""
+    d = 3
+    Xt, X, y = _problem(d=d, seed=3)
+    ystd = go.standardize_targets(y)[0]
+    l1, alpha, l2 = 0.8, 1.3, np.array([0.4, 0.9, 0.6])
+    members = [go.KernelTerm("rq", go.Hyper(), go.Hyper()), go.KernelTerm("matern52", go.Hyper(), None)]
+    for composition, combine in (("product", lambda a, b: a * b), ("sum", lambda a, b: a + b)):
+        spec = go.GPSpec(d=d, num_idx=np.arange(d), lo=np.zeros(d), hi=np.ones(d), members=members, composition=composition,
+                         noise=go.Hyper(1e-4, True, None, 0.05))
+        p = go.GPParams(lengthscale=np.full(d, l1), noise=0.04, mean=0.0, member_ls=[np.full(d, l1), l2],
+                        member_scale=np.array([0.7, 1.0]), rq_alpha=np.array([alpha, 1.0]))
+        k_sk = combine(ConstantKernel(0.7) * RationalQuadratic(length_scale=l1, alpha=alpha), Matern(length_scale=l2, nu=2.5))
+        assert np.allclose(go.cross_cov(spec, p, X, Xt), k_sk(X, Xt), rtol=1e-12, atol=1e-14)
+        full = k_sk + WhiteKernel(0.04)
+        gpr = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xt, ystd)
+        lml, grad_log = gpr.log_marginal_likelihood(full.theta, eval_gradient=True)
+        dt = go.data_term(spec, p, Xt, ystd)
+        assert math.isclose(dt.value, lml, rel_tol=1e-10)
+        # sklearn theta: [log 0.7, log alpha?...]: order follows the kernel tree: constant, (rq: alpha, length_scale), matern ls.., noise
+        names = [h.name for h in full.hyperparameters]
+        got = {}
+        got["k1__k1__constant_value"] = dt.g_member_scale[0] * 0.7
+        got["k1__k2__length_scale"] = float(dt.g_member_ls[0].sum()) * l1  # isotropic: the ARD slots add up
+        got["k1__k2__alpha"] = dt.g_alpha[0] * alpha
+        ref = dict(zip(names, np.split(grad_log, np.cumsum([h.n_elements for h in full.hyperparameters])[:-1])))
+        for key, val in ref.items():
+            if key.endswith("k1__k1__constant_value"):
+                assert np.allclose(val, got["k1__k1__constant_value"], rtol=1e-7)
+            elif key.endswith("k1__k2__length_scale") and val.size == 1:
+                assert np.allclose(val, got["k1__k2__length_scale"], rtol=1e-7)
+            elif key.endswith("alpha"):
+                assert np.allclose(val, got["k1__k2__alpha"], rtol=1e-7)
+            elif key.endswith("length_scale"):
+                assert np.allclose(val, dt.g_member_ls[1] * l2, rtol=1e-7, atol=1e-10)
+            elif key.endswith("noise_level"):
+                assert np.allclose(val, dt.g_noise * 0.04, rtol=1e-7)
+            else:
+                raise AssertionError(f"unexpected scikit-learn hyper-parameter {key}")
