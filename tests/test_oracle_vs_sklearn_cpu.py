@@ -122,3 +122,38 @@ def test_rational_quadratic_products_and_sums_against_scikit_learn():
                 assert np.allclose(val, dt.g_noise * 0.04, rtol=1e-7)
             else:
                 raise AssertionError(f"unexpected scikit-learn hyper-parameter {key}")
+
+
+def test_leave_one_out_criterion_against_brute_force_refits_with_scikit_learn():
+    """The LOO pseudo-likelihood of the transfer-learning presets (presets/baybe.py:269-281): sum_i log N(y_i | mu_-i,
+    s2_-i) with the moments of a GP conditioned on all other points at the same hyper-parameters.  The oracle gets them
+    from one inverse; here every point is really left out and scikit-learn does the conditioning."""
+    d, n = 3, 18
+    Xt, _, y = _problem(n=n, d=d, seed=7)
+    ystd = go.standardize_targets(y)[0]
+    ls, os_, noise, mean = np.array([0.5, 0.9, 0.7]), 1.3, 0.05, -0.1
+    spec = _single("matern52", d)
+    spec.criterion = "loo"
+    p = go.GPParams(lengthscale=ls, noise=noise, mean=mean, outputscale=os_)
+    kern = ConstantKernel(os_) * Matern(length_scale=ls, nu=2.5) + WhiteKernel(noise)
+    total = 0.0
+    for i in range(n):
+        keep = np.arange(n) != i
+        gpr = sk.GaussianProcessRegressor(kernel=kern, alpha=0.0, optimizer=None).fit(Xt[keep], ystd[keep] - mean)
+        m, s = gpr.predict(Xt[i : i + 1], return_std=True)  # predictive of the OBSERVATION: the WhiteKernel is part of the prior
+        total += -0.5 * math.log(2 * math.pi * s[0] ** 2) - 0.5 * (ystd[i] - mean - m[0]) ** 2 / s[0] ** 2
+    dt = go.data_term(spec, p, Xt, ystd)
+    assert math.isclose(dt.value, total, rel_tol=1e-9)
+    # and its gradient by central differences of that brute-force value would cost n fits per parameter; the analytic
+    # gradient is covered against autograd (tests/test_host_logic_cpu.py) - here only the lengthscale of dimension 0
+    def brute(l0):
+        k2 = ConstantKernel(os_) * Matern(length_scale=np.array([l0, ls[1], ls[2]]), nu=2.5) + WhiteKernel(noise)
+        t = 0.0
+        for i in range(n):
+            keep = np.arange(n) != i
+            g = sk.GaussianProcessRegressor(kernel=k2, alpha=0.0, optimizer=None).fit(Xt[keep], ystd[keep] - mean)
+            m, s = g.predict(Xt[i : i + 1], return_std=True)
+            t += -0.5 * math.log(2 * math.pi * s[0] ** 2) - 0.5 * (ystd[i] - mean - m[0]) ** 2 / s[0] ** 2
+        return t
+    e = 1e-5
+    assert math.isclose(dt.g_ls[0], (brute(ls[0] + e) - brute(ls[0] - e)) / (2 * e), rel_tol=1e-5, abs_tol=1e-6)
