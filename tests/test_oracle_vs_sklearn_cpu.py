@@ -157,3 +157,32 @@ def test_leave_one_out_criterion_against_brute_force_refits_with_scikit_learn():
         return t
     e = 1e-5
     assert math.isclose(dt.g_ls[0], (brute(ls[0] + e) - brute(ls[0] - e)) / (2 * e), rel_tol=1e-5, abs_tol=1e-6)
+
+
+@pytest.mark.parametrize("q", [0, 1, 2, 3])
+def test_piecewise_polynomial_kernel_is_the_textbook_one_and_positive_definite(q):
+    """No library here implements gpytorch's PiecewisePolynomialKernel; its definition is Rasmussen & Williams (2006), eq.
+    (4.21): k_pp,q(r) = (1 - r)_+^(j + q) P_q(r), j = floor(D / 2) + q + 1, with the polynomials written out below.  Two pins:
+    the oracle equals those formulas, and the Gram matrix of random points in D dimensions is positive semi-definite - which
+    the family guarantees for exactly this exponent j (a smaller one loses it)."""
+    D, n = 5, 120
+    rng = np.random.default_rng(q)
+    X = rng.random((n, D))
+    ls = 0.8 + rng.random(D)
+    r = np.sqrt(go._scaled_sqdist(X, X, ls))
+    j = D // 2 + q + 1
+    textbook = {
+        0: lambda r: np.maximum(0, 1 - r) ** j,
+        1: lambda r: np.maximum(0, 1 - r) ** (j + 1) * ((j + 1) * r + 1),
+        2: lambda r: np.maximum(0, 1 - r) ** (j + 2) * ((j * j + 4 * j + 3) * r**2 + (3 * j + 6) * r + 3) / 3,
+        3: lambda r: np.maximum(0, 1 - r) ** (j + 3)
+        * ((j**3 + 9 * j * j + 23 * j + 15) * r**3 + (6 * j * j + 36 * j + 45) * r**2 + (15 * j + 45) * r + 15) / 15,
+    }[q](r)
+    K = go.base_kernel_from_r2(f"piecewise{q}", r * r, D)
+    assert np.allclose(K, textbook, rtol=1e-12, atol=1e-15)
+    assert 0.05 < (K > 0).mean() < 0.99  # compact support is actually exercised
+    assert np.linalg.eigvalsh(K).min() > -1e-10
+    # with too small an exponent the same construction stops being a valid kernel in D dimensions
+    bad = np.maximum(0, 1 - r) ** 1 if q == 0 else None
+    if bad is not None:
+        assert np.linalg.eigvalsh(bad).min() < -1e-6
