@@ -59,6 +59,30 @@ def _content_hash(arr: np.ndarray):
     return hash(tuple(parts))
 
 
+def _frame_content_hash(df: pd.DataFrame):
+    """Content hash of a DataFrame's values without materialising them as one array: every column's buffer on a thread
+    pool (xxhash releases the GIL); columns that are not plain numeric arrays go through ``_content_hash``."""
+    try:
+        import xxhash
+    except ImportError:  # pragma: no cover
+        return _content_hash(df.to_numpy())
+    if df.shape[1] == 0 or not df.iloc[:, 0].to_numpy().flags.c_contiguous:
+        return _content_hash(df.to_numpy())  # one 2-D block: ``to_numpy`` is a view, its columns are strided
+    cols = [df.iloc[:, j].to_numpy() for j in range(df.shape[1])]
+
+    def one(a):
+        if a.dtype == object or not a.flags.c_contiguous:
+            return _content_hash(a)
+        return xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
+
+    if df.shape[0] * df.shape[1] < (1 << 21):
+        return hash(tuple(one(a) for a in cols))
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(8) as pool:
+        return hash(tuple(pool.map(one, cols)))
+
+
 def _is_multi_output(objective) -> bool:
     """``Objective.is_multi_output`` (objectives/base.py): False for single-target AND desirability objectives."""
     flag = getattr(objective, "is_multi_output", None)
@@ -250,11 +274,13 @@ class HipRecommenderImpl:
         comp_rep = subspace_discrete.comp_rep
         # The resident copy is keyed on the CONTENT of the comp rep (xxh3 over all N x d doubles: ~10 ms at 1e6 x 20,
         # against 50 ms for re-encoding and re-uploading them), so an edit of any row is noticed
-        values = comp_rep.to_numpy(dtype=np.float64)  # a view of the frame's block where pandas can give one
+        # (hashed column by column: a column of a numeric frame is a view of its block, whereas ``to_numpy()`` of a frame
+        # with one block per column interleaves all N x d values into a new array - 11 ms of every call at 1e6 x 20)
         idx = comp_rep.index
         idx_key = (idx.start, idx.stop, idx.step) if isinstance(idx, pd.RangeIndex) else _content_hash(np.asarray(idx))
-        key = (comp_rep.shape, tuple(comp_rep.columns), _content_hash(values), idx_key)
+        key = (comp_rep.shape, tuple(comp_rep.columns), _frame_content_hash(comp_rep), idx_key)
         if self._cand_cache is None or self._cand_cache[0] != key:
+            values = comp_rep.to_numpy(dtype=np.float64)
             X = torch.from_numpy(np.ascontiguousarray(values))
             if self.shard is not None:
                 if self.shard.N_total != len(comp_rep):
