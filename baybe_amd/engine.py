@@ -18,6 +18,7 @@ from scipy import optimize as sopt
 from baybe_amd import _lib
 from baybe_amd._lib import HipError, HipUnavailableError
 from baybe_amd.gp_spec import (
+    FastObjective,
     GPParams,
     GPSpec,
     initial_params,
@@ -192,7 +193,9 @@ class HipGP:
     def data_term(self, params: GPParams):
         """Device data term (MLL or LOO) and its gradient in theta layout; (None, None) if the
         train covariance is not positive definite."""
-        theta = theta_from_params(self.spec, params)
+        return self._data_term_theta(theta_from_params(self.spec, params))
+
+    def _data_term_theta(self, theta: np.ndarray):
         val = C.c_double()
         grad = np.zeros_like(theta)
         rc = self._check(self._lib.bbh_fit_value_grad(self._h, _dp(theta), C.byref(val), _dp(grad)), "bbh_fit_value_grad")
@@ -211,7 +214,15 @@ class HipGP:
         spec = self.spec
         n = self.n
 
+        fast = FastObjective(spec, n) if FastObjective.applies(spec) else None
+
         def fun(raw):
+            if fast is not None:  # single-task, single-kernel models: the same maps as below in a few vectorised operations
+                theta, nat = fast.theta(raw)
+                val, g = self._data_term_theta(theta)
+                if val is None:
+                    return float("inf"), np.zeros_like(raw)
+                return fast.objective(raw, nat, val, g)
             p = unpack_raw(spec, raw)
             val, g = self.data_term(p)
             if val is None:

@@ -529,3 +529,82 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         i += T * T
         g.append(np.diag(S) * sigmoid(raw[i : i + T]))
     return -total / n, -np.concatenate(g) / n
+
+
+class FastObjective:
+    """The same raw <-> theta map and objective assembly as ``unpack_raw`` / ``theta_from_params`` /
+    ``objective_from_data_term`` for single-task, single-kernel models, as a handful of vectorised operations over
+    precomputed index / constraint / prior tables (the general functions cost ~36 us of Python per objective evaluation,
+    a tenth of an evaluation on the device at n = 512).  ``FastObjective.applies(spec)`` says whether a model qualifies;
+    ``tests/test_host_logic_cpu.py`` checks it against the general functions for every preset and kernel kind."""
+
+    @staticmethod
+    def applies(spec: GPSpec) -> bool:
+        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard
+
+    def __init__(self, spec: GPSpec, n: int):
+        self.n = int(n)
+        dn = spec.dn
+        lower, transformed, index, groups = [], [], [], []
+
+        def add(count, lo, tr, theta_pos, prior):
+            start = len(lower)
+            lower.extend([lo] * count)
+            transformed.extend([tr] * count)
+            index.extend(range(theta_pos, theta_pos + count))
+            if prior is not None:
+                groups.append((slice(start, start + count),) + self._prior_constants(prior))
+
+        soft_nz = spec.noise_constraint != "box"
+        add(1, spec.noise_lower if soft_nz else 0.0, soft_nz, 0, spec.noise_prior)
+        add(1, 0.0, False, 1, None)  # constant mean
+        if spec.use_outputscale:
+            add(1, 0.0, True, 2, spec.outputscale_prior)
+        soft_ls = spec.ls_constraint != "box"
+        add(dn, 0.0, soft_ls, 3, spec.ls_prior)
+        if spec.kernel == "rq":
+            add(1, 0.0, True, 3 + dn, None)
+        self.lower = np.array(lower, dtype=np.float64)
+        self.soft = np.array(transformed, dtype=bool)
+        self.any_soft = bool(self.soft.any())
+        self.index = np.array(index, dtype=np.int64)
+        self.groups = groups
+        self.base = np.zeros(3 + dn + (1 if spec.kernel == "rq" else 0))
+        self.base[2] = 1.0
+
+    @staticmethod
+    def _prior_constants(prior):
+        if prior[0] == "gamma":
+            _, c, r = prior
+            return ("gamma", c - 1.0, r, c * math.log(r) - float(gammaln(c)))
+        if prior[0] == "lognormal":
+            _, mu, sd = prior
+            return ("lognormal", mu, sd, -math.log(sd) - 0.5 * math.log(2 * math.pi))
+        raise ValueError(f"unknown prior kind {prior[0]!r}")
+
+    def theta(self, raw: np.ndarray):
+        """(theta for the device, natural values per raw slot)."""
+        nat = np.array(raw, dtype=np.float64)
+        if self.any_soft:
+            nat[self.soft] = self.lower[self.soft] + softplus(nat[self.soft])
+        theta = self.base.copy()
+        theta[self.index] = nat
+        return theta, nat
+
+    def objective(self, raw: np.ndarray, nat: np.ndarray, value: float, grad_theta: np.ndarray):
+        """-(data term + log priors) / n and its gradient w.r.t. the raw vector."""
+        g = grad_theta[self.index]
+        total = value
+        for sl, kind, a, b, const in self.groups:
+            x = nat[sl]
+            if kind == "gamma":  # a = c - 1, b = rate
+                total += float((const + a * np.log(x) - b * x).sum())
+                g[sl] += a / x - b
+            else:  # lognormal: a = mu, b = sd
+                lx = np.log(x)
+                z = (lx - a) / b
+                total += float((const - lx - 0.5 * z * z).sum())
+                g[sl] += (-1.0 - z / b) / x
+        if self.any_soft:
+            g[self.soft] *= sigmoid(np.asarray(raw)[self.soft])
+        return -total / self.n, -g / self.n

@@ -257,6 +257,37 @@ def test_composite_kernel_parameterisation_against_the_autograd_oracle():
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), ProductKernel([RBFKernel()] * 5))
 
 
+def test_fast_objective_equals_the_general_functions_for_every_single_kernel_model():
+    """``gp_spec.FastObjective`` (the vectorised raw <-> theta map and objective assembly the fit uses for single-task,
+    single-kernel models) against ``unpack_raw`` / ``theta_from_params`` / ``objective_from_data_term``: every preset, every
+    kernel kind incl. RQ (alpha slot) and piecewise-polynomial, scaled and unscaled, box and softplus constraints."""
+    from baybe_amd.kernels import (GammaPrior, LogNormalPrior, MaternKernel, PiecewisePolynomialKernel, RBFKernel, RQKernel,
+                                   ScaleKernel, apply_kernel_spec)
+
+    d, n = 6, 37
+    rng = np.random.default_rng(11)
+    specs = [gp_spec.from_preset(pr, d, np.zeros(d), np.ones(d)) for pr in gp_spec.PRESETS]
+    for kern in (MaternKernel(1.5, GammaPrior(3, 1)), ScaleKernel(RBFKernel(LogNormalPrior(0.2, 0.7), 0.4), GammaPrior(2, 0.2), 3.0),
+                 RQKernel(GammaPrior(2, 2)), ScaleKernel(RQKernel()), ScaleKernel(PiecewisePolynomialKernel(2, GammaPrior(3, 1), 2.0))):
+        specs.append(apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern))
+    for spec in specs:
+        assert gp_spec.FastObjective.applies(spec)
+        fast = gp_spec.FastObjective(spec, n)
+        raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec)) + 0.3 * rng.standard_normal(len(gp_spec.raw_bounds(spec)))
+        for i, (lo, _) in enumerate(gp_spec.raw_bounds(spec)):
+            if lo is not None:
+                raw[i] = lo + abs(raw[i] - lo) + 1e-3
+        theta, nat = fast.theta(raw)
+        ref_theta = gp_spec.theta_from_params(spec, gp_spec.unpack_raw(spec, raw))
+        assert theta.shape == ref_theta.shape and np.array_equal(theta, ref_theta)
+        val, grad_theta = float(rng.standard_normal()), rng.standard_normal(len(theta))
+        f0, g0 = gp_spec.objective_from_data_term(spec, raw, n, val, grad_theta.copy())
+        f1, g1 = fast.objective(raw, nat, val, grad_theta.copy())
+        assert math.isclose(f0, f1, rel_tol=1e-14, abs_tol=1e-15) and np.allclose(g0, g1, rtol=1e-14, atol=1e-16)
+    tl = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=2)
+    assert not gp_spec.FastObjective.applies(tl)
+
+
 # ---- backtesting driver: lookup semantics (simulation/lookup.py:19-150), no device needed ---------------
 def test_lookup_dataframe_callable_and_impute_modes():
     import pandas as pd
