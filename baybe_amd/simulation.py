@@ -164,3 +164,32 @@ def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe
             head = pd.DataFrame({"Scenario": name, "Random_Seed": case["Random_Seed"], "Initial_Data": idx}, index=res.index)
             frames.append(pd.concat([head, res], axis=1))
     return pd.concat(frames, ignore_index=True)
+
+
+def simulate_transfer_learning(campaign, lookup: pd.DataFrame, /, *, batch_size: int = 1, n_doe_iterations: int | None = None,
+                               n_mc_iterations: int = 1, random_seed: int | None = None) -> pd.DataFrame:
+    """``baybe.simulation.transfer_learning.simulate_transfer_learning`` (simulation/transfer_learning.py:16-99): the
+    search space is partitioned into its tasks, and every task is simulated as its own scenario with the lookup rows of
+    all OTHER tasks as training data (``lookup`` is both the loop-closing element and the source of off-task data, hence
+    dataframe lookups and discrete spaces only).  Result: the frame of ``simulate_scenarios`` with the tasks in the
+    ``Scenario`` column."""
+    if not isinstance(lookup, pd.DataFrame):
+        raise TypeError("simulate_transfer_learning needs a dataframe lookup (it also supplies the off-task training data).")
+    space_type = getattr(getattr(campaign.searchspace, "type", None), "name", "DISCRETE")
+    if str(space_type).upper() != "DISCRETE":
+        raise NotImplementedError("Currently, only purely discrete search spaces are supported.")
+    parameters = getattr(campaign, "parameters", None) or campaign.searchspace.parameters
+    task_params = [p for p in parameters if type(p).__name__ == "TaskParameter"]
+    if len(task_params) != 1:
+        raise NotImplementedError("Currently, transfer learning supports exactly one task parameter.")
+    task_param = task_params[0]
+    scenarios = {}
+    for task in task_param.values:
+        # a campaign that recommends for this task only ...
+        campaign_task = deepcopy(campaign)
+        campaign_task.toggle_discrete_candidates(pd.DataFrame({task_param.name: [task]}), exclude=True, complement=True)
+        # ... and knows every measurement of the other tasks
+        campaign_task.add_measurements(lookup[lookup[task_param.name] != task])
+        scenarios[task] = campaign_task
+    return simulate_scenarios(scenarios, lookup, batch_size=batch_size, n_doe_iterations=n_doe_iterations,
+                              n_mc_iterations=n_mc_iterations, random_seed=random_seed, impute_mode="ignore")

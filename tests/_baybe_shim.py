@@ -166,10 +166,16 @@ class Campaign:
                                   index=searchspace.discrete.exp_rep.index)
 
     def _match(self, df):
+        """Index labels of the search-space rows matching the rows of ``df`` on the parameter columns it has (all of them
+        for measurements; a subset - e.g. only the task column - for candidate toggles, campaign.py:404-470)."""
         exp = self.searchspace.discrete.exp_rep
-        cols = list(exp.columns)
-        merged = df[cols].merge(exp.reset_index(), on=cols, how="left")
+        cols = [c for c in exp.columns if c in df.columns]
+        merged = df[cols].drop_duplicates().merge(exp.reset_index(), on=cols, how="left")
         return merged["index"].dropna().astype(int).to_numpy()
+
+    @property
+    def parameters(self):
+        return self.searchspace.parameters
 
     def add_measurements(self, df):
         self.measurements = pd.concat([self.measurements, df], ignore_index=True)

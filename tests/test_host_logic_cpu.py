@@ -333,3 +333,46 @@ def test_scenario_rollout_cases_and_content_hash():
     h = _content_hash(a)
     a[4321, 5] += 1e-12  # any row, any column
     assert _content_hash(a) != h and _content_hash(a) == _content_hash(a.copy())
+
+
+def test_simulate_transfer_learning_partitions_by_task_and_trains_on_the_other_tasks():
+    """``simulate_transfer_learning`` (simulation/transfer_learning.py:16-99) with a recommender stub (no device): one
+    scenario per task, candidates of that task only, every lookup row of the other tasks as training data, the rollout
+    structure of ``simulate_scenarios``."""
+    import pandas as pd
+
+    from _baybe_shim import Campaign, NumericalDiscreteParameter, NumericalTarget, SearchSpace, SingleTargetObjective, TaskParameter
+    from baybe_amd.simulation import simulate_transfer_learning
+
+    vals = np.arange(4) / 3.0
+    params = [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals), TaskParameter("task", ["A", "B", "C"])]
+    space = SearchSpace.from_product(params)
+    exp = space.discrete.exp_rep
+    lookup = exp.copy()
+    lookup["yield"] = -(lookup["x0"] - 0.3) ** 2 - (lookup["x1"] - 0.6) ** 2 + lookup["task"].map({"A": 0.0, "B": 0.5, "C": -0.5})
+    seen = []
+
+    class FirstRows:  # recommends the first candidates, records what it was given
+        def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None):
+            cand = searchspace.discrete.get_candidates()[0] if hasattr(searchspace.discrete, "get_candidates") else searchspace.discrete.exp_rep
+            seen.append((set(cand["task"]), set(measurements["task"]), len(measurements)))
+            return cand.iloc[:batch_size]
+
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), FirstRows())
+    res = simulate_transfer_learning(camp, lookup, batch_size=2, n_doe_iterations=3, n_mc_iterations=2)
+    assert list(res.columns[:3]) == ["Scenario", "Random_Seed", "Initial_Data"]
+    assert sorted(res["Scenario"].unique()) == ["A", "B", "C"] and len(res) == 3 * 2 * 3
+    assert set(res["Random_Seed"]) == {1337, 1338}
+    per_task = len(exp) // 3
+    for cand_tasks, train_tasks, n_train in seen:
+        assert len(cand_tasks) == 1  # only the scenario's task is recommended from
+        (t,) = cand_tasks
+        # the other tasks' rows are all there from the start; the own task only through the loop's measurements
+        assert train_tasks - {t} == {"A", "B", "C"} - {t} and n_train >= 2 * per_task
+    first = [s for s in seen if s[2] == 2 * per_task]
+    assert len(first) == 3 * 2  # the first call of every case sees exactly the off-task data
+    with pytest.raises(TypeError):
+        simulate_transfer_learning(camp, lambda df: df)
+    no_task = Campaign(SearchSpace.from_product(params[:2]), SingleTargetObjective(NumericalTarget("yield")), FirstRows())
+    with pytest.raises(NotImplementedError):
+        simulate_transfer_learning(no_task, lookup.drop(columns=["task"]))

@@ -557,3 +557,22 @@ def test_simulate_scenarios_runs_every_case_and_matches_single_runs():
     assert paired[["Random_Seed", "Initial_Data"]].drop_duplicates().to_numpy().tolist() == [[1337, 0], [1338, 1]]
     with pytest.raises(ValueError):
         simulate_scenarios({"a": scenarios["qLogEI"]}, truth, n_mc_iterations=None)
+
+
+def test_simulate_transfer_learning_with_the_hip_recommender():
+    """``simulate_transfer_learning`` (simulation/transfer_learning.py:16-99) end to end: one scenario per task, the ICM
+    model trained on the other tasks' lookup rows plus the loop's own measurements."""
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from baybe_amd.simulation import simulate_transfer_learning
+
+    vals = np.arange(5) / 4.0
+    params = [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals), TaskParameter("task", ["A", "B"])]
+    space = SearchSpace.from_product(params)
+    lookup = space.discrete.exp_rep.copy()
+    lookup["yield"] = -(lookup["x0"] - 0.25) ** 2 - (lookup["x1"] - 0.75) ** 2 + lookup["task"].map({"A": 0.0, "B": 0.4})
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), HipBotorchRecommender())
+    res = simulate_transfer_learning(camp, lookup, batch_size=2, n_doe_iterations=3)
+    assert sorted(res["Scenario"].unique()) == ["A", "B"] and len(res) == 2 * 3
+    best = {t: lookup.loc[lookup["task"] == t, "yield"].max() for t in ("A", "B")}
+    for t in ("A", "B"):  # the other task's data points at the optimum: it is found within three batches of two
+        assert res.loc[res["Scenario"] == t, "yield_CumBest"].iloc[-1] > best[t] - 0.07
