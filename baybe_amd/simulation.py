@@ -139,9 +139,34 @@ def _rollout_cases(n_mc_iterations, n_initial_data, random_seed) -> list[dict]:
     return [{"Random_Seed": first + s, "Initial_Data": i} for s in range(int(n_mc_iterations)) for i in data]
 
 
+def _simulate_partitions(campaign, lookup, groupby, **kwargs) -> pd.DataFrame:
+    """``_simulate_groupby`` (simulation/scenarios.py:235-334): with ``groupby`` parameter names the discrete search space
+    is split into the groups of equal values of those parameters and the loop is run once per group, recommending from that
+    group only; the group's values lead the result rows.  Groups in which nothing can be simulated are skipped."""
+    if not groupby:
+        return simulate_experiment(campaign, lookup, **kwargs)
+    groupby = list(groupby)
+    exp = campaign.searchspace.discrete.exp_rep
+    param_cols = [c for c in exp.columns]
+    frames = []
+    for key, part in exp.groupby(groupby, sort=True):
+        focused = deepcopy(campaign)
+        focused.toggle_discrete_candidates(part[param_cols], exclude=True, complement=True)
+        try:
+            res = simulate_experiment(focused, lookup, **kwargs)
+        except NothingToSimulateError:
+            continue
+        key = key if isinstance(key, tuple) else (key,)
+        head = pd.DataFrame([key] * len(res), columns=groupby, index=res.index)
+        frames.append(pd.concat([head, res], axis=1))
+    if not frames:
+        raise NothingToSimulateError()
+    return pd.concat(frames, ignore_index=True)
+
+
 def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe_iterations: int | None = None,
-                       initial_data: list | None = None, n_mc_iterations: int | None = 1, random_seed: int | None = None,
-                       impute_mode: str = "error") -> pd.DataFrame:
+                       initial_data: list | None = None, groupby: list | None = None, n_mc_iterations: int | None = 1,
+                       random_seed: int | None = None, impute_mode: str = "error") -> pd.DataFrame:
     """``baybe.simulation.scenarios.simulate_scenarios`` (simulation/scenarios.py:94-232) for discrete GP campaigns:
     every scenario (a campaign) is run once per rollout case (random seed x initial data set) through
     ``simulate_experiment``; the result frames are concatenated with the leading columns ``Scenario``, ``Random_Seed``
@@ -150,7 +175,8 @@ def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe
     The reference fans the cases out to worker processes (xyzpy) when ``parallelize_simulation_runs`` is set; here they
     run one after the other on the device, where a case is a few milliseconds per iteration, and the recommender
     objects of the scenarios keep their device handles (each case works on a deep copy of the campaign's host state
-    only).  ``groupby`` partitions and ``noise_percent`` of the reference are not part of this driver."""
+    only).  ``groupby`` partitions the search space as in the reference (one loop per group, the group's values in leading
+    columns after ``Initial_Data``); ``noise_percent`` (parameter noise) is not part of this driver."""
     if not scenarios:
         raise ValueError("no scenarios given")
     cases = _rollout_cases(n_mc_iterations, len(initial_data) if initial_data is not None else None, random_seed)
@@ -159,15 +185,16 @@ def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe
         for case in cases:
             idx = case["Initial_Data"]
             data = None if initial_data is None else initial_data[int(idx)]
-            res = simulate_experiment(campaign, lookup, batch_size=batch_size, n_doe_iterations=n_doe_iterations,
-                                      initial_data=data, random_seed=case["Random_Seed"], impute_mode=impute_mode)
+            res = _simulate_partitions(campaign, lookup, groupby, batch_size=batch_size, n_doe_iterations=n_doe_iterations,
+                                       initial_data=data, random_seed=case["Random_Seed"], impute_mode=impute_mode)
             head = pd.DataFrame({"Scenario": name, "Random_Seed": case["Random_Seed"], "Initial_Data": idx}, index=res.index)
             frames.append(pd.concat([head, res], axis=1))
     return pd.concat(frames, ignore_index=True)
 
 
 def simulate_transfer_learning(campaign, lookup: pd.DataFrame, /, *, batch_size: int = 1, n_doe_iterations: int | None = None,
-                               n_mc_iterations: int = 1, random_seed: int | None = None) -> pd.DataFrame:
+                               groupby: list | None = None, n_mc_iterations: int = 1,
+                               random_seed: int | None = None) -> pd.DataFrame:
     """``baybe.simulation.transfer_learning.simulate_transfer_learning`` (simulation/transfer_learning.py:16-99): the
     search space is partitioned into its tasks, and every task is simulated as its own scenario with the lookup rows of
     all OTHER tasks as training data (``lookup`` is both the loop-closing element and the source of off-task data, hence
@@ -191,5 +218,5 @@ def simulate_transfer_learning(campaign, lookup: pd.DataFrame, /, *, batch_size:
         # ... and knows every measurement of the other tasks
         campaign_task.add_measurements(lookup[lookup[task_param.name] != task])
         scenarios[task] = campaign_task
-    return simulate_scenarios(scenarios, lookup, batch_size=batch_size, n_doe_iterations=n_doe_iterations,
+    return simulate_scenarios(scenarios, lookup, batch_size=batch_size, n_doe_iterations=n_doe_iterations, groupby=groupby,
                               n_mc_iterations=n_mc_iterations, random_seed=random_seed, impute_mode="ignore")

@@ -376,3 +376,37 @@ def test_simulate_transfer_learning_partitions_by_task_and_trains_on_the_other_t
     no_task = Campaign(SearchSpace.from_product(params[:2]), SingleTargetObjective(NumericalTarget("yield")), FirstRows())
     with pytest.raises(NotImplementedError):
         simulate_transfer_learning(no_task, lookup.drop(columns=["task"]))
+
+
+def test_simulate_scenarios_groupby_partitions_the_search_space():
+    """``groupby`` (simulation/scenarios.py:235-334): one loop per group of equal values of the named parameters, the search
+    restricted to that group, the group's values in leading columns."""
+    import pandas as pd
+
+    from _baybe_shim import Campaign, NumericalDiscreteParameter, NumericalTarget, SearchSpace, SingleTargetObjective
+    from baybe_amd.simulation import simulate_scenarios
+
+    vals = np.arange(4) / 3.0
+    params = [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals), NumericalDiscreteParameter("g", [0.0, 1.0])]
+    space = SearchSpace.from_product(params)
+    lookup = space.discrete.exp_rep.copy()
+    lookup["yield"] = lookup["x0"] + lookup["x1"] + 10 * lookup["g"]
+    seen = []
+
+    class FirstRows:
+        def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None):
+            cand = searchspace.discrete.get_candidates()[0] if hasattr(searchspace.discrete, "get_candidates") else searchspace.discrete.exp_rep
+            seen.append(set(cand["g"]))
+            return cand.iloc[:batch_size]
+
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), FirstRows())
+    res = simulate_scenarios({"s": camp}, lookup, batch_size=2, n_doe_iterations=2, groupby=["g"])
+    assert list(res.columns[:4]) == ["Scenario", "Random_Seed", "Initial_Data", "g"]
+    assert sorted(res["g"].unique()) == [0.0, 1.0] and len(res) == 2 * 2
+    assert all(len(gs) == 1 for gs in seen) and {next(iter(gs)) for gs in seen} == {0.0, 1.0}
+    # measurements of a group come from that group only
+    for gval, block in res.groupby("g"):
+        flat = [v for row in block["yield_Measurements"] for v in row]
+        assert all((v >= 10) == (gval == 1.0) for v in flat)
+    plain = simulate_scenarios({"s": camp}, lookup, batch_size=2, n_doe_iterations=2)
+    assert "g" not in plain.columns[:4] and len(plain) == 2
