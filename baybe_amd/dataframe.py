@@ -139,3 +139,23 @@ def fuzzy_row_match(left_df: pd.DataFrame, right_df: pd.DataFrame, parameters: S
     ``left_df`` matched by the rows of ``right_df``.  Builds the row index on every call; keep a ``FuzzyRowMatcher`` per
     search space to pay for it once."""
     return FuzzyRowMatcher(left_df, parameters).match(right_df)
+
+
+def add_parameter_noise(data: pd.DataFrame, parameters: Sequence, noise_type: str = "absolute", noise_level: float = 1.0) -> pd.DataFrame:
+    """``baybe.utils.dataframe.add_parameter_noise`` (utils/dataframe.py:124-175): uniform noise on the values of the numerical
+    parameters of a recommendation frame - additive in [-level, level] ("absolute") or multiplicative in [1 - level/100, 1 +
+    level/100] ("relative_percent") - drawn from numpy's global generator, one draw per parameter and row; continuous
+    parameters are clipped to their bounds.  Changes ``data`` in place and returns it."""
+    if noise_type not in ("relative_percent", "absolute"):
+        raise ValueError(f"Parameter 'noise_type' was {noise_type} but must be either 'absolute' or 'relative_percent'.")
+    for prm in parameters:
+        if not prm.is_numerical:
+            continue
+        n = len(data)
+        if noise_type == "absolute":
+            data[prm.name] = data[prm.name] + np.random.uniform(-noise_level, noise_level, n)
+        else:
+            data[prm.name] = data[prm.name] * np.random.uniform(1.0 - noise_level / 100.0, 1.0 + noise_level / 100.0, n)
+        if getattr(prm, "is_continuous", False):
+            data[prm.name] = data[prm.name].clip(prm.bounds.lower, prm.bounds.upper)
+    return data

@@ -71,7 +71,7 @@ def _cumargmax(arr: np.ndarray) -> np.ndarray:
 
 def simulate_experiment(campaign, lookup, /, *, batch_size: int = 1, n_doe_iterations: int | None = None,
                         initial_data: pd.DataFrame | None = None, random_seed: int | None = None,
-                        impute_mode: str = "error") -> pd.DataFrame:
+                        impute_mode: str = "error", noise_percent: float | None = None) -> pd.DataFrame:
     """One closed optimisation loop; returns the reference's result frame (``simulation/core.py:64-82``)."""
     if getattr(campaign, "objective", None) is None:
         raise ValueError("The given campaign has no objective defined, hence there are no targets to be tracked.")
@@ -104,6 +104,11 @@ def simulate_experiment(campaign, lookup, /, *, batch_size: int = 1, n_doe_itera
         look_up_targets(measured, targets, lookup, impute_mode)
         rows.append({"Iteration": k, "Num_Experiments": n_exp,
                      **{f"{t.name}_Measurements": measured[t.name].to_list() for t in targets}})
+        if noise_percent:  # imperfect execution of the recommendation: relative noise on the numerical parameter values
+            from baybe_amd.dataframe import add_parameter_noise
+
+            parameters = getattr(campaign, "parameters", None) or campaign.searchspace.parameters
+            add_parameter_noise(measured, parameters, noise_type="relative_percent", noise_level=noise_percent)
         campaign.add_measurements(measured)
         k += 1
     if not rows:
@@ -166,7 +171,8 @@ def _simulate_partitions(campaign, lookup, groupby, **kwargs) -> pd.DataFrame:
 
 def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe_iterations: int | None = None,
                        initial_data: list | None = None, groupby: list | None = None, n_mc_iterations: int | None = 1,
-                       random_seed: int | None = None, impute_mode: str = "error") -> pd.DataFrame:
+                       random_seed: int | None = None, impute_mode: str = "error",
+                       noise_percent: float | None = None) -> pd.DataFrame:
     """``baybe.simulation.scenarios.simulate_scenarios`` (simulation/scenarios.py:94-232) for discrete GP campaigns:
     every scenario (a campaign) is run once per rollout case (random seed x initial data set) through
     ``simulate_experiment``; the result frames are concatenated with the leading columns ``Scenario``, ``Random_Seed``
@@ -176,7 +182,8 @@ def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe
     run one after the other on the device, where a case is a few milliseconds per iteration, and the recommender
     objects of the scenarios keep their device handles (each case works on a deep copy of the campaign's host state
     only).  ``groupby`` partitions the search space as in the reference (one loop per group, the group's values in leading
-    columns after ``Initial_Data``); ``noise_percent`` (parameter noise) is not part of this driver."""
+    columns after ``Initial_Data``), ``noise_percent`` perturbs the numerical parameter values of every measured batch before it
+    is added (``add_parameter_noise``)."""
     if not scenarios:
         raise ValueError("no scenarios given")
     cases = _rollout_cases(n_mc_iterations, len(initial_data) if initial_data is not None else None, random_seed)
@@ -186,7 +193,8 @@ def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe
             idx = case["Initial_Data"]
             data = None if initial_data is None else initial_data[int(idx)]
             res = _simulate_partitions(campaign, lookup, groupby, batch_size=batch_size, n_doe_iterations=n_doe_iterations,
-                                       initial_data=data, random_seed=case["Random_Seed"], impute_mode=impute_mode)
+                                       initial_data=data, random_seed=case["Random_Seed"], impute_mode=impute_mode,
+                                       noise_percent=noise_percent)
             head = pd.DataFrame({"Scenario": name, "Random_Seed": case["Random_Seed"], "Initial_Data": idx}, index=res.index)
             frames.append(pd.concat([head, res], axis=1))
     return pd.concat(frames, ignore_index=True)

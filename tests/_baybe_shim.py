@@ -20,6 +20,8 @@ import pandas as pd
 
 
 class NumericalDiscreteParameter:
+    is_numerical, is_discrete, is_continuous = True, True, False  # baybe/parameters/base.py flags
+
     def __init__(self, name, values):
         self.name, self.values = name, tuple(float(v) for v in values)
 
@@ -30,6 +32,8 @@ class NumericalDiscreteParameter:
 
 class TaskParameter:
     """INT-encoded task column (baybe/parameters/categorical.py:86-91)."""
+
+    is_numerical, is_discrete, is_continuous = False, True, False
 
     def __init__(self, name, values, active_values=None):
         self.name, self.values = name, tuple(values)
@@ -178,8 +182,15 @@ class Campaign:
         return self.searchspace.parameters
 
     def add_measurements(self, df):
+        """campaign.py:330-372: append, and mark the search-space rows the measurements belong to - exact rows where there
+        are any, otherwise the nearest rows (``fuzzy_row_match``: numerical values may deviate from the grid)."""
         self.measurements = pd.concat([self.measurements, df], ignore_index=True)
-        self._meta.loc[self._match(df), "measured"] = True
+        hits = self._match(df)
+        if len(hits) < len(df):
+            from baybe_amd.dataframe import fuzzy_row_match
+
+            hits = fuzzy_row_match(self.searchspace.discrete.exp_rep, df, self.searchspace.parameters)
+        self._meta.loc[hits, "measured"] = True
 
     def toggle_discrete_candidates(self, constraints, exclude, complement=False):
         """``Campaign.toggle_discrete_candidates`` (campaign.py:404-470) for a dataframe of rows."""

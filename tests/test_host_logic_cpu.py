@@ -410,3 +410,49 @@ def test_simulate_scenarios_groupby_partitions_the_search_space():
         assert all((v >= 10) == (gval == 1.0) for v in flat)
     plain = simulate_scenarios({"s": camp}, lookup, batch_size=2, n_doe_iterations=2)
     assert "g" not in plain.columns[:4] and len(plain) == 2
+
+
+def test_noise_percent_perturbs_the_measured_parameters_and_rows_are_still_matched():
+    """``noise_percent`` (simulation/core.py:187-195 -> ``add_parameter_noise``): every measured batch enters the campaign
+    with its numerical parameter values off the grid by at most that percentage; the campaign marks the nearest grid rows as
+    measured (fuzzy matching), so nothing is recommended twice; the run is reproducible under ``random_seed``."""
+    import pandas as pd
+
+    from _baybe_shim import Campaign, NumericalDiscreteParameter, NumericalTarget, SearchSpace, SingleTargetObjective
+    from baybe_amd.dataframe import add_parameter_noise
+    from baybe_amd.simulation import simulate_experiment
+
+    vals = 1.0 + np.arange(5) / 4.0
+    params = [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals)]
+    space = SearchSpace.from_product(params)
+    lookup = space.discrete.exp_rep.copy()
+    lookup["yield"] = lookup["x0"] * lookup["x1"]
+    batches = []
+
+    class FirstRows:
+        def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None):
+            cand = searchspace.discrete.get_candidates()[0] if hasattr(searchspace.discrete, "get_candidates") else searchspace.discrete.exp_rep
+            batches.append((cand.index[:batch_size].tolist(), None if measurements is None else measurements.copy()))
+            return cand.iloc[:batch_size]
+
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), FirstRows())
+    res = simulate_experiment(camp, lookup, batch_size=3, n_doe_iterations=4, random_seed=7, noise_percent=3.0)
+    picked = [i for idx, _ in batches for i in idx]
+    assert len(picked) == len(set(picked)) == 12  # fuzzy matching kept the bookkeeping intact
+    last = batches[-1][1]
+    grid = set(np.round(vals, 12))
+    off = [v for v in last["x0"].tolist() + last["x1"].tolist() if round(v, 12) not in grid]
+    assert len(off) >= 0.9 * 2 * len(last)  # the values really left the grid ...
+    exp = space.discrete.exp_rep
+    for (_, row), true_idx in zip(last.iterrows(), [i for idx, _ in batches[:-1] for i in idx]):
+        for c in ("x0", "x1"):  # ... by at most 3 %
+            assert abs(row[c] / exp.loc[true_idx, c] - 1.0) <= 0.03 + 1e-12
+        assert row["yield"] == lookup.loc[true_idx, "yield"]  # targets were looked up before the noise was applied
+    again = simulate_experiment(camp, lookup, batch_size=3, n_doe_iterations=4, random_seed=7, noise_percent=3.0)
+    assert again.equals(res)
+    df = pd.DataFrame({"x0": [1.0, 2.0], "x1": [1.0, 1.0]})
+    np.random.seed(0)
+    add_parameter_noise(df, params, noise_type="absolute", noise_level=0.1)
+    assert (abs(df["x0"] - [1.0, 2.0]) <= 0.1).all() and (df["x0"] != [1.0, 2.0]).all()
+    with pytest.raises(ValueError):
+        add_parameter_noise(df, params, noise_type="nope")
