@@ -597,7 +597,7 @@ int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_
                            double* cross_dev) {
   if (N <= 0) return 0;
   const int64_t np = h->np, ldk = np + 16;
-  const int64_t chunk = 16384;
+  const int64_t chunk = N < 16384 ? bbh_round_up(N, 64) : 16384;  // (small candidate sets: a small workspace)
   const size_t need = sizeof(double) * ((size_t)chunk * ldk + (size_t)chunk * np + 2 * h->dn);
   int rc = bbh_ensure_ws(h, need);
   if (rc) return rc;
