@@ -40,8 +40,10 @@ def _content_hash(arr: np.ndarray):
     single-dtype DataFrame hands out its block that way - so nothing is copied), large buffers in 8 slices on a thread
     pool (xxhash releases the GIL)."""
     arr = np.asarray(arr)
+    if arr.size == 0:
+        return hash((arr.shape, str(arr.dtype)))
     if arr.dtype == object:
-        return hash(tuple(arr.tolist()))
+        return hash((arr.shape, tuple(arr.ravel().tolist())))
     if not arr.flags.c_contiguous:
         arr = arr.T if arr.T.flags.c_contiguous else np.ascontiguousarray(arr)
     try:
@@ -61,7 +63,9 @@ def _content_hash(arr: np.ndarray):
 
 def _frame_content_hash(df: pd.DataFrame):
     """Content hash of a DataFrame's values without materialising them as one array: every column's buffer on a thread
-    pool (xxhash releases the GIL); columns that are not plain numeric arrays go through ``_content_hash``."""
+    pool (xxhash releases the GIL); columns that are not plain numeric arrays go through ``_content_hash``.  Equal keys
+    imply equal content; the same content in another memory layout (a row-major block against a column-major copy) may key
+    differently, which costs one re-upload and nothing else."""
     try:
         import xxhash
     except ImportError:  # pragma: no cover

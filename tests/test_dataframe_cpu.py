@@ -74,3 +74,30 @@ def test_product_space_measurements_find_their_rows_and_the_index_is_reusable():
     empty_nan = noisy.iloc[:2].copy()
     empty_nan.iloc[0, 1] = np.nan  # NaN never equals the minimum difference: no match, row dropped
     assert matcher.match(empty_nan).tolist() == [rows[1]]
+
+
+def test_frame_content_hash_sees_every_edit_without_materialising_the_frame():
+    """``recommenders._frame_content_hash`` keys the resident candidate matrix: any changed value, in a single-block frame
+    (built from one 2-D array) or a block-per-column frame, changes the key; equal content gives equal keys whatever the
+    block layout of the copy."""
+    from baybe_amd.recommenders import _frame_content_hash
+
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 11, size=(5000, 7)) / 10.0
+    single = pd.DataFrame(arr.copy(), columns=[f"x{i}" for i in range(7)])
+    per_col = pd.DataFrame({c: single[c].to_numpy().copy() for c in single.columns})
+    for frame in (single, per_col):
+        key = _frame_content_hash(frame)
+        assert key == _frame_content_hash(frame)  # (equal keys imply equal content; a copy in another memory layout may
+        #                                           key differently, which only costs one spurious re-upload)
+        for r, c in ((0, 0), (4999, 6), (1234, 3)):
+            edited = frame.copy()
+            edited.iloc[r, c] += 1e-12
+            assert _frame_content_hash(edited) != key
+    big = pd.DataFrame({f"x{i}": rng.random(150_000) for i in range(16)})  # above the thread-pool threshold
+    key = _frame_content_hash(big)
+    big.iloc[77_777, 9] = -1.0
+    assert _frame_content_hash(big) != key
+    mixed = pd.DataFrame({"a": [1.0, 2.0], "b": ["u", "v"]})
+    assert _frame_content_hash(mixed) == _frame_content_hash(mixed.copy()) != _frame_content_hash(mixed.assign(b=["u", "w"]))
+    assert isinstance(_frame_content_hash(pd.DataFrame(index=range(3))), int)
