@@ -36,9 +36,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');
   if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
   if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
-  if (const char* e = getenv("BBH_W32")) h->use_w32 = (e[0] != '0');
   if (const char* e = getenv("BBH_COOP")) h->coop_mode = atoi(e);
-  if (const char* e = getenv("BBH_COOP_NT")) h->coop_nt = atoi(e);
   if (const char* e = getenv("BBH_POTRF_REG")) h->potrf_register_form = (e[0] != '0');
   if (const char* e = getenv("BBH_FIT_OVERLAP")) h->fit_overlap = (e[0] != '0');
   *out = h;

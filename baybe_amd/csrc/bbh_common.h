@@ -179,12 +179,13 @@ struct bbh_handle {
   int kv_global_mode = -1;        // env BBH_KV_GLOBAL: 0 never use global slabs, 1 always, unset: by size
   int kv_lds_blocks = -1;         // env BBH_KV_LDS: cap on LDS-cached k-blocks per wave (-1 = as many as fit)
   int num_cu = 256;               // compute units of the device (sizes the slab pool of the kernel-value cache)
-  int wmax = 16;                  // column blocks per pass of the fused kernel: 16 (two waves per SIMD) or 32 (one)
+  int wmax = 16;                  // column blocks per pass of the windowed fused kernel (two waves per SIMD)
   bool fit_overlap = true;        // env BBH_FIT_OVERLAP=0: the inverse of the factor strictly after the factorisation (A/B)
   hipStream_t side_stream = nullptr;  // second stream of the fit (rows of L^-1 next to the trailing updates)
   hipStream_t fit_stream = nullptr;   // stream the captured evaluation graph is replayed on
   bool potrf_tiles = true, tiles_ready = false;  // env BBH_POTRF_TILES=0: per-step launches instead of the one-launch tile-dataflow factorisation (np <= 1024)
-  int tile_spin_limit = 1 << 20, tile_spin_limit_set = -1;  // env BBH_TILE_SPIN: polls (~1 us each) before a waiting tile gives up
+  int tile_spin_limit = 1 << 17, tile_spin_limit_set = -1;  // env BBH_TILE_SPIN: polls (~1 us each) before a waiting tile gives up (a whole factorisation takes ~200 us)
+  int tiles_per_device = 0;           // workgroups of the tile kernel the device holds at once (occupancy x CUs)
   int* d_tileflags = nullptr;         // [2][16][16] publish flags of the L- and X-tiles (epoch-stamped)
   int tile_epoch = 0;
   hipGraphExec_t fit_exec = nullptr;  // one evaluation of the fit objective, captured per model (bbh_fit_value_grad)
@@ -193,14 +194,13 @@ struct bbh_handle {
   int* pin_info = nullptr;
   hipEvent_t side_events[2] = {nullptr, nullptr};
   bool potrf_register_form = false;  // env BBH_POTRF_REG=1: 64x64 diagonal blocks by the one-wave register kernel (A/B)
-  int coop_nt = 0;                // env BBH_COOP_NT: candidate tiles per workgroup of the cooperative form (2: two tiles where instantiated; default one)
   int coop_mode = 1;              // env BBH_COOP: 0 never use the cooperative form, 1 where it pays (default), 2 wherever instantiated
   bool coop_ready = false;        // operand slices of the cooperative form are packed for the current factorisation
+  bool coop2_ready = false;       // ... of the two-sweep cooperative form (512 < n <= 1024; shares d_rstream / coop_g0)
   double* d_rstream = nullptr;    // [4 waves][rstream_frags][64]
   int64_t rstream_frags = 0;
   int coop_g0 = 0;
   int last_form = -1;             // bbh_last_posterior_form
-  bool use_w32 = false;           // env BBH_W32=1: one-wave-per-SIMD form where instantiated (A/B; measured slower so far)
   int64_t nb_ext = 0;             // blocks incl. pending points (mean/cross pass)
   // pending state
   int p = 0;
@@ -272,6 +272,7 @@ void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int
               int64_t strideB, double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 // In-place blocked Cholesky of the np x np matrix K (lower), with X = L^-1; info!=0 on failure.
 void bbh_potrf_trtri(bbh_handle* h);
+void bbh_potrf_tiles_mark_unusable(int device);  // a tile-dataflow launch gave up: per-step launches from now on, process-wide
 void bbh_ensure_side_stream(bbh_handle* h);  // creates the fit's second stream and its events (not during a capture)
 void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,
                 const double* x, double* y);   // y = A x   (row-major A)

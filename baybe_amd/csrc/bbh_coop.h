@@ -95,7 +95,9 @@ __host__ __device__ constexpr int coop_frags_before(int G) { return 16 * (G * BB
 // NT = candidate tiles (of 16) per workgroup.  NT = 2: every operand fragment that comes back from memory feeds two
 // MFMAs (one per tile), which halves the vector-memory traffic per MFMA, at the price of a second set of accumulators
 // (2 x 64 registers: 256 VGPRs in all, no spills).  Measured: not faster than NT = 1 (4.72 vs 4.68 ms) - see bbh_panel.hip.
-template <int G, int KD, int KVF, bool PRODUCE, int NT>
+// OPEN: the operand slice continues behind this group with at least BBH_COOP_PAIRS more fragment pairs whatever the model
+// size (the two-sweep form, bbh_coop2.h): the ring is always refilled and the waits never shorten.
+template <int G, int KD, int KVF, bool PRODUCE, int NT, bool OPEN = false>
 __device__ __forceinline__ void coop_group(const WaveCtx (&c)[NT], const double* rs, const double* tfn, const bbh_lds_double* kv_cur,
                                            bbh_lds_double* kv_mine_next, const bbh_lds_double* alpha_next, int tbn, int cw,
                                            d4 (&acc)[NT][BBH_COOP_ROUNDS], d2 (&ring)[BBH_COOP_PAIRS], double (&accm)[NT]) {
@@ -106,7 +108,7 @@ __device__ __forceinline__ void coop_group(const WaveCtx (&c)[NT], const double*
   constexpr int CNT = BBH_COOP_ROUNDS - G;  // ring fragments per (k-block, k-step): slots G .. 7
   constexpr int FULL = CNT - 1;             // of which always multiplied
   constexpr int TOT = 16 * CNT;             // fragments of this group (even: pairs never straddle groups)
-  constexpr int REM = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(G + 1);  // fragments after this group
+  constexpr int REM = OPEN ? (1 << 20) : coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(G + 1);  // fragments after this group
   constexpr int HOSTS = 12 * FULL;  // MFMA slots of k-blocks 1..3 that carry the micro-steps of the production
   constexpr int STEPS = NT * BBH_KV_STEPS;  // micro-steps of this wave's production: tile 0's, then tile 1's
   const unsigned lane8 = (unsigned)c[0].l * 8u, lane16 = (unsigned)c[0].l * 16u;
@@ -426,8 +428,6 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
 bool bbh_coop_launch(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_a(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_b(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
-// two candidate tiles per workgroup (grid = ceil(N / 32) workgroups): Matérn-5/2, 6 k-steps
-bool bbh_coop_launch_w2(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 
 #define BBH_COOP_DISPATCH_KD(KDV, NTV)                                                                                        \
   if (kd == KDV) {                                                                                                       \

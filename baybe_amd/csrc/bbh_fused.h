@@ -943,5 +943,3 @@ void bbh_fused_launch_kd6(int kind, bool has_tbl, dim3 grid, dim3 block, size_t 
 void bbh_fused_launch_kd8(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd12(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
 void bbh_fused_launch_kd16(int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);
-// one wave per SIMD, windows of 32 column blocks (WMAX = 32); returns false when there is no such instantiation
-bool bbh_fused_launch_w32(int kd, int kind, bool has_tbl, dim3 grid, dim3 block, size_t lds, hipStream_t s, const FusedArgs& a);

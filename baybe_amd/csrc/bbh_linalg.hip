@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
 
 // =====================================================================================================================
 // The whole factorisation L = chol(A), X = L^-1 of an np x np matrix (np <= 1024) in ONE launch: tile dataflow.
-// One workgroup per 64 x 64 tile, all resident at once (<= 256 workgroups, one per CU: 101 KB of LDS each):
+// One workgroup per 64 x 64 tile, all resident at once (<= 256 workgroups, one per CU: 135 KB of LDS each):
 //   L-tile (I, K), K <= I-2: a = A_IK;  for J < K: a -= L_IJ L_KJ^T as soon as both are published;  then wait for D_K,
 //                           L_IK = a D_K^T, publish.
 //   row head I:             the tiles (I, I-1) and (I, I) together: the same updates for both, then L_{I,I-1} = a_left
@@ -621,21 +621,37 @@ void bbh_ensure_side_stream(bbh_handle* h) {
 }
 
 // one launch for the whole factorisation + inverse (np <= 1024): see bbh_potrf_tiles_kernel
+// A launch that gave up (info = -7: its workgroups were not all co-resident - partitioned compute modes, another process
+// holding CUs) costs up to pd_spin_limit polls; that outcome is remembered per device for the whole process, so that only
+// the first model ever pays it (bbh_model.hip reports it through bbh_potrf_tiles_mark_unusable).
+static bool g_tiles_unusable[64];
+void bbh_potrf_tiles_mark_unusable(int device) { g_tiles_unusable[device & 63] = true; }
+
 static bool bbh_potrf_tiles(bbh_handle* h) {
   const int64_t np = h->np;
   const int nbk = (int)(np / 64);
-  if (!h->potrf_tiles || nbk > 16) return false;
-  static const size_t lds = sizeof(double) * 4 * 64 * PD_LD;
+  if (!h->potrf_tiles || nbk > 16 || g_tiles_unusable[h->device & 63]) return false;
+  // Never inside a stream capture (BBH_FIT_GRAPH=1): the epoch is a by-value kernel argument, so every replay of the captured
+  // launch would wait for the flag value the previous replay already left behind (all waits pass at once, tiles read
+  // unfinished blocks), and the one-time set-up below must not run while capturing.  The captured evaluation uses the
+  // per-step launches.
+  if (h->fit_graph_mode || (h->fit_stream && h->stream == h->fit_stream)) return false;
+  const int ntiles = nbk + (nbk - 1) * (nbk - 2) / 2 + nbk * (nbk - 1) / 2;  // row heads, other L-tiles, X-tiles
+  static const size_t lds = sizeof(double) * 4 * 64 * PD_LD;  // 135 KB: one workgroup per CU
   if (!h->tiles_ready) {
+    int per_cu = 0;
     if (hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bbh_potrf_tiles_kernel, 256, lds) != hipSuccess ||
         hipMalloc((void**)&h->d_tileflags, sizeof(int) * 2 * 16 * 16) != hipSuccess ||
         hipMemset(h->d_tileflags, 0, sizeof(int) * 2 * 16 * 16) != hipSuccess) {
       (void)hipGetLastError();
       h->potrf_tiles = false;
       return false;
     }
+    h->tiles_per_device = per_cu * h->num_cu;  // workgroups of this kernel the device can hold at once
     h->tiles_ready = true;
   }
+  if (ntiles > h->tiles_per_device) return false;  // the dataflow needs every tile resident: not on this device / partition
   if (h->tile_spin_limit != h->tile_spin_limit_set) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(pd_spin_limit), &h->tile_spin_limit, sizeof(int)) != hipSuccess) {
       (void)hipGetLastError();
@@ -648,7 +664,6 @@ static bool bbh_potrf_tiles(bbh_handle* h) {
   hipMemsetAsync(h->d_X, 0, sizeof(double) * np * np, s);  // the upper tiles of L^-1 (XᵀX reads the full matrix)
   hipMemsetAsync(h->d_info, 0, sizeof(int), s);
   const int epoch = ++h->tile_epoch;
-  const int ntiles = nbk + (nbk - 1) * (nbk - 2) / 2 + nbk * (nbk - 1) / 2;  // row heads, other L-tiles, X-tiles
   hipLaunchKernelGGL(bbh_potrf_tiles_kernel, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np,
                      h->d_tileflags, h->d_tileflags + 256, epoch, h->d_info);
   return true;

@@ -554,6 +554,7 @@ static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
   if (info == -7 && h->potrf_tiles) {  // tile-dataflow launch gave up: redo with the per-step path
     h->potrf_tiles = false;
+    if (h->tile_spin_limit >= 1024) bbh_potrf_tiles_mark_unusable(h->device);
     return bbh_chol_and_alpha(h, jitter, info_out);
   }
   *info_out = info;
@@ -681,6 +682,7 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
   }
   if (*h->pin_info == -7 && h->potrf_tiles) {  // the tile-dataflow launch gave up (workgroups not co-resident): per-step path
     h->potrf_tiles = false;
+    if (h->tile_spin_limit >= 1024) bbh_potrf_tiles_mark_unusable(h->device);  // (not when a test forced the give-up with a tiny poll budget)
     if (h->fit_exec) {
       hipGraphExecDestroy(h->fit_exec);
       h->fit_exec = nullptr;

@@ -27,7 +27,7 @@
 // rsq/Taylor Matérn evaluation, and a per-wave cache of kernel values instead of recomputation in later
 // passes.  K(X*,X) is never materialised.  Device code: bbh_fused.h (instantiated per k-step count in
 // bbh_fused_kd{0,2,4,6,8,12,16}.hip); this file holds operand packing, launch logic and the related kernels.
-#include "bbh_coop.h"
+#include "bbh_coop2.h"
 
 // ---- operand packing ------------------------------------------------------------------------
 // R fragments of one pass: for tb in [0, j1), r in 0..3, jb in [max(j0, tb), j1):
@@ -67,6 +67,61 @@ __global__ void bbh_pack_coop_kernel(const double* __restrict__ X, int64_t np, i
     const int64_t fr = base + s;  // fragment pairs are stored lane-interleaved: pair fr / 2, lane l, half fr % 2
     out[((int64_t)w * frags + (fr & ~(int64_t)1)) * 64 + 2 * l + (fr & 1)] = (k <= j) ? X[j * np + k] : 0.0;
   }
+}
+
+// Operand slices of the two-sweep cooperative form (bbh_coop2.h), one workgroup per fragment f of wave w's slice:
+//   sweep A  groups G = g0 .. 7: k-block tb = 4 (G - g0) + i, slot rho = G + s -> column block 4 (rho - g0) + (rho odd ? 3 - w : w)
+//   rect     groups kg = 0 .. 7 - g0: tb = 4 kg + i, slot s = 0 .. 7 -> column block 4 (8 - g0 + s) + (s odd ? 3 - w : w)
+//   sweep B  groups G = 0 .. 7: tb = 4 (8 - g0 + G) + i, slot rho = G + s -> column block 4 (8 - g0 + rho) + (rho odd ? 3 - w : w)
+// each group ordered (k-block i, k-step r, slot s); then 2 BBH_COOP_PAIRS zero fragments (requested by the ring, never used)
+__global__ void bbh_pack_coop2_kernel(const double* __restrict__ X, int64_t np, int g0, int64_t frags, double* __restrict__ out) {
+  const int w = blockIdx.y, l = threadIdx.x;
+  int64_t f = blockIdx.x;
+  const int64_t fr = f;
+  int tb = -1, jb = 0, r = 0;
+  const int RA = BBH_COOP_ROUNDS - g0;
+  bool done = false;
+  for (int G = g0; G < BBH_COOP_ROUNDS && !done; G++) {  // sweep A
+    const int cnt = BBH_COOP_ROUNDS - G;
+    if (f < 16 * cnt) {
+      const int ir = (int)(f / cnt), s = (int)(f % cnt), rho = G + s;
+      tb = 4 * (G - g0) + (ir >> 2);
+      r = ir & 3;
+      jb = 4 * (rho - g0) + ((rho & 1) ? 3 - w : w);
+      done = true;
+    } else {
+      f -= 16 * cnt;
+    }
+  }
+  for (int kg = 0; kg < RA && !done; kg++) {  // rectangular part
+    if (f < 16 * BBH_COOP_ROUNDS) {
+      const int ir = (int)(f / BBH_COOP_ROUNDS), s = (int)(f % BBH_COOP_ROUNDS);
+      tb = 4 * kg + (ir >> 2);
+      r = ir & 3;
+      jb = 4 * (RA + s) + ((s & 1) ? 3 - w : w);
+      done = true;
+    } else {
+      f -= 16 * BBH_COOP_ROUNDS;
+    }
+  }
+  for (int G = 0; G < BBH_COOP_ROUNDS && !done; G++) {  // sweep B
+    const int cnt = BBH_COOP_ROUNDS - G;
+    if (f < 16 * cnt) {
+      const int ir = (int)(f / cnt), s = (int)(f % cnt), rho = G + s;
+      tb = 4 * (RA + G) + (ir >> 2);
+      r = ir & 3;
+      jb = 4 * (RA + rho) + ((rho & 1) ? 3 - w : w);
+      done = true;
+    } else {
+      f -= 16 * cnt;
+    }
+  }
+  double v = 0.0;
+  if (done) {
+    const int64_t k = 16 * (int64_t)tb + 4 * r + (l >> 4), j = 16 * (int64_t)jb + (l & 15);
+    if (k <= j) v = X[j * np + k];
+  }
+  out[((int64_t)w * frags + (fr & ~(int64_t)1)) * 64 + 2 * l + (fr & 1)] = v;  // lane-interleaved fragment pairs
 }
 
 // Bm[i][0] = alpha[i] (i < np), everything else zero
@@ -139,13 +194,7 @@ int bbh_pack_operands(bbh_handle* h) {
   // ---- pass decomposition: full 16-block windows first, the remainder last ----
   std::vector<int> widths;
   {
-    // One wave per SIMD with windows of 32 column blocks (bbh_fused.h, WMAX = 32) when there is such an
-    // instantiation for this model and more than one 16-block window would be needed otherwise.
-    const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
-    h->wmax = (h->use_w32 && h->use_pipeline && nb > 16 && nb % 32 == 0 &&
-               bbh_fused_launch_w32(h->kd, h->desc.kernel_kind, has_tbl0, dim3(0), dim3(0), 0, nullptr, FusedArgs{}))
-                  ? 32
-                  : 16;
+    h->wmax = 16;
     int64_t left = nb;
     while (left >= h->wmax) {
       widths.push_back(h->wmax);
@@ -216,6 +265,25 @@ int bbh_pack_operands(bbh_handle* h) {
                          h->d_rstream);
       h->coop_g0 = g0;
       h->coop_ready = true;
+    }
+  }
+  // ---- operand slices of the two-sweep cooperative form (512 < n <= 1024) ----
+  h->coop2_ready = false;
+  {
+    const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
+    if (h->coop_mode > 0 && h->use_pipeline && nb > 4 * BBH_COOP_ROUNDS && nb <= 8 * BBH_COOP_ROUNDS && nb % 4 == 0 &&
+        bbh_coop2_launch(h->kd, h->desc.kernel_kind, has_tbl0, dim3(0), 0, nullptr, CoopArgs{})) {
+      const int g0 = 2 * BBH_COOP_ROUNDS - (int)(nb / 4);
+      const int64_t frags = coop2_frags(g0);
+      if (!h->d_rstream || h->rstream_frags != frags) {
+        if (h->d_rstream) hipFree(h->d_rstream);
+        h->d_rstream = nullptr;
+        BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rstream, sizeof(double) * 4 * frags * 64));
+        h->rstream_frags = frags;
+      }
+      hipLaunchKernelGGL(bbh_pack_coop2_kernel, dim3((unsigned)frags, 4), dim3(64), 0, s, h->d_X, np, g0, frags, h->d_rstream);
+      h->coop_g0 = g0;
+      h->coop2_ready = true;
     }
   }
   // ---- training fragments (+ one all-padding block reserved for pending points) ----
@@ -324,7 +392,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     // LDS users without costing the second workgroup per CU (half of the CU's LDS per workgroup) stay in
     // wave-private LDS (2 KB per k-block and wave); the rest goes to slabs in global memory claimed per wave.
     a.ncache = (int)(h->nb - h->pass_w_last);
-    const size_t lds_wg = (h->wmax == 32) ? h->lds_per_block : h->lds_per_block / 2;  // workgroups per CU: 1 / 2
+    const size_t lds_wg = h->lds_per_block / 2;  // two workgroups per CU
     const size_t budget = lds_wg > lds ? lds_wg - lds : 0;
     int nl = (int)(budget / (4 * 256 * sizeof(double)));
     if (h->kv_lds_blocks >= 0 && nl > h->kv_lds_blocks) nl = h->kv_lds_blocks;
@@ -370,30 +438,34 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     ca.rstream = h->d_rstream;
     ca.frags = h->rstream_frags;
     ca.g0 = h->coop_g0;
-    // Two candidate tiles per workgroup (env BBH_COOP_NT=2, where instantiated): every operand fragment feeds two MFMAs,
-    // i.e. half the vector-memory traffic per MFMA, 256 VGPRs, no spills - and no faster: 4.72 vs 4.68 ms on the bench
-    // shape (profiles/r02_libs_nt2.log).  What the MFMA pipe loses is per candidate (kernel values on the shared fp64
-    // pipe, per-tile set-up), not per operand fragment; the one-tile form stays the default.
-    const bool two = h->coop_nt == 2 && bbh_coop_launch_w2(kdc, a.kind, has_tbl, dim3(0), 0, nullptr, ca);
-    const int nt = two ? 2 : 1;
-    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + nt * (2 * 4 * 256 + 128));
-    const dim3 cgrid((unsigned)((N + 16 * nt - 1) / (16 * nt)));
-    if (two)
-      bbh_coop_launch_w2(kdc, a.kind, has_tbl, cgrid, clds, h->stream, ca);
-    else
-      bbh_coop_launch(kdc, a.kind, has_tbl, cgrid, clds, h->stream, ca);
+    // (Two candidate tiles per workgroup - every operand fragment feeding two MFMAs, half the vector-memory traffic per MFMA -
+    // was built and measured in round 2: 4.72 vs 4.68 ms on the bench shape, profiles/r02_libs_nt2.log.  What the MFMA pipe
+    // loses is per candidate, not per operand fragment; the variant was removed from the library, coop_group keeps its NT
+    // template parameter.)
+    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (2 * 4 * 256 + 128));
+    const dim3 cgrid((unsigned)((N + 15) / 16));
+    bbh_coop_launch(kdc, a.kind, has_tbl, cgrid, clds, h->stream, ca);
     h->last_form = 1;
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;
   }
-  if (with_var) h->last_form = 0;
-  if (h->wmax == 32 && with_var && !(kdp && a.mean_valu)) {
-    h->err = "BBH_W32=1 (experimental one-wave-per-SIMD form): variance passes without pending columns only";
-    return -6;
+  // Two-sweep cooperative form (512 < n <= 1024): workgroups of 16 candidates instead of 64 (at N = 1e5 the windowed form's
+  // 1563 workgroups are three rounds of the 512 resident slots - a quarter of the launch is tail) and no kernel-value cache
+  // outside LDS; BBH_COOP=0 keeps the windowed form.
+  if (h->coop2_ready && kdc && with_var && coop_mean_valu && !a.qz) {
+    CoopArgs ca;
+    ca.f = a;
+    ca.rstream = h->d_rstream;
+    ca.frags = h->rstream_frags;
+    ca.g0 = h->coop_g0;
+    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (size_t)(BBH_COOP_ROUNDS - ca.g0) * 4 * 256 + 2 * 4 * 256 + 128);
+    bbh_coop2_launch(kdc, a.kind, has_tbl, dim3((unsigned)((N + 15) / 16)), clds, h->stream, ca);
+    h->last_form = 3;
+    BBH_HIP_TRY(h, hipGetLastError());
+    return 0;
   }
-  if (kdp && h->wmax == 32 && with_var)
-    bbh_fused_launch_w32(kdp, a.kind, has_tbl, grid, block, lds, h->stream, a);
-  else if (kdp == 2)
+  if (with_var) h->last_form = 0;
+  if (kdp == 2)
     bbh_fused_launch_kd2(a.kind, has_tbl, grid, block, lds, h->stream, a);
   else if (kdp == 4)
     bbh_fused_launch_kd4(a.kind, has_tbl, grid, block, lds, h->stream, a);

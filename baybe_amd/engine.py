@@ -84,19 +84,59 @@ class ModelFittingError(RuntimeError):
     """Hyper-parameter fit / factorisation failed (mirrors baybe.exceptions.ModelFittingError)."""
 
 
+# Device handles of closed / collected HipGP objects, per device ordinal: a backtesting run creates (and drops) one
+# model per scenario case (``simulate_scenarios`` deep-copies the campaign, simulation/scenarios.py:296); re-using the
+# handle keeps its streams, events, workspaces and grow-only device buffers instead of paying hipMalloc / hipFree per case.
+_HANDLE_POOL: dict = {}
+_HANDLE_POOL_MAX = 8  # idle handles kept per device
+pool_stats = {"created": 0, "reused": 0}
+
+
+def _pool_key(device: int):
+    """A handle reads its A/B switches (``BBH_*`` environment variables) when it is created: handles are
+    only handed on between objects created under the same switches."""
+    import os
+
+    return (int(device), tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("BBH_"))))
+
+
+def _acquire_handle(lib, device: int):
+    free = _HANDLE_POOL.get(_pool_key(device))
+    if free:
+        pool_stats["reused"] += 1
+        return free.pop()
+    h = C.c_void_p()
+    rc = lib.bbh_create(int(device), C.byref(h))
+    if rc != 0:
+        raise HipUnavailableError(
+            f"bbh_create(device={device}) failed with {rc}: no usable HIP device. "
+            "This path has no CPU fallback."
+        )
+    pool_stats["created"] += 1
+    return h
+
+
+def drain_handle_pool():
+    """Destroy the idle device handles (tests; before a process gives its device away)."""
+    lib = _lib.load_library()
+    for free in _HANDLE_POOL.values():
+        while free:
+            lib.bbh_destroy(free.pop())
+
+
 class HipGP:
-    """A GP surrogate living on one HIP device."""
+    """A GP surrogate living on one HIP device.
+
+    The object can be copied and pickled (``copy.deepcopy`` of campaigns / surrogates is what the reference's
+    backtesting drivers do: ``simulation/core.py:124``, ``scenarios.py:296``, ``transfer_learning.py:78``,
+    ``surrogates/composite.py:54``): the copy carries the model description, the training data and the fitted
+    hyper-parameters - not the device handle - and re-creates its device state (handle from the pool, upload,
+    factorisation with the same hyper-parameters) the first time it is used."""
 
     def __init__(self, device: int = 0):
         self._lib = _lib.load_library()
-        self._h = C.c_void_p()
-        rc = self._lib.bbh_create(int(device), C.byref(self._h))
-        if rc != 0:
-            self._h = None
-            raise HipUnavailableError(
-                f"bbh_create(device={device}) failed with {rc}: no usable HIP device. "
-                "This path has no CPU fallback."
-            )
+        self._handle = _acquire_handle(self._lib, device)
+        self._pool_key = _pool_key(device)
         self.device = int(device)
         self.spec: GPSpec | None = None
         self.params: GPParams | None = None
@@ -105,12 +145,57 @@ class HipGP:
         self.ysd = 1.0
         self.jitter = 0.0
         self._comm = None  # (rank, world) once bbh_comm_init has run on this handle
+        self._model_args = None  # (noise_mask, standardization) of the last set_model: what a copy needs to rebuild
+        self._X_train = self._y_train = None
 
     # ---- plumbing -------------------------------------------------------------------------
+    @property
+    def _h(self):
+        """The device handle; a copied / unpickled object builds its device state here, on first use."""
+        if self._handle is None and getattr(self, "_restorable", False):
+            self._restore()
+        return self._handle
+
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.bbh_destroy(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            key = self._pool_key
+            if self._comm is not None or len(_HANDLE_POOL.setdefault(key, [])) >= _HANDLE_POOL_MAX:
+                self._lib.bbh_destroy(self._handle)  # a handle that owns a communicator is not handed on
+            else:  # back to its defaults: legacy stream, no timing
+                self._lib.bbh_set_stream(self._handle, None)
+                self._lib.bbh_timing_enable(self._handle, 0)
+                _HANDLE_POOL[key].append(self._handle)
+            self._handle = None
+        self._restorable = False
+
+    # ---- copies ---------------------------------------------------------------------------
+    def __getstate__(self):
+        return {
+            "device": self.device, "spec": self.spec, "params": self.params, "n": self.n, "ybar": self.ybar,
+            "ysd": self.ysd, "jitter": self.jitter, "X_train": self._X_train, "y_train": self._y_train,
+            "model_args": self._model_args,
+        }
+
+    def __setstate__(self, st):
+        self._lib = None
+        self._handle = None
+        self.device, self.spec, self.params = st["device"], st["spec"], st["params"]
+        self.n, self.ybar, self.ysd, self.jitter = st["n"], st["ybar"], st["ysd"], st["jitter"]
+        self._X_train, self._y_train, self._model_args = st["X_train"], st["y_train"], st["model_args"]
+        self._comm = None
+        self._restorable = True
+
+    def _restore(self):
+        self._restorable = False
+        self._lib = _lib.load_library()
+        self._handle = _acquire_handle(self._lib, self.device)
+        self._pool_key = _pool_key(self.device)
+        if self.spec is not None and self._X_train is not None:
+            params = self.params
+            mask, std = self._model_args or (None, None)
+            self.set_model(self.spec, self._X_train, self._y_train, noise_mask=mask, standardization=std)
+            if params is not None:
+                self.factorize(params)
 
     def __del__(self):
         try:
@@ -189,6 +274,8 @@ class HipGP:
         self.params = None
         self._X_train = X
         self._y_train = y
+        self._model_args = (None if noise_mask is None else np.array(noise_mask, dtype=np.uint8),
+                            None if not standardization else (float(standardization[0]), float(standardization[1])))
 
     def data_term(self, params: GPParams):
         """Device data term (MLL or LOO) and its gradient in theta layout; (None, None) if the
@@ -476,7 +563,7 @@ class HipGP:
     # ---- instrumentation ------------------------------------------------------------------
     def posterior_kernel_form(self) -> str:
         """Which form of the fused posterior kernel the last variance pass ran as."""
-        return {0: "windowed", 1: "cooperative", 2: "materialised"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
+        return {0: "windowed", 1: "cooperative", 2: "materialised", 3: "cooperative-2sweep"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
 
     def timing(self, enable: bool):
         self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")

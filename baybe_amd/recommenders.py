@@ -132,6 +132,35 @@ class HipRecommenderImpl:
     supports_discrete_subset_generating_constraints: ClassVar[bool] = True
     is_available = _availability_property()
 
+    # ---- copies (simulation/core.py:124, scenarios.py:296, transfer_learning.py:78 deep-copy whole campaigns) --------
+    _SHARED_ON_COPY: ClassVar[tuple] = ("_cand_cache", "shard")  # resident candidate matrix (up to 160 MB of HBM): shared, read-only
+    _DROPPED_ON_COPY: ClassVar[tuple] = ("_nehvi",)  # per-call acquisition state holding device handles: rebuilt by every recommend()
+
+    def __deepcopy__(self, memo):
+        from copy import deepcopy
+
+        cls = type(self)
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for a in attrs.fields(cls):
+            val = getattr(self, a.name)
+            if a.name in self._DROPPED_ON_COPY:
+                val = None
+            elif a.name not in self._SHARED_ON_COPY:
+                val = deepcopy(val, memo)
+            object.__setattr__(new, a.name, val)
+        return new
+
+    def __getstate__(self):
+        """Pickling: as ``__deepcopy__``, but the device-resident candidate matrix stays behind too (it is uploaded again
+        from the search space on first use)."""
+        return {a.name: (None if a.name in self._DROPPED_ON_COPY or a.name == "_cand_cache" else getattr(self, a.name))
+                for a in attrs.fields(type(self))}
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            object.__setattr__(self, k, v)
+
     # ---- BayesianRecommender surface -----------------------------------------------------------
     def _get_acquisition_function(self, objective, override=None):
         """Native acquisition spec for the context (default choice: pure/bayesian/base.py:70-74); BayBE's own

@@ -6,11 +6,15 @@ recommend → look up → add measurements, with the ``Iteration / Num_Experimen
 uses: dataframe or callable lookups (``simulation/lookup.py:19-150``), ``impute_mode`` "error" /
 "ignore" / "worst" / "best" / "mean", an optional initial data set.  It is plain control flow around the
 campaign object it is given (BayBE's ``Campaign`` or anything with ``recommend`` / ``add_measurements`` /
-``objective``); what is specific to this package is that the recommender's device state persists over
-the iterations (resident candidate matrix, one handle per target).  Fits restart from the prior mode in
-every iteration, as in the reference: warm-starting L-BFGS-B from the previous optimum was tried and
-dropped — on the multi-modal marginal likelihood it settled in optima up to 3 % worse and did not save
-evaluations (31 vs 33 on the 3-parameter test space).
+``objective``); what is specific to this package is how the device state survives the deep copies the drivers
+make (``simulation/core.py:124``, ``scenarios.py:296``, ``transfer_learning.py:78``): a copied recommender SHARES
+the device-resident candidate matrix of the original (one upload per search space, however many cases run), a
+copied surrogate carries its data and fitted hyper-parameters and rebuilds its device model on first use, and the
+handles of finished cases go back to a per-device pool (``baybe_amd.engine.pool_stats``), so the cases of a
+scenario run on one handle per target.  Fits restart from the prior mode in every iteration, as in the reference;
+warm-starting L-BFGS-B from the previous optimum is opt-in (``HipGaussianProcessSurrogate(warm_start=True)``): on
+the multi-modal marginal likelihood it settled in optima up to 3 % worse and did not save evaluations (31 vs 33 on
+the 3-parameter test space).
 """
 
 from __future__ import annotations
@@ -186,6 +190,8 @@ def simulate_scenarios(scenarios: dict, lookup, /, *, batch_size: int = 1, n_doe
     is added (``add_parameter_noise``)."""
     if not scenarios:
         raise ValueError("no scenarios given")
+    if initial_data is not None and len(initial_data) < 1:  # ``_Rollouts.n_initial_data`` carries a ge(1) validator
+        raise ValueError("'initial_data' must contain at least one data set when it is given.")
     cases = _rollout_cases(n_mc_iterations, len(initial_data) if initial_data is not None else None, random_seed)
     frames = []
     for name, campaign in scenarios.items():

@@ -169,7 +169,19 @@ class HipGPSurrogateImpl:
             self._engine.factorize(self.fixed_hyperparameters)
             self._fit_info = None
         else:
-            self._fit_info = self._engine.fit()
+            # warm_start (opt-in; the reference always restarts from the prior modes): begin L-BFGS-B at the previous optimum
+            prev = self._fit_info.params if (self.warm_start and self._fit_info is not None) else None
+            if prev is not None:
+                from baybe_amd.gp_spec import initial_params, pack_raw
+
+                if pack_raw(spec, prev).shape != pack_raw(spec, initial_params(spec)).shape:
+                    prev = None  # the model changed shape (another search space / task count)
+            try:
+                self._fit_info = self._engine.fit(p0=prev)
+            except Exception:
+                if prev is None:
+                    raise
+                self._fit_info = self._engine.fit()
         self._searchspace, self._objective, self._measurements_hash = searchspace, objective, mhash
 
     def to_botorch(self):
@@ -285,7 +297,7 @@ class HipCompositeImpl:
             t = self.template
             self._models = [
                 type(t)(kernel=t.kernel, use_outputscale=t.use_outputscale, preset=t.preset, device=t.device,
-                        fixed_hyperparameters=_per_target(t.fixed_hyperparameters, i), target_index=i)
+                        warm_start=t.warm_start, fixed_hyperparameters=_per_target(t.fixed_hyperparameters, i), target_index=i)
                 for i in range(m)
             ]
         for model in self._models:
@@ -325,6 +337,9 @@ def gp_surrogate_fields(with_runtime_state: bool = True) -> dict:
         "preset": field(default="BAYBE", converter=lambda v: str(getattr(v, "value", v)).upper()),
         "device": field(default=0),  # HIP device ordinal
         "fixed_hyperparameters": field(default=None, eq=False),  # GPParams: skip the fit (parity / benchmarking)
+        # start every refit at the previous optimum instead of the prior modes (backtesting loops; not what the reference
+        # does, so off by default - see baybe_amd/simulation.py)
+        "warm_start": field(default=False, eq=False),
         # runtime state, not part of the specification (pattern of gaussian_process/core.py:211-212)
         "_engine": field(init=False, default=None, eq=False, repr=False),
         "_fit_info": field(init=False, default=None, eq=False, repr=False),

@@ -207,33 +207,8 @@ def test_pipelined_kernel_matches_plain_form(monkeypatch, N, d, n, kernel):
         assert np.array_equal(out[name][1], out["no_cache"][1])
 
 
-def test_two_tile_cooperative_form_matches_the_one_tile_form(monkeypatch):
-    """BBH_COOP_NT=2: two candidate tiles per workgroup share every operand fragment (bbh_coop.h, NT = 2); same
-    per-candidate arithmetic in the same order as the one-tile form, so the results are identical - ragged last tile,
-    odd tile count and a single row included."""
-    import torch
-
-    from baybe_amd import engine, gp_spec
-
-    d, n = 20, 512
-    X, Xt, y = make_problem(5000 + 17, d, n, seed=31)
-    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
-    ls, nz, _ = fixed_theta(d)
-    out = {}
-    for nt in ("1", "2"):
-        monkeypatch.setenv("BBH_COOP_NT", nt)
-        g = engine.HipGP(0)
-        g.set_model(spec, Xt, y)
-        g.factorize(gp_spec.GPParams(np.full(d, ls), nz, 0.1))
-        out[nt] = [tuple(t.clone() for t in g.posterior(X[:rows])) for rows in (len(X), 33, 1)]
-        assert g.posterior_kernel_form() == "cooperative"
-        g.close()
-    for (m1, v1), (m2, v2) in zip(out["1"], out["2"]):
-        assert torch.equal(m1, m2) and torch.equal(v1, v2)
-
-
 @pytest.mark.parametrize("N,d,n", [(1, 4, 300), (63, 6, 257), (65, 3, 320), (1000, 7, 513), (130, 20, 777),
-                                   (4097, 14, 272), (17, 30, 1041)])
+                                   (4097, 14, 272), (17, 30, 1041), (333, 15, 1024), (49, 9, 600)])
 def test_multi_pass_edges_fused_matches_unfused(gp, N, d, n):
     """Ragged candidate counts (partial tiles, partial workgroups) against every pass layout of the
     fused kernel (last-pass widths 4/8/12/16, 2-5 passes, slab cache in use): the fused launch must agree
@@ -760,3 +735,30 @@ def test_tile_dataflow_factorisation_and_its_fallback(monkeypatch):
         assert np.allclose(out["tiles"][1], out[mode][1], rtol=1e-9, atol=1e-11 * np.abs(out["tiles"][1]).max())
         assert np.allclose(out["tiles"][2], out[mode][2], rtol=1e-10, atol=1e-12) and np.allclose(out["tiles"][3], out[mode][3], rtol=1e-8)
     assert out["steps"][0] == out["fallback"][0]  # the fallback IS the per-step path
+
+
+def test_fit_through_the_captured_graph_matches_the_launch_path(monkeypatch):
+    """BBH_FIT_GRAPH=1 replays one captured evaluation per objective call (the tile-dataflow factorisation took its
+    epoch as a by-value kernel argument, so from the second replay on every wait passed at once).  The captured evaluation
+    now uses the per-step launches; value, gradient at several points and the whole fit must equal the launch path."""
+    from baybe_amd import engine, gp_spec
+
+    d, n = 6, 200
+    X, Xt, y = make_problem(2000, d, n, seed=77)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    ls, nz, _ = fixed_theta(d)
+    points = [gp_spec.GPParams(np.full(d, ls * f), nz * f, 0.05 * f) for f in (1.0, 0.7, 1.4, 0.9)]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BBH_FIT_GRAPH", mode)
+        g = engine.HipGP(0)
+        g.set_model(spec, Xt, y)
+        evals = [g.data_term(p) for p in points]  # the graph is replayed from the second evaluation on
+        fi = g.fit()
+        out[mode] = (evals, fi)
+        g.close()
+    for (v0, g0), (v1, g1) in zip(out["0"][0], out["1"][0]):
+        assert math.isclose(v0, v1, rel_tol=1e-11)
+        assert np.allclose(g0, g1, rtol=1e-8, atol=1e-10 * np.abs(g0).max())
+    assert math.isclose(out["0"][1].fun, out["1"][1].fun, rel_tol=1e-8)
+    assert np.allclose(out["0"][1].params.lengthscale, out["1"][1].params.lengthscale, rtol=1e-4)

@@ -456,3 +456,25 @@ def test_noise_percent_perturbs_the_measured_parameters_and_rows_are_still_match
     assert (abs(df["x0"] - [1.0, 2.0]) <= 0.1).all() and (df["x0"] != [1.0, 2.0]).all()
     with pytest.raises(ValueError):
         add_parameter_noise(df, params, noise_type="nope")
+
+
+def test_engine_state_pickles_without_a_device():
+    """``HipGP.__getstate__`` / ``__setstate__`` carry model description, data and hyper-parameters - never the ctypes
+    handle (``deepcopy`` of a fitted surrogate raised "ctypes objects containing pointers cannot be pickled").
+    Exercised here without the library: the object is rebuilt but never used."""
+    import copy
+    import pickle
+
+    from baybe_amd import engine, gp_spec
+
+    gp = engine.HipGP.__new__(engine.HipGP)
+    spec = gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
+    prm = gp_spec.GPParams(np.array([0.3, 0.4, 0.5]), 0.01, 0.1)
+    gp.__setstate__({"device": 0, "spec": spec, "params": prm, "n": 4, "ybar": 0.5, "ysd": 2.0, "jitter": 0.0,
+                     "X_train": np.arange(12.0).reshape(4, 3), "y_train": np.arange(4.0), "model_args": (None, None)})
+    for clone in (copy.deepcopy(gp), pickle.loads(pickle.dumps(gp))):
+        assert clone._handle is None and clone._restorable and clone.n == 4 and clone.ysd == 2.0
+        assert np.array_equal(clone._X_train, gp._X_train) and clone._X_train is not gp._X_train
+        assert np.array_equal(clone.params.lengthscale, prm.lengthscale) and clone.spec.d == 3
+        clone.close()  # nothing to release
+        assert not clone._restorable
