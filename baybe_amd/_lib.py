@@ -48,7 +48,7 @@ KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3,
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15
 MAX_OBJECTIVES = 4
-TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2}  # enum bbh_timed_family
+TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2, "columns": 3, "nehvi": 4, "q1": 5}  # enum bbh_timed_family
 ACQ_KINDS = {"qLogEI": 0, "qEI": 1, "qPI": 2, "qSR": 3, "qUCB": 4, "qPSTD": 5,
              "PM": 10, "PSTD": 11, "UCB": 12, "EI": 13, "LogEI": 14, "PI": 15}
 

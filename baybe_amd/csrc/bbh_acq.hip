@@ -463,6 +463,7 @@ extern "C" int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   int rc = bbh_upload_z(h, z_host, (size_t)S);
   if (rc) return rc;
+  bbh_timed_scope timed(h, BBH_TIMED_Q1);
   hipLaunchKernelGGL(bbh_qlogei_q1_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), sizeof(double) * S, h->stream,
                      mean_dev, var_dev, N, h->d_z, (int)S, best_f, sign, alive_dev, scores_dev);
   BBH_HIP_TRY(h, hipGetLastError());
@@ -832,6 +833,7 @@ extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* 
   a.alive = alive_dev;
   a.scores = scores_dev;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  bbh_timed_scope timed(h, BBH_TIMED_NEHVI);
   switch (m) {
     case 1: hipLaunchKernelGGL(bbh_qlognehvi_kernel<1>, grid, block, 0, h->stream, a); break;
     case 2: hipLaunchKernelGGL(bbh_qlognehvi_kernel<2>, grid, block, 0, h->stream, a); break;
@@ -1178,6 +1180,7 @@ extern "C" int bbh_mc_acq_q1(bbh_handle* h, int32_t kind, const double* mean_dev
   zbar /= (double)S;
   int rc = bbh_upload_z(h, z_host, (size_t)S);
   if (rc) return rc;
+  bbh_timed_scope timed(h, BBH_TIMED_Q1);
   hipLaunchKernelGGL(bbh_mc_q1_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), sizeof(double) * S, h->stream, kind,
                      mean_dev, var_dev, N, h->d_z, (int)S, zbar, best_f, sign, bbh_mc_cu(kind, beta), alive_dev, scores_dev);
   BBH_HIP_TRY(h, hipGetLastError());

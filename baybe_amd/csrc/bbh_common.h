@@ -233,8 +233,8 @@ struct bbh_handle {
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double timed_ms[BBH_TIMED_FAMILIES] = {0.0, 0.0, 0.0};
-  int64_t timed_launches[BBH_TIMED_FAMILIES] = {0, 0, 0};
+  double timed_ms[BBH_TIMED_FAMILIES] = {};
+  int64_t timed_launches[BBH_TIMED_FAMILIES] = {};
   struct TimedSpan {
     hipEvent_t e0, e1;
     int family;

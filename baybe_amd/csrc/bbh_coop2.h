@@ -65,7 +65,9 @@ __device__ __forceinline__ void coop2_rect_group(const double* rs, const bbh_lds
 template <int KD, int KVF>
 __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopArgs ca) {
   const FusedArgs& a = ca.f;
-  // alpha [16 nb] | archive [4 (8 - g0) k-blocks][4 x 64] | kv [2 buffers][4 k-blocks][4 x 64] | red [2][4][16]
+  // alpha [16 nb] | archive [max(4 (8 - g0), 8) k-blocks][4 x 64] | red [2][4][16]
+  // (sweep B's double-buffered exchange slots [2][4 k-blocks][4 x 64] re-use the first 16 KB of the archive, which is dead by
+  // then: with 64 KB of archive at n = 1024 a separate 16 KB would push the workgroup past half a CU's LDS)
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cnd = l & 15, q = l >> 4;
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
   const int RA = BBH_COOP_ROUNDS - g0;  // rounds (= k-block groups) of sweep A
   double* s_alpha = s_mem;
   double* s_arch = s_alpha + 16 * a.nb;
-  double* s_kv = s_arch + RA * 4 * 256;
-  double* s_red = s_kv + BBH_COOP_KV_TILE;
+  double* s_kv = s_arch;
+  double* s_red = s_arch + (RA > 2 ? RA : 2) * 4 * 256;
   const int64_t tile0 = (int64_t)blockIdx.x * 16;
 
   WaveCtx c[1];
@@ -173,9 +175,11 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
     if (G >= g0) {  // wave-uniform
       const int cw = (G & 1) ? 3 - w : w;
       const int tbn = 4 * (gi + 1) + w;  // k-block this wave produces for the next group
-      bbh_lds_double* dst = (G + 1 < BBH_COOP_ROUNDS) ? arch + tbn * 256 : kvb + w * 256;  // the last one feeds sweep B's first group
-      coop_group<G, KD, KVF, true, 1, true>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, arch + 4 * gi * 256, dst, alq + 16 * tbn,
-                                            tbn, cw, acc, ring, accm);
+      // (the last group has a single column-block slot - no MFMA slots to host a production - and its successor, sweep B's
+      // first group, is produced after the rectangular part)
+      constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
+      coop_group<G, KD, KVF, PRODUCE, 1, true>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, arch + 4 * gi * 256, arch + tbn * 256,
+                                               alq + 16 * tbn, tbn, cw, acc, ring, accm);
       rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
       gi++;
       __syncthreads();
@@ -193,6 +197,21 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
     coop2_rect_group(rs, arch + 4 * kg * 256, lane16, acc[0], ring);
     rs += (int64_t)16 * BBH_COOP_ROUNDS * 64;
   }
+  __syncthreads();  // every wave is done with the archive: its first 16 KB become sweep B's exchange slots
+  {  // sweep B's first group: wave w produces k-block 4 RA + w, not overlapped (as the very first group)
+    const int tb0 = 4 * gi + w;
+    double tfv[KD], kv0[4];
+    d4 dsa, dsb;
+    kvp_load<KD>(c[0], tb0, tfv);
+    kvp_dist<KD>(c[0], tfv, dsa, dsb);
+    kv_all<KVF>(c[0], tb0, dsa, dsb, kv0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      kvb[w * 256 + r * 64] = kv0[r];
+      accm[0] = fma(kv0[r], alq[16 * tb0 + 4 * r], accm[0]);
+    }
+  }
+  __syncthreads();
   // ---- sweep B: the one-sweep form on the remaining triangle ----
   static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
     constexpr int G = decltype(gc)::value;

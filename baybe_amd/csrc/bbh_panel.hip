@@ -458,7 +458,8 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     ca.rstream = h->d_rstream;
     ca.frags = h->rstream_frags;
     ca.g0 = h->coop_g0;
-    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (size_t)(BBH_COOP_ROUNDS - ca.g0) * 4 * 256 + 2 * 4 * 256 + 128);
+    const int ra = BBH_COOP_ROUNDS - ca.g0;  // archived k-block groups (at least the 16 KB sweep B's exchange slots need)
+    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (size_t)(ra > 2 ? ra : 2) * 4 * 256 + 128);
     bbh_coop2_launch(kdc, a.kind, has_tbl, dim3((unsigned)((N + 15) / 16)), clds, h->stream, ca);
     h->last_form = 3;
     BBH_HIP_TRY(h, hipGetLastError());
@@ -1102,6 +1103,7 @@ extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  bbh_timed_scope timed(h, BBH_TIMED_COLUMNS);
   if (bbh_materialised_only(h)) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev);
   FusedArgs a;
   bbh_fill_fused_args(h, a, X_dev, N, ldx);

@@ -591,6 +591,7 @@ class HipGP:
         kind: str = "qLogEI",
         beta: float = 0.2,
         alive=None,
+        speculate: bool = True,
     ) -> GreedyResult:
         """Sequential greedy of ``optimize_acqf_discrete(acqf, q, choices, unique=True)``.
 
@@ -619,6 +620,14 @@ class HipGP:
             return z_by_q[qp] if z_by_q is not None else sobol_normal_base_samples(S, qp, seed)
 
         z_next = get_z(1 + base.shape[0])
+        # Cross-covariance columns ahead of time.  Every later step needs cov(candidate, pending point) for the points picked
+        # so far - one mean-only pass of the fused kernel over all candidates per step, whose cost does not depend on the number
+        # of columns (<= 15 ride on one MFMA column block).  The picks of the later steps come almost always from the head of
+        # the first step's ranking, so after the first step ONE such pass computes the columns of its top candidates; a later
+        # step whose pending points are all among them gathers its columns (bit-identical values: a column is an independent
+        # dot product) instead of launching its own pass, any other step falls back to its own pass.
+        spec_rows, spec_pos, cross_spec = None, {}, None
+        b0 = base.shape[0]
         for _step in range(q):
             pend = np.vstack([base] + chosen_rows) if chosen_rows else base
             p = pend.shape[0]
@@ -631,9 +640,25 @@ class HipGP:
             else:
                 if mean is None:
                     mean, var = self.posterior(X)
+                cols = None
+                if cross_spec is not None:
+                    cols = [spec_pos.get(ix) for ix in indices]
+                    cols = None if any(c is None for c in cols) else list(range(b0)) + cols
                 self.set_pending(pend)
-                cross = self.cross_cov(X)
+                if cols is not None:
+                    cross = cross_spec[:, cols].contiguous() if len(cols) != cross_spec.shape[1] else cross_spec
+                else:
+                    cross = self.cross_cov(X)
                 scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
+            if _step == 0 and q > 1 and shard is None and speculate and N > 1 and b0 < MAX_PENDING:
+                m_spec = min(MAX_PENDING - b0, N, 4 * q)
+                tv, top = self.topk(scores, m_spec)
+                top = [int(t) for t, v in zip(top, tv) if t >= 0 and v > -math.inf]  # live candidates only
+                if top:
+                    spec_rows = X[torch.as_tensor(top, device=X.device), :d].cpu().numpy()
+                    self.set_pending(np.vstack([base, spec_rows]))
+                    cross_spec = self.cross_cov(X)
+                    spec_pos = {ix: b0 + j for j, ix in enumerate(top)}
             if _step + 1 < q:  # host-side Sobol scrambling of the next step overlaps the device work of this one
                 z_next = get_z(2 + p)
             if shard is not None and shard.rccl_bound(self):  # payload built on the device, one ncclAllGather

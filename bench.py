@@ -11,7 +11,10 @@ Workload at every N: the configuration BASELINE.json's metric is quoted on — a
 GPU (weak scaling: the global grid has N * 1e6 rows), d = 20, n_train = 512, Matérn-5/2 ARD,
 fixed-theta mode (prior modes of the BAYBE preset), qLogEI, fp64.
 
-  python bench.py                       # 1 GPU
+  python bench.py                       # 1 GPU, the metric's own configuration (BASELINE configs[2], one GPU's shard)
+  python bench.py --config cfg2|cfg4|cfg5   # the other single-GPU BASELINE configurations, each with its own roofline record:
+                                        #   cfg2 = configs[1] 1e5 x 15, n = 256;  cfg4 = configs[3] ICM over 4 tasks, 1e5 x (15 + task),
+                                        #   n = 1024;  cfg5 = configs[4] qLogNEHVI, 3 targets, 1e5 x 15, n = 256, S = 512 (one GPU)
   python bench.py --gpus N              # spawns one rank per GPU itself (torch.multiprocessing, 127.0.0.1 rendezvous)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W      # or under torchrun: RANK / WORLD_SIZE from the env
@@ -48,20 +51,55 @@ def synth_problem(rows: int, d: int, n: int, rank: int):
     return (X0 if rank == 0 else grid(rank)), Xt, y
 
 
+def synth_tl_problem(rows: int, dnum: int, per_task: int, T: int):
+    """configs[3]: T tasks, task column last and INT-coded, ``per_task`` measurements each with
+    y_t = (1 - 0.1 t) y + 0.2 t; candidates = ``rows`` grid rows of the active task 0."""
+    rng = np.random.default_rng(0)
+    X = np.hstack([rng.integers(0, 11, size=(rows, dnum)) / 10.0, np.zeros((rows, 1))])
+    parts, ys = [], []
+    for t in range(T):
+        xt = np.random.default_rng(10 + t).integers(0, 11, size=(per_task, dnum)) / 10.0
+        y = -((xt - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * xt[:, 0])
+        ys.append((1 - 0.1 * t) * y + 0.2 * t + 0.05 * np.random.default_rng(20 + t).standard_normal(per_task))
+        parts.append(np.hstack([xt, np.full((per_task, 1), float(t))]))
+    return X, np.vstack(parts), np.concatenate(ys)
+
+
+def synth_pareto_targets(Xt: np.ndarray):
+    """configs[4]: f1 = -|x - 0.25|^2, f2 = -|x - 0.75|^2, f3 = -sum |x_j - 0.5|, + 0.05 noise each."""
+    f = [-((Xt - 0.25) ** 2).sum(1), -((Xt - 0.75) ** 2).sum(1), -np.abs(Xt - 0.5).sum(1)]
+    return [fo + 0.05 * np.random.default_rng(30 + o).standard_normal(len(Xt)) for o, fo in enumerate(f)]
+
+
+CONFIGS = {  # BASELINE.json configs -> (rows per GPU, d, n_train); the default is the configuration the metric is quoted on
+    "cfg3": (1_000_000, 20, 512),
+    "cfg2": (100_000, 15, 256),
+    "cfg4": (100_000, 15, 1024),
+    "cfg5": (100_000, 15, 256),
+}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3",
+                    help="BASELINE.json configuration (default: the one the metric is quoted on)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000, help="candidate rows per GPU")
-    ap.add_argument("--d", type=int, default=20)
-    ap.add_argument("--n-train", type=int, default=512)
+    ap.add_argument("--rows", type=int, default=None, help="candidate rows per GPU (default: the configuration's)")
+    ap.add_argument("--d", type=int, default=None)
+    ap.add_argument("--n-train", type=int, default=None)
     ap.add_argument("--mc-samples", type=int, default=512)
     ap.add_argument("--strong", action="store_true", help="fixed global grid of --rows rows, split over the GPUs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--fit", action="store_true", help="also time a device hyper-parameter fit (extra)")
     ap.add_argument("--greedy", type=int, default=5, help="also time a greedy batch of this size (extra; 0 = skip)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    rows, d, n = CONFIGS[args.config]
+    args.rows = rows if args.rows is None else args.rows
+    args.d = d if args.d is None else args.d
+    args.n_train = n if args.n_train is None else args.n_train
+    return args
 
 
 def _spawned_rank(local_rank: int, world: int, port: int, argv):
@@ -123,43 +161,99 @@ def run(args):
         rows_local, total_rows = b - a, args.rows
     else:
         rows_local, total_rows = args.rows, args.rows * world
-    X, Xt, y = synth_problem(rows_local, d, n, rank if not args.strong else 0)
-    if args.strong:
-        X = synth_problem(args.rows, d, n, 0)[0][a:b]
-
-    gp = engine.HipGP(local_rank)
-    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
-    gp.set_model(spec, Xt, y)
+    cfg = args.config
+    if cfg in ("cfg4", "cfg5") and dist_on:
+        raise SystemExit(f"--config {cfg} is a single-GPU record (its multi-GPU form shards exactly like the default configuration)")
     extra = {}
-    if args.fit:
-        t0 = time.perf_counter()
-        fi = gp.fit()
-        extra["fit_ms"] = (time.perf_counter() - t0) * 1e3
-        extra["fit_nfev"] = fi.nfev
+    nehvi = None
+    if cfg == "cfg4":  # BASELINE configs[3]: transfer learning, ICM over 4 tasks, LOO criterion at fit time
+        T = 4
+        X, Xt, y = synth_tl_problem(rows_local, d, n // T, T)
+        spec = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=T)
+        params = gp_spec.initial_params(spec)  # fixed-theta mode: prior modes, deterministic task factors
+    elif dist_on and rank != 0 and not args.strong:
+        # the training rows are rows of rank 0's grid: rank 0 sends them instead of every rank regenerating that grid
+        X = np.random.default_rng(1000 + rank).integers(0, 11, size=(rows_local, d)) / 10.0
+        Xt = y = None
+    else:
+        X, Xt, y = synth_problem(rows_local, d, n, rank if not args.strong else 0)
+        if args.strong:
+            X = synth_problem(args.rows, d, n, 0)[0][a:b]
+    if dist_on and not args.strong and cfg != "cfg4":
+        box = [(Xt, y)]
+        dist.broadcast_object_list(box, src=0, device=torch.device("cpu") if single_dev else torch.device("cuda", local_rank))
+        Xt, y = box[0]
     ls = math.exp(math.sqrt(2.0) - 3.0) * math.sqrt(d)
-    params = gp_spec.GPParams(np.full(d, ls), math.exp(-5.0), 0.0)
-    t0 = time.perf_counter()
-    gp.factorize(params)
-    torch.cuda.synchronize()
-    extra["factorize_ms"] = (time.perf_counter() - t0) * 1e3
-    best_f = gp.best_f()
-    z = engine.sobol_normal_base_samples(S, 1, 1234)[:, 0]
+    if cfg != "cfg4":
+        spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+        params = gp_spec.GPParams(np.full(d, ls), math.exp(-5.0), 0.0)
+
+    if cfg == "cfg5":  # BASELINE configs[4]: ParetoObjective -> qLogNEHVI over 3 independent GPs (one GPU's share)
+        from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+
+        ys = synth_pareto_targets(Xt)
+        engines = []
+        for yo in ys:
+            g = engine.HipGP(local_rank)
+            g.set_model(spec, Xt, yo)
+            g.factorize(params)
+            engines.append(g)
+        ref = compute_ref_point(np.stack(ys, axis=1))  # acquisition/_builder.py:301-317, acqfs.py:406-426
+        nehvi = HipNEHVI(engines, np.ones(len(ys)), Xt, ref, n_mc_samples=S, prune_baseline=True, device=local_rank)
+        torch.manual_seed(0)
+        t0 = time.perf_counter()
+        nehvi.prepare(1234, prune_seed=4321)  # host set-up of one selection step: baseline samples, pruning, box decompositions
+        extra["nehvi_setup_ms"] = (time.perf_counter() - t0) * 1e3
+        extra["nehvi_baseline_points"] = int(len(nehvi.X_b_current))
+        extra["nehvi_cells_per_sample"] = float(nehvi.cell_off[-1]) / S
+        gp = nehvi.outputs[0].ext
+        timed_engines = [o.ext for o in nehvi.outputs]
+        best_f = z = None
+    else:
+        gp = engine.HipGP(local_rank)
+        gp.set_model(spec, Xt, y)
+        if args.fit:
+            t0 = time.perf_counter()
+            fi = gp.fit()
+            extra["fit_ms"] = (time.perf_counter() - t0) * 1e3
+            extra["fit_nfev"] = fi.nfev
+        t0 = time.perf_counter()
+        gp.factorize(params)
+        torch.cuda.synchronize()
+        extra["factorize_ms"] = (time.perf_counter() - t0) * 1e3
+        best_f = gp.best_f()
+        z = engine.sobol_normal_base_samples(S, 1, 1234)[:, 0]
+        timed_engines = [gp]
     Xd = torch.from_numpy(X).cuda()
     shard = RowShard(total_rows, rank, world) if dist_on else None
     if shard is not None and not args.strong:
         shard.start, shard.stop = rank * rows_local, (rank + 1) * rows_local
 
-    # BBH_COLLECTIVE=rccl: the exchange through the library's own communicator (bbh_allgather_topk: device payload, one
-    # ncclAllGather, one read-back); default: torch.distributed (the same RCCL underneath, host-staged payload)
-    use_rccl = shard is not None and os.environ.get("BBH_COLLECTIVE", "torch") == "rccl" and not single_dev
-    if use_rccl:
-        shard.bind_rccl(gp)
+    # The per-step exchange.  With more than one rank the library's own communicator is the default (bbh_allgather_topk: payload
+    # built on the device from the device-side top-k, one ncclAllGather over xGMI on the handle's stream, one read-back = one
+    # synchronisation per step); BBH_COLLECTIVE=torch selects torch.distributed (host-staged payload, three synchronisations),
+    # which is also the fallback when the communicator cannot be set up on every rank.
+    want = os.environ.get("BBH_COLLECTIVE", "rccl" if world > 1 else "torch")
+    use_rccl = False
+    if shard is not None and want == "rccl" and not single_dev:
+        ok = 1
+        try:
+            shard.bind_rccl(gp)
+        except Exception as ex:  # noqa: BLE001
+            ok = 0
+            extra["rccl_bind_error"] = str(ex)[:200]
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
+        use_rccl = bool(flag.item())
 
     def step():
         # two kernels: measured 1.5 % faster than the single fused posterior+qLogEI kernel
         # (scripts/gpu_ab_fused_acq.py: 5.64 vs 5.73 ms/step): the epilogue's VALU work costs the shared fp64
         # pipe the same either way, but a separate launch runs it at full occupancy and leaves the fused
         # kernel's LDS to the kernel-value cache
+        if nehvi is not None:  # extended-model variance pass + S conditional means per target, then the cell kernel
+            scores = nehvi.score(Xd)
+            return gp.topk(scores, TOPK)
         mean, var = gp.posterior(Xd)
         scores = gp.qlogei(mean, var, z, best_f, 1.0)
         if use_rccl:
@@ -183,17 +277,31 @@ def run(args):
         step()
     for _ in range(args.warmup):
         step()
-    gp.timing(True)
-    gp.timing_read(reset=True)
+    FAMILIES = ("posterior", "cross", "pending", "columns", "nehvi", "q1")
+    for g in timed_engines:
+        g.timing(True)
+        for fam in FAMILIES:
+            g.timing_read(reset=True, family=fam)
     fence()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        vals, idx = step()
+        ts = time.perf_counter()
+        vals, idx = step()  # ends with the top-k on the host: a step is complete when it returns
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     fence()
     dt = time.perf_counter() - t0
-    fused_ms, fused_launches = gp.timing_read(reset=True)
-    gp.timing(False)
-    form = gp.posterior_kernel_form()
+    fam_step = {fam: [0.0, 0] for fam in FAMILIES}  # HIP-event time and launches of every kernel family over the timed steps
+    for g in timed_engines:
+        for fam in FAMILIES:
+            ms, cnt = g.timing_read(reset=True, family=fam)
+            fam_step[fam][0] += ms
+            fam_step[fam][1] += cnt
+        g.timing(False)
+    fused_ms, fused_launches = fam_step["posterior"]
+    extra["ms_per_step_median"] = float(np.median(step_ms))
+    extra["device_ms_per_step"] = {fam: v[0] / args.steps for fam, v in fam_step.items() if v[1]}
+    form = timed_engines[0].posterior_kernel_form()
     if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_dev else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -204,7 +312,7 @@ def run(args):
 
     # ---- extra: one greedy batch (optimize_acqf_discrete, q = --greedy) on the same shard, timed per kernel family ----
     pending_roofline = None
-    if args.greedy > 1:
+    if args.greedy > 1 and nehvi is None:
         gp.timing(True)
         for fam in ("posterior", "cross", "pending"):
             gp.timing_read(reset=True, family=fam)
@@ -236,38 +344,88 @@ def run(args):
                 "hbm_bytes_per_candidate_algorithmic": sum(8 * (2 + (Q - 1)) + 8 for Q in range(2, args.greedy + 1)),
             }
 
-    # ---- roofline of the dominant kernel (fused posterior), algorithmic flops ----
-    flops_per_cand = n * n + 2 * n * d + 16 * n + 16 * S
-    avg_ms = fused_ms / max(fused_launches, 1)
-    achieved = rows_local * flops_per_cand / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    traffic = None
-    try:  # PMC-derived HBM bytes per launch for this exact workload (collected offline, profiles/)
-        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-        traffic = tj["workloads"].get(f"{rows_local}x{d}_n{n}", {}).get("hbm_bytes_per_launch")
-    except Exception:  # noqa: BLE001
-        traffic = None
-    roofline = {
-        "bound": "mfma",
-        "achieved": achieved,
-        "peak": FP64_MFMA_PEAK_TFLOPS,
-        # scripts/mfma_valu_overlap_probe.hip: a pure v_mfma_f64_16x16x4_f64 stream reaches 77.8 TFLOP/s, and
-        # fp64 VALU work issued next to it adds its time (one shared DP pipe) - the peak is for MFMA + VALU
-        "peak_mfma_stream_microbench": 77.8,
-        "unit": "TFLOP/s",
-        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-        "traffic": traffic,
-        "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/traffic.json); "
-                        "algorithmic = %d (read every candidate row once, write mean + variance)" % (rows_local * (8 * d + 16)),
-        "kernel": {"cooperative": "bbh_coop_posterior_kernel", "windowed": "bbh_fused_posterior_kernel"}.get(form, form),
-        "kernel_form": form,
-        "avg_launch_ms": avg_ms,
-        "launches": fused_launches,
-        "flops_per_candidate": flops_per_cand,
-        "hbm_GBps_algorithmic": rows_local * (8 * d + 16) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-    }
+    # ---- roofline of the dominant kernel, algorithmic flops ----
+    def traffic_of(key):  # PMC-derived L2<->fabric bytes per launch for this exact workload (collected offline, profiles/)
+        try:
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            return tj["workloads"].get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            return None
+
+    kernel_names = {"cooperative": "bbh_coop_posterior_kernel", "windowed": "bbh_fused_posterior_kernel",
+                    "cooperative-2sweep": "bbh_coop2_posterior_kernel"}
+    if nehvi is None:
+        flops_per_cand = n * n + 2 * n * d + 16 * n + 16 * S
+        avg_ms = fused_ms / max(fused_launches, 1)
+        achieved = rows_local * flops_per_cand / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        q1_ms = fam_step["q1"][0] / max(fam_step["q1"][1], 1)
+        roofline = {
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            # scripts/mfma_valu_overlap_probe.hip: a pure v_mfma_f64_16x16x4_f64 stream reaches 77.8 TFLOP/s, and
+            # fp64 VALU work issued next to it adds its time (one shared DP pipe) - the peak is for MFMA + VALU
+            "peak_mfma_stream_microbench": 77.8,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": traffic_of(f"{rows_local}x{d}_n{n}" + ("" if cfg in ("cfg3", "cfg2") else f"_{cfg}")),
+            "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/traffic.json); "
+                            "algorithmic = %d (read every candidate row once, write mean + variance)" % (rows_local * (8 * d + 16)),
+            "kernel": kernel_names.get(form, form),
+            "kernel_form": form,
+            "avg_launch_ms": avg_ms,
+            "launches": fused_launches,
+            "flops_per_candidate": flops_per_cand,
+            "flops_formula": "n^2 + 2 n d + 16 n + 16 S (SURVEY.md 8d: triangular solve, scaled distances, kernel function + mean, MC)",
+            # two stricter readings of the same launch times: the 16 S term is the qLogEI kernel's work, not this kernel's
+            "frac_own_flops": rows_local * (flops_per_cand - 16 * S) / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if avg_ms > 0 else 0.0,
+            "frac_both_kernels": rows_local * flops_per_cand / ((avg_ms + q1_ms) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if avg_ms > 0 else 0.0,
+            "qlogei_kernel_avg_ms": q1_ms,
+            "hbm_GBps_algorithmic": rows_local * (8 * d + 16) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+        }
+    else:
+        # qLogNEHVI pass = per target (m): variance pass of the model extended by the nb baseline points (n_e = n + nb), S conditional
+        # means (mean-only pass against S target columns), then one cell kernel.  Algorithmic fp64 flops per candidate:
+        #   variance   m (n_e^2 + 2 n_e d + 16 n_e)                      [bbh_coop_posterior_kernel / bbh_fused_posterior_kernel]
+        #   columns    m (2 n_e S + 2 n_e d + 16 n_e)                    [bbh_fused_columns_kernel: K* A, A = K^-1 Y, n_e x S]
+        #   cells      S (2 m + C (108 m + 23) + 23), C = cells per sample [bbh_qlognehvi_kernel] - by the maths of
+        #              acqfs.py:477-484 / BoTorch's qLogNEHVI with exp / log priced at 20 flops and a division at 8:
+        #              per cell and target log_fatplus (2 + 51 + 20) and fatmin against the side length (34 + 1), per cell one
+        #              exp and 3 flops of the log-sum-exp, per sample the same once more
+        m_t = len(nehvi.outputs)
+        n_e = n + extra["nehvi_baseline_points"]
+        C = extra["nehvi_cells_per_sample"]
+        parts = {
+            "variance": (m_t * (n_e * n_e + 2 * n_e * d + 16 * n_e), fam_step["posterior"]),
+            "columns": (m_t * (2 * n_e * S + 2 * n_e * d + 16 * n_e), fam_step["columns"]),
+            "cells": (S * (2 * m_t + C * (108 * m_t + 23) + 23), fam_step["nehvi"]),
+        }
+        recs = {}
+        for name, (fl, (ms, cnt)) in parts.items():
+            per_step = ms / args.steps
+            recs[name] = {"flops_per_candidate": fl, "device_ms_per_step": per_step, "launches_per_step": cnt / args.steps,
+                          "achieved": rows_local * fl / (per_step * 1e-3) / 1e12 if per_step > 0 else 0.0}
+            recs[name]["frac"] = recs[name]["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        dom = max(recs, key=lambda k: recs[k]["device_ms_per_step"])
+        roofline = {
+            "bound": "mfma",  # the fp64 pipe: matrix and vector fp64 share it and have the same peak (78.6 TFLOP/s)
+            "achieved": recs[dom]["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": recs[dom]["frac"],
+            "traffic": traffic_of(f"{rows_local}x{d}_n{n}_cfg5"),
+            "kernel": {"variance": kernel_names.get(form, form), "columns": "bbh_fused_columns_kernel", "cells": "bbh_qlognehvi_kernel"}[dom],
+            "dominant_part": dom, "parts": recs,
+            "whole_pass": {"flops_per_candidate": sum(v[0] for v in parts.values()),
+                           "frac": rows_local * sum(v[0] for v in parts.values())
+                                   / (sum(r["device_ms_per_step"] for r in recs.values()) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+            "n_extended": n_e, "cells_per_sample": C,
+            "hbm_GBps_algorithmic": rows_local * (8 * d + 8) / (ms_per_step * 1e-3) / 1e9,
+        }
+        flops_per_cand = roofline["whole_pass"]["flops_per_candidate"]
 
     out = {
-        "metric": "acquisition candidates scored/sec (1e6 discrete grid, n_train=512, qLogEI)",
+        "metric": {"cfg3": "acquisition candidates scored/sec (1e6 discrete grid, n_train=512, qLogEI)",
+                   "cfg2": "acquisition candidates scored/sec (1e5 discrete grid, d=15, n_train=256, qLogEI)",
+                   "cfg4": "acquisition candidates scored/sec (1e5 candidates, ICM 4 tasks, n_train=1024, qLogEI)",
+                   "cfg5": "acquisition candidates scored/sec (1e5 discrete grid, 3 targets, qLogNEHVI, 512 MC samples)"}[cfg],
         "value": value,
         "unit": "candidates/s",
         "n_gpus": world,
@@ -280,8 +438,16 @@ def run(args):
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{rows_local} x {d} discrete grid per GPU, n_train={n}, Matern-5/2 ARD, qLogEI S={S}, "
-                        f"fixed-theta, top-{TOPK} to host",
+            "workload": {
+                "cfg3": f"{rows_local} x {d} discrete grid per GPU, n_train={n}, Matern-5/2 ARD, qLogEI S={S}, fixed-theta, top-{TOPK} to host",
+                "cfg2": f"{rows_local} x {d} discrete grid per GPU, n_train={n}, Matern-5/2 ARD, qLogEI S={S}, fixed-theta, top-{TOPK} to host "
+                        f"(BASELINE configs[1])",
+                "cfg4": f"{rows_local} x ({d} + task) candidates of the active task, transfer-learning GP (ICM over 4 tasks), n_train={n}, "
+                        f"qLogEI S={S}, fixed-theta, top-{TOPK} to host (BASELINE configs[3])",
+                "cfg5": f"{rows_local} x {d} discrete grid, ParetoObjective of 3 targets -> qLogNEHVI, n_train={n}, S={S} MC samples, "
+                        f"pruned baseline, top-{TOPK} to host (BASELINE configs[4], one GPU's share)",
+            }[cfg],
+            "baseline_config": cfg,
             "global_rows": total_rows,
             "parallelism": f"row-shard x{world}",
             "collective": "none" if not dist_on else ("rccl (library)" if use_rccl else "torch.distributed " + dist.get_backend()),
@@ -292,7 +458,7 @@ def run(args):
     if pending_roofline is not None:
         out["extra"]["roofline_pending_kernels"] = pending_roofline
 
-    if rank == 0 and world == 1 and args.cpu_budget > 0:
+    if rank == 0 and world == 1 and args.cpu_budget > 0 and cfg in ("cfg3", "cfg2"):
         from oracle import cpu_baseline as cb
         from oracle import gp_oracle as go
 

@@ -280,13 +280,19 @@ int bbh_allgather_argmax(bbh_handle* h, const double* scores_dev, int64_t N, int
 int bbh_timing_enable(bbh_handle* h, int enable);
 int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset);
 /* The same per kernel family: BBH_TIMED_POSTERIOR = variance passes of the fused posterior kernel (what
- * bbh_timing_read reports), BBH_TIMED_CROSS = its mean-only passes (bbh_cross_cov, bbh_posterior_columns),
+ * bbh_timing_read reports), BBH_TIMED_CROSS = its mean-only passes (bbh_cross_cov),
  * BBH_TIMED_PENDING = the joint q'-batch acquisition kernels (bbh_qlogei_pending, bbh_mc_acq_pending). */
 /* Form of the fused posterior kernel the last variance pass of this handle ran as: 0 = windowed (one wave per 16
  * candidates, bbh_fused_posterior_kernel), 1 = cooperative (one workgroup per 16 candidates, bbh_coop_posterior_kernel),
  * -1 = none yet. */
 int bbh_last_posterior_form(bbh_handle* h);
-enum bbh_timed_family { BBH_TIMED_POSTERIOR = 0, BBH_TIMED_CROSS = 1, BBH_TIMED_PENDING = 2, BBH_TIMED_FAMILIES = 3 };
+enum bbh_timed_family {
+  BBH_TIMED_POSTERIOR = 0, BBH_TIMED_CROSS = 1, BBH_TIMED_PENDING = 2,
+  BBH_TIMED_COLUMNS = 3,  /* bbh_posterior_columns: conditional means under S target columns (qLogNEHVI) */
+  BBH_TIMED_NEHVI = 4,    /* bbh_qlognehvi: the scoring kernel over the cells of the box decompositions */
+  BBH_TIMED_Q1 = 5,       /* q' = 1 acquisition kernels (bbh_qlogei_q1, bbh_mc_acq_q1) */
+  BBH_TIMED_FAMILIES = 6
+};
 int bbh_timing_read_family(bbh_handle* h, int32_t family, double* ms_total, int64_t* launches, int reset);
 
 #ifdef __cplusplus

@@ -137,26 +137,35 @@ def test_device_fit_reaches_the_oracle_optimum_at_n512():
 
 
 def test_device_fit_reaches_the_oracle_optimum_at_n1024_icm(cfg4):
-    """configs[3]'s model (ICM over 4 tasks, n = 1024, LOO criterion), no iteration cap: device fit against the oracle's fit
-    from the same start.  The LOO surface of the task covariance is flat along some directions, so the hyper-parameters are
-    compared through what they determine - the objective value (1e-8) and the fitted task covariance / lengthscales (1e-2) -
-    and the oracle's objective is evaluated AT the device's optimum as well (the two optima are the same point of the same
-    function, not two functions that happen to share a minimum)."""
-    from baybe_amd import gp_spec
+    """configs[3]'s model (ICM over 4 tasks, n = 1024, LOO criterion), no iteration cap: the device's complete L-BFGS-B run
+    against the oracle's complete run, stored in tests/golden/cfg4_oracle_fit.npz (make_golden_cfg4_fit.py; about 1000
+    evaluations of 0.3 - 0.5 s - ten minutes, so it is not repeated here).
+
+    What can be asked of two complete runs: the LOO surface is flat along the task-covariance directions, both runs stop on
+    scipy's relative-reduction test (``ftol``) with a gradient of ~5e-3 still standing, and the end point is chaotic at that
+    level - the ORACLE ITSELF ends at -0.62268223 on the build container (8 BLAS threads) and at -0.62270299 on the GPU box
+    (128 threads): 2.1e-5 apart in the objective, 1 % in the lengthscales.  So: (i) the oracle's objective evaluated AT the
+    device's end point equals the device's value to 1e-9 (same function); (ii) the two end values agree to 5e-5 and the
+    device's is not worse than the oracle's by more than that; (iii) lengthscales within 3 %, task covariance within 5 %;
+    (iv) the oracle's gradient at the device's end point is as small as at its own (<= 2e-2)."""
+    from baybe_amd import gp_spec  # noqa: F401
     from oracle import gp_oracle as go
 
     X, Xt, y, spec, gp = cfg4
+    gold = np.load(GOLD / "cfg4_oracle_fit.npz")
     fi = gp.fit()
     ospec = oracle_spec(spec)
     ystd, _, _ = go.standardize_targets(y)
     Xn = go.normalize_inputs(ospec, Xt)
-    fo = go.fit_hyperparameters(ospec, Xn, ystd)
-    print(f"n=1024 ICM fit: device fun {fi.fun:.12f} nfev {fi.nfev}; oracle fun {fo.fun:.12f} nfev {fo.nfev}")
-    at_dev, _ = go.fit_objective(ospec, go.pack_raw(ospec, _oparams_icm(fi.params)), Xn, ystd)
+    at_dev, grad_dev = go.fit_objective(ospec, go.pack_raw(ospec, _oparams_icm(fi.params)), Xn, ystd)
+    print(f"n=1024 ICM fit: device fun {fi.fun:.12f} nfev {fi.nfev}; oracle (golden) fun {float(gold['fun']):.12f} nfev {int(gold['nfev'])}; "
+          f"oracle objective at the device optimum {at_dev:.12f}, |grad|_max {np.abs(grad_dev).max():.2e}")
     assert abs(at_dev - fi.fun) <= 1e-9 * max(1.0, abs(fi.fun))
-    assert abs(fi.fun - fo.fun) <= 1e-8 * max(1.0, abs(fo.fun))
-    assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=1e-2)
-    assert np.allclose(fi.params.task_B(), fo.params.task_B(), rtol=1e-2, atol=1e-4)
+    assert abs(fi.fun - float(gold["fun"])) <= 5e-5 and fi.fun <= float(gold["fun"]) + 5e-5
+    assert np.allclose(fi.params.lengthscale, gold["lengthscale"], rtol=3e-2)
+    assert np.allclose(fi.params.task_B(), gold["task_B"], rtol=5e-2)
+    assert math.isclose(fi.params.noise, float(gold["noise"]), rel_tol=5e-2)
+    assert np.abs(grad_dev).max() <= 2e-2
 
 
 def _oparams_icm(p):
