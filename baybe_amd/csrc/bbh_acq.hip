@@ -16,6 +16,9 @@
 #ifndef BBH_PENDING_LSE
 #define BBH_PENDING_LSE 0
 #endif
+#ifndef BBH_PENDING_FAST
+#define BBH_PENDING_FAST 1  // joint q'-batch qLogEI kernels: reduced-precision logarithms where the power tau_max = 0.01 absorbs them
+#endif
 
 // fatplus(x; tau) / tau = softplus(t) + 0.1 / (1 + t^2),  t = x / tau; torch softplus threshold 20
 __device__ __forceinline__ double bbh_fatplus_core(double t) {
@@ -286,6 +289,59 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
 #if BBH_PENDING_LSE
   double ref = -INFINITY;
 #endif
+#if BBH_PENDING_FAST && !BBH_PENDING_LSE
+  // exp(fatmax_s) / tau_relu = fmx acc^tau_max with fmx = max_r fatplus(t_sr) and acc = sum_r u_r^2, u_r = 2 tau / (2 tau + D_r),
+  // D_r = log(fmx / fatplus(t_sr)) >= 0.  fmx enters linearly and is kept to full precision, but acc enters through the power
+  // tau_max = 0.01: an absolute error of 1e-7 in u_r^2 changes the sample's term by 1e-9 relative.  So D_r never needs a
+  // double-precision logarithm:  rho = fatplus_r / fmx, x = 1 - rho;  x < 0.15: D = -log1p(-x) = x + x^2/2 + ... + x^7/7
+  // (truncation 3e-8 at the edge, where u = 0.11 and du^2/dD = 100 u^3 = 0.13);  otherwise D = -ln 2 log2f(rho) in single
+  // precision (error ~1e-7; rho below the float range gives D = inf, u = 0: u^2 < 6e-8 there anyway).  The reciprocal is the
+  // bare v_rcp_f64 seed (2^-26), log(acc) for acc in [1, Q] single precision as well.  Per sample and point ~33 instead of
+  // ~55 VALU instructions, per sample 13 instead of 34 (BBH_PENDING_FAST=0 at compile time restores the former sequence).
+  for (int s = 0; s < S; s++) {
+    const double* zs = s_zq + (int64_t)s * Q;
+    double zr[Q], fp[Q];
+#pragma unroll
+    for (int c = 0; c < Q; c++) zr[c] = zs[c];
+    double fmx = 0.0;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+      double y = m[r];
+#pragma unroll
+      for (int c = 0; c <= r; c++) y = fma(L[r * (r + 1) / 2 + c], zr[c], y);
+      const double tt = (sign * y - best_f) * inv_tau;
+      fp[r] = bbh_fatplus_core(tt);
+      fmx = fmax(fmx, fp[r]);
+    }
+    double inv = __builtin_amdgcn_rcp(fmx);
+    inv = fma(fma(-fmx, inv, 1.0), inv, inv);
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+      const double rho = fp[r] * inv;
+      const double x = 1.0 - rho;
+      double ds = fma(x, 1.0 / 7.0, 1.0 / 6.0);
+      ds = fma(ds, x, 0.2);
+      ds = fma(ds, x, 0.25);
+      ds = fma(ds, x, 1.0 / 3.0);
+      ds = fma(ds, x, 0.5);
+      ds = fma(ds, x, 1.0);
+      ds *= x;
+      const double dl = -0.6931471805599453 * (double)__log2f((float)rho);
+      const double dd = (x < 0.15) ? ds : dl;
+      const double u = (2.0 * TAU_MAX) * __builtin_amdgcn_rcp(2.0 * TAU_MAX + dd);  // dd = inf -> 0
+      acc = fma(u, u, acc);
+    }
+    // acc in [1, Q]: acc^0.01 = exp(w), w = 0.01 ln acc in [0, 0.028): Taylor to the 5th power (7e-13 at w = 0.028)
+    const double w = (TAU_MAX * 0.6931471805599453) * (double)__log2f((float)acc);
+    double e = fma(w, 1.0 / 120.0, 1.0 / 24.0);
+    e = fma(e, w, 1.0 / 6.0);
+    e = fma(e, w, 0.5);
+    e = fma(e, w, 1.0);
+    e = fma(e, w, 1.0);
+    sum = fma(fmx, e, sum);
+  }
+#else
   for (int s = 0; s < S; s++) {
     const double* zs = s_zq + (int64_t)s * Q;
     double zr[Q], li[Q], fp[Q];
@@ -333,6 +389,7 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
     sum = fma(fmx, e, sum);
 #endif
   }
+#endif
 #if BBH_PENDING_LSE
   scores[i] = ref + log(sum) - log((double)S);
 #else
@@ -789,6 +846,97 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_kernel(const NehviArgs a) {
   a.scores[i] = (sref > -INFINITY) ? sref + log(ssum) - log((double)a.S) : -INFINITY;
 }
 
+// The same value with the sums over cells and samples taken in the LINEAR domain:
+//   score = log( (1/S) sum_s sum_c prod_o exp(fatmin(li_o, ll_o)) ),
+//   exp(fatmin(a, b)) = min(e^a, e^b) (1 + u^2)^(-tau_max),  u = 2 tau_max / (2 tau_max + |a - b|),
+// where e^a = tau_relu fatplus(t) is at hand BEFORE any logarithm is taken and e^b is the cell's side length.  Every term is a
+// product of m side lengths >= ~1e-25 (the fat tail 0.1 tau_relu / (1 + t^2) at |t| <= 1e10), far inside the fp64 range, so
+// nothing needs the log domain; what the log-domain form pays per (cell, target) - two double-precision logarithms, and per
+// cell an exponential for the streaming log-sum-exp - shrinks to series and single-precision logarithms (see the loop body: the
+// power tau_max = 0.01 absorbs their error).  BBH_NEHVI_LOG=1 selects the log-domain kernel (A/B, tests).
+// One thread per candidate and SAMPLE SLICE (blockIdx.y of gridDim.y slices): with one thread per candidate a 1e5-row
+// candidate set is 1563 wavefronts - 1.5 per SIMD, each a long dependent chain - and the kernel ran at a fifth of the VALU
+// issue rate; the slices bring the launch to >= 8 waves per SIMD.  All lanes of a wave work on the same samples, so the
+// cell data stays wave-uniform (scalar loads).  The slices' partial sums are combined in a fixed order by
+// bbh_qlognehvi_finish_kernel (sums of positive terms in the linear domain: no atomics, reproducible).
+template <int M>
+__global__ __launch_bounds__(256) void bbh_qlognehvi_lin_kernel(const NehviArgs a, const double* __restrict__ cell_len,
+                                                                double* __restrict__ partial) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N) return;
+  const int per = (a.S + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int s_begin = (int)blockIdx.y * per, s_end = (s_begin + per < a.S) ? s_begin + per : a.S;
+  if (a.alive && !a.alive[i]) {
+    partial[(int64_t)blockIdx.y * a.N + i] = 0.0;
+    return;
+  }
+  double sd[M], sg[M];
+  const double* trow[M];
+#pragma unroll
+  for (int o = 0; o < M; o++) {
+    sd[o] = bbh_safe_sd(a.var[o][i]);
+    sg[o] = a.sign[o];
+    trow[o] = a.tmat[o] + i * (int64_t)a.S;
+  }
+  const double inv_tau = 1.0 / TAU_RELU;
+  double total = 0.0;
+  for (int s = s_begin; s < s_end; s++) {
+    double f[M];
+#pragma unroll
+    for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s]);
+    const int64_t c0 = a.cell_off[s], c1 = a.cell_off[s + 1];
+    double ssum = 0.0;
+    for (int64_t c = c0; c < c1; c++) {
+      double prod = 1.0;
+#pragma unroll
+      for (int o = 0; o < M; o++) {
+        const double B = cell_len[c * M + o];
+        const double fp = bbh_fatplus_core((f[o] - a.cell_lo[c * M + o]) * inv_tau);
+        const double A = TAU_RELU * fp;
+        // |li - ll| = -log(rho), rho = min(A, B) / max(A, B): a 7-term series of -log1p(-x) next to rho = 1 (x = 1 - rho <
+        // 0.15, where the term is sensitive: d log(term) = u^3 d|li - ll|), single precision beyond (u < 0.11 there: an error of
+        // 1e-7 moves the term by 1e-10 relative).  B = inf (cell unbounded above): rho = 0, u = 0.  No double-precision
+        // logarithm is left: inside a wave some lane is nearly always close to rho = 1, so a wave-uniform skip never skipped.
+        const double mn = fmin(A, B), mxv = fmax(A, B);
+        double inv = __builtin_amdgcn_rcp(mxv);
+        inv = fma(fma(-mxv, inv, 1.0), inv, inv);
+        const double rho = (mxv < INFINITY) ? mn * inv : 0.0;
+        const double x1 = 1.0 - rho;
+        double ds = fma(x1, 1.0 / 7.0, 1.0 / 6.0);
+        ds = fma(ds, x1, 0.2);
+        ds = fma(ds, x1, 0.25);
+        ds = fma(ds, x1, 1.0 / 3.0);
+        ds = fma(ds, x1, 0.5);
+        ds = fma(ds, x1, 1.0);
+        ds *= x1;
+        const double dl = -0.6931471805599453 * (double)__log2f((float)rho);  // rho = 0 -> inf
+        const double diff = (x1 < 0.15) ? ds : dl;
+        const double u = (2.0 * TAU_MAX) * __builtin_amdgcn_rcp(fma(2.0, TAU_MAX, diff));  // bare seed (2^-26); diff = inf -> 0
+        const double w = u * u;
+        // log1p(w), w in [0, 1]: series below 0.03 (error w^5 / 5 < 5e-9), single precision above (1.2e-7) - times tau_max = 0.01
+        const double lps = w * fma(w, fma(w, fma(w, -0.25, 1.0 / 3.0), -0.5), 1.0);
+        const double lpf = 0.6931471805599453 * (double)__log2f((float)(1.0 + w));
+        const double lp = (w < 0.03) ? lps : lpf;
+        const double x = TAU_MAX * lp;  // in [0, 0.00694]
+        const double e = fma(x, fma(x, fma(x, fma(x, fma(x, -1.0 / 120.0, 1.0 / 24.0), -1.0 / 6.0), 0.5), -1.0), 1.0);  // exp(-x)
+        prod *= mn * e;
+      }
+      ssum += prod;
+    }
+    total += ssum;
+  }
+  partial[(int64_t)blockIdx.y * a.N + i] = total;
+}
+
+__global__ __launch_bounds__(256) void bbh_qlognehvi_finish_kernel(const double* __restrict__ partial, int slices, int64_t N, int S,
+                                                                   const uint8_t* __restrict__ alive, double* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double total = 0.0;
+  for (int k = 0; k < slices; k++) total += partial[(int64_t)k * N + i];
+  scores[i] = (total > 0.0 && !(alive && !alive[i])) ? log(total) - log((double)S) : -INFINITY;
+}
+
 extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
                              const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
                              const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
@@ -806,13 +954,15 @@ extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* 
     h->err = "bbh_qlognehvi: inconsistent cell arrays";
     return -1;
   }
-  // one upload: zx [S*m] | cell_lo [ncells*m] | cell_ll [ncells*m] | cell_off [S+1] (int64, 8-byte slots)
-  const size_t nd = (size_t)S * m + 2 * (size_t)ncells * m;
+  // one upload: zx [S*m] | cell_lo [ncells*m] | cell_ll [ncells*m] | cell_len [ncells*m] | cell_off [S+1] (int64, 8-byte slots)
+  const size_t nd = (size_t)S * m + 3 * (size_t)ncells * m;
   std::vector<double> buf(nd + (size_t)S + 1);
   memcpy(buf.data(), zx_host, sizeof(double) * S * m);
   if (ncells > 0) {
     memcpy(buf.data() + S * m, cell_lo_host, sizeof(double) * ncells * m);
     memcpy(buf.data() + S * m + ncells * m, cell_loglen_host, sizeof(double) * ncells * m);
+    double* len = buf.data() + S * m + 2 * ncells * m;  // side lengths e^ll (inf for cells unbounded above)
+    for (int64_t e = 0; e < ncells * m; e++) len[e] = exp(cell_loglen_host[e]);
   }
   memcpy(buf.data() + nd, cell_off_host, sizeof(int64_t) * (S + 1));
   int rc = bbh_upload_z(h, buf.data(), buf.size());
@@ -834,6 +984,28 @@ extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* 
   a.scores = scores_dev;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
   bbh_timed_scope timed(h, BBH_TIMED_NEHVI);
+  const char* env_log = getenv("BBH_NEHVI_LOG");
+  if (!(env_log && env_log[0] == '1')) {  // linear-domain sums (default)
+    const double* len = h->d_z + S * m + 2 * ncells * m;
+    // sample slices: ~16 waves per SIMD (4 SIMDs per CU; 11.3 / 10.4 / 10.0 / 9.8 ms for 6 / 12 / 24 / 48 slices at 1e5 candidates), each slice at least 8 samples
+    int64_t slices = ((int64_t)16 * 4 * h->num_cu * 64 + N - 1) / N;
+    if (const char* e = getenv("BBH_NEHVI_SLICES")) slices = atoi(e);
+    if (slices > S / 8) slices = S / 8;
+    if (slices > 64) slices = 64;
+    if (slices < 1) slices = 1;
+    rc = bbh_ensure_ws(h, sizeof(double) * (size_t)slices * (size_t)N);
+    if (rc) return rc;
+    dim3 sgrid(grid.x, (unsigned)slices);
+    switch (m) {
+      case 1: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<1>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      case 2: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<2>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      case 3: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<3>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      default: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<4>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+    }
+    hipLaunchKernelGGL(bbh_qlognehvi_finish_kernel, grid, block, 0, h->stream, h->d_ws, (int)slices, N, (int)S, alive_dev, scores_dev);
+    BBH_HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
   switch (m) {
     case 1: hipLaunchKernelGGL(bbh_qlognehvi_kernel<1>, grid, block, 0, h->stream, a); break;
     case 2: hipLaunchKernelGGL(bbh_qlognehvi_kernel<2>, grid, block, 0, h->stream, a); break;

@@ -232,13 +232,23 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   int xcol[KD];
   double xval[NT][KD], xscl[KD], xofs[KD];
   const double* xr[NT];
+  // the training fragments of this wave's first k-block are requested before anything else: their round trip passes under
+  // the candidate-row loads instead of following them (the per-tile set-up is a chain of memory round trips: at n = 128 a tile
+  // is 8 us of which the MFMA work is 5)
+  double tfv0[KD];
+  kvp_load<KD>(a.trainfrag + l, w, tfv0);
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const int64_t row = (tile0 + 16 * t + cnd < a.N) ? tile0 + 16 * t + cnd : a.N - 1;
     xr[t] = a.X + row * a.ldx;
   }
+  if (a.numcol_identity) {  // the numerical columns are the leading comp-rep columns, in order: no index round trip
 #pragma unroll
-  for (int k = 0; k < KD; k++) xcol[k] = a.numcol[(4 * k + q < a.dn) ? 4 * k + q : a.dn - 1];
+    for (int k = 0; k < KD; k++) xcol[k] = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
+  } else {
+#pragma unroll
+    for (int k = 0; k < KD; k++) xcol[k] = a.numcol[(4 * k + q < a.dn) ? 4 * k + q : a.dn - 1];
+  }
 #pragma unroll
   for (int k = 0; k < KD; k++) {
     const int dimc = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
       for (int t = 0; t < NT; t++)
         for (int r = 0; r < 4; r++) kv0[t][r] = 0.5 + 0.001 * (double)(l + r);
     } else {
-      kvp_load<KD>(c[0], w, tfv);
+#pragma unroll
+      for (int k = 0; k < KD; k++) tfv[k] = tfv0[k];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         d4 dsa, dsb;

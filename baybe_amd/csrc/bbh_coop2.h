@@ -82,10 +82,17 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
   WaveCtx c[1];
   int xcol[KD];
   double xval[KD], xscl[KD], xofs[KD];
+  double tfv0[KD];  // training fragments of this wave's first k-block, requested first (see bbh_coop.h)
+  kvp_load<KD>(a.trainfrag + l, w, tfv0);
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
+  if (a.numcol_identity) {
 #pragma unroll
-  for (int k = 0; k < KD; k++) xcol[k] = a.numcol[(4 * k + q < a.dn) ? 4 * k + q : a.dn - 1];
+    for (int k = 0; k < KD; k++) xcol[k] = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
+  } else {
+#pragma unroll
+    for (int k = 0; k < KD; k++) xcol[k] = a.numcol[(4 * k + q < a.dn) ? 4 * k + q : a.dn - 1];
+  }
 #pragma unroll
   for (int k = 0; k < KD; k++) {
     const int dimc = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
@@ -154,10 +161,9 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
     coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, lane16);
   });
   {  // the first group's kernel values: wave w produces k-block w, not overlapped with anything
-    double tfv[KD], kv0[4];
+    double kv0[4];
     d4 dsa, dsb;
-    kvp_load<KD>(c[0], w, tfv);
-    kvp_dist<KD>(c[0], tfv, dsa, dsb);
+    kvp_dist<KD>(c[0], tfv0, dsa, dsb);
     kv_all<KVF>(c[0], w, dsa, dsb, kv0);
     __syncthreads();  // alpha is in LDS
 #pragma unroll

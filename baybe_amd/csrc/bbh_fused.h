@@ -57,6 +57,7 @@ struct FusedArgs {
   int nl;         // kernel-value cache: k-blocks [0, nl) live in wave-private LDS, [nl, ncache) in the global slab
   int has_tbl;    // task / outputscale table in use
   int mean_valu;  // no pending columns: the mean contraction runs on the VALU against alpha in LDS
+  int numcol_identity;  // numcol[j] == j for every numerical column (cooperative forms: skips the index load)
 };
 
 typedef __attribute__((address_space(3))) double bbh_lds_double;
@@ -238,10 +239,14 @@ __device__ __forceinline__ void pass_body(const WaveCtx& c, const double* rf, in
 // distance MFMAs, slices 1-2 evaluate two kernel values each, slice 3 carries the mean MFMAs.
 // =====================================================================================================
 template <int KD>
-__device__ __forceinline__ void kvp_load(const WaveCtx& c, int tb, double (&tfv)[KD]) {
-  const double* tf = c.tf + (int64_t)tb * KD * 64;
+__device__ __forceinline__ void kvp_load(const double* tf_lane, int tb, double (&tfv)[KD]) {  // tf_lane = trainfrag + lane
+  const double* tf = tf_lane + (int64_t)tb * KD * 64;
 #pragma unroll
   for (int k = 0; k < KD; k++) tfv[k] = tf[k * 64];
+}
+template <int KD>
+__device__ __forceinline__ void kvp_load(const WaveCtx& c, int tb, double (&tfv)[KD]) {
+  kvp_load<KD>(c.tf, tb, tfv);
 }
 
 #if BBH_DIST_ASM

@@ -375,6 +375,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   // (bbh_set_model rounds kd up to one of these when d allows); everything else takes the plain form
   const bool rbf = (a.kind == BBH_KERNEL_RBF), m32 = (a.kind == BBH_KERNEL_MATERN32);
   a.has_tbl = has_tbl ? 1 : 0;
+  a.numcol_identity = 1;
+  for (int j = 0; j < h->dn; j++)
+    if (h->numcol[j] != j) a.numcol_identity = 0;
   const int kdp = ((m52 || ((rbf || m32) && !has_tbl)) && h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
   a.nblk = (N + 63) / 64;
   dim3 grid((unsigned)a.nblk), block(256);
@@ -427,7 +430,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   // Cooperative form (n <= 512, variance pass without pending columns): ahead of the windowed form once a second
   // 16-block window would be needed (n > 256: 4.70 vs 5.17 ms on the bench shape), level at n = 256, a few per cent behind
   // below; for small candidate sets its four waves per tile cut the latency to a third (0.016 vs 0.052 ms for 1000 rows).
-  const bool coop_pays = h->coop_mode == 2 || h->nb > 16 || N <= 16384;
+  // (round 3, profiles/r03_ab_small_n.log: with the hoisted set-up loads the cooperative form is level or ahead for every
+  // n <= 256 and candidate count from 1e4 to 1e6 - its 16-candidate workgroups quantise the tail of a launch four times finer)
+  const bool coop_pays = true;
   // (its own instantiation set: also RBF with a task table - the multi-task HVARFNER / BOTORCH presets - which the
   // windowed pipelined form does not have)
   const int kdc = (h->use_pipeline && (h->kd == 2 || h->kd == 4 || h->kd == 6 || h->kd == 8 || h->kd == 12 || h->kd == 16)) ? h->kd : 0;
@@ -1006,6 +1011,7 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
 }
 
 static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev, int64_t N, int64_t ldx) {
+  a.numcol_identity = 0;
   a.X = X_dev;
   a.N = N;
   a.ldx = ldx;

@@ -134,8 +134,8 @@ class HipGP:
     factorisation with the same hyper-parameters) the first time it is used."""
 
     def __init__(self, device: int = 0):
-        self._lib = _lib.load_library()
-        self._handle = _acquire_handle(self._lib, device)
+        self._libobj = _lib.load_library()
+        self._handle = _acquire_handle(self._libobj, device)
         self._pool_key = _pool_key(device)
         self.device = int(device)
         self.spec: GPSpec | None = None
@@ -149,6 +149,13 @@ class HipGP:
         self._X_train = self._y_train = None
 
     # ---- plumbing -------------------------------------------------------------------------
+    @property
+    def _lib(self):
+        """The bound shared library (loaded on first use in a copied / unpickled object)."""
+        if self._libobj is None:
+            self._libobj = _lib.load_library()
+        return self._libobj
+
     @property
     def _h(self):
         """The device handle; a copied / unpickled object builds its device state here, on first use."""
@@ -177,7 +184,7 @@ class HipGP:
         }
 
     def __setstate__(self, st):
-        self._lib = None
+        self._libobj = None
         self._handle = None
         self.device, self.spec, self.params = st["device"], st["spec"], st["params"]
         self.n, self.ybar, self.ysd, self.jitter = st["n"], st["ybar"], st["ysd"], st["jitter"]
@@ -187,7 +194,6 @@ class HipGP:
 
     def _restore(self):
         self._restorable = False
-        self._lib = _lib.load_library()
         self._handle = _acquire_handle(self._lib, self.device)
         self._pool_key = _pool_key(self.device)
         if self.spec is not None and self._X_train is not None:

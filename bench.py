@@ -329,18 +329,21 @@ def run(args):
         extra[f"greedy_q{args.greedy}_ms"] = g_wall
         extra[f"greedy_q{args.greedy}_device_ms"] = {k: v[0] for k, v in fam_ms.items()}
         extra[f"greedy_q{args.greedy}_indices"] = gres.indices
-        # Roofline of the joint q'-batch kernels (bbh_qlogei_pending_q_kernel<Q>), steps 2..q.  VALU-bound: per
-        # candidate, sample and step with q' = Q points: Q(Q+1)/2 FMAs (affine map) + Q (fatplus: 13) + Q (log: 26)
-        # + Q (fatmax term: 11) + 40 (log of the sum, power, accumulation) fp64 instructions; an FMA counts 2 flops
-        # against the 78.6 TFLOP/s vector peak, i.e. the instruction rate is priced at 39.3e12 / s.
-        inst = sum(S * (Q * (Q + 1) // 2 + Q * (13 + 26 + 11) + 40) + 3 * Q * Q * Q for Q in range(2, args.greedy + 1))
+        # Roofline of the joint q'-batch kernels (bbh_qlogei_pending_q_kernel<Q>), steps 2..q: bound by the fp64 vector pipe.
+        # ALGORITHMIC flops by the maths of BoTorch's qLogEI (not by this kernel's instruction tally), with exp / log priced at 20
+        # flops and a division at 8: per candidate, MC sample and step with q' = Q points - affine map y = m + L z: Q (Q + 1);
+        # per point t = (y - best_f) / tau (2), fatplus = softplus(t) + 0.1 / (1 + t^2) (exp + log + 11 = 51), log (20), fatmax term
+        # (alpha / (alpha + (M - li) / tau))^alpha (14); per sample max / sum / tau log(sum) (25) and the exp + accumulate of the
+        # log-mean-exp (22): Q (Q + 1) + 87 Q + 47; plus the joint Cholesky factor, Q^3 / 3 flops per candidate and step.
+        flops_p = sum(S * (Q * (Q + 1) + 87 * Q + 47) + Q * Q * Q // 3 for Q in range(2, args.greedy + 1))
         p_ms, p_n = fam_ms["pending"]
         if p_n:
-            ach = rows_local * inst / (p_ms * 1e-3) / 1e12
+            ach = rows_local * flops_p / (p_ms * 1e-3) / 1e12
             pending_roofline = {
-                "kernel": "bbh_qlogei_pending_q_kernel<2..%d>" % args.greedy, "bound": "valu-fp64",
-                "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS / 2, "unit": "T fp64 instructions/s", "frac": ach / (FP64_MFMA_PEAK_TFLOPS / 2),
-                "instructions_per_candidate": inst, "launches": p_n, "total_ms": p_ms,
+                "kernel": "bbh_qlogei_pending_q_kernel<2..%d>" % args.greedy, "bound": "fp64 vector pipe (mfma peak: matrix = vector)",
+                "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "flops_per_candidate": flops_p, "flops_formula": "sum over q' = Q of S (Q (Q + 1) + 87 Q + 47) + Q^3 / 3",
+                "launches": p_n, "total_ms": p_ms,
                 "hbm_bytes_per_candidate_algorithmic": sum(8 * (2 + (Q - 1)) + 8 for Q in range(2, args.greedy + 1)),
             }
 

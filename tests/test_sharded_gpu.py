@@ -256,3 +256,31 @@ def test_bench_sharded_path_over_rccl_with_one_rank(collective):
     assert plain["config"]["collective"] == "none"
     assert sharded["config"]["collective"] == ("rccl (library)" if collective == "rccl" else "torch.distributed nccl")
     assert sharded["extra"]["greedy_q3_indices"] == plain["extra"]["greedy_q3_indices"] and sharded["n_gpus"] == 1
+
+
+def test_bench_two_gpus_over_the_library_communicator():
+    """``bench.py --gpus 2`` on two real devices: one rank per GPU, the per-step exchange through the library's own RCCL
+    communicator (the default for more than one rank: payload built on the device, one ncclAllGather over xGMI, one
+    read-back).  Skipped where fewer than two devices are visible (the gpurun box has one); the driver's 8-GPU run takes
+    this path."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible HIP devices")
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_SINGLE_DEVICE",
+                                                             "BBH_COLLECTIVE")}
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "200000",
+           "--cpu-budget", "0", "--greedy", "3"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["collective"] == "rccl (library)" and rec["config"]["global_rows"] == 400000
+    single = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "1", "--warmup", "1", "--rows", "400000", "--cpu-budget",
+                             "0", "--greedy", "0", "--strong"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert single.returncode == 0 and rec["value"] > 0
