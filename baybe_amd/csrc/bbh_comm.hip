@@ -149,6 +149,14 @@ extern "C" int bbh_comm_destroy(bbh_handle* h) {
   return 0;
 }
 
+// A rank whose local part failed (top-k workspace, device error) still joins the collective - the others are already inside
+// it and would block for ever - with this payload: score -inf, index -2 in every slot.  Every rank sees it after the gather
+// and returns the same error.  (All ranks must call with identical k / d: the payload size is part of the collective.)
+__global__ void bbh_pack_failed_kernel(double* out, int64_t doubles) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < doubles) out[e] = (e & 1) ? -2.0 : -INFINITY;
+}
+
 static int gather(bbh_handle* h, CommState* st, size_t doubles, std::vector<double>& host) {
   RcclApi* api = rccl_api(&h->err);
   if (!api) return -7;
@@ -181,19 +189,30 @@ extern "C" int bbh_allgather_topk(bbh_handle* h, const double* scores_dev, int64
   double* dv = nullptr;
   int64_t* di = nullptr;
   const int64_t have = N < k ? N : k;
+  int local_rc = 0;
+  std::string local_err;
   if (have > 0) {
-    rc = bbh_topk_device(h, scores_dev, N, have, &dv, &di);
-    if (rc) return rc;
+    local_rc = bbh_topk_device(h, scores_dev, N, have, &dv, &di);
+    local_err = h->err;
   }
-  hipLaunchKernelGGL(bbh_pack_topk_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, h->stream, dv, di, have, k, row_offset,
-                     st->d_send);
+  if (local_rc)
+    hipLaunchKernelGGL(bbh_pack_failed_kernel, dim3((unsigned)((2 * k + 255) / 256)), dim3(256), 0, h->stream, st->d_send, 2 * k);
+  else
+    hipLaunchKernelGGL(bbh_pack_topk_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, h->stream, dv, di, have, k, row_offset,
+                       st->d_send);
   std::vector<double> host;
   rc = gather(h, st, (size_t)2 * k, host);
   if (rc) return rc;
-  // merge: descending score, ties -> lower global index; ranks' padding (index < 0) and NaN never win
+  for (size_t e = 0; e < host.size() / 2; e++)
+    if (host[2 * e + 1] == -2.0) {  // some rank failed locally: the same error on every rank
+      h->err = local_rc ? "bbh_allgather_topk: local selection failed: " + local_err : "bbh_allgather_topk: the local selection of another rank failed";
+      return -10;
+    }
+  // merge: descending score, ties -> lower global index; ranks' padding (index < 0), dead candidates (-inf) and NaN never win
   std::vector<std::pair<double, int64_t>> all;
   for (size_t e = 0; e < host.size() / 2; e++)
-    if (host[2 * e + 1] >= 0.0 && host[2 * e] == host[2 * e]) all.emplace_back(host[2 * e], (int64_t)host[2 * e + 1]);
+    if (host[2 * e + 1] >= 0.0 && host[2 * e] == host[2 * e] && host[2 * e] > -INFINITY)
+      all.emplace_back(host[2 * e], (int64_t)host[2 * e + 1]);
   std::sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
   for (int64_t j = 0; j < k; j++) {
     vals_host[j] = j < (int64_t)all.size() ? all[j].first : -INFINITY;
@@ -220,9 +239,11 @@ extern "C" int bbh_allgather_argmax(bbh_handle* h, const double* scores_dev, int
   if (rc) return rc;
   double* dv = nullptr;
   int64_t* di = nullptr;
+  int local_rc = 0;
+  std::string local_err;
   if (N > 0) {
-    rc = bbh_topk_device(h, scores_dev, N, 1, &dv, &di);
-    if (rc) return rc;
+    local_rc = bbh_topk_device(h, scores_dev, N, 1, &dv, &di);
+    local_err = h->err;
   } else {  // an empty shard still takes part in the collective
     rc = bbh_ensure_ws(h, 64);
     if (rc) return rc;
@@ -234,14 +255,22 @@ extern "C" int bbh_allgather_argmax(bbh_handle* h, const double* scores_dev, int
     BBH_HIP_TRY(h, hipMemcpyAsync(di, &none, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
-  hipLaunchKernelGGL(bbh_pack_winner_kernel, dim3(1), dim3(64), 0, h->stream, dv, di, row_offset, X_dev, ldx, d, st->d_send);
+  if (local_rc)
+    hipLaunchKernelGGL(bbh_pack_failed_kernel, dim3(1), dim3(256), 0, h->stream, st->d_send, (int64_t)2);
+  else
+    hipLaunchKernelGGL(bbh_pack_winner_kernel, dim3(1), dim3(64), 0, h->stream, dv, di, row_offset, X_dev, ldx, d, st->d_send);
   std::vector<double> host;
   rc = gather(h, st, (size_t)2 + d, host);
   if (rc) return rc;
+  for (int r = 0; r < st->world; r++)
+    if (host[(size_t)r * (2 + d) + 1] == -2.0) {
+      h->err = local_rc ? "bbh_allgather_argmax: local selection failed: " + local_err : "bbh_allgather_argmax: the local selection of another rank failed";
+      return -10;
+    }
   int best = -1;
   for (int r = 0; r < st->world; r++) {
     const double v = host[(size_t)r * (2 + d)], gi = host[(size_t)r * (2 + d) + 1];
-    if (gi < 0.0 || v != v) continue;
+    if (gi < 0.0 || v != v || !(v > -INFINITY)) continue;  // padding, NaN, a shard whose candidates are all dead
     if (best < 0 || v > host[(size_t)best * (2 + d)] ||
         (v == host[(size_t)best * (2 + d)] && gi < host[(size_t)best * (2 + d) + 1]))
       best = r;

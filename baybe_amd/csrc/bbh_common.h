@@ -196,6 +196,10 @@ struct bbh_handle {
   bool potrf_register_form = false;  // env BBH_POTRF_REG=1: 64x64 diagonal blocks by the one-wave register kernel (A/B)
   int coop_mode = 1;              // env BBH_COOP: 0 never use the cooperative form, 1 where it pays (default), 2 wherever instantiated
   bool coop_ready = false;        // operand slices of the cooperative form are packed for the current factorisation
+  bool coopg_ready = false;       // ... of the cooperative form with the generic production (composite / RQ / piecewise models, bbh_coopg.h)
+  double* d_trainfrag_f = nullptr;  // [F][nb + 1][kd][64] per-factor training fragments (coopg)
+  double* d_sclofs_f = nullptr;     // [F][2][dn] per-factor candidate scale / offset (coopg)
+  int64_t tf_f_elems = 0;
   bool coop2_ready = false;       // ... of the two-sweep cooperative form (512 < n <= 1024; shares d_rstream / coop_g0)
   double* d_rstream = nullptr;    // [4 waves][rstream_frags][64]
   int64_t rstream_frags = 0;

@@ -1,0 +1,241 @@
+// Cooperative form of the fused posterior kernel with a GENERIC kernel-value production: composite kernels (ProductKernel /
+// AdditiveKernel of up to four stationary ARD factors, baybe/kernels/composite.py:60-91) and the single kernels that have no
+// software-pipelined instantiation (rational quadratic, piecewise polynomial; baybe/kernels/basic.py:115-131,203-216), n <= 512.
+//
+// These models used to take the materialised-K* path for every posterior-shaped call: [K(X*, X)] written to and re-read
+// from HBM per 16384-candidate chunk (8 n bytes per candidate and pass, ~47 x the algorithmic traffic), an elementwise
+// kernel on libm sqrt / exp, a plain (not triangular) GEMM and an epilogue - 23.5 ms per 1e6 candidates at n = 512 against
+// 4.7 ms for the fused single-kernel form.  Here the structure of bbh_coop.h is kept - one workgroup per 16 candidates, the
+// column blocks of L^-T dealt to the four waves, every kernel value computed once per tile by the wave whose turn it is and
+// handed to the others through LDS - and only the production differs: per factor one distance GEMM against that factor's own
+// training fragments (its lengthscales) and candidate fragments, one evaluation of that factor's kernel function (the staged
+// rsq / minimax sequences of bbh_fused.h for Matérn-5/2, -3/2 and RBF; libm for the others), then the product / sum, the
+// per-factor scales and the task / outputscale table.  The production is NOT interleaved with the variance MFMAs (it runs as a
+// block at the start of a group, before the wave touches its operand ring), so a wave's fp64 pipe idles through the
+// dependency chains of one production per group; the other waves of the SIMD fill them.
+#pragma once
+#include "bbh_coop.h"
+
+struct CoopGArgs {
+  CoopArgs c;
+  int F, combine, has_tbl, jb;
+  int kind[BBH_MAX_FACTORS];
+  double fos[BBH_MAX_FACTORS];    // per-factor scales (1 for a single kernel)
+  double alpha[BBH_MAX_FACTORS];  // RQ alpha per factor
+  const double* trainfrag_f;      // [F][nb + 1][KD][64]
+  int64_t tf_stride;              // doubles per factor
+  const double* sclofs_f;         // [F][2][dn]
+  double prior_k0;                // k(x, x) without the table / outputscale: prod_f fos_f or sum_f fos_f
+};
+
+// one k-block's kernel values (4 per lane) for all factors, combined
+template <int KD, int F>
+__device__ __forceinline__ void coopg_produce(const CoopGArgs& g, const WaveCtx& c, const double (&cf)[F][KD], int tb,
+                                              double (&out)[4]) {
+  double acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = g.combine ? 0.0 : 1.0;
+  bool pad[4] = {false, false, false, false};
+#pragma unroll
+  for (int f = 0; f < F; f++) {
+    double tfv[KD];
+    kvp_load<KD>(g.trainfrag_f + (int64_t)f * g.tf_stride + c.l, tb, tfv);
+    d4 da = {0.0, 0.0, 0.0, 0.0}, db = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < KD; k += 2) {
+      da = mfma_f64(tfv[k], cf[f][k], da);
+      if (k + 1 < KD) db = mfma_f64(tfv[k + 1], cf[f][k + 1], db);
+    }
+    double kv[4];
+    const int kind = g.kind[f];  // wave-uniform
+    if (kind == BBH_KERNEL_MATERN52) {
+      kv_all<0>(c, tb, da, db, kv);
+    } else if (kind == BBH_KERNEL_RBF) {
+      kv_all<2>(c, tb, da, db, kv);
+    } else if (kind == BBH_KERNEL_MATERN32) {
+      kv_all<4>(c, tb, da, db, kv);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double r2 = fmax(da[r] + db[r], 0.0);
+        if (kind == BBH_KERNEL_RQ)
+          kv[r] = exp(-g.alpha[f] * log1p(r2 / (2.0 * g.alpha[f])));
+        else
+          kv[r] = bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, g.jb, r2, false);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (f == 0) pad[r] = (da[r] + db[r]) > 1e7;  // padding rows carry |a|^2 = 1e8: exactly 0 for every kernel kind
+      const double u = g.fos[f] * kv[r];
+      acc[r] = g.combine ? acc[r] + u : acc[r] * u;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double v = pad[r] ? 0.0 : acc[r];
+    if (g.has_tbl) v *= c.tbl[c.tc * c.T + c.taskext[16 * tb + 4 * r + c.q]];
+    out[r] = v;
+  }
+}
+
+template <int KD, int F>
+__global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopGArgs g) {
+  const CoopArgs& ca = g.c;
+  const FusedArgs& a = ca.f;
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];  // alpha [16 nb] | kv [2][4][256] | red [2][4][16]
+  const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cnd = l & 15, q = l >> 4;
+  double* s_alpha = s_mem;
+  double* s_kv = s_alpha + 16 * a.nb;
+  double* s_red = s_kv + BBH_COOP_KV_TILE;
+  const int64_t tile0 = (int64_t)blockIdx.x * 16;
+
+  // candidate fragments per factor: b = x * scl_f + ofs_f, augmented with [1, |b|^2]
+  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
+  const double* xr = a.X + row * a.ldx;
+  double xval[KD];
+#pragma unroll
+  for (int k = 0; k < KD; k++) {
+    const int dimc = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
+    xval[k] = xr[a.numcol_identity ? dimc : a.numcol[dimc]];
+  }
+  for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
+  double cf[F][KD];
+#pragma unroll
+  for (int f = 0; f < F; f++) {
+    const double* scl = g.sclofs_f + (int64_t)f * 2 * a.dn;
+    const double* ofs = scl + a.dn;
+    double nbsum = 0.0;
+#pragma unroll
+    for (int k = 0; k < KD; k++) {
+      const int dim = 4 * k + q;
+      double v = 0.0;
+      if (dim < a.dn) {
+        v = fma(xval[k], scl[dim], ofs[dim]);
+        nbsum = fma(v, v, nbsum);
+      }
+      cf[f][k] = v;
+    }
+    nbsum += __shfl_xor(nbsum, 16, 64);
+    nbsum += __shfl_xor(nbsum, 32, 64);
+#pragma unroll
+    for (int k = 0; k < KD; k++) {
+      if (4 * k + q == a.dn) cf[f][k] = 1.0;
+      if (4 * k + q == a.dn + 1) cf[f][k] = nbsum;
+    }
+  }
+  int tc = 0;
+  if (g.has_tbl && a.task_col >= 0) {
+    tc = (int)xr[a.task_col];
+    tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+  }
+  WaveCtx c[1];
+  c[0].tf = a.trainfrag + l;
+  c[0].candl = nullptr;
+  c[0].mb = nullptr;
+  c[0].tbl = a.tasktbl;
+  c[0].taskext = a.taskext;
+  c[0].kvc = nullptr;
+  c[0].kvl = (bbh_lds_double*)nullptr;
+  c[0].nl = 0;
+  c[0].ncache = 0;
+  c[0].al = (const bbh_lds_double*)nullptr;
+  c[0].kd = KD;
+  c[0].kind = a.kind;
+  c[0].T = a.T;
+  c[0].tc = tc;
+  c[0].q = q;
+  c[0].l = l;
+  c[0].dn = a.dn;
+
+  bbh_lds_double* kvb = (bbh_lds_double*)(s_kv + l);
+  const bbh_lds_double* alq = (const bbh_lds_double*)(s_alpha + q);
+  const int g0 = ca.g0;
+  double accm[1] = {0.0};
+  d4 acc[1][BBH_COOP_ROUNDS];
+#pragma unroll
+  for (int s = 0; s < BBH_COOP_ROUNDS; s++) acc[0][s] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* rs = ca.rstream + (int64_t)w * ca.frags * 64;
+  d2 ring[BBH_COOP_PAIRS];
+  static_for<0, BBH_COOP_PAIRS>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, (unsigned)l * 16u);
+  });
+  {  // the first group's kernel values: wave w produces k-block w
+    double kv0[4];
+    coopg_produce<KD, F>(g, c[0], cf, w, kv0);
+    __syncthreads();  // alpha is in LDS
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      kvb[((g0 & 1) * 4 + w) * 256 + r * 64] = kv0[r];
+      accm[0] = fma(kv0[r], alq[16 * w + 4 * r], accm[0]);
+    }
+  }
+  __syncthreads();
+
+  static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+    if (G >= g0) {  // wave-uniform
+      const int cw = (G & 1) ? 3 - w : w;
+      if constexpr (G + 1 < BBH_COOP_ROUNDS) {  // produce k-block tbn for the next group first: its loads and its dependency
+        const int tbn = 4 * (G + 1 - g0) + w;   // chains are out of the way before the counted waits of the operand ring begin
+        double kvn[4];
+        coopg_produce<KD, F>(g, c[0], cf, tbn, kvn);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          kvb[(((G + 1) & 1) * 4 + w) * 256 + r * 64] = kvn[r];
+          accm[0] = fma(kvn[r], alq[16 * tbn + 4 * r], accm[0]);
+        }
+      }
+      coop_group<G, KD, 0, false, 1>(c, rs, nullptr, kvb + (G & 1) * 4 * 256, nullptr, nullptr, 0, cw, acc, ring, accm);
+      rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
+      if constexpr (G + 1 < BBH_COOP_ROUNDS) __syncthreads();
+    }
+  });
+
+  double ss[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < BBH_COOP_ROUNDS; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) ss[r] = fma(acc[0][s][r], acc[0][s][r], ss[r]);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double v = ss[r];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    ss[r] = v;
+  }
+  double mp = accm[0];
+  mp += __shfl_xor(mp, 16, 64);
+  mp += __shfl_xor(mp, 32, 64);
+  double* red_v = s_red;
+  double* red_m = red_v + 64;
+  if (cnd == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) red_v[w * 16 + q + 4 * r] = ss[r];
+  }
+  if (q == 0) red_m[w * 16 + cnd] = mp;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int m = threadIdx.x;
+    const int64_t gidx = tile0 + m;
+    const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
+    const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
+    double pv = a.prior_scale * g.prior_k0, mc = a.mean_const;
+    if (g.has_tbl) {
+      pv = a.tasktbl[tc * a.T + tc] * g.prior_k0;
+      if (a.taskmean) mc = a.taskmean[tc];
+    }
+    if (gidx < a.N) {
+      if (a.mean) a.mean[gidx] = a.ybar + a.ysd * (mc + sm);
+      if (a.var) a.var[gidx] = a.ysd * a.ysd * (pv - sv);
+    }
+  }
+}
+
+// Instantiations (bbh_fused_coopg.hip): 2, 4, 6, 8 k-steps of the distance GEMM (d <= 30), 1 - 4 factors.
+// false: no instantiation for this model; grid.x == 0 only asks.
+bool bbh_coopg_launch(int kd, int F, dim3 grid, size_t lds, hipStream_t s, const CoopGArgs& a);

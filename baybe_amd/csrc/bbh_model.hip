@@ -339,7 +339,7 @@ static void bbh_free_model(bbh_handle* h) {
   void* ptrs[] = {h->d_xnT,   h->d_task,    h->d_ystd,      h->d_theta, h->d_K,     h->d_X,       h->d_M,
                   h->d_Q,     h->d_Q2,      h->d_D,         h->d_tmp,   h->d_r,     h->d_t,       h->d_alpha,
                   h->d_u,     h->d_w,       h->d_q,         h->d_partial, h->d_out, h->d_info,    h->d_trainfrag,
-                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag, h->d_pendT, h->d_colA, h->d_Mpart};
+                  h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag, h->d_pendT, h->d_colA, h->d_Mpart, h->d_trainfrag_f, h->d_sclofs_f};
   for (void* p : ptrs)
     if (p) hipFree(p);
   h->d_xnT = h->d_ystd = h->d_theta = h->d_K = h->d_X = h->d_M = h->d_Q = h->d_Q2 = h->d_D = h->d_tmp = nullptr;
@@ -349,6 +349,9 @@ static void bbh_free_model(bbh_handle* h) {
   h->d_pass_off = nullptr;
   h->d_nmask = nullptr;
   h->d_pendT = h->d_colA = h->d_Mpart = nullptr;
+  h->d_trainfrag_f = h->d_sclofs_f = nullptr;
+  h->tf_f_elems = 0;
+  h->coopg_ready = false;
   h->colA_elems = 0;
   if (h->fit_exec) hipGraphExecDestroy(h->fit_exec);
   h->fit_exec = nullptr;

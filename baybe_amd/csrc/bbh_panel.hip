@@ -28,6 +28,7 @@
 // passes.  K(X*,X) is never materialised.  Device code: bbh_fused.h (instantiated per k-step count in
 // bbh_fused_kd{0,2,4,6,8,12,16}.hip); this file holds operand packing, launch logic and the related kernels.
 #include "bbh_coop2.h"
+#include "bbh_coopg.h"
 
 // ---- operand packing ------------------------------------------------------------------------
 // R fragments of one pass: for tb in [0, j1), r in 0..3, jb in [max(j0, tb), j1):
@@ -152,9 +153,9 @@ __global__ void bbh_set_beta_kernel(const double* __restrict__ betaT, int64_t ld
 // pts: normalised numerical coordinates [cnt, dn] of the real points in this range (row 0 is
 // point index 16 tb0); anything beyond cnt is padding (huge distance -> kernel value 0).
 static void host_pack_trainfrag(const bbh_handle* h, const double* pts, int64_t cnt, int64_t tb0, int64_t tb1,
-                                std::vector<double>& out) {
+                                std::vector<double>& out, const double* ls = nullptr) {
   const int dn = h->dn, kd = h->kd;
-  const double* ls = h->theta.data() + 3;
+  if (!ls) ls = h->theta.data() + 3;
   out.assign((size_t)(tb1 - tb0) * kd * 64, 0.0);
   std::vector<double> a(dn);
   for (int64_t tb = tb0; tb < tb1; tb++)
@@ -184,6 +185,18 @@ static void host_pack_trainfrag(const bbh_handle* h, const double* pts, int64_t 
           out[((size_t)(tb - tb0) * kd + k) * 64 + qq * 16 + c16] = v;
         }
     }
+}
+
+// Models the generic-production cooperative kernel covers: everything bbh_materialised_only() sends to the materialised-K*
+// path whose factors are Matérn-5/2, -3/2, RBF, rational quadratic or piecewise polynomial (Matérn-1/2 needs the
+// direct-difference distances near r = 0 and keeps that path), n <= 512, d <= 30.
+static bool bbh_coopg_model(const bbh_handle* h) {
+  if (!bbh_materialised_only(h) || h->coop_mode <= 0 || !h->use_pipeline) return false;
+  if (h->nb > 4 * BBH_COOP_ROUNDS || h->nb % 4 != 0 || h->nb > 256) return false;
+  const bbh_kern_spec ks = bbh_kern_spec_of(h);
+  for (int f = 0; f < ks.F; f++)
+    if (ks.kind[f] == BBH_KERNEL_MATERN12) return false;
+  return bbh_coopg_launch(h->kd, ks.F, dim3(0), 0, nullptr, CoopGArgs{});
 }
 
 int bbh_pack_operands(bbh_handle* h) {
@@ -267,6 +280,47 @@ int bbh_pack_operands(bbh_handle* h) {
       h->coop_ready = true;
     }
   }
+  // ---- generic-production cooperative form: the same operand slices, per-factor training fragments and candidate scaling ----
+  h->coopg_ready = false;
+  if (bbh_coopg_model(h)) {
+    const bbh_kern_spec ks = bbh_kern_spec_of(h);
+    const int g0 = BBH_COOP_ROUNDS - (int)(nb / 4);
+    const int64_t frags = coop_frags_before(BBH_COOP_ROUNDS) - coop_frags_before(g0);
+    if (!h->d_rstream || h->rstream_frags != frags) {
+      if (h->d_rstream) hipFree(h->d_rstream);
+      h->d_rstream = nullptr;
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rstream, sizeof(double) * 4 * frags * 64));
+      h->rstream_frags = frags;
+    }
+    hipLaunchKernelGGL(bbh_pack_coop_kernel, dim3(16, (unsigned)(BBH_COOP_ROUNDS - g0), 4), dim3(64), 0, s, h->d_X, np, g0, frags,
+                       h->d_rstream);
+    h->coop_g0 = g0;
+    const int64_t per = (nb + 1) * (int64_t)kd * 64;
+    if (!h->d_trainfrag_f || h->tf_f_elems != per * ks.F) {
+      if (h->d_trainfrag_f) hipFree(h->d_trainfrag_f);
+      if (h->d_sclofs_f) hipFree(h->d_sclofs_f);
+      h->d_trainfrag_f = h->d_sclofs_f = nullptr;
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_trainfrag_f, sizeof(double) * per * ks.F));
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_sclofs_f, sizeof(double) * 2 * dn * BBH_MAX_FACTORS));
+      h->tf_f_elems = per * ks.F;
+    }
+    std::vector<double> tff, sof((size_t)2 * dn * ks.F);
+    for (int f = 0; f < ks.F; f++) {
+      const double* ls = th + ks.ls_off[f];
+      std::vector<double> one;
+      host_pack_trainfrag(h, h->xn_host.data(), h->n, 0, nb + 1, one, ls);
+      tff.insert(tff.end(), one.begin(), one.end());
+      for (int j = 0; j < dn; j++) {
+        const double rng = h->hi[j] - h->lo[j];
+        sof[(size_t)f * 2 * dn + j] = 1.0 / (rng * ls[j]);
+        sof[(size_t)f * 2 * dn + dn + j] = -(h->lo[j] / rng + h->xcenter[j]) / ls[j];
+      }
+    }
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag_f, tff.data(), sizeof(double) * tff.size(), hipMemcpyHostToDevice, s));
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_sclofs_f, sof.data(), sizeof(double) * sof.size(), hipMemcpyHostToDevice, s));
+    BBH_HIP_TRY(h, hipStreamSynchronize(s));  // the staging vectors go out of scope
+    h->coopg_ready = true;
+  }
   // ---- operand slices of the two-sweep cooperative form (512 < n <= 1024) ----
   h->coop2_ready = false;
   {
@@ -319,7 +373,10 @@ int bbh_pack_operands(bbh_handle* h) {
 int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                      double* cross_dev, bool with_var) {
   if (N <= 0) return 0;
-  if (bbh_materialised_only(h))  // composite / piecewise kernels: materialised-K* path (fused qLogEI: applied by the caller)
+  // composite / RQ / piecewise kernels: the cooperative form with the generic production for variance passes without pending
+  // columns (bbh_coopg.h), otherwise the materialised-K* path (fused qLogEI: applied by the caller)
+  const bool coopg = h->coopg_ready && with_var && h->p == 0 && !cross_dev && !h->fuse_qz && h->use_mean_valu;
+  if (bbh_materialised_only(h) && !coopg)
     return bbh_launch_unfused_ext(h, X_dev, N, ldx, mean_dev, with_var ? var_dev : nullptr, cross_dev);
   FusedArgs a;
   a.X = X_dev;
@@ -427,6 +484,35 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     a.slab_flags = h->d_slab_flags;
   }
   bbh_timed_scope timed(h, with_var ? BBH_TIMED_POSTERIOR : BBH_TIMED_CROSS);
+  if (coopg) {
+    const bbh_kern_spec ks = bbh_kern_spec_of(h);
+    const double* th = h->theta.data();
+    CoopGArgs g;
+    g.c.f = a;
+    g.c.f.mean_valu = 1;
+    g.c.rstream = h->d_rstream;
+    g.c.frags = h->rstream_frags;
+    g.c.g0 = h->coop_g0;
+    g.F = ks.F;
+    g.combine = ks.combine;
+    g.has_tbl = has_tbl ? 1 : 0;
+    g.jb = ks.jb;
+    g.prior_k0 = (ks.F > 1 && ks.combine) ? 0.0 : 1.0;
+    for (int f = 0; f < BBH_MAX_FACTORS; f++) {
+      g.kind[f] = ks.kind[f < ks.F ? f : 0];
+      g.fos[f] = (ks.F > 1 && f < ks.F) ? th[ks.fos_off + f] : 1.0;
+      g.alpha[f] = (ks.alpha_off >= 0 && f < ks.F) ? th[ks.alpha_off + f] : 1.0;
+      if (ks.F > 1 && f < ks.F) g.prior_k0 = ks.combine ? g.prior_k0 + g.fos[f] : g.prior_k0 * g.fos[f];
+    }
+    g.trainfrag_f = h->d_trainfrag_f;
+    g.tf_stride = (h->nb + 1) * (int64_t)h->kd * 64;
+    g.sclofs_f = h->d_sclofs_f;
+    const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (2 * 4 * 256 + 128));
+    bbh_coopg_launch(h->kd, ks.F, dim3((unsigned)((N + 15) / 16)), clds, h->stream, g);
+    h->last_form = 4;
+    BBH_HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
   // Cooperative form (n <= 512, variance pass without pending columns): ahead of the windowed form once a second
   // 16-block window would be needed (n > 256: 4.70 vs 5.17 ms on the bench shape), level at n = 256, a few per cent behind
   // below; for small candidate sets its four waves per tile cut the latency to a third (0.016 vs 0.052 ms for 1000 rows).

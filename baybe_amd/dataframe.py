@@ -48,6 +48,17 @@ def _split_columns(parameters):
     return cat, num
 
 
+def _numeric_values(df: pd.DataFrame, col: str) -> np.ndarray:
+    """Column of a numerical parameter as float64 - the ``normalize_input_dtypes`` step of the reference
+    (``utils/dataframe.py:418-419, 745-795``): integer columns are converted silently, anything else that is not already float
+    (strings read back from a CSV, objects) with the reference's warning.  Categorical columns are compared as they are, in
+    the reference as here."""
+    ser = df[col]
+    if not pd.api.types.is_float_dtype(ser) and not pd.api.types.is_integer_dtype(ser):
+        warnings.warn(f"The following columns have unexpected data types: {[col]}. Converting to float internally.", UserWarning)
+    return np.asarray(ser, dtype=np.float64)
+
+
 class FuzzyRowMatcher:
     """Index over the rows of ``left_df`` for repeated ``fuzzy_row_match`` calls with the same parameters."""
 
@@ -68,7 +79,7 @@ class FuzzyRowMatcher:
         self._mult = (np.random.default_rng(0x5EED).integers(1, 2**63, size=len(cols), dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
         keys = np.zeros(len(left_df), dtype=np.uint64)
         for ci, col in enumerate(cols):
-            values = np.asarray(left_df[col], dtype=np.float64) if col in self.num_cols else np.asarray(left_df[col])
+            values = _numeric_values(left_df, col) if col in self.num_cols else np.asarray(left_df[col])
             levels, codes = np.unique(values, return_inverse=True)  # sorted levels: nearest-value search for numbers
             self.levels[col] = levels
             self._codes[:, ci] = codes
@@ -102,7 +113,7 @@ class FuzzyRowMatcher:
                 f"dataframe. Parameters not found: {diff})"
             )
         cols = self.cat_cols + self.num_cols
-        per_col = [self._codes_for(c, right_df[c].to_numpy()) for c in cols]
+        per_col = [self._codes_for(c, _numeric_values(right_df, c) if c in self.num_cols else right_df[c].to_numpy()) for c in cols]
         matched, multiple = [], []
         for r in range(len(right_df)):
             options = [per_col[ci][r] for ci in range(len(cols))]

@@ -101,3 +101,25 @@ def test_frame_content_hash_sees_every_edit_without_materialising_the_frame():
     mixed = pd.DataFrame({"a": [1.0, 2.0], "b": ["u", "v"]})
     assert _frame_content_hash(mixed) == _frame_content_hash(mixed.copy()) != _frame_content_hash(mixed.assign(b=["u", "w"]))
     assert isinstance(_frame_content_hash(pd.DataFrame(index=range(3))), int)
+
+
+def test_numerical_columns_are_normalised_to_float_like_the_reference():
+    """``normalize_input_dtypes`` (utils/dataframe.py:418-419, 745-795): a numerical column that arrives as integers or as
+    strings (read back from a CSV) still matches; non-integer dtypes raise the reference's warning."""
+    import warnings
+
+    from baybe_amd.dataframe import fuzzy_row_match
+
+    class P:
+        def __init__(self, name, num):
+            self.name, self.is_numerical, self.is_discrete = name, num, True
+
+    left = pd.DataFrame({"x": [0.0, 1.0, 2.0, 0.0, 1.0, 2.0], "c": ["a", "a", "a", "b", "b", "b"]})
+    params = [P("x", True), P("c", False)]
+    as_int = pd.DataFrame({"x": [2, 0], "c": ["b", "a"]})
+    assert list(fuzzy_row_match(left, as_int, params)) == [5, 0]
+    as_str = pd.DataFrame({"x": ["1", "2.0"], "c": ["a", "b"]})
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert list(fuzzy_row_match(left, as_str, params)) == [1, 5]
+    assert any("unexpected data types" in str(w.message) for w in rec)
