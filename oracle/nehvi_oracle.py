@@ -173,6 +173,12 @@ def logmeanexp_with_neginf(v: np.ndarray) -> float:
     return float(M + np.log(np.exp(v - M).mean()))
 
 
+def _solve_lower(L: np.ndarray, b: np.ndarray) -> np.ndarray:
+    import scipy.linalg as sla
+
+    return sla.solve_triangular(L, b, lower=True)
+
+
 # ---- the acquisition -----------------------------------------------------------------------------------
 class NEHVIOracle:
     """qLogNEHVI over m independent GPs (``go.GPModel``), q = 1 t-batches."""
@@ -196,13 +202,29 @@ class NEHVIOracle:
         self.cells = [nondominated_cells(self.obj_b[s], self.ref) for s in range(S)]
 
     def candidate_samples(self, x: np.ndarray) -> np.ndarray:
-        """f(x)_s [S, m]: joint draw with the baseline through the (n_b+1) Cholesky factor."""
+        """f(x)_s [S, m]: joint draw with the baseline through the CACHED baseline factor, as BoTorch's
+        ``sample_cached_cholesky`` (botorch/utils/low_rank.py) does it [UPSTREAM]: with the joint posterior covariance of
+        [X_b; x] partitioned into the baseline block (factor L_b, cached when the acquisition function is built), the
+        cross block c and the candidate's variance v,
+
+            l = L_b^-1 c,   s = psd_safe_cholesky(v - l.l)  (1 x 1: jitter 1e-8, 1e-7, 1e-6 when it is not positive),
+            f(x) = mu_x + z_b . l + s z_x.
+
+        The jitter therefore only ever touches the candidate's conditional variance - a candidate that coincides with a
+        baseline point is drawn as that point's sampled value plus sqrt(1e-8) z_x - and never the baseline factor (an
+        earlier version of this oracle re-factorised the whole (n_b + 1) matrix with diagonal jitter, which moves such a
+        candidate's tail value: sqrt(2e-8) instead of sqrt(1e-8))."""
         S, _, m = self.z.shape
         out = np.empty((S, m))
         for o, mod in enumerate(self.models):
             mu, cov = mod.posterior_joint(np.vstack([self.Xb, np.atleast_2d(x)]))
-            L = go._safe_cholesky(cov)
-            out[:, o] = mu[-1] + self.z[:, :, o] @ L[-1, :]
+            nb = len(self.Xb)
+            if nb:
+                l = _solve_lower(self.L_b[o], cov[:nb, -1])
+            else:
+                l = np.zeros(0)
+            sd = go._safe_sqrt_var(np.array([cov[-1, -1] - l @ l]))[0]
+            out[:, o] = mu[-1] + self.z[:, :nb, o] @ l + sd * self.z[:, nb, o]
         return out
 
     def value(self, x: np.ndarray) -> float:

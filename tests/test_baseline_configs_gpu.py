@@ -2,8 +2,8 @@
 scripts that printed).  The oracle is the checker: live on samples / slices it finishes in seconds, and through
 tests/golden/cfg2_full_ranking.npz, for which it ranked ALL 1e5 rows offline (make_golden_full_ranking.py).
 
-Tolerances: posterior 1e-9 / 1e-8 relative, qLogEI scores 1e-8 absolute, qLogNEHVI scores 2e-5 absolute (log of a
-sum over boxes of products of smoothed side lengths; BoTorch's own fat-tail constants), indices identical."""
+Tolerances: posterior 1e-9 / 1e-8 relative, qLogEI and qLogNEHVI scores 1e-8 absolute (round 2 held qLogNEHVI to 2e-5 without a
+reason: the observed deviations are ~1e-10, recorded in profiles/r03_observed_deviations.json), indices identical."""
 
 import math
 import os
@@ -83,11 +83,17 @@ def test_cfg3_full_set_ranking_matches_the_oracle():
     assert float(g["min_gap_top16"]) > 1e-6  # the head of the ranking is not a numerical coin toss
     vals, idx = gp.topk(torch.from_numpy(s).cuda(), 16)
     assert np.array_equal(idx, g["top_idx"][:16]) and np.allclose(vals, g["top_val"][:16], rtol=0, atol=1e-8)
+    from conftest import record_deviation
+
+    record_deviation("cfg3_qlogei_scores_every_256th_of_1e6", np.abs(s[::256] - g["sample_scores"]).max(), 1e-8)
+    record_deviation("cfg3_posterior_mean_rel", (np.abs(_np(m)[rows] - g["post_mean"]) / np.abs(g["post_mean"])).max(), 1e-9)
+    record_deviation("cfg3_posterior_var_rel", (np.abs(_np(v)[rows] - g["post_var"]) / g["post_var"]).max(), 1e-8)
     assert np.allclose(s[::256], g["sample_scores"], rtol=0, atol=1e-8)
     assert math.isclose(float(s.sum()), float(g["score_sum"]), rel_tol=1e-10)
     assert math.isclose(float(np.abs(s).sum()), float(g["score_abs_sum"]), rel_tol=1e-10)
     res = gp.greedy_qlogei(Xd, q, seed=seed)
     assert res.indices == g["greedy_idx"].tolist()
+    record_deviation("cfg3_greedy_q5_values", np.abs(np.array(res.values) - g["greedy_val"]).max(), 1e-8)
     assert np.allclose(res.values, g["greedy_val"], rtol=0, atol=1e-8)
     gp.close()
 
@@ -315,12 +321,19 @@ def test_cfg5_qlognehvi_scores_at_full_size(cfg5, S):
     orc = no.NEHVIOracle(models, signs, Xt[keep], ref, no.sobol_normal_base_samples_nd(S, len(keep) + 1, m, seed))
     assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)  # same box decompositions, sample by sample
     top = np.argsort(-sg, kind="stable")[:12]
-    pick = np.concatenate([np.random.default_rng(S).choice(N, 500, replace=False), top])
+    # 500 random rows, the head of the device's ranking, and grid rows that ARE baseline points (singular joint covariance: the
+    # candidate's conditional variance gets the 1 x 1 jitter rule, oracle and device alike)
+    base_rows = np.array([int(np.nonzero((np.abs(X - xb).sum(1) < 1e-12))[0][0]) for xb in Xt[keep][:8]])
+    pick = np.concatenate([np.random.default_rng(S).choice(N, 500, replace=False), top, base_rows])
     so = orc.values(X[pick])
-    dup = np.array([(np.abs(Xt - x).sum(1) < 1e-12).any() for x in X[pick]])  # training rows are part of the grid
-    assert np.allclose(sg[pick][~dup], so[~dup], rtol=0, atol=2e-5), np.abs(sg[pick] - so)[~dup].max()
+    from conftest import record_deviation
+
+    dev = np.abs(sg[pick] - so)
+    record_deviation(f"qlognehvi_scores_cfg5[S={S}]", dev.max(), 1e-8)
+    record_deviation(f"qlognehvi_scores_cfg5_duplicate_rows[S={S}]", dev[-len(base_rows):].max(), 1e-8)
+    assert np.allclose(sg[pick], so, rtol=0, atol=1e-8), dev.max()
     # among the sample and the head of the device's ranking, oracle and device agree on the best row
-    assert int(np.argmax(so[~dup])) == int(np.argmax(sg[pick][~dup]))
+    assert int(np.argmax(so)) == int(np.argmax(sg[pick]))
 
 
 def test_cfg5_greedy_pair_matches_the_oracle(cfg5):
@@ -347,7 +360,7 @@ def test_cfg5_greedy_pair_matches_the_oracle(cfg5):
         picks.append(int(np.argmax(v)))
         vals.append(v[picks[-1]])
         alive[picks[-1]] = False
-    assert res.indices == picks and np.allclose(res.values, vals, rtol=0, atol=2e-5)
+    assert res.indices == picks and np.allclose(res.values, vals, rtol=0, atol=1e-8)
     # full set: two distinct rows, each at least as good as the slice's pick of the same step
     full = hv.greedy(Xd, 2, seed=seed, prune_seed=pseed)
     assert len(set(full.indices)) == 2 and full.values[0] >= res.values[0] - 1e-12

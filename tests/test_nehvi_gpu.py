@@ -9,6 +9,7 @@ import pytest
 from _problems import make_grid
 
 pytestmark = pytest.mark.gpu
+NEHVI_ATOL = 1e-8  # qLogNEHVI scores, absolute (the tolerance of the qLogEI scores)
 
 
 def _targets(X, rng, noise=0.05):
@@ -55,13 +56,20 @@ def test_scores_match_oracle(m, signs):
     z = no.sobol_normal_base_samples_nd(S, len(Xt) + 1, m, seed)
     orc = no.NEHVIOracle(models, signs, Xt, ref, z)
     so = orc.values(X[:60])
-    # candidates coinciding with a baseline point have a singular joint covariance: BoTorch (and the
-    # oracle) jitter the whole (n_b+1) matrix, the device jitters the conditional variance; both give
-    # "no improvement" (deep fat tail), but not the same tail value -> compared loosely.
+    # Candidates coinciding with a baseline point have a singular joint covariance.  BoTorch draws them through the cached
+    # baseline factor (sample_cached_cholesky): only the candidate's 1 x 1 conditional variance gets psd_safe_cholesky's
+    # jitter - the oracle restates that, the device applies the same rule (bbh_safe_sd), so they are compared like every
+    # other row.  Round 2 held this comparison to 2e-5 and excluded the duplicates; the samples agree to 1e-14 and the
+    # scores to ~3e-10 (single-precision logarithms under the power tau_max = 0.01, bbh_qlognehvi_lin_kernel).
+    from conftest import record_deviation
+
     dup = np.array([(np.abs(Xt - x).sum(1) < 1e-12).any() for x in X[:60]])
-    print("max |diff| regular", np.abs(sg[:60] - so)[~dup].max(), "duplicates", int(dup.sum()))
-    assert np.allclose(sg[:60][~dup], so[~dup], rtol=0, atol=2e-5), np.abs(sg[:60] - so)[~dup].max()
-    assert (sg[:60][dup] < so[~dup].max() - 5).all() and (so[dup] < so[~dup].max() - 5).all()
+    dev = np.abs(sg[:60] - so)
+    record_deviation(f"qlognehvi_scores_small[m={m},signs={'mixed' if (signs < 0).any() else 'max'}]", dev.max(), NEHVI_ATOL)
+    record_deviation(f"qlognehvi_scores_small_duplicate_rows[m={m},signs={'mixed' if (signs < 0).any() else 'max'}]", dev[dup].max() if dup.any() else 0.0, NEHVI_ATOL)
+    assert dup.sum() >= 1
+    assert np.allclose(sg[:60], so, rtol=0, atol=NEHVI_ATOL), dev.max()
+    assert (sg[:60][dup] < so[~dup].max() - 5).all()  # "no improvement": deep in the fat tail
     assert int(np.argmax(sg[:60])) == int(np.argmax(so))
     # cells on the device side equal the oracle's per-sample decompositions
     assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)
@@ -95,7 +103,7 @@ def test_pruning_and_greedy_match_oracle():
         vals.append(v[i])
         alive[i] = False
     assert res.indices == picks
-    assert np.allclose(res.values, vals, rtol=0, atol=2e-5)
+    assert np.allclose(res.values, vals, rtol=0, atol=NEHVI_ATOL)
 
 
 def test_pareto_recommendation_through_the_plugin_surface():
