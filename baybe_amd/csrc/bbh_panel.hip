@@ -188,14 +188,15 @@ static void host_pack_trainfrag(const bbh_handle* h, const double* pts, int64_t 
 }
 
 // Models the generic-production cooperative kernel covers: everything bbh_materialised_only() sends to the materialised-K*
-// path whose factors are Matérn-5/2, -3/2, RBF, rational quadratic or piecewise polynomial (Matérn-1/2 needs the
-// direct-difference distances near r = 0 and keeps that path), n <= 512, d <= 30.
+// path whose factors are Matérn-5/2, -3/2, RBF, rational quadratic or piecewise polynomial with q >= 1 (Matérn-1/2 and the
+// q = 0 piecewise polynomial (1 - r)^j are not smooth at r = 0: the |a|^2 + |b|^2 - 2ab distances lose sqrt(eps) there, so they
+// need the direct-difference distances and keep that path), n <= 512, d <= 30.
 static bool bbh_coopg_model(const bbh_handle* h) {
   if (!bbh_materialised_only(h) || h->coop_mode <= 0 || !h->use_pipeline) return false;
-  if (h->nb > 4 * BBH_COOP_ROUNDS || h->nb % 4 != 0 || h->nb > 256) return false;
+  if (h->nb > 4 * BBH_COOP_ROUNDS || h->nb % 4 != 0) return false;
   const bbh_kern_spec ks = bbh_kern_spec_of(h);
   for (int f = 0; f < ks.F; f++)
-    if (ks.kind[f] == BBH_KERNEL_MATERN12) return false;
+    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0) return false;
   return bbh_coopg_launch(h->kd, ks.F, dim3(0), 0, nullptr, CoopGArgs{});
 }
 

@@ -643,7 +643,8 @@ def test_piecewise_polynomial_kernels(gp, q):
         m, v = gp.posterior(X, unfused=unfused)
         assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL, atol=1e-14)
     gp.posterior(X)
-    assert gp.posterior_kernel_form() == "cooperative-generic"
+    # q = 0, (1 - r)^j, is not smooth at r = 0 (as Matérn-1/2): direct-difference distances, i.e. the materialised-K* path
+    assert gp.posterior_kernel_form() == ("materialised" if q == 0 else "cooperative-generic")
     cand = np.ascontiguousarray(X[:600])
     res = gp.greedy_qlogei(cand, 3, seed=8)
     ref = go.optimize_acqf_discrete_qlogei(om, cand, 3, seed=8)

@@ -56,20 +56,22 @@ def test_scores_match_oracle(m, signs):
     z = no.sobol_normal_base_samples_nd(S, len(Xt) + 1, m, seed)
     orc = no.NEHVIOracle(models, signs, Xt, ref, z)
     so = orc.values(X[:60])
-    # Candidates coinciding with a baseline point have a singular joint covariance.  BoTorch draws them through the cached
-    # baseline factor (sample_cached_cholesky): only the candidate's 1 x 1 conditional variance gets psd_safe_cholesky's
-    # jitter - the oracle restates that, the device applies the same rule (bbh_safe_sd), so they are compared like every
-    # other row.  Round 2 held this comparison to 2e-5 and excluded the duplicates; the samples agree to 1e-14 and the
-    # scores to ~3e-10 (single-precision logarithms under the power tau_max = 0.01, bbh_qlognehvi_lin_kernel).
+    # Candidates coinciding with a baseline point have a singular joint covariance.  BoTorch draws a candidate through the
+    # cached baseline factor (sample_cached_cholesky): only its 1 x 1 conditional variance goes through psd_safe_cholesky -
+    # the oracle restates that and the device applies the same rule (bbh_safe_sd).  For such a row that variance is rounding
+    # noise around zero (|v| ~ 1e-16), and whether the 1e-8 jitter applies depends on its SIGN - in BoTorch as here - so the
+    # row's value is one of two deep-tail numbers (sd = 1e-4 or ~1e-8) on either side; they are held to "no improvement" (far
+    # below the best value), every other row to 1e-8.  Round 2 held the regular rows to 2e-5 without a reason: the samples
+    # agree to 1e-14, the scores to ~3e-10 (single-precision logarithms under the power tau_max = 0.01 in the cell kernel).
     from conftest import record_deviation
 
     dup = np.array([(np.abs(Xt - x).sum(1) < 1e-12).any() for x in X[:60]])
     dev = np.abs(sg[:60] - so)
-    record_deviation(f"qlognehvi_scores_small[m={m},signs={'mixed' if (signs < 0).any() else 'max'}]", dev.max(), NEHVI_ATOL)
-    record_deviation(f"qlognehvi_scores_small_duplicate_rows[m={m},signs={'mixed' if (signs < 0).any() else 'max'}]", dev[dup].max() if dup.any() else 0.0, NEHVI_ATOL)
+    tag = f"m={m},signs={'mixed' if (signs < 0).any() else 'max'}"
+    record_deviation(f"qlognehvi_scores_small[{tag}]", dev[~dup].max(), NEHVI_ATOL)
     assert dup.sum() >= 1
-    assert np.allclose(sg[:60], so, rtol=0, atol=NEHVI_ATOL), dev.max()
-    assert (sg[:60][dup] < so[~dup].max() - 5).all()  # "no improvement": deep in the fat tail
+    assert np.allclose(sg[:60][~dup], so[~dup], rtol=0, atol=NEHVI_ATOL), dev[~dup].max()
+    assert (sg[:60][dup] < so[~dup].max() - 5).all() and (so[dup] < so[~dup].max() - 5).all()
     assert int(np.argmax(sg[:60])) == int(np.argmax(so))
     # cells on the device side equal the oracle's per-sample decompositions
     assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)
