@@ -2,8 +2,9 @@
 scripts that printed).  The oracle is the checker: live on samples / slices it finishes in seconds, and through
 tests/golden/cfg2_full_ranking.npz, for which it ranked ALL 1e5 rows offline (make_golden_full_ranking.py).
 
-Tolerances: posterior 1e-9 / 1e-8 relative, qLogEI and qLogNEHVI scores 1e-8 absolute (round 2 held qLogNEHVI to 2e-5 without a
-reason: the observed deviations are ~1e-10, recorded in profiles/r03_observed_deviations.json), indices identical."""
+Tolerances: posterior 1e-9 / 1e-8 relative, qLogEI scores 1e-8 absolute, qLogNEHVI scores 1e-6 absolute with the 99 % quantile at
+1e-8 (round 2 held qLogNEHVI to 2e-5 without a reason: see test_cfg5_qlognehvi_scores_at_full_size for where 1e-6 comes from;
+observed deviations are recorded in profiles/r03_observed_deviations.json), indices identical."""
 
 import math
 import os
@@ -331,9 +332,16 @@ def test_cfg5_qlognehvi_scores_at_full_size(cfg5, S):
 
     dup = np.array([(np.abs(Xt[keep] - x).sum(1) < 1e-12).any() for x in X[pick]])
     dev = np.abs(sg[pick] - so)
-    record_deviation(f"qlognehvi_scores_cfg5[S={S}]", dev[~dup].max(), 1e-8)
+    # Tolerance: the smoothing constant tau_relu = 1e-6 makes a score as sensitive as 1 / tau_relu to the sampled value f of a
+    # candidate that lands within ~tau_relu of a cell boundary in a sample that dominates its sum.  Device and oracle agree on
+    # those values to 3.5e-13 (different but equivalent factorisations: extended model vs cached baseline factor,
+    # scripts/gpu_nehvi_probe.py), which bounds the score deviation by 3.5e-7; observed: one row of 1024 at 8.5e-8 (value
+    # -22.8, both cell kernels - linear- and log-domain - agree with each other to 5e-10 there), every other row <= 4e-10.
+    record_deviation(f"qlognehvi_scores_cfg5[S={S}]", dev[~dup].max(), 1e-6)
+    record_deviation(f"qlognehvi_scores_cfg5_median[S={S}]", float(np.median(dev[~dup])), 1e-6)
     assert dup.sum() >= 8
-    assert np.allclose(sg[pick][~dup], so[~dup], rtol=0, atol=1e-8), dev[~dup].max()
+    assert np.allclose(sg[pick][~dup], so[~dup], rtol=0, atol=1e-6), dev[~dup].max()
+    assert np.quantile(dev[~dup], 0.99) <= 1e-8
     assert (sg[pick][dup] < so[~dup].max() - 5).all() and (so[dup] < so[~dup].max() - 5).all()
     # among the sample and the head of the device's ranking, oracle and device agree on the best row
     assert int(np.argmax(so)) == int(np.argmax(sg[pick]))
@@ -363,7 +371,7 @@ def test_cfg5_greedy_pair_matches_the_oracle(cfg5):
         picks.append(int(np.argmax(v)))
         vals.append(v[picks[-1]])
         alive[picks[-1]] = False
-    assert res.indices == picks and np.allclose(res.values, vals, rtol=0, atol=1e-8)
+    assert res.indices == picks and np.allclose(res.values, vals, rtol=0, atol=1e-6)
     # full set: two distinct rows, each at least as good as the slice's pick of the same step
     full = hv.greedy(Xd, 2, seed=seed, prune_seed=pseed)
     assert len(set(full.indices)) == 2 and full.values[0] >= res.values[0] - 1e-12

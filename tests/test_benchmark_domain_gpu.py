@@ -68,3 +68,115 @@ def test_hartmann_3d_discretized_convergence():
     assert hip.mean() < rnd.mean() - 0.2, (hip.tolist(), rnd.tolist())  # random search: -3.2 / -3.5 after 30 draws
     curve = res[(res["Scenario"] == "HIP Recommender") & (res["Initial_Data"] == 0)]["target_CumBest"].to_numpy()
     assert (np.diff(curve) <= 1e-12).all()  # a convergence curve: monotone
+
+
+# ---- the synthetic transfer-learning domains of /root/reference/benchmarks/domains/__init__.py:42-65 ---------------------
+# hartmann_tl_3_20_15 / hartmann_tl_inv_3_20_15 / hartmann_tl_shift_3_20_15 (hartmann/convergence_tl.py:29-253) and
+# easom_tl_47_negate_noise5 (easom/convergence_tl.py:25-190): a discretised target function, a source function (noisy / negated /
+# shifted copy) whose sampled values enter as measurements of a second task, scenarios "<p>" (search space with a TaskParameter,
+# p % of the source grid as initial data), "<p>_naive" (no task parameter, the same data taken at face value) and "0" /
+# "0_naive" (no source data).  Campaigns are BayBE's default two-phase ones (random until there is data, then Bayesian): the
+# Bayesian phase is the HIP recommender.  Run at the reference's SMOKETEST size (its RunMode.SMOKETEST: batch 2, 2 iterations, 2
+# Monte-Carlo runs; a few more iterations here) - the check is the content of the result frame, not a convergence plot.
+# Not restated: the chemistry domains (direct_arylation, aryl_halides: 10 of the 19 entries) need the reference's data files
+# and substance encodings; hartmann_3d / hartmann_6d / michalewicz_tl_continuous / synthetic_2C1D_1C are continuous or hybrid.
+class TwoPhase:
+    """``TwoPhaseMetaRecommender`` (recommenders/meta/sequential.py:48-60) with its defaults: random while there are no
+    measurements, the Bayesian recommender afterwards."""
+
+    def __init__(self, seed, bayes):
+        self.initial, self.bayes = RandomRecommender(seed), bayes
+
+    def recommend(self, batch_size, searchspace, objective=None, measurements=None, pending_experiments=None):
+        rec = self.initial if measurements is None or len(measurements) == 0 else self.bayes
+        return rec.recommend(batch_size, searchspace, objective, measurements, pending_experiments)
+
+
+def _tl_benchmark(target_fn, source_fn, grids, minimize, percentages, *, batch_size=2, n_doe=4, n_mc=2, seed=1337):
+    """The body shared by the reference's synthetic TL benchmarks (hartmann/convergence_tl.py:69-183, easom/...:66-177)."""
+    from _baybe_shim import TaskParameter
+    from baybe_amd.recommenders import HipBotorchRecommender
+    from baybe_amd.simulation import simulate_scenarios
+
+    names = list(grids)
+    params = [NumericalDiscreteParameter(n, grids[n]) for n in names]
+    task = TaskParameter("Function", ("Target_Function", "Source_Function"), active_values=("Target_Function",))
+    space_tl, space_naive = SearchSpace.from_product(params + [task]), SearchSpace.from_product(params)
+    obj = SingleTargetObjective(NumericalTarget("Target", minimize=minimize))
+    mesh = np.stack(np.meshgrid(*[grids[n] for n in names]), -1).reshape(-1, len(names))
+    rng = np.random.default_rng(seed)
+    source = pd.DataFrame(mesh, columns=names)
+    source["Target"] = source_fn(mesh, rng)
+    source["Function"] = "Source_Function"
+
+    def lookup(df):
+        return pd.DataFrame({"Target": target_fn(df[names].to_numpy(dtype=float))}, index=df.index)
+
+    frames = []
+    for p in percentages:
+        samples = [source.sample(frac=p, random_state=int(rng.integers(1 << 30))) for _ in range(n_mc)]
+        scen = {f"{int(100 * p)}": Campaign(space_tl, obj, TwoPhase(seed, HipBotorchRecommender())),
+                f"{int(100 * p)}_naive": Campaign(space_naive, obj, TwoPhase(seed, HipBotorchRecommender()))}
+        frames.append(simulate_scenarios(scen, lookup, initial_data=samples, batch_size=batch_size, n_doe_iterations=n_doe,
+                                         n_mc_iterations=None, impute_mode="error", random_seed=seed))
+    scen0 = {"0": Campaign(space_tl, obj, TwoPhase(seed, HipBotorchRecommender())),
+             "0_naive": Campaign(space_naive, obj, TwoPhase(seed, HipBotorchRecommender()))}
+    frames.append(simulate_scenarios(scen0, lookup, batch_size=batch_size, n_doe_iterations=n_doe, n_mc_iterations=n_mc,
+                                     impute_mode="error", random_seed=seed))
+    res = pd.concat(frames, ignore_index=True)
+    assert list(res.columns[:3]) == ["Scenario", "Random_Seed", "Initial_Data"]
+    assert {"Iteration", "Num_Experiments", "Target_Measurements", "Target_IterBest", "Target_CumBest"} <= set(res.columns)
+    assert len(res) == (2 * len(percentages) + 2) * n_mc * n_doe
+    for _, run in res.groupby(["Scenario", "Random_Seed", "Initial_Data"], dropna=False):  # convergence curves are monotone
+        d = np.diff(run.sort_values("Iteration")["Target_CumBest"].to_numpy())
+        assert (d <= 1e-12).all() if minimize else (d >= -1e-12).all()
+    return res, float(target_fn(mesh).min() if minimize else target_fn(mesh).max())
+
+
+def _final(res, scenario):
+    last = res[res["Iteration"] == res["Iteration"].max()]
+    return last[last["Scenario"] == scenario]["Target_CumBest"].to_numpy()
+
+
+@pytest.mark.parametrize("variant", ["hartmann_tl_3_20_15", "hartmann_tl_inv_3_20_15", "hartmann_tl_shift_3_20_15"])
+def test_hartmann_transfer_learning_domains(variant):
+    grids = {f"x{k}": np.linspace(0.0, 1.0, 20) for k in range(3)}
+    negate, shift = variant == "hartmann_tl_inv_3_20_15", np.array([0.2, 0.0, 0.0]) if "shift" in variant else np.zeros(3)
+
+    def source(X, rng):  # ShiftedHartmann(shift, noise_std=0.15, negate) (hartmann/utils.py:9-100)
+        y = hartmann3(X + shift[None, :])
+        return (-y if negate else y) + 0.15 * rng.standard_normal(len(X))
+
+    res, best = _tl_benchmark(hartmann3, source, grids, True, [0.05], n_doe=4, n_mc=2)
+    assert abs(best + 3.8324342572721695) < 1e-6  # optimal_target_values of the reference's benchmark definition
+    tl, blind = _final(res, "5"), _final(res, "0")
+    if variant == "hartmann_tl_3_20_15":
+        # 400 noisy source values of the same function: the transfer-learning campaign starts in the right basin ...
+        assert tl.mean() < -3.3 and tl.mean() < blind.mean() - 0.3, (tl, blind)
+        # ... and so does the naive one here (the source IS the target up to noise)
+        assert _final(res, "5_naive").mean() < -3.3
+    elif variant == "hartmann_tl_shift_3_20_15":
+        # a shifted source still helps the task-aware model, and misleads the naive one less than it helps
+        assert tl.mean() < blind.mean() + 0.05, (tl, blind)
+    else:
+        # negated source ("negative transfer", what this benchmark exists to show): the task covariance of the ICM model is
+        # positively constrained (PositiveIndexKernel), so 400 values of -f cannot be used and pull the first batches away from
+        # the optimum; the run must complete with finite curves, nothing more is asserted
+        assert np.isfinite(tl).all() and np.isfinite(_final(res, "5_naive")).all()
+
+
+def test_easom_transfer_learning_domain():
+    """easom_tl_47_negate_noise5: negated Easom on a 47 x 47 grid over [-10, 10]^2 (a needle at (pi, pi)), maximised; source =
+    the same with noise 0.05."""
+    grids = {f"x{k}": np.linspace(-10.0, 10.0, 47) for k in range(2)}
+
+    def easom_neg(X):
+        return np.cos(X[:, 0]) * np.cos(X[:, 1]) * np.exp(-((X[:, 0] - np.pi) ** 2) - (X[:, 1] - np.pi) ** 2)
+
+    res, best = _tl_benchmark(easom_neg, lambda X, rng: easom_neg(X) + 0.05 * rng.standard_normal(len(X)), grids, False, [0.1],
+                              n_doe=4, n_mc=2)
+    assert best > 0.8  # the grid comes within 0.1 of the needle
+    assert np.isfinite(res["Target_CumBest"]).all()
+    # 10 % of the source grid = 221 noisy values, a handful of them on the needle's flank: the task-aware campaign finds the
+    # needle region at least as well as the one without any data
+    assert _final(res, "10").mean() >= _final(res, "0").mean() - 1e-9
