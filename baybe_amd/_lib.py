@@ -78,6 +78,7 @@ SIGNATURES = {
     "bbh_posterior_joint": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "bbh_set_mean_columns": (C.c_int, [C.c_void_p, c_double_p, C.c_int64]),
     "bbh_posterior_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "bbh_posterior_columns_sm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "bbh_train_posterior_mean": (C.c_int, [C.c_void_p, c_double_p]),
     "bbh_qlogei_q1": (
         C.c_int,
@@ -97,6 +98,11 @@ SIGNATURES = {
          C.c_double, C.c_void_p, C.c_void_p],
     ),
     "bbh_qlognehvi": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
+         C.c_int64, c_int64_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_qlognehvi_sm": (
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
          C.c_int64, c_int64_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p],

@@ -780,6 +780,7 @@ struct NehviArgs {
   const int64_t* cell_off; // [S + 1]
   const double* cell_lo;   // [ncells, m]
   const double* cell_ll;   // [ncells, m]
+  int sample_major;        // tmat[o] is [S, N] (bbh_posterior_columns_sm) instead of [N, S]
   const uint8_t* alive;
   double* scores;
 };
@@ -809,15 +810,16 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_kernel(const NehviArgs a) {
   for (int o = 0; o < M; o++) {
     sd[o] = bbh_safe_sd(a.var[o][i]);
     sg[o] = a.sign[o];
-    trow[o] = a.tmat[o] + i * (int64_t)a.S;
+    trow[o] = a.sample_major ? a.tmat[o] + i : a.tmat[o] + i * (int64_t)a.S;
   }
+  const int64_t tstride = a.sample_major ? a.N : 1;
   const double inv_tau = 1.0 / TAU_RELU;
   const double log_tau = log(TAU_RELU);
   double sref = -INFINITY, ssum = 0.0;  // streaming log-sum-exp over MC samples
   for (int s = 0; s < a.S; s++) {
     double f[M];
 #pragma unroll
-    for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s]);
+    for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s * tstride]);
     double cref = -INFINITY, csum = 0.0;  // streaming log-sum-exp over the cells of this sample
     const int64_t c0 = a.cell_off[s], c1 = a.cell_off[s + 1];
     for (int64_t c = c0; c < c1; c++) {
@@ -872,18 +874,19 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_lin_kernel(const NehviArgs 
   }
   double sd[M], sg[M];
   const double* trow[M];
+  const int64_t tstride = a.sample_major ? a.N : 1;  // between consecutive samples of this candidate
 #pragma unroll
   for (int o = 0; o < M; o++) {
     sd[o] = bbh_safe_sd(a.var[o][i]);
     sg[o] = a.sign[o];
-    trow[o] = a.tmat[o] + i * (int64_t)a.S;
+    trow[o] = a.sample_major ? a.tmat[o] + i : a.tmat[o] + i * (int64_t)a.S;
   }
   const double inv_tau = 1.0 / TAU_RELU;
   double total = 0.0;
   for (int s = s_begin; s < s_end; s++) {
     double f[M];
 #pragma unroll
-    for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s]);
+    for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s * tstride]);
     const int64_t c0 = a.cell_off[s], c1 = a.cell_off[s + 1];
     double ssum = 0.0;
     for (int64_t c = c0; c < c1; c++) {
@@ -937,10 +940,31 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_finish_kernel(const double*
   scores[i] = (total > 0.0 && !(alive && !alive[i])) ? log(total) - log((double)S) : -INFINITY;
 }
 
+static int bbh_qlognehvi_impl(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                             const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                             const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
+                             const uint8_t* alive_dev, double* scores_dev, bool sample_major);
+
 extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
                              const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
                              const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
                              const uint8_t* alive_dev, double* scores_dev) {
+  return bbh_qlognehvi_impl(h, m, N, tmat_dev, var_dev, sign_host, zx_host, S, cell_off_host, cell_lo_host, cell_loglen_host, alive_dev,
+                            scores_dev, false);
+}
+
+extern "C" int bbh_qlognehvi_sm(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                                const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                                const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
+                                const uint8_t* alive_dev, double* scores_dev) {
+  return bbh_qlognehvi_impl(h, m, N, tmat_dev, var_dev, sign_host, zx_host, S, cell_off_host, cell_lo_host, cell_loglen_host, alive_dev,
+                            scores_dev, true);
+}
+
+static int bbh_qlognehvi_impl(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                             const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                             const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
+                             const uint8_t* alive_dev, double* scores_dev, bool sample_major) {
   if (!h) return -1;
   if (m < 1 || m > BBH_MAX_OBJECTIVES || N < 0 || S < 1 || !tmat_dev || !var_dev || !sign_host || !zx_host ||
       !cell_off_host || !scores_dev) {
@@ -982,6 +1006,7 @@ extern "C" int bbh_qlognehvi(bbh_handle* h, int32_t m, int64_t N, const double* 
   a.cell_off = (const int64_t*)(h->d_z + nd);
   a.alive = alive_dev;
   a.scores = scores_dev;
+  a.sample_major = sample_major ? 1 : 0;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
   bbh_timed_scope timed(h, BBH_TIMED_NEHVI);
   const char* env_log = getenv("BBH_NEHVI_LOG");

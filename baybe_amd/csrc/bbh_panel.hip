@@ -936,7 +936,10 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
 // colfrag layout: [group][k-step][column block (8)][64 lanes], lane l <- Acol[4 ks + (l>>4)][128 g + 16 cb + (l&15)].
 template <bool HAS_TBL, int KIND>
 __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedArgs a, const double* __restrict__ colfrag,
-                                                                   int64_t col0, int64_t ldt, double* __restrict__ tmat) {
+                                                                   int64_t col0, int64_t str_c, int64_t str_s, int64_t s_total,
+                                                                   double* __restrict__ tmat) {
+  // tmat element (candidate i, column s) at i * str_c + s * str_s: candidate-major [N, ldt] (str_c = ldt, str_s = 1) or
+  // sample-major [S, N] (str_c = 1, str_s = N); columns >= s_total (padding of the last 128-column group) are not written
   extern __shared__ __attribute__((aligned(16))) double s_cand[];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cnd = l & 15, q = l >> 4;
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedAr
     if (gi < a.N) {
 #pragma unroll
       for (int cb = 0; cb < 8; cb++)
-        tmat[gi * ldt + col0 + 16 * cb + cnd] = a.ybar + a.ysd * (mc + acc[cb][r]);
+        if (col0 + 16 * cb + cnd < s_total) tmat[gi * str_c + (col0 + 16 * cb + cnd) * str_s] = a.ybar + a.ysd * (mc + acc[cb][r]);
     }
   }
 }
@@ -1147,7 +1150,8 @@ static void bbh_fill_fused_args(bbh_handle* h, FusedArgs& a, const double* X_dev
 // tmat[i][c] = ybar + ysd * (mean_const(task of i) + P[i][c]) for the real columns of a padded product P [Nc, spad]
 __global__ void bbh_columns_affine_kernel(const double* __restrict__ P, int64_t spad, int64_t Nc, int64_t S,
                                           const double* __restrict__ X, int64_t ldx, const double* __restrict__ theta,
-                                          int T, int task_col, int hoff, double ybar, double ysd, double* __restrict__ tmat) {
+                                          int T, int task_col, int hoff, double ybar, double ysd, double* __restrict__ tmat,
+                                          int64_t str_c, int64_t str_s) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Nc * S) return;
   const int64_t i = e / S, c = e % S;
@@ -1157,11 +1161,11 @@ __global__ void bbh_columns_affine_kernel(const double* __restrict__ P, int64_t 
     t = t < 0 ? 0 : (t >= T ? T - 1 : t);
     mc = theta[hoff + T + t];
   }
-  tmat[i * S + c] = ybar + ysd * (mc + P[i * spad + c]);
+  tmat[i * str_c + c * str_s] = ybar + ysd * (mc + P[i * spad + c]);
 }
 
 // composite kernels: conditional means under the alternative target columns as K* A on the generic GEMM
-static int bbh_columns_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
+static int bbh_columns_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev, bool sample_major) {
   const int64_t np = h->np, S = h->ncols, spad = bbh_round_up(S, 128);
   const int64_t chunk = 8192;
   const size_t need = sizeof(double) * ((size_t)chunk * np + (size_t)chunk * spad + 2 * h->dn);
@@ -1182,13 +1186,13 @@ static int bbh_columns_unfused(bbh_handle* h, const double* X_dev, int64_t N, in
     bbh_gemm(s, false, false, Ncpad, spad, np, 1.0, Kst, np, 0, h->d_colA, spad, 0, 0.0, P, spad, 0, 1);
     hipLaunchKernelGGL(bbh_columns_affine_kernel, dim3((unsigned)((Nc * S + 255) / 256)), dim3(256), 0, s, P, spad, Nc, S,
                        X_dev + s0 * ldx, ldx, h->d_theta, h->T, h->desc.task_col, bbh_hadamard_offset(h), h->ybar, h->ysd,
-                       tmat_dev + s0 * S);
+                       sample_major ? tmat_dev + s0 : tmat_dev + s0 * S, sample_major ? (int64_t)1 : S, sample_major ? N : (int64_t)1);
   }
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
 }
 
-extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
+static int bbh_posterior_columns_impl(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev, bool sample_major) {
   if (!h) return -1;
   if (!h->factorized || h->ncols < 1 || !h->d_colfrag || !tmat_dev || N < 0 || (N > 0 && !X_dev) || ldx < h->desc.d) {
     h->err = "bbh_posterior_columns: call bbh_set_mean_columns first / bad arguments";
@@ -1197,7 +1201,7 @@ extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   bbh_timed_scope timed(h, BBH_TIMED_COLUMNS);
-  if (bbh_materialised_only(h)) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev);
+  if (bbh_materialised_only(h)) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev, sample_major);
   FusedArgs a;
   bbh_fill_fused_args(h, a, X_dev, N, ldx);
   const bool has_tbl = (h->T > 1) || h->desc.use_outputscale;
@@ -1206,35 +1210,29 @@ extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t
   dim3 grid((unsigned)((N + 63) / 64)), block(256);
   const int64_t S = h->ncols, spad = bbh_round_up(S, 128), groups = spad / 128;
   const int64_t nks = h->np / 4;
-  // the last group may be partially padded: write it through a bounce buffer only if S % 128 != 0
-  double* bounce = nullptr;
-  if (S % 128 != 0) {
-    int rc = bbh_ensure_ws(h, sizeof(double) * (size_t)N * 128);
-    if (rc) return rc;
-    bounce = h->d_ws;
-  }
-  for (int64_t g = 0; g < groups; g++) {
+  const int64_t str_c = sample_major ? 1 : S, str_s = sample_major ? N : 1;
+  for (int64_t g = 0; g < groups; g++) {  // the last group may be partially padding: its columns >= S are not written
     const double* cf = h->d_colfrag + g * nks * 8 * 64;
-    const bool partial = (g == groups - 1) && bounce;
-    double* out = partial ? bounce : tmat_dev;
-    const int64_t col0 = partial ? 0 : 128 * g;
-    const int64_t ldt = partial ? 128 : S;
+    const int64_t col0 = 128 * g;
     if (has_tbl && m52)
-      hipLaunchKernelGGL((bbh_fused_columns_kernel<true, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<true, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a, cf, col0, str_c, str_s, S, tmat_dev);
     else if (has_tbl)
-      hipLaunchKernelGGL((bbh_fused_columns_kernel<true, -1>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<true, -1>), grid, block, lds, h->stream, a, cf, col0, str_c, str_s, S, tmat_dev);
     else if (m52)
-      hipLaunchKernelGGL((bbh_fused_columns_kernel<false, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<false, BBH_KERNEL_MATERN52>), grid, block, lds, h->stream, a, cf, col0, str_c, str_s, S, tmat_dev);
     else
-      hipLaunchKernelGGL((bbh_fused_columns_kernel<false, -1>), grid, block, lds, h->stream, a, cf, col0, ldt, out);
-    if (partial) {
-      const int64_t w = S - 128 * g;
-      BBH_HIP_TRY(h, hipMemcpy2DAsync(tmat_dev + 128 * g, sizeof(double) * S, bounce, sizeof(double) * 128,
-                                      sizeof(double) * w, N, hipMemcpyDeviceToDevice, h->stream));
-    }
+      hipLaunchKernelGGL((bbh_fused_columns_kernel<false, -1>), grid, block, lds, h->stream, a, cf, col0, str_c, str_s, S, tmat_dev);
   }
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
+}
+
+extern "C" int bbh_posterior_columns(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
+  return bbh_posterior_columns_impl(h, X_dev, N, ldx, tmat_dev, false);
+}
+
+extern "C" int bbh_posterior_columns_sm(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* tmat_dev) {
+  return bbh_posterior_columns_impl(h, X_dev, N, ldx, tmat_dev, true);
 }
 
 // prior covariance among q points given as raw rows (normalised on the fly), direct differences

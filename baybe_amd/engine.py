@@ -392,13 +392,15 @@ class HipGP:
         self._ncols = Y.shape[1]
         self._check(self._lib.bbh_set_mean_columns(self._h, _dp(Y), Y.shape[1]), "bbh_set_mean_columns")
 
-    def posterior_columns(self, X):
-        """[N, S] posterior means of the candidates under each target column."""
+    def posterior_columns(self, X, sample_major: bool = False):
+        """Posterior means of the candidates under each target column: [N, S], or [S, N] with ``sample_major`` (the layout
+        the qLogNEHVI scoring kernel reads coalesced)."""
         torch = self._torch()
         X = self._as_dev(X)
         N = X.shape[0]
-        tmat = torch.empty((N, self._ncols), dtype=torch.float64, device=X.device)
-        self._check(self._lib.bbh_posterior_columns(self._h, X.data_ptr(), N, X.stride(0), tmat.data_ptr()), "bbh_posterior_columns")
+        tmat = torch.empty((self._ncols, N) if sample_major else (N, self._ncols), dtype=torch.float64, device=X.device)
+        fn = self._lib.bbh_posterior_columns_sm if sample_major else self._lib.bbh_posterior_columns
+        self._check(fn(self._h, X.data_ptr(), N, X.stride(0), tmat.data_ptr()), "bbh_posterior_columns")
         return tmat
 
     def train_posterior_mean(self) -> np.ndarray:

@@ -153,7 +153,7 @@ class HipNEHVI:
         tmats, vars_ = [], []
         for out in self.outputs:
             _, var = out.ext.posterior(X_dev)
-            tmats.append(out.ext.posterior_columns(X_dev))
+            tmats.append(out.ext.posterior_columns(X_dev, sample_major=True))
             vars_.append(var)
         N = X_dev.shape[0]
         scores = torch.empty(N, dtype=torch.float64, device=X_dev.device)
@@ -163,7 +163,7 @@ class HipNEHVI:
         sg = np.ascontiguousarray(self.signs)
         zx = np.ascontiguousarray(self.zx)
         off = np.ascontiguousarray(self.cell_off, dtype=np.int64)
-        rc = self._lib.bbh_qlognehvi(
+        rc = self._lib.bbh_qlognehvi_sm(
             h._h, self.m, N, tp, vp, _dp(sg), _dp(zx), self.S, off.ctypes.data_as(_lib.c_int64_p),
             _dp(self.cell_lo) if len(self.cell_lo) else None, _dp(self.cell_ll) if len(self.cell_ll) else None,
             alive.data_ptr() if alive is not None else None, scores.data_ptr(),
