@@ -45,6 +45,14 @@ class KernelFactor:
     scaled: bool = False
     outputscale_prior: tuple | None = None
     outputscale_init: float | None = None
+    active: "np.ndarray | None" = None  # bool [dn]: the numerical columns the factor acts on (``parameter_names``); None = all
+
+
+# Lengthscale of a numerical column a kernel does NOT act on (``BasicKernel.parameter_names``, kernels/base.py:198-240: gpytorch
+# ``active_dims``): (dx / 1e150)^2 = 1e-300 vanishes next to any real contribution in double precision, so the column drops out of
+# every distance - in the Gram matrix, the gradient pairs (d/dl ~ dx^2 / l^3 underflows to 0) and the fused kernels alike - without
+# any device code knowing about subsets.  The slot is pinned by equal L-BFGS-B bounds and carries no prior.
+INACTIVE_LS = 1e150
 
 
 @dataclass
@@ -76,6 +84,16 @@ class GPSpec:
     # composite kernels: 2..4 factors combined as a product or a sum; factors[0] IS (kernel, ls_*) above
     factors: "list[KernelFactor] | None" = None
     combine: str = "product"  # "product" (ProductKernel) | "sum" (AdditiveKernel)
+    active: "np.ndarray | None" = None  # bool [dn]: columns the (first) kernel acts on (``parameter_names``); None = all
+
+    def active_mask(self, k: int = 0) -> "np.ndarray | None":
+        """Column mask of factor ``k`` (0 = the single kernel / first factor), None when it acts on every numerical column."""
+        a = self.active if (k == 0 or not self.factors) else self.factors[k].active
+        return None if a is None or bool(np.all(a)) else np.asarray(a, dtype=bool)
+
+    @property
+    def has_subsets(self) -> bool:
+        return any(self.active_mask(k) is not None for k in range(self.n_factors))
 
     @property
     def n_factors(self) -> int:
@@ -101,6 +119,7 @@ class GPSpec:
         f0 = factors[0]
         self.kernel, self.ls_constraint, self.ls_prior, self.ls_init = f0.kernel, f0.ls_constraint, f0.ls_prior, f0.ls_init
         self.ls_lower = f0.ls_lower if f0.ls_constraint == "box" else self.ls_lower
+        self.active = f0.active
         self.factors, self.combine = factors, combine
         return self
 
@@ -275,6 +294,21 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
                                 for f in spec.factors], dtype=np.float64)
     if spec.has_rq:
         p.alpha = np.array([float(softplus(0.0)) if k == "rq" else 1.0 for k in spec.factor_kinds])
+    return _pin_inactive(spec, p)
+
+
+def _pin_inactive(spec: GPSpec, p: GPParams) -> GPParams:
+    """Lengthscales of the columns a kernel does not act on: ``INACTIVE_LS`` (see there)."""
+    for k in range(spec.n_factors):
+        m = spec.active_mask(k)
+        if m is not None:
+            arr = p.lengthscale if k == 0 else p.factor_ls[k - 1]
+            arr = np.array(arr, dtype=np.float64)
+            arr[~m] = INACTIVE_LS
+            if k == 0:
+                p.lengthscale = arr
+            else:
+                p.factor_ls[k - 1] = arr
     return p
 
 
@@ -310,7 +344,7 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
         for k, f in enumerate(spec.factors):
             if f.scaled:
                 p.factor_os[k] = float(max(draw(f.outputscale_prior, 1, p.factor_os[k])[0], 1e-6))
-    return p
+    return _pin_inactive(spec, p)
 
 
 # ---- natural parameters <-> the device theta vector [noise, mean, outputscale, ls.., B.., (noise_t.., mean_t..)] ------
@@ -398,13 +432,18 @@ def raw_bounds(spec: GPSpec):
         b.append((None, None))
     if spec.factors and spec.factors[0].scaled:
         b.append((None, None))
-    b += [((spec.ls_lower, None) if spec.ls_constraint == "box" else (None, None))] * spec.dn
+    def ls_bounds(k, lower, box):
+        m = spec.active_mask(k)
+        pin = INACTIVE_LS if box else float(inv_softplus(np.array([INACTIVE_LS]))[0])  # raw value of a pinned slot
+        return [((pin, pin) if (m is not None and not m[j]) else ((lower, None) if box else (None, None))) for j in range(spec.dn)]
+
+    b += ls_bounds(0, spec.ls_lower, spec.ls_constraint == "box")
     if spec.factor_kinds[0] == "rq":
         b.append((None, None))
-    for f in (spec.factors or [])[1:]:
+    for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             b.append((None, None))
-        b += [((f.ls_lower, None) if f.ls_constraint == "box" else (None, None))] * spec.dn
+        b += ls_bounds(k + 1, f.ls_lower, f.ls_constraint == "box")
         if f.kernel == "rq":
             b.append((None, None))
     if spec.n_tasks > 1:
@@ -427,6 +466,18 @@ def _prior_logp_and_grad(prior, x):
         lp = -lx - math.log(sd) - 0.5 * math.log(2 * math.pi) - 0.5 * ((lx - mu) / sd) ** 2
         return float(lp.sum()), (-1.0 - (lx - mu) / sd**2) / x
     raise ValueError(f"unknown prior kind {kind!r}")
+
+
+def _ls_prior_logp_and_grad(prior, ls, mask):
+    """Lengthscale prior over the columns the kernel acts on (gpytorch registers a lengthscale of ``len(active_dims)`` entries);
+    gradient scattered back into the full [dn] layout, zero in the pinned slots."""
+    if mask is None:
+        return _prior_logp_and_grad(prior, ls)
+    ls = np.asarray(ls, dtype=np.float64)
+    lp, g_act = _prior_logp_and_grad(prior, ls[mask])
+    g = np.zeros_like(ls)
+    g[mask] = g_act
+    return lp, g
 
 
 def _task_correlation_prior(prior, B):
@@ -466,7 +517,7 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         g_noise, g_mean = grad_theta[0:1], grad_theta[1:2]
     g_os = grad_theta[2]
     g_ls = grad_theta[3 : 3 + dn]
-    lp_ls, glp_ls = _prior_logp_and_grad(spec.ls_prior, p.lengthscale)
+    lp_ls, glp_ls = _ls_prior_logp_and_grad(spec.ls_prior, p.lengthscale, spec.active_mask(0))
     lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.atleast_1d(p.noise))
     lp_os, glp_os = 0.0, np.zeros(1)
     if spec.use_outputscale:
@@ -496,6 +547,8 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
     gl = g_ls + glp_ls
     if spec.ls_constraint != "box":
         gl = gl * sigmoid(raw[i : i + dn])
+    if spec.active_mask(0) is not None:
+        gl = np.where(spec.active_mask(0), gl, 0.0)
     g.append(gl)
     i += dn
     if spec.factor_kinds[0] == "rq":  # softplus chain, no prior
@@ -505,11 +558,13 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         if f.scaled:
             total += scale_slot(k + 1, f, i)
             i += 1
-        lp_f, glp_f = _prior_logp_and_grad(f.ls_prior, p.factor_ls[k])
+        lp_f, glp_f = _ls_prior_logp_and_grad(f.ls_prior, p.factor_ls[k], spec.active_mask(k + 1))
         total += lp_f
         gf = grad_theta[base + k * dn : base + (k + 1) * dn] + glp_f
         if f.ls_constraint != "box":
             gf = gf * sigmoid(raw[i : i + dn])
+        if spec.active_mask(k + 1) is not None:
+            gf = np.where(spec.active_mask(k + 1), gf, 0.0)
         g.append(gf)
         i += dn
         if f.kernel == "rq":
@@ -540,7 +595,7 @@ class FastObjective:
 
     @staticmethod
     def applies(spec: GPSpec) -> bool:
-        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard
+        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard and not spec.has_subsets
 
     def __init__(self, spec: GPSpec, n: int):
         self.n = int(n)

@@ -32,17 +32,23 @@ class LogNormalPrior:
     scale: float = field(converter=float, validator=gt(0.0))
 
 
+def _names(v):
+    return None if v is None else tuple(v)
+
+
 @define(frozen=True)
 class MaternKernel:
     nu: float = field(default=2.5, converter=float, validator=in_([0.5, 1.5, 2.5]))
     lengthscale_prior = field(default=None)
     lengthscale_initial_value: float | None = field(default=None)
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)  # kernels/base.py:198-214
 
 
 @define(frozen=True)
 class RBFKernel:
     lengthscale_prior = field(default=None)
     lengthscale_initial_value: float | None = field(default=None)
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
 
 
 @define(frozen=True)
@@ -60,6 +66,7 @@ class RQKernel:
 
     lengthscale_prior = field(default=None)
     lengthscale_initial_value: float | None = field(default=None)
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
 
 
 @define(frozen=True)
@@ -109,8 +116,41 @@ def _basic_kind(kernel) -> str | None:
     return None
 
 
-def apply_kernel_spec(spec, kernel):
-    """Configure a ``GPSpec`` from a (BayBE or mirror) kernel specification object."""
+def _active_mask(spec, kernel, searchspace):
+    """``BasicKernel._get_dimensions`` (kernels/base.py:216-240): the comp-rep columns of the named parameters become the
+    kernel's ``active_dims`` (ARD over exactly those).  Returned as a mask over the NUMERICAL columns of the model."""
+    names = getattr(kernel, "parameter_names", None)
+    if not names:
+        return None
+    if type(kernel).__name__ == "PiecewisePolynomialKernel":
+        raise IncompatibilityError("PiecewisePolynomialKernel on a parameter subset is not available on the HIP path "
+                                   "(its exponent depends on the number of active dimensions).")
+    if searchspace is None:
+        raise IncompatibilityError("A kernel with 'parameter_names' needs the search space to resolve them.")
+    cols = list(searchspace.comp_rep_columns)
+    idx = set()
+    for nm in names:
+        if hasattr(searchspace, "get_comp_rep_parameter_indices"):
+            idx.update(int(i) for i in searchspace.get_comp_rep_parameter_indices(nm))
+        else:  # one comp-rep column per parameter (numerical discrete parameters), or columns prefixed with the name
+            hit = [i for i, c in enumerate(cols) if c == nm or str(c).startswith(f"{nm}_")]
+            if not hit:
+                raise ValueError(f"Parameter '{nm}' named by a kernel is not part of the search space.")
+            idx.update(hit)
+    import numpy as np
+
+    num = [int(j) for j in spec.num_idx]
+    if spec.task_idx is not None and spec.task_idx in idx:
+        raise IncompatibilityError("The task parameter cannot be part of a kernel's 'parameter_names' on the HIP path.")
+    mask = np.array([j in idx for j in num], dtype=bool)
+    if not mask.any():
+        raise ValueError("A kernel's 'parameter_names' select no numerical column.")
+    return mask
+
+
+def apply_kernel_spec(spec, kernel, searchspace=None):
+    """Configure a ``GPSpec`` from a (BayBE or mirror) kernel specification object; ``searchspace`` resolves
+    ``parameter_names`` (kernels restricted to a parameter subset)."""
     name = type(kernel).__name__
     if name == "ScaleKernel":
         if not getattr(kernel, "outputscale_trainable", True):
@@ -144,10 +184,9 @@ def apply_kernel_spec(spec, kernel):
                     f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial "
                     f"factors, each optionally in a ScaleKernel, are)."
                 )
-            if getattr(member, "parameter_names", None):
-                raise IncompatibilityError("Kernels restricted to a parameter subset are not available on the HIP path.")
             factors.append(KernelFactor(kind, "softplus", 0.0, _prior_tuple(getattr(member, "lengthscale_prior", None)),
-                                        getattr(member, "lengthscale_initial_value", None), scaled, os_prior, os_init))
+                                        getattr(member, "lengthscale_initial_value", None), scaled, os_prior, os_init,
+                                        _active_mask(spec, member, searchspace)))
         return spec.set_factors(factors, "product" if name == "ProductKernel" else "sum")
     kind = _basic_kind(kernel)
     if kind is None:
@@ -156,8 +195,7 @@ def apply_kernel_spec(spec, kernel):
             f"ScaleKernel, and Product / Additive kernels of them are)."
         )
     spec.kernel = kind
-    if getattr(kernel, "parameter_names", None):
-        raise IncompatibilityError("Kernels restricted to a parameter subset are not available on the HIP path.")
+    spec.active = _active_mask(spec, kernel, searchspace)
     spec.ls_constraint = "softplus"
     spec.ls_prior = _prior_tuple(getattr(kernel, "lengthscale_prior", None))
     spec.ls_init = getattr(kernel, "lengthscale_initial_value", None)

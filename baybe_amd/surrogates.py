@@ -161,7 +161,7 @@ class HipGPSurrogateImpl:
             from baybe_amd.kernels import apply_kernel_spec
 
             spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks)
-            apply_kernel_spec(spec, self.kernel)
+            apply_kernel_spec(spec, self.kernel, searchspace)
         if self._engine is None:
             self._engine = HipGP(self.device)
         self._engine.set_model(spec, train_x, train_y)

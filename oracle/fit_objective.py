@@ -103,11 +103,11 @@ def parameter_layout(spec) -> list[RawParameter]:
                 out.append(RawParameter(f"{leaf}.raw_outputscale", (), 0.0, True, _prior(term.outputscale.prior), m))
                 leaf += ".base_kernel"
             h = term.lengthscale
-            out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, spec.dn), h.lower, h.transformed, _prior(h.prior), m))
+            out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, len(spec.dims_of(m))), h.lower, h.transformed, _prior(h.prior), m))
             if term.kernel == "rq":  # gpytorch RQKernel registers raw_alpha (Positive(), no prior) after the lengthscale
                 out.append(RawParameter(f"{leaf}.raw_alpha", (1,), 0.0, True, None, m))
     else:
-        out.append(RawParameter(f"{base}.raw_lengthscale", (1, spec.dn), spec.ls_lower if box_ls else 0.0, not box_ls,
+        out.append(RawParameter(f"{base}.raw_lengthscale", (1, len(spec.dims_of(None))), spec.ls_lower if box_ls else 0.0, not box_ls,
                                 _prior(spec.ls_prior)))
         if spec.kernel == "rq":
             out.append(RawParameter(f"{base}.raw_alpha", (1,), 0.0, True, None))
@@ -178,21 +178,22 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     """K(X, X) without noise on the normalised inputs: stationary ARD kernel (x outputscale) (x B[t, t'])."""
     Xnum = Xn[:, torch.as_tensor(np.asarray(spec.num_idx))]
 
-    def gram(kind, lengthscale, alpha=None):
-        Xs = Xnum / lengthscale.reshape(1, -1)
+    def gram(kind, lengthscale, alpha=None, dims=None):  # dims: the kernel's active_dims (all numerical columns if None)
+        Xa = Xnum if dims is None else Xnum[:, torch.as_tensor(np.asarray(dims))]
+        Xs = Xa / lengthscale.reshape(1, -1)
         diff = Xs[:, None, :] - Xs[None, :, :]
-        return _base_kernel(kind, (diff * diff).sum(-1), Xnum.shape[1], alpha)
+        return _base_kernel(kind, (diff * diff).sum(-1), Xa.shape[1], alpha)
 
     members = getattr(spec, "members", None)
     if members:
         K = None
         for m, term in enumerate(members):
-            Km = gram(term.kernel, nat[f"lengthscale.{m}"], nat.get(f"alpha.{m}"))
+            Km = gram(term.kernel, nat[f"lengthscale.{m}"], nat.get(f"alpha.{m}"), term.active_dims)
             if term.outputscale is not None:
                 Km = Km * nat[f"outputscale.{m}"]
             K = Km if K is None else (K * Km if spec.composition == "product" else K + Km)
     else:
-        K = gram(spec.kernel, nat["lengthscale"], nat.get("alpha"))
+        K = gram(spec.kernel, nat["lengthscale"], nat.get("alpha"), getattr(spec, "active_dims", None))
     if spec.use_outputscale:
         K = K * nat["outputscale"]
     if spec.n_tasks > 1:

@@ -92,6 +92,8 @@ class KernelTerm:
     kernel: str = "matern52"
     lengthscale: Hyper = field(default_factory=Hyper)
     outputscale: "Hyper | None" = None
+    active_dims: "np.ndarray | None" = None  # positions among the numerical columns the kernel acts on (gpytorch active_dims
+    # from ``BasicKernel.parameter_names``, baybe/kernels/base.py:198-240); its lengthscale has len(active_dims) entries
 
 
 @dataclass
@@ -116,6 +118,12 @@ class GPSpec:
     correlation_prior: tuple | None = None  # ("beta", 2.5, 1.5): BetaPrior on the lower-triangle task correlations
     members: "list[KernelTerm] | None" = None  # base kernels of a ProductKernel / AdditiveKernel (replaces `kernel`)
     composition: str = "product"  # "product" | "sum"
+    active_dims: "np.ndarray | None" = None  # single kernel on a parameter subset (see KernelTerm.active_dims)
+
+    def dims_of(self, m: int | None = None) -> np.ndarray:
+        """Positions (among the numerical columns) base kernel ``m`` - or the single kernel - acts on."""
+        a = self.active_dims if (m is None or not self.members) else self.members[m].active_dims
+        return np.arange(len(self.num_idx)) if a is None else np.asarray(a, dtype=np.int64)
 
     @property
     def dn(self) -> int:
@@ -209,14 +217,14 @@ def initial_params(spec, task_init=1.0):
     T = int(spec.n_tasks)
     per_task = spec.task_model == "per_task"
     return GPParams(
-        lengthscale=np.full(spec.dn, spec.lengthscale.start()),
+        lengthscale=np.full(len(spec.dims_of(0 if spec.members else None)), spec.lengthscale.start()),
         noise=np.full(T, spec.noise.start()) if per_task else spec.noise.start(),
         mean=np.zeros(T) if per_task else 0.0,
         outputscale=spec.outputscale.start() if spec.use_outputscale else 1.0,
         task_W=np.full((T, T), task_init / math.sqrt(T)) if T > 1 else None,
         task_v=np.full(T, math.log(2.0)) if T > 1 else None,
         target_scaled=spec.index_kernel_scaling == "target",
-        member_ls=[np.full(spec.dn, t.lengthscale.start()) for t in spec.members] if spec.members else None,
+        member_ls=[np.full(len(spec.dims_of(m)), t.lengthscale.start()) for m, t in enumerate(spec.members)] if spec.members else None,
         member_scale=np.array([1.0 if t.outputscale is None else t.outputscale.start() for t in spec.members])
         if spec.members else None,
         rq_alpha=np.array([math.log(2.0) if k == "rq" else 1.0 for k in kernel_names(spec)]) if "rq" in kernel_names(spec) else None,
@@ -341,15 +349,19 @@ def _alpha_of(p: GPParams, m: int):
 
 def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> list[np.ndarray]:
     """Scaled Gram matrix of every base kernel of a composite (numerical columns only)."""
-    return [p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A, B, p.member_ls[m]), A.shape[1], _alpha_of(p, m))
-            for m, t in enumerate(spec.members)]
+    out = []
+    for m, t in enumerate(spec.members):
+        c = spec.dims_of(m)
+        out.append(p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A[:, c], B[:, c], p.member_ls[m]), len(c), _alpha_of(p, m)))
+    return out
 
 
 def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> np.ndarray:
     """The kernel over the numerical columns without outer outputscale / task factor: the single stationary kernel, or
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
     if not spec.members:
-        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A, B, p.lengthscale), A.shape[1], _alpha_of(p, 0))
+        c = spec.dims_of(None)
+        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A[:, c], B[:, c], p.lengthscale), len(c), _alpha_of(p, 0))
     grams = member_grams(spec, p, A, B)
     out = grams[0].copy()
     for Km in grams[1:]:
@@ -414,6 +426,9 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
            w = alpha/d,  d = diag(M).
     """
     n = Xn.shape[0]
+    if spec.active_dims is not None or any(t.active_dims is not None for t in (spec.members or [])):
+        raise NotImplementedError("analytic data-term gradients are not restated for kernels on parameter subsets; "
+                                  "use fit_objective (autograd)")
     trow = task_rows(spec, Xn)
     Kf = cross_cov(spec, p, Xn, Xn)
     Ky = Kf + np.diag(p.noise_of(trow))

@@ -59,6 +59,26 @@ def oracle_spec(spec):
         correlation_prior=spec.task_prior,
         members=[go.KernelTerm(f.kernel,
                                go.Hyper(f.ls_lower if f.ls_constraint == "box" else 0.0, f.ls_constraint != "box", f.ls_prior, f.ls_init),
-                               go.Hyper(0.0, True, f.outputscale_prior, f.outputscale_init) if f.scaled else None)
-                 for f in spec.factors] if spec.factors else None,
-        composition=spec.combine)
+                               go.Hyper(0.0, True, f.outputscale_prior, f.outputscale_init) if f.scaled else None,
+                               None if spec.active_mask(k) is None else np.nonzero(spec.active_mask(k))[0])
+                 for k, f in enumerate(spec.factors)] if spec.factors else None,
+        composition=spec.combine,
+        active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0])
+
+
+def oracle_params(spec, p):
+    """The oracle's ``GPParams`` for the product's (``baybe_amd.gp_spec``): same values; lengthscales of kernels on a parameter
+    subset carry only the active entries on the oracle's side (gpytorch's lengthscale has ``len(active_dims)`` entries)."""
+    from oracle import gp_oracle as go
+
+    def act(ls, k):
+        m = spec.active_mask(k)
+        ls = np.array(ls, dtype=float)
+        return ls if m is None else ls[m]
+
+    return go.GPParams(act(p.lengthscale, 0), p.noise, p.mean, p.outputscale,
+                       None if p.task_W is None else p.task_W.copy(), None if p.task_v is None else p.task_v.copy(),
+                       bool(getattr(p, "task_unit_scale", False)),
+                       None if p.factor_ls is None else [act(p.lengthscale, 0)] + [act(a, k + 1) for k, a in enumerate(p.factor_ls)],
+                       None if p.factor_os is None else np.array(p.factor_os, dtype=float),
+                       None if getattr(p, "alpha", None) is None else np.array(p.alpha, dtype=float))

@@ -478,3 +478,42 @@ def test_engine_state_pickles_without_a_device():
         assert np.array_equal(clone.params.lengthscale, prm.lengthscale) and clone.spec.d == 3
         clone.close()  # nothing to release
         assert not clone._restorable
+
+
+def test_parameter_subsets_pin_the_inactive_lengthscales():
+    """``parameter_names`` on the product side is host logic only: pinned raw slots (equal bounds), priors over the active
+    columns, a gradient of zero in the pinned slots; the oracle's description of the same model has len(active_dims) entries."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from _problems import oracle_params, oracle_spec
+    from baybe_amd import gp_spec
+    from baybe_amd.exceptions import IncompatibilityError
+    from baybe_amd.kernels import GammaPrior, MaternKernel, PiecewisePolynomialKernel, ProductKernel, RBFKernel, ScaleKernel, apply_kernel_spec
+
+    class Space:
+        comp_rep_columns = ("a", "b", "c", "d")
+
+    spec = gp_spec.GPSpec.baybe_default(4, np.zeros(4), np.ones(4))
+    apply_kernel_spec(spec, ProductKernel([MaternKernel(2.5, GammaPrior(3, 1), parameter_names=["a", "b"]),
+                                           ScaleKernel(RBFKernel(GammaPrior(2, 1), parameter_names=["b", "c", "d"]))]), Space())
+    assert spec.active_mask(0).tolist() == [True, True, False, False] and spec.active_mask(1).tolist() == [False, True, True, True]
+    p = gp_spec.initial_params(spec)
+    assert (p.lengthscale[2:] == gp_spec.INACTIVE_LS).all() and p.factor_ls[0][0] == gp_spec.INACTIVE_LS
+    raw, bounds = gp_spec.pack_raw(spec, p), gp_spec.raw_bounds(spec)
+    pinned = [i for i, b in enumerate(bounds) if b[0] is not None and b[0] == b[1]]
+    assert len(pinned) == 3 and all(raw[i] == bounds[i][0] for i in pinned)
+    q = gp_spec.unpack_raw(spec, raw)
+    assert np.array_equal(q.lengthscale, p.lengthscale) and np.array_equal(q.factor_ls[0], p.factor_ls[0])
+    theta = gp_spec.theta_from_params(spec, q)
+    f, g = gp_spec.objective_from_data_term(spec, raw, 10, -3.0, np.ones_like(theta))
+    assert np.isfinite(f) and all(g[i] == 0.0 for i in pinned)  # no prior on, no gradient through, a pinned slot
+    ospec, op = oracle_spec(spec), oracle_params(spec, p)
+    assert len(op.member_ls[0]) == 2 and len(op.member_ls[1]) == 3 and list(ospec.members[1].active_dims) == [1, 2, 3]
+    assert not gp_spec.FastObjective.applies(spec)
+    with pytest.raises(IncompatibilityError):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(4, np.zeros(4), np.ones(4)),
+                          ProductKernel([MaternKernel(2.5, parameter_names=["zz"]), RBFKernel()]), None)
+    with pytest.raises(ValueError):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(4, np.zeros(4), np.ones(4)), MaternKernel(2.5, parameter_names=["zz"]), Space())
