@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_$CFG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python $ROOT/bench.py --config $CFG --steps 20 --warmup 3 --cpu-budget 0 > "$OUT/stats.log" 2>&1
-tail -1 "$OUT/stats.log" > "$OUT/bench_line.json"
+grep "^{\"metric\"" "$OUT/stats.log" | tail -1 > "$OUT/bench_line.json"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   name=$(echo "$grp" | tr ' ' '+')
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- python $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --cpu-budget 0 --greedy 0 > "$OUT/pmc_$name.log" 2>&1
