@@ -82,8 +82,6 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
   WaveCtx c[1];
   int xcol[KD];
   double xval[KD], xscl[KD], xofs[KD];
-  double tfv0[KD];  // training fragments of this wave's first k-block, requested first (see bbh_coop.h)
-  kvp_load<KD>(a.trainfrag + l, w, tfv0);
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
   if (a.numcol_identity) {
@@ -161,8 +159,9 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
     coop_gload2<(i % 4) * 1024>(ring[i], rs + (i / 4) * 512, lane16);
   });
   {  // the first group's kernel values: wave w produces k-block w, not overlapped with anything
-    double kv0[4];
+    double kv0[4], tfv0[KD];
     d4 dsa, dsb;
+    kvp_load<KD>(c[0], w, tfv0);
     kvp_dist<KD>(c[0], tfv0, dsa, dsb);
     kv_all<KVF>(c[0], w, dsa, dsb, kv0);
     __syncthreads();  // alpha is in LDS
@@ -175,61 +174,60 @@ __global__ __launch_bounds__(256, 2) void bbh_coop2_posterior_kernel(const CoopA
   __syncthreads();  // k-blocks 0 .. 3 are complete in the archive
 
   int gi = 0;  // k-block group being consumed (k-blocks 4 gi .. 4 gi + 3)
-  // ---- sweep A: rounds g0 .. 7 of the one-sweep numbering, values archived ----
-  static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
-    constexpr int G = decltype(gc)::value;
-    if (G >= g0) {  // wave-uniform
-      const int cw = (G & 1) ? 3 - w : w;
-      const int tbn = 4 * (gi + 1) + w;  // k-block this wave produces for the next group
-      // (the last group has a single column-block slot - no MFMA slots to host a production - and its successor, sweep B's
-      // first group, is produced after the rectangular part)
-      constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
-      coop_group<G, KD, KVF, PRODUCE, 1, true>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, arch + 4 * gi * 256, arch + tbn * 256,
-                                               alq + 16 * tbn, tbn, cw, acc, ring, accm);
-      rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
-      gi++;
+  double ss[4] = {0.0, 0.0, 0.0, 0.0};
+  // The two sweeps run through ONE copy of the group code (a two-trip loop that is not unrolled): instantiated twice, the
+  // register allocator carried the second copy's constants and addresses across the first and spilled 50 - 67 VGPRs
+  // (0.42 GB of scratch stores per 1e5-candidate launch); as one copy the kernel needs no scratch at all.
+#pragma nounroll
+  for (int sw = 0; sw < 2; sw++) {
+    const int gs = sw ? 0 : g0;  // sweep A: rounds g0 .. 7 of the one-sweep numbering; sweep B: all eight
+    static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int G = decltype(gc)::value;
+      if (G >= gs) {  // wave-uniform
+        const int cw = (G & 1) ? 3 - w : w;
+        const int tbn = 4 * (gi + 1) + w;  // k-block this wave produces for the next group
+        // (the last group has a single column-block slot - no MFMA slots to host a production; sweep B's first group is
+        // produced after the rectangular part)
+        constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
+        // sweep A: kernel values are archived, k-block tb in slot tb; sweep B: double-buffered exchange slots (the archive's first 16 KB)
+        const int cur = sw ? (G & 1) * 4 : 4 * gi;
+        const int nxt = sw ? ((G + 1) & 1) * 4 + w : tbn;
+        coop_group<G, KD, KVF, PRODUCE, 1, true>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, arch + cur * 256, arch + nxt * 256,
+                                                 alq + 16 * tbn, tbn, cw, acc, ring, accm);
+        rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
+        gi++;
+        if (PRODUCE || sw == 0) __syncthreads();
+      }
+    });
+    if (sw == 0) {
+#pragma unroll
+      for (int s = 0; s < BBH_COOP_ROUNDS; s++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) ss[r] = fma(acc[0][s][r], acc[0][s][r], ss[r]);
+        acc[0][s] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
+      // ---- rectangular part: the archived k-blocks against the column blocks of sweep B ----
+      for (int kg = 0; kg < RA; kg++) {
+        coop2_rect_group(rs, arch + 4 * kg * 256, lane16, acc[0], ring);
+        rs += (int64_t)16 * BBH_COOP_ROUNDS * 64;
+      }
+      __syncthreads();  // every wave is done with the archive: its first 16 KB become sweep B's exchange slots
+      {  // sweep B's first group: wave w produces k-block 4 RA + w, not overlapped (as the very first group)
+        const int tb0 = 4 * gi + w;
+        double tfv[KD], kv0[4];
+        d4 dsa, dsb;
+        kvp_load<KD>(c[0], tb0, tfv);
+        kvp_dist<KD>(c[0], tfv, dsa, dsb);
+        kv_all<KVF>(c[0], tb0, dsa, dsb, kv0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          kvb[w * 256 + r * 64] = kv0[r];
+          accm[0] = fma(kv0[r], alq[16 * tb0 + 4 * r], accm[0]);
+        }
+      }
       __syncthreads();
     }
-  });
-  double ss[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < BBH_COOP_ROUNDS; s++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) ss[r] = fma(acc[0][s][r], acc[0][s][r], ss[r]);
-    acc[0][s] = (d4){0.0, 0.0, 0.0, 0.0};
   }
-  // ---- rectangular part: the archived k-blocks against the column blocks of sweep B ----
-  for (int kg = 0; kg < RA; kg++) {
-    coop2_rect_group(rs, arch + 4 * kg * 256, lane16, acc[0], ring);
-    rs += (int64_t)16 * BBH_COOP_ROUNDS * 64;
-  }
-  __syncthreads();  // every wave is done with the archive: its first 16 KB become sweep B's exchange slots
-  {  // sweep B's first group: wave w produces k-block 4 RA + w, not overlapped (as the very first group)
-    const int tb0 = 4 * gi + w;
-    double tfv[KD], kv0[4];
-    d4 dsa, dsb;
-    kvp_load<KD>(c[0], tb0, tfv);
-    kvp_dist<KD>(c[0], tfv, dsa, dsb);
-    kv_all<KVF>(c[0], tb0, dsa, dsb, kv0);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      kvb[w * 256 + r * 64] = kv0[r];
-      accm[0] = fma(kv0[r], alq[16 * tb0 + 4 * r], accm[0]);
-    }
-  }
-  __syncthreads();
-  // ---- sweep B: the one-sweep form on the remaining triangle ----
-  static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
-    constexpr int G = decltype(gc)::value;
-    const int cw = (G & 1) ? 3 - w : w;
-    const int tbn = 4 * (gi + 1) + w;
-    constexpr bool PRODUCE = G + 1 < BBH_COOP_ROUNDS;
-    coop_group<G, KD, KVF, PRODUCE, 1, true>(c, rs, a.trainfrag + (int64_t)tbn * KD * 64, kvb + (G & 1) * 4 * 256,
-                                             kvb + (((G + 1) & 1) * 4 + w) * 256, alq + 16 * tbn, tbn, cw, acc, ring, accm);
-    rs += (int64_t)16 * (BBH_COOP_ROUNDS - G) * 64;
-    gi++;
-    if constexpr (PRODUCE) __syncthreads();
-  });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last requests (the unused tail of the slice)
 
   // ---- ||v||^2 over this wave's column blocks, then over the 16 columns of a block (lanes), then over the waves ----
