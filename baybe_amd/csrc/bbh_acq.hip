@@ -222,14 +222,24 @@ __device__ __forceinline__ double bbh_fast_log_pos(double x) {
 // per 64 threads - one wave per two SIMDs - and took 30 ms per greedy step on 1e6 candidates, six times the
 // fused posterior; this one runs 256-thread workgroups at full occupancy.  The arithmetic (operation order
 // included) is that of the LDS form, so both give bit-identical scores.
+// SAMPLE SLICES (gridDim.y > 1, linear-domain form only): blockIdx.y takes the samples [y per, (y + 1) per) and writes the partial sum
+// of its terms to partial[y][i]; bbh_pending_finish_kernel adds the slices in a fixed order and takes the logarithm.  With one
+// thread per candidate a 1e5-row candidate set is 1563 wavefronts, 1.5 per SIMD, each one long dependent chain: the slices bring
+// the launch to the occupancy a 1e6-row set has (the joint Cholesky factor is recomputed per slice: Q^3 / 3 flops against
+// per x Q x 40).
 template <int Q>
 __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
     const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ cross, int64_t N,
-    const double* __restrict__ mean_p, const double* __restrict__ cov_pp, const double* __restrict__ z, int S,
-    double best_f, double sign, const uint8_t* __restrict__ alive, double* __restrict__ scores) {
-  extern __shared__ double s_zq[];  // [S * Q] base samples, then mean_p [Q - 1], cov_pp [(Q - 1)^2]
+    const double* __restrict__ mean_p, const double* __restrict__ cov_pp, const double* __restrict__ z, int S_total,
+    double best_f, double sign, const uint8_t* __restrict__ alive, double* __restrict__ scores, double* __restrict__ partial) {
+  extern __shared__ double s_zq[];  // [S * Q] base samples of this slice, then mean_p [Q - 1], cov_pp [(Q - 1)^2]
   constexpr int P = Q - 1;
-  double* s_mp = s_zq + (int64_t)S * Q;
+  const int per = (S_total + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int s_begin = (int)blockIdx.y * per;
+  const int S = (s_begin + per <= S_total) ? per : (S_total > s_begin ? S_total - s_begin : 0);  // samples of this slice
+  z += (int64_t)s_begin * Q;
+  if (partial) scores = partial + (int64_t)blockIdx.y * N;
+  double* s_mp = s_zq + (int64_t)per * Q;
   double* s_cpp = s_mp + P;
   for (int e = threadIdx.x; e < S * Q; e += 256) s_zq[e] = z[e];
   for (int e = threadIdx.x; e < P; e += 256) s_mp[e] = mean_p[e];
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   if (alive && !alive[i]) {
-    scores[i] = -INFINITY;
+    scores[i] = partial ? 0.0 : -INFINITY;
     return;
   }
   double L[Q * (Q + 1) / 2];
@@ -393,17 +403,29 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
 #if BBH_PENDING_LSE
   scores[i] = ref + log(sum) - log((double)S);
 #else
-  scores[i] = LOG_TAU_RELU + log(sum) - log((double)S);
+  scores[i] = partial ? sum : LOG_TAU_RELU + log(sum) - log((double)S_total);
 #endif
+}
+
+__global__ __launch_bounds__(256) void bbh_pending_finish_kernel(const double* __restrict__ partial, int slices, int64_t N, int S,
+                                                                 const uint8_t* __restrict__ alive, double* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double total = 0.0;
+  for (int k = 0; k < slices; k++) total += partial[(int64_t)k * N + i];  // NaN (no positive definite factor) propagates
+  scores[i] = (alive && !alive[i]) ? -INFINITY : LOG_TAU_RELU + log(total) - log((double)S);
 }
 
 template <int Q>
 static void bbh_launch_pending_q(hipStream_t st, const double* mean, const double* var, const double* cross, int64_t N,
                                  const double* mp, const double* cpp, const double* z, int S, double best_f, double sign,
-                                 const uint8_t* alive, double* scores) {
-  const size_t lds = sizeof(double) * ((size_t)S * Q + (Q - 1) + (size_t)(Q - 1) * (Q - 1));
-  hipLaunchKernelGGL((bbh_qlogei_pending_q_kernel<Q>), dim3((unsigned)((N + 255) / 256)), dim3(256), lds, st, mean, var,
-                     cross, N, mp, cpp, z, S, best_f, sign, alive, scores);
+                                 const uint8_t* alive, double* scores, int slices, double* partial) {
+  const int per = (S + slices - 1) / slices;
+  const size_t lds = sizeof(double) * ((size_t)per * Q + (Q - 1) + (size_t)(Q - 1) * (Q - 1));
+  hipLaunchKernelGGL((bbh_qlogei_pending_q_kernel<Q>), dim3((unsigned)((N + 255) / 256), (unsigned)slices), dim3(256), lds, st, mean, var,
+                     cross, N, mp, cpp, z, S, best_f, sign, alive, scores, slices > 1 ? partial : nullptr);
+  if (slices > 1)
+    hipLaunchKernelGGL(bbh_pending_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, slices, N, S, alive, scores);
 }
 
 // ---- first-index argmax -----------------------------------------------------------------------
@@ -552,11 +574,25 @@ extern "C" int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const d
   const double* dmp = dz + S * (p + 1);
   const double* dcpp = dmp + p;
   const bool fits = sizeof(double) * ((size_t)S * (p + 1) + p + (size_t)p * p) <= 60 * 1024;  // z in LDS
+  // sample slices for small candidate sets (~16 waves per SIMD; linear-domain form; each slice at least 32 samples)
+  int slices = 1;
+#if BBH_PENDING_FAST && !BBH_PENDING_LSE
+  if (fits && !h->pending_lds_form && p + 1 <= 14) {
+    int64_t want = ((int64_t)16 * 4 * h->num_cu * 64) / N;
+    if (const char* e = getenv("BBH_PENDING_SLICES")) want = atoi(e);
+    if (want > S / 32) want = S / 32;
+    slices = (int)(want < 1 ? 1 : (want > 32 ? 32 : want));
+    if (slices > 1) {
+      rc = bbh_ensure_ws(h, sizeof(double) * (size_t)slices * (size_t)N);
+      if (rc) return rc;
+    }
+  }
+#endif
   bbh_timed_scope timed(h, BBH_TIMED_PENDING);
 #define BBH_PENDING_Q(QV)                                                                                        \
   case QV:                                                                                                       \
     bbh_launch_pending_q<QV>(h->stream, mean_dev, var_dev, cross_dev, N, dmp, dcpp, dz, (int)S, best_f, sign,    \
-                             alive_dev, scores_dev);                                                             \
+                             alive_dev, scores_dev, slices, h->d_ws);                                            \
     break;
   switch (fits && !h->pending_lds_form ? p + 1 : 0) {
     BBH_PENDING_Q(2)

@@ -212,8 +212,12 @@ __device__ __forceinline__ void coop_group(const WaveCtx (&c)[NT], const double*
   }
 }
 
-template <int KD, int KVF, int NT>
-__global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel(const CoopArgs ca) {
+// GMIN: the first round that can exist.  GMIN = 4 (n <= 256) instantiates only rounds 4 .. 7: four accumulator blocks instead of
+// eight, 115 - 123 VGPRs instead of 153 - 193, i.e. four workgroups per CU instead of two or three - the small models BayBE
+// campaigns live in have little MFMA work per tile to hide the per-tile set-up and the kernel-value chains behind.  GMIN = 6
+// (n <= 128): two accumulator blocks, <= 102 VGPRs, five workgroups per CU.
+template <int KD, int KVF, int NT, int GMIN = 0>
+__global__ __launch_bounds__(256, (GMIN >= 6 ? 5 : GMIN >= 4 ? 4 : BBH_COOP_WAVES)) void bbh_coop_posterior_kernel(const CoopArgs ca) {
   const FusedArgs& a = ca.f;
   extern __shared__ __attribute__((aligned(16))) double s_mem[];  // alpha [16 nb] | kv [NT][2][4][256] | red [NT][2][4][16]
   const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
   }
   __syncthreads();  // group g0 is complete in LDS
 
-  static_for<0, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
+  static_for<GMIN, BBH_COOP_ROUNDS>([&](auto gc) __attribute__((always_inline)) {
     constexpr int G = decltype(gc)::value;
     if (G >= g0) {  // wave-uniform: a smaller model occupies the last rounds only
       const int cw = (G & 1) ? 3 - w : w;
@@ -439,6 +443,8 @@ __global__ __launch_bounds__(256, BBH_COOP_WAVES) void bbh_coop_posterior_kernel
 bool bbh_coop_launch(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_a(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 bool bbh_coop_launch_b(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
+// n <= 256 (g0 >= 4): the four-round instantiations (Matérn-5/2 with and without table; 2, 4, 6, 8 k-steps)
+bool bbh_coop_launch_small(int kd, int kind, bool has_tbl, dim3 grid, size_t lds, hipStream_t s, const CoopArgs& a);
 
 #define BBH_COOP_DISPATCH_KD(KDV, NTV)                                                                                        \
   if (kd == KDV) {                                                                                                       \

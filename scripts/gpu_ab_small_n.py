@@ -24,17 +24,20 @@ for (d, n) in ((15, 256), (15, 192), (15, 128), (10, 64), (6, 32)):
     for N in (10_000, 30_000, 100_000, 200_000, 400_000, 1_000_000):
         Xd = torch.from_numpy(Xall[:N]).cuda()
         t = {}
-        for f, g in gs.items():
-            for _ in range(3): g.posterior(Xd)
-            torch.cuda.synchronize(); g.timing_read(reset=True)
+        variants = (("0", "1"), ("2", "0"), ("2", "1"))  # (handle, BBH_COOP_SMALL): windowed, eight-round coop, four-round coop
+        for f, sm in variants:
+            os.environ["BBH_COOP_SMALL"] = sm
+            for _ in range(3): gs[f].posterior(Xd)
+            torch.cuda.synchronize(); gs[f].timing_read(reset=True)
         for rnd in range(3):
-            for f, g in gs.items():
-                for _ in range(10): g.posterior(Xd)
+            for f, sm in variants:
+                os.environ["BBH_COOP_SMALL"] = sm
+                for _ in range(10): gs[f].posterior(Xd)
                 torch.cuda.synchronize()
-                ms, cnt = g.timing_read(reset=True)
-                t.setdefault(f, []).append(ms / cnt)
+                ms, cnt = gs[f].timing_read(reset=True)
+                t.setdefault((f, sm), []).append(ms / cnt)
         fl = N * (n * n + 2 * n * d + 16 * n)
-        a, b = np.median(t["0"]), np.median(t["2"])
-        print(f"d={d} n={n} N={N}: windowed {a*1e3:.1f} us ({fl / (a * 1e-3) / 78.6e12:.3f})  cooperative {b*1e3:.1f} us ({fl / (b * 1e-3) / 78.6e12:.3f})"
-              f"  -> {'coop' if b < a else 'windowed'}", flush=True)
+        a, b, c = (np.median(t[v]) for v in variants)
+        print(f"d={d} n={n} N={N}: windowed {a*1e3:.1f} us ({fl / (a * 1e-3) / 78.6e12:.3f})  cooperative 8 rounds {b*1e3:.1f} us ({fl / (b * 1e-3) / 78.6e12:.3f})"
+              f"  4 rounds / 4 workgroups per CU {c*1e3:.1f} us ({fl / (c * 1e-3) / 78.6e12:.3f})", flush=True)
     for g in gs.values(): g.close()
