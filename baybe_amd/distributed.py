@@ -45,7 +45,15 @@ class RowShard:
     def bind_rccl(self, engine) -> None:
         """Create the library-side RCCL communicator of ``engine`` (a ``HipGP`` handle) for this shard layout: rank 0's
         ncclUniqueId travels through ``agree`` (one torch.distributed broadcast), then every rank joins."""
-        uid = self.agree(engine.comm_unique_id() if self.rank == 0 else None)
+        uid = None
+        if self.rank == 0:
+            try:
+                uid = engine.comm_unique_id()
+            except Exception as ex:  # noqa: BLE001  (RCCL not loadable): every rank must learn of it - the others wait in `agree`
+                uid = ("error", str(ex))
+        uid = self.agree(uid)
+        if isinstance(uid, tuple):
+            raise RuntimeError(f"rank 0 could not create an ncclUniqueId: {uid[1]}")
         engine.comm_init(self.rank, self.world, uid)
         self.use_rccl = True
 

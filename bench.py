@@ -245,6 +245,8 @@ def run(args):
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
         use_rccl = bool(flag.item())
+        if not use_rccl:
+            shard.use_rccl = False  # (a rank whose own set-up succeeded must not take the library path alone)
 
     def step():
         # two kernels: measured 1.5 % faster than the single fused posterior+qLogEI kernel
