@@ -46,7 +46,8 @@ class ModelDesc(C.Structure):
 KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3,
                 "piecewise0": 4, "piecewise1": 5, "piecewise2": 6, "piecewise3": 7, "rq": 8}  # enum bbh_kernel_kind
 CRITERIA = {"mll": 0, "loo": 1}
-MAX_PENDING = 15
+MAX_PENDING = 15  # pending points per cross-covariance pass / in the handle's pending state (BBH_MAX_PENDING)
+MAX_PENDING_BIG = 63  # joint q'-batches through bbh_qlogei_pending_big: q' = 1 + pending <= 64 (qLogEI)
 MAX_OBJECTIVES = 4
 TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2, "columns": 3, "nehvi": 4, "q1": 5}  # enum bbh_timed_family
 ACQ_KINDS = {"qLogEI": 0, "qEI": 1, "qPI": 2, "qSR": 3, "qUCB": 4, "qPSTD": 5,
@@ -106,6 +107,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
          C.c_int64, c_int64_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p],
+    ),
+    "bbh_qlogei_pending_big": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int64,
+         C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     ),
     "bbh_mc_acq_q1": (
         C.c_int,

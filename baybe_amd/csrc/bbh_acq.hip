@@ -617,6 +617,122 @@ extern "C" int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const d
   return 0;
 }
 
+// ---- joint q'-batches beyond 16 points ------------------------------------------------------------------------------------
+// The reference has no cap on batch_size + pending experiments (botorch/discrete.py:120-126); the register form above holds
+// q' <= 14, the LDS form q' <= 16.  For larger q' the thread-private Cholesky factor (q' (q' + 1) / 2 doubles: 4.2 KB at q' = 32)
+// lives in a global workspace, element e of candidate i at Lws[e N + i] (coalesced across the wave), the per-sample
+// log-fat-softplus values in LDS ([q'][64]); mean_p / cov_pp / z are read from global memory at wave-uniform addresses.  Same
+// arithmetic and operation order as bbh_qlogei_pending_kernel (log-domain streaming form, psd_safe_cholesky's jitter retries).
+// Memory-bound on the factor (q'^2 / 2 loads per sample): ~0.1 s per 1e5 candidates at q' = 32 - a correctness path for the
+// rare large batch, not a tuned one.
+#define QBIG_MAX 64
+__global__ __launch_bounds__(64) void bbh_qlogei_pending_big_kernel(
+    const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ cross, int64_t N, int p,
+    const double* __restrict__ mean_p, const double* __restrict__ cov_pp, const double* __restrict__ z, int S,
+    double best_f, double sign, const uint8_t* __restrict__ alive, double* __restrict__ scores, double* __restrict__ Lws) {
+  extern __shared__ double s_li[];  // [q][64]
+  const int t = threadIdx.x;
+  const int q = p + 1;
+  const int64_t i = (int64_t)blockIdx.x * 64 + t;
+  if (i >= N) return;
+  if (alive && !alive[i]) {
+    scores[i] = -INFINITY;
+    return;
+  }
+  double* L = Lws + i;  // L[tri(r, c) * N]
+  const double v0 = var[i];
+  double jitter = 0.0;
+  bool ok = false;
+  for (int attempt = 0; attempt < 4 && !ok; attempt++) {
+    ok = true;
+    for (int r = 0; r < q && ok; r++) {
+      for (int c = 0; c <= r; c++) {
+        double sacc;
+        if (r == 0)
+          sacc = v0;
+        else if (c == 0)
+          sacc = cross[i * p + (r - 1)];
+        else
+          sacc = cov_pp[(r - 1) * p + (c - 1)];
+        if (r == c) sacc += jitter;
+        for (int k = 0; k < c; k++) sacc -= L[(int64_t)tri(r, k) * N] * L[(int64_t)tri(c, k) * N];
+        if (r == c) {
+          if (!(sacc > 0.0)) {
+            ok = false;
+            break;
+          }
+          L[(int64_t)tri(r, r) * N] = sqrt(sacc);
+        } else {
+          L[(int64_t)tri(r, c) * N] = sacc / L[(int64_t)tri(c, c) * N];
+        }
+      }
+    }
+    if (!ok) jitter = 1e-8 * pow(10.0, (double)attempt);
+  }
+  if (!ok) {
+    scores[i] = NAN;
+    return;
+  }
+  const double m0 = mean[i];
+  const double inv_tau = 1.0 / TAU_RELU;
+  double sum = 0.0, ref = -INFINITY;
+  for (int s = 0; s < S; s++) {
+    const double* zs = z + (int64_t)s * q;
+    double mx = -INFINITY;
+    for (int r = 0; r < q; r++) {
+      double y = (r == 0) ? m0 : mean_p[r - 1];
+      for (int c = 0; c <= r; c++) y = fma(L[(int64_t)tri(r, c) * N], zs[c], y);
+      const double tt = (sign * y - best_f) * inv_tau;
+      const double v = log(TAU_RELU) + log(bbh_fatplus_core(tt));
+      s_li[r * 64 + t] = v;
+      mx = fmax(mx, v);
+    }
+    double acc = 0.0;
+    for (int r = 0; r < q; r++) {
+      const double u = 2.0 / (2.0 + (mx - s_li[r * 64 + t]) / TAU_MAX);
+      acc = fma(u, u, acc);
+    }
+    const double fm = mx + TAU_MAX * log(acc);
+    if (fm > ref) {
+      sum = sum * exp(ref - fm) + 1.0;
+      ref = fm;
+    } else {
+      sum += exp(fm - ref);
+    }
+  }
+  scores[i] = ref + log(sum) - log((double)S);
+}
+
+extern "C" int bbh_qlogei_pending_big(bbh_handle* h, const double* mean_dev, const double* var_dev, const double* cross_dev,
+                                      int64_t N, int64_t p, const double* mean_p_host, const double* cov_pp_host,
+                                      const double* z_host, int64_t S, double best_f, double sign, const uint8_t* alive_dev,
+                                      double* scores_dev) {
+  if (!h) return -1;
+  if (!mean_dev || !var_dev || !cross_dev || !mean_p_host || !cov_pp_host || !z_host || !scores_dev || N < 0 || S < 1 || p < 1 ||
+      p + 1 > QBIG_MAX) {
+    h->err = "bbh_qlogei_pending_big: bad arguments (1 <= p <= 63 pending points)";
+    return -1;
+  }
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  const int64_t q = p + 1;
+  std::vector<double> buf((size_t)S * q + p + (size_t)p * p);
+  memcpy(buf.data(), z_host, sizeof(double) * S * q);
+  memcpy(buf.data() + S * q, mean_p_host, sizeof(double) * p);
+  memcpy(buf.data() + S * q + p, cov_pp_host, sizeof(double) * p * p);
+  int rc = bbh_upload_z(h, buf.data(), buf.size());
+  if (rc) return rc;
+  rc = bbh_ensure_ws(h, sizeof(double) * (size_t)(q * (q + 1) / 2) * (size_t)N);
+  if (rc) return rc;
+  const double* dz = h->d_z;
+  bbh_timed_scope timed(h, BBH_TIMED_PENDING);
+  hipLaunchKernelGGL(bbh_qlogei_pending_big_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), sizeof(double) * q * 64, h->stream,
+                     mean_dev, var_dev, cross_dev, N, (int)p, dz + S * q, dz + S * q + p, dz, (int)S, best_f, sign, alive_dev,
+                     scores_dev, h->d_ws);
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
 extern "C" int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,
                           int64_t* best_idx_host) {
   if (!h) return -1;

@@ -31,6 +31,7 @@ from baybe_amd.gp_spec import (
 )
 
 MAX_PENDING = _lib.MAX_PENDING
+MAX_PENDING_BIG = _lib.MAX_PENDING_BIG
 
 
 def _dp(a: np.ndarray):
@@ -504,6 +505,40 @@ class HipGP:
         self._check(self._lib.bbh_cross_cov(self._h, X.data_ptr(), N, X.stride(0), cross.data_ptr()), "bbh_cross_cov")
         return cross
 
+    def cross_cov_many(self, X, X_pending: np.ndarray):
+        """[N, p] posterior cross-covariances with ANY number of pending points: one mean-only pass per chunk of <= 15 (a column
+        does not depend on the other pending points).  Leaves the handle's pending state at the last chunk."""
+        torch = self._torch()
+        P = np.ascontiguousarray(np.atleast_2d(X_pending), dtype=np.float64)
+        cols = []
+        for c0 in range(0, len(P), MAX_PENDING):
+            self.set_pending(P[c0 : c0 + MAX_PENDING])
+            cols.append(self.cross_cov(X))
+        return cols[0] if len(cols) == 1 else torch.cat(cols, dim=1).contiguous()
+
+    def qlogei_pending_big(self, mean, var, cross, X_pending: np.ndarray, z: np.ndarray, best_f: float, sign: float = 1.0,
+                           alive=None):
+        """qLogEI of N t-batches [x_i ; pending] for 16 ... 63 pending points (``bbh_qlogei_pending_big``): the joint
+        posterior of the pending points comes from ``posterior_joint``, their cross-covariances from ``cross_cov_many``."""
+        torch = self._torch()
+        P = np.ascontiguousarray(np.atleast_2d(X_pending), dtype=np.float64)
+        p = P.shape[0]
+        if not MAX_PENDING < p <= MAX_PENDING_BIG or cross.shape[1] != p:
+            raise ValueError(f"qlogei_pending_big handles {MAX_PENDING + 1} ... {MAX_PENDING_BIG} pending points")
+        mp, cpp = self.posterior_joint(P)
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        N = mean.shape[0]
+        scores = torch.empty(N, dtype=torch.float64, device=mean.device)
+        cpp = np.ascontiguousarray(cpp, dtype=np.float64)
+        self._check(
+            self._lib.bbh_qlogei_pending_big(
+                self._h, mean.data_ptr(), var.data_ptr(), cross.data_ptr(), N, p, _dp(np.ascontiguousarray(mp)), _dp(cpp), _dp(z),
+                z.shape[0], float(best_f), float(sign), alive.data_ptr() if alive is not None else None, scores.data_ptr(),
+            ),
+            "bbh_qlogei_pending_big",
+        )
+        return scores
+
     def qlogei_pending(self, mean, var, cross, z: np.ndarray, best_f: float, sign: float = 1.0, alive=None):
         torch = self._torch()
         z = np.ascontiguousarray(z, dtype=np.float64)
@@ -634,7 +669,7 @@ class HipGP:
         # the first step's ranking, so after the first step ONE such pass computes the columns of its top candidates; a later
         # step whose pending points are all among them gathers its columns (bit-identical values: a column is an independent
         # dot product) instead of launching its own pass, any other step falls back to its own pass.
-        spec_rows, spec_pos, cross_spec = None, {}, None
+        spec_rows, spec_pos, cross_spec, big_cross = None, {}, None, None
         b0 = base.shape[0]
         for _step in range(q):
             pend = np.vstack([base] + chosen_rows) if chosen_rows else base
@@ -648,16 +683,32 @@ class HipGP:
             else:
                 if mean is None:
                     mean, var = self.posterior(X)
-                cols = None
-                if cross_spec is not None:
-                    cols = [spec_pos.get(ix) for ix in indices]
-                    cols = None if any(c is None for c in cols) else list(range(b0)) + cols
-                self.set_pending(pend)
-                if cols is not None:
-                    cross = cross_spec[:, cols].contiguous() if len(cols) != cross_spec.shape[1] else cross_spec
+                if p > MAX_PENDING:
+                    # more than 15 pending points (the reference has no cap): columns of earlier steps are kept, the new pick's
+                    # column comes from a one-point pass; the joint kernel takes the pending statistics explicitly
+                    if kind != "qLogEI":
+                        raise ValueError(f"joint q-batches beyond {MAX_PENDING + 1} points are available for qLogEI only")
+                    if p > MAX_PENDING_BIG:
+                        raise ValueError(f"at most {MAX_PENDING_BIG} pending points (batch size + pending experiments <= "
+                                         f"{MAX_PENDING_BIG + 1}) are supported by the HIP path")
+                    if big_cross is None or big_cross.shape[1] != p - 1:
+                        big_cross = self.cross_cov_many(X, pend)
+                    else:
+                        big_cross = torch.cat([big_cross, self.cross_cov_many(X, pend[-1:])], dim=1).contiguous()
+                    scores = self.qlogei_pending_big(mean, var, big_cross, pend, z, best_f, sign, alive)
                 else:
-                    cross = self.cross_cov(X)
-                scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
+                    cols = None
+                    if cross_spec is not None:
+                        cols = [spec_pos.get(ix) for ix in indices]
+                        cols = None if any(c is None for c in cols) else list(range(b0)) + cols
+                    self.set_pending(pend)
+                    if cols is not None:
+                        cross = cross_spec[:, cols].contiguous() if len(cols) != cross_spec.shape[1] else cross_spec
+                    else:
+                        cross = self.cross_cov(X)
+                    if p == MAX_PENDING:
+                        big_cross = cross  # the next step continues from these columns
+                    scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
             if _step == 0 and q > 1 and shard is None and speculate and N > 1 and b0 < MAX_PENDING:
                 m_spec = min(MAX_PENDING - b0, N, 4 * q)
                 tv, top = self.topk(scores, m_spec)
@@ -687,5 +738,5 @@ class HipGP:
             indices.append(int(idx))
             values.append(float(val))
             chosen_rows.append(np.asarray(row, dtype=np.float64).reshape(1, d))
-        self.set_pending(None if base.shape[0] == 0 else base)
+        self.set_pending(None if (base.shape[0] == 0 or base.shape[0] > MAX_PENDING) else base)
         return GreedyResult(indices, values)

@@ -245,9 +245,12 @@ class HipRecommenderImpl:
         acqf = self._acqf_in_use
         if acqf is not None and (acqf.supports_multi_output or getattr(acqf, "is_analytic", False)):
             return
-        if batch_size + n_pend > _lib.MAX_PENDING + 1:
+        # qLogEI: up to 64 points (beyond 16 through bbh_qlogei_pending_big, the factor in a global workspace); the other MC
+        # acquisition functions: 16
+        cap = (_lib.MAX_PENDING_BIG if getattr(acqf, "kind", None) == "qLogEI" else _lib.MAX_PENDING) + 1
+        if batch_size + n_pend > cap:
             raise IncompatibilityError(
-                f"batch_size ({batch_size}) + pending experiments ({n_pend}) exceeds {_lib.MAX_PENDING + 1}, the largest "
+                f"batch_size ({batch_size}) + pending experiments ({n_pend}) exceeds {cap}, the largest "
                 f"joint q-batch of the HIP kernels; recommend in smaller batches (marking earlier ones as pending)."
             )
 

@@ -842,3 +842,36 @@ def test_kernels_on_parameter_subsets(gp, which):
     res = gp.greedy_qlogei(cand, 3, seed=12)
     ref = go.optimize_acqf_discrete_qlogei(om, cand, 3, seed=12)
     assert list(res.indices) == list(ref.indices) and np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL)
+
+
+def test_joint_batches_beyond_sixteen_points(gp):
+    """``optimize_acqf_discrete`` has no cap on batch_size + pending experiments (botorch/discrete.py:120-126); the register / LDS
+    kernels hold 16 points.  Beyond that ``bbh_qlogei_pending_big`` keeps the per-candidate Cholesky factors in a global
+    workspace: a greedy batch of 19 with 3 pending experiments (q' up to 22) must be the oracle's, step by step - including the
+    steps on either side of the hand-over at 16 points - and the recommender accepts the batch."""
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    d, n, N, q = 4, 30, 500, 19
+    X, Xt, y = make_problem(N + 3, d, n, seed=71)
+    pend, X = X[N:], np.ascontiguousarray(X[:N])
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    gp.set_model(spec, Xt, y)
+    fi = gp.fit()
+    om = go.GPModel(_ospec(spec), _oparams(fi.params), Xt, y)
+    res = gp.greedy_qlogei(X, q, S=128, seed=21, X_pending=pend)
+    ref = go.optimize_acqf_discrete_qlogei(om, X, q, S=128, seed=21, X_pending=pend)
+    assert list(res.indices) == list(ref.indices), (res.indices, ref.indices)
+    assert np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL), np.abs(np.array(res.values) - np.array(ref.values)).max()
+    assert len(set(res.indices)) == q
+    # the many-point cross-covariance helper: columns are independent of the chunking
+    P = X[res.indices[:17]]
+    many = _np(gp.cross_cov_many(X, P))
+    gp.set_pending(P[:15]); first = _np(gp.cross_cov(X))
+    gp.set_pending(P[15:]); rest = _np(gp.cross_cov(X))
+    gp.set_pending(None)
+    assert np.array_equal(many, np.hstack([first, rest]))
+    with pytest.raises(ValueError):
+        gp.greedy_qlogei(X, 5, S=64, seed=1, X_pending=X[:62])  # 62 + 4 picks > 63 pending points
+    with pytest.raises(ValueError):
+        gp.greedy_qlogei(X, 18, S=64, seed=1, kind="qEI")  # the other MC functions stop at 16 points

@@ -99,8 +99,9 @@ def test_native_flow_after_the_fit_uses_the_reference_signatures(classes, monkey
     rec = r.recommend(3, space, obj, meas)
     assert seen == {"setup": True, "n_candidates": 36} and list(rec.index) == [0, 1, 2]
     assert r.calls == ["BayesianRecommender.recommend", "PureRecommender.recommend"]
-    with pytest.raises(IncompatibilityError, match="exceeds 16"):
-        r.recommend(17, space, obj, meas)
+    # the joint q-batch of qLogEI (the default) holds up to 64 points (the reference has no cap), the other MC functions 16
+    with pytest.raises(IncompatibilityError, match="exceeds 64"):
+        r.recommend(65, space, obj, meas)
 
 
 def test_objective_and_acquisition_checks_happen_before_any_fit(classes):
