@@ -549,25 +549,40 @@ extern "C" int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double
   return 0;
 }
 
+// p <= 15 pending points with the pending statistics given explicitly (the handle's own, or a caller's - see
+// bbh_qlogei_pending_big)
+static int bbh_qlogei_pending_impl(bbh_handle* h, const double* mean_dev, const double* var_dev, const double* cross_dev, int64_t N,
+                                   int p, const double* mp_host, const double* cpp_host, const double* z_host, int64_t S,
+                                   double best_f, double sign, const uint8_t* alive_dev, double* scores_dev);
+
 extern "C" int bbh_qlogei_pending(bbh_handle* h, const double* mean_dev, const double* var_dev,
                                   const double* cross_dev, int64_t N, const double* z_host, int64_t S, double best_f,
                                   double sign, const uint8_t* alive_dev, double* scores_dev) {
   if (!h) return -1;
-  const int p = h->p;
-  if (!mean_dev || !var_dev || !cross_dev || !z_host || !scores_dev || N < 0 || S < 1 || p < 1) {
+  if (h->p < 1) {
+    h->err = "bbh_qlogei_pending: bad arguments / no pending points set";
+    return -1;
+  }
+  return bbh_qlogei_pending_impl(h, mean_dev, var_dev, cross_dev, N, h->p, h->pend_mean.data(), h->pend_cov.data(), z_host, S, best_f,
+                                 sign, alive_dev, scores_dev);
+}
+
+static int bbh_qlogei_pending_impl(bbh_handle* h, const double* mean_dev, const double* var_dev, const double* cross_dev, int64_t N,
+                                   int p, const double* mp_host, const double* cpp_host, const double* z_host, int64_t S,
+                                   double best_f, double sign, const uint8_t* alive_dev, double* scores_dev) {
+  if (!mean_dev || !var_dev || !cross_dev || !z_host || !scores_dev || !mp_host || !cpp_host || N < 0 || S < 1 || p < 1 ||
+      p > BBH_MAX_PENDING) {
     h->err = "bbh_qlogei_pending: bad arguments / no pending points set";
     return -1;
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
-  // device buffer: z [S, 1+p] followed by the cached pending posterior mean_p [p], cov_pp [p,p]
-  const std::vector<double>& mp = h->pend_mean;
-  const std::vector<double>& cpp = h->pend_cov;
+  // device buffer: z [S, 1+p] followed by the pending posterior mean_p [p], cov_pp [p,p]
   int rc;
   std::vector<double> buf((size_t)S * (p + 1) + p + (size_t)p * p);
   memcpy(buf.data(), z_host, sizeof(double) * S * (p + 1));
-  memcpy(buf.data() + S * (p + 1), mp.data(), sizeof(double) * p);
-  memcpy(buf.data() + S * (p + 1) + p, cpp.data(), sizeof(double) * p * p);
+  memcpy(buf.data() + S * (p + 1), mp_host, sizeof(double) * p);
+  memcpy(buf.data() + S * (p + 1) + p, cpp_host, sizeof(double) * p * p);
   rc = bbh_upload_z(h, buf.data(), buf.size());
   if (rc) return rc;
   const double* dz = h->d_z;
@@ -714,6 +729,9 @@ extern "C" int bbh_qlogei_pending_big(bbh_handle* h, const double* mean_dev, con
     return -1;
   }
   if (N == 0) return 0;
+  if (p <= BBH_MAX_PENDING)  // the register / LDS kernels, with the caller's statistics instead of the handle's
+    return bbh_qlogei_pending_impl(h, mean_dev, var_dev, cross_dev, N, (int)p, mean_p_host, cov_pp_host, z_host, S, best_f, sign,
+                                   alive_dev, scores_dev);
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   const int64_t q = p + 1;
   std::vector<double> buf((size_t)S * q + p + (size_t)p * p);

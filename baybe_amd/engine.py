@@ -517,15 +517,16 @@ class HipGP:
         return cols[0] if len(cols) == 1 else torch.cat(cols, dim=1).contiguous()
 
     def qlogei_pending_big(self, mean, var, cross, X_pending: np.ndarray, z: np.ndarray, best_f: float, sign: float = 1.0,
-                           alive=None):
-        """qLogEI of N t-batches [x_i ; pending] for 16 ... 63 pending points (``bbh_qlogei_pending_big``): the joint
-        posterior of the pending points comes from ``posterior_joint``, their cross-covariances from ``cross_cov_many``."""
+                           alive=None, stats=None):
+        """qLogEI of N t-batches [x_i ; pending] with explicit pending statistics (``bbh_qlogei_pending_big``), 1 ... 63
+        pending points: ``stats`` = (mean [p], cov [p, p]) of the pending points, by default from ``posterior_joint``; their
+        cross-covariances from ``cross_cov`` / ``cross_cov_many``."""
         torch = self._torch()
         P = np.ascontiguousarray(np.atleast_2d(X_pending), dtype=np.float64)
         p = P.shape[0]
-        if not MAX_PENDING < p <= MAX_PENDING_BIG or cross.shape[1] != p:
-            raise ValueError(f"qlogei_pending_big handles {MAX_PENDING + 1} ... {MAX_PENDING_BIG} pending points")
-        mp, cpp = self.posterior_joint(P)
+        if not 1 <= p <= MAX_PENDING_BIG or cross.shape[1] != p:
+            raise ValueError(f"qlogei_pending_big handles 1 ... {MAX_PENDING_BIG} pending points")
+        mp, cpp = stats if stats is not None else self.posterior_joint(P)
         z = np.ascontiguousarray(z, dtype=np.float64)
         N = mean.shape[0]
         scores = torch.empty(N, dtype=torch.float64, device=mean.device)
@@ -662,6 +663,9 @@ class HipGP:
         def get_z(qp: int) -> np.ndarray:
             return z_by_q[qp] if z_by_q is not None else sobol_normal_base_samples(S, qp, seed)
 
+        if q > 0 and N > 0:  # the first pass is enqueued before the host scrambles the first step's base samples (0.6 ms)
+            self.set_pending(None)  # (a variance pass without pending columns: the cooperative kernel forms)
+            mean, var = self.posterior(X)
         z_next = get_z(1 + base.shape[0])
         # Cross-covariance columns ahead of time.  Every later step needs cov(candidate, pending point) for the points picked
         # so far - one mean-only pass of the fused kernel over all candidates per step, whose cost does not depend on the number
@@ -669,15 +673,15 @@ class HipGP:
         # the first step's ranking, so after the first step ONE such pass computes the columns of its top candidates; a later
         # step whose pending points are all among them gathers its columns (bit-identical values: a column is an independent
         # dot product) instead of launching its own pass, any other step falls back to its own pass.
-        spec_rows, spec_pos, cross_spec, big_cross = None, {}, None, None
+        spec_rows, spec_pos, cross_spec, big_cross, spec_stats = None, {}, None, None, None
         b0 = base.shape[0]
         for _step in range(q):
             pend = np.vstack([base] + chosen_rows) if chosen_rows else base
             p = pend.shape[0]
             z = z_next
             if p == 0:
-                self.set_pending(None)
                 if mean is None:  # first step: posterior of every candidate, cached for the later steps
+                    self.set_pending(None)
                     mean, var = self.posterior(X)
                 scores = self.mc_acq(kind, mean, var, z[:, 0], best_f, sign, beta, alive)
             else:
@@ -701,21 +705,29 @@ class HipGP:
                     if cross_spec is not None:
                         cols = [spec_pos.get(ix) for ix in indices]
                         cols = None if any(c is None for c in cols) else list(range(b0)) + cols
-                    self.set_pending(pend)
-                    if cols is not None:
+                    if cols is not None and kind == "qLogEI" and spec_stats is not None:
+                        # columns AND pending statistics are sub-blocks of what the speculative pass left: no bbh_pending_set
+                        # round trip (0.15 - 0.3 ms of host work per step)
                         cross = cross_spec[:, cols].contiguous() if len(cols) != cross_spec.shape[1] else cross_spec
+                        ix = np.asarray(cols)
+                        scores = self.qlogei_pending_big(mean, var, cross, pend, z, best_f, sign, alive,
+                                                         stats=(spec_stats[0][ix], spec_stats[1][np.ix_(ix, ix)]))
                     else:
-                        cross = self.cross_cov(X)
+                        self.set_pending(pend)
+                        if cols is not None:
+                            cross = cross_spec[:, cols].contiguous() if len(cols) != cross_spec.shape[1] else cross_spec
+                        else:
+                            cross = self.cross_cov(X)
+                        scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
                     if p == MAX_PENDING:
                         big_cross = cross  # the next step continues from these columns
-                    scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
             if _step == 0 and q > 1 and shard is None and speculate and N > 1 and b0 < MAX_PENDING:
                 m_spec = min(MAX_PENDING - b0, N, 4 * q)
                 tv, top = self.topk(scores, m_spec)
                 top = [int(t) for t, v in zip(top, tv) if t >= 0 and v > -math.inf]  # live candidates only
                 if top:
                     spec_rows = X[torch.as_tensor(top, device=X.device), :d].cpu().numpy()
-                    self.set_pending(np.vstack([base, spec_rows]))
+                    spec_stats = self.set_pending(np.vstack([base, spec_rows]))  # (mean, cov) of base + speculative points
                     cross_spec = self.cross_cov(X)
                     spec_pos = {ix: b0 + j for j, ix in enumerate(top)}
             if _step + 1 < q:  # host-side Sobol scrambling of the next step overlaps the device work of this one

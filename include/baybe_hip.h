@@ -215,8 +215,10 @@ int bbh_mc_acq_q1(bbh_handle* h, int32_t kind, const double* mean_dev, const dou
 int bbh_mc_acq_pending(bbh_handle* h, int32_t kind, const double* mean_dev, const double* var_dev,
                        const double* cross_dev, int64_t N, const double* z_host, int64_t S, double best_f,
                        double sign, double beta, const uint8_t* alive_dev, double* scores_dev);
-/* qLogEI of N t-batches [x_i ; pending] with MORE than 15 pending points (1 <= p <= 63; the reference's optimize_acqf_discrete
- * has no cap on batch_size + pending experiments, baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126).  The caller
+/* qLogEI of N t-batches [x_i ; pending] with the pending statistics GIVEN by the caller, 1 <= p <= 63 pending points - in
+ * particular more than 15 (the reference's optimize_acqf_discrete has no cap on batch_size + pending experiments,
+ * baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126); p <= 15 runs the kernels of bbh_qlogei_pending (a greedy loop
+ * that already holds the statistics of a superset of its picks saves the bbh_pending_set round trip per step).  The caller
  * supplies what bbh_pending_set keeps for p <= 15: cross_dev [N, p] (columns from bbh_cross_cov over chunks of <= 15 pending
  * points - a column does not depend on the other pending points), mean_p_host [p] and cov_pp_host [p, p] (bbh_posterior_joint of
  * the pending points), z_host [S, 1 + p].  The per-candidate Cholesky factors live in a global workspace of
