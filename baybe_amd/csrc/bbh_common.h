@@ -77,7 +77,18 @@ __host__ __device__ inline double bbh_piecewise(int q, int jb, double r2, bool w
 // alpha: only the RQ kernel)
 // (not inlined: nine kinds with their libm calls, called once per factor and entry - inlined into the unrolled K* kernel it
 // made 23 000 instructions, far beyond the instruction cache)
+// dot-product kinds: the per-factor metric is s = sum_j (x_j / w_j)(x'_j / w_j) instead of a scaled squared distance
+#define BBH_KIND_IS_DOT(kind) ((kind) >= BBH_KERNEL_LINEAR)
+#define BBH_KIND_HAS_ALPHA(kind) ((kind) == BBH_KERNEL_RQ || (kind) >= BBH_KERNEL_POLY1)  // RQ alpha / polynomial offset slot
+// one dimension's contribution to a factor's metric
+__host__ __device__ __forceinline__ double bbh_metric_term(int kind, double xa, double xb, double invw) {
+  if (BBH_KIND_IS_DOT(kind)) return (xa * invw) * (xb * invw);
+  const double df = (xa - xb) * invw;
+  return df * df;
+}
 __host__ __device__ __attribute__((noinline)) inline double bbh_kbase(int kind, double r2, int jb, double alpha = 1.0) {
+  if (kind == BBH_KERNEL_LINEAR) return r2;  // (the variance is the outputscale / factor scale)
+  if (kind >= BBH_KERNEL_POLY1) return bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1 + 1);
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
   if (kind == BBH_KERNEL_RQ) return exp(-alpha * log1p(r2 / (2.0 * alpha)));
   if (kind >= BBH_KERNEL_PIECEWISE0 && kind <= BBH_KERNEL_PIECEWISE3) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);
@@ -289,7 +300,8 @@ void bbh_launch_gram(bbh_handle* h, double jitter);
 bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h);
 int bbh_hadamard_offset(const bbh_handle* h);
 double bbh_prior_base(const bbh_handle* h);
-bool bbh_materialised_only(const bbh_handle* h);  // composite / piecewise-polynomial models: no fused kernel form  // k(x, x) without the task factor
+bool bbh_materialised_only(const bbh_handle* h);
+bool bbh_has_dot_kind(const bbh_handle* h);  // a Linear / Polynomial kernel somewhere: k(x, x) is not constant  // composite / piecewise-polynomial models: no fused kernel form  // k(x, x) without the task factor
 int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                            double* cross_dev);  // composite kernels: every posterior output through the materialised K*  // per-task noise block in theta (means follow at + T), -1 = none
 

@@ -17,6 +17,10 @@
 // ---- stationary kernels as functions of the scaled squared distance -----------------------
 // g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3
 __device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double alpha) {
+  // dot-product kinds, k = f(s) with s = sum_j x_j x'_j / w_j^2: dk/dw_j = -2 f'(s) x_j x'_j / w_j^3, i.e. g = -2 f'(s) with the
+  // product x_j x'_j in the place of Delta_j^2 (the Linear kernel's ARD variances are v_j = 1 / w_j^2)
+  if (kind == BBH_KERNEL_LINEAR) return -2.0;
+  if (kind >= BBH_KERNEL_POLY1) return -2.0 * (double)(kind - BBH_KERNEL_POLY1 + 1) * bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1);
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
   if (kind == BBH_KERNEL_RQ) return exp(-(alpha + 1.0) * log1p(r2 / (2.0 * alpha)));  // (1 + u)^-(alpha + 1), u = r^2 / (2 alpha)
   if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, true);
@@ -73,11 +77,8 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
   }
   double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
-    const double dx = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + b];
-    for (int f = 0; f < ks.F; f++) {
-      const double df = dx * s_invls[f * dn + j];
-      r2[f] += df * df;
-    }
+    const double xa = xnT[(int64_t)j * np + a], xb = xnT[(int64_t)j * np + b];
+    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], xa, xb, s_invls[f * dn + j]);
   }
   double k = bbh_kcomp(ks, theta, r2);
   if (ks.use_os) k *= theta[TH_OS];
@@ -198,11 +199,8 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   const int ta = (T > 1) ? task[a] : 0, tb = (T > 1) ? task[bb] : 0;
   double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
-    const double dx = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
-    for (int f = 0; f < ks.F; f++) {
-      const double df = dx / theta[ks.ls_off[f] + j];
-      r2[f] += df * df;
-    }
+    const double xa = xnT[(int64_t)j * np + a], xb = xnT[(int64_t)j * np + bb];
+    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], xa, xb, 1.0 / theta[ks.ls_off[f] + j]);
   }
   const double os = ks.use_os ? theta[TH_OS] : 1.0;
   const double Bab = (T > 1) ? theta[TH_LS + dn + ta * T + tb] : 1.0;
@@ -249,8 +247,8 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     const double Gg = G * bbh_gfun(ks.kind[f], r2[f], ks.jb, al[f]) * os * Bab * wf[f] * fos;
     for (int j = 0; j < dn; j++) {
       const double l = theta[ks.ls_off[f] + j];
-      const double df = xnT[(int64_t)j * np + a] - xnT[(int64_t)j * np + bb];
-      double v = Gg * df * df / (l * l * l);
+      const double xa = xnT[(int64_t)j * np + a], xb = xnT[(int64_t)j * np + bb];
+      double v = Gg * (BBH_KIND_IS_DOT(ks.kind[f]) ? xa * xb : (xa - xb) * (xa - xb)) / (l * l * l);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
       if (lane == 0) prow[ks.ls_off[f] + j] = v;
@@ -266,6 +264,9 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
       if (ks.kind[f] == BBH_KERNEL_RQ) {
         const double u = r2[f] / (2.0 * al[f]);
         v = G * os * Bab * wf[f] * fos * kf[f] * (u / (1.0 + u) - log1p(u));
+      } else if (ks.kind[f] >= BBH_KERNEL_POLY1) {  // d/d offset (s + offset)^p = p (s + offset)^(p - 1)
+        const int pw = ks.kind[f] - BBH_KERNEL_POLY1 + 1;
+        v = G * os * Bab * wf[f] * fos * (double)pw * bbh_powi(r2[f] + al[f], pw - 1);
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -298,10 +299,17 @@ __global__ __launch_bounds__(256) void bbh_grad_reduce_kernel(const double* __re
 
 // -----------------------------------------------------------------------------------------
 // any factor (or the single kernel) a rational-quadratic kernel: theta carries F alpha slots at its end
-static bool bbh_has_rq(const bbh_handle* h) {
-  if (h->F <= 1) return h->desc.kernel_kind == BBH_KERNEL_RQ;
+static bool bbh_has_rq(const bbh_handle* h) {  // (RQ alpha or polynomial offset: one slot per factor)
+  if (h->F <= 1) return BBH_KIND_HAS_ALPHA(h->desc.kernel_kind);
   for (int f = 0; f < h->F; f++)
-    if (h->desc.factor_kind[f] == BBH_KERNEL_RQ) return true;
+    if (BBH_KIND_HAS_ALPHA(h->desc.factor_kind[f])) return true;
+  return false;
+}
+
+bool bbh_has_dot_kind(const bbh_handle* h) {
+  if (h->F <= 1) return BBH_KIND_IS_DOT(h->desc.kernel_kind);
+  for (int f = 0; f < h->F; f++)
+    if (BBH_KIND_IS_DOT(h->desc.factor_kind[f])) return true;
   return false;
 }
 
@@ -384,7 +392,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->err = "bbh_set_model: bad arguments";
     return -1;
   }
-  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_RQ || desc->d < 1 || desc->n_tasks < 1 ||
+  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_POLY4 || desc->d < 1 || desc->n_tasks < 1 ||
       (desc->n_tasks > 1 && (desc->task_col < 0 || desc->task_col >= desc->d)) ||
       (desc->criterion != BBH_CRITERION_MLL && desc->criterion != BBH_CRITERION_LOO)) {
     h->err = "bbh_set_model: invalid model description";
@@ -393,7 +401,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   if (desc->n_factors > 1) {
     bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1) &&
               desc->factor_kind[0] == desc->kernel_kind;
-    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_RQ;
+    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_POLY4;
     if (!ok) {
       h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1, factor_kind[0] == kernel_kind)";
       return -1;

@@ -196,7 +196,7 @@ static bool bbh_coopg_model(const bbh_handle* h) {
   if (h->nb > 4 * BBH_COOP_ROUNDS || h->nb % 4 != 0) return false;
   const bbh_kern_spec ks = bbh_kern_spec_of(h);
   for (int f = 0; f < ks.F; f++)
-    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0) return false;
+    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0 || BBH_KIND_IS_DOT(ks.kind[f])) return false;
   return bbh_coopg_launch(h->kd, ks.F, dim3(0), 0, nullptr, CoopGArgs{});
 }
 
@@ -613,13 +613,10 @@ __global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict
       const double x = xnT[(int64_t)j * np + i];
 #pragma unroll
       for (int c = 0; c < BBH_KSTAR_CB; c++) {
-        const double dx = s_xc[c * dn + j] - x;
+        const double xc = s_xc[c * dn + j];
 #pragma unroll
         for (int f = 0; f < BBH_MAX_FACTORS; f++)
-          if (f < ks.F) {
-            const double df = dx * s_il[f * dn + j];
-            r2[c][f] = fma(df, df, r2[c][f]);
-          }
+          if (f < ks.F) r2[c][f] += bbh_metric_term(ks.kind[f], xc, x, s_il[f * dn + j]);
       }
     }
   const int ti = (T > 1 && i < n) ? task[i] : 0;
@@ -640,12 +637,28 @@ __global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict
   }
 }
 
+// k(x, x) of every candidate without outer outputscale / task factor (dot-product kernels: not a constant)
+__global__ __launch_bounds__(256) void bbh_kdiag_kernel(const double* __restrict__ X, int64_t Nc, int64_t ldx,
+                                                        const double* __restrict__ theta, const int* __restrict__ numcol,
+                                                        const double* __restrict__ lo, const double* __restrict__ hi, int dn,
+                                                        const bbh_kern_spec ks, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nc) return;
+  double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < dn; j++) {
+    const double x = (X[i * ldx + numcol[j]] - lo[j]) / (hi[j] - lo[j]);
+    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], x, x, 1.0 / theta[ks.ls_off[f] + j]);
+  }
+  out[i] = bbh_kcomp(ks, theta, r2);
+}
+
 __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __restrict__ Kst, const double* __restrict__ V,
                                                             const double* __restrict__ alpha,
                                                             const double* __restrict__ X, int64_t ldx, int64_t Nc,
                                                             int64_t np, const double* __restrict__ theta, int dn,
                                                             double prior_base, int T, int task_col, int hoff, double ybar, double ysd,
-                                                            double* __restrict__ mean, double* __restrict__ var) {
+                                                            double* __restrict__ mean, double* __restrict__ var,
+                                                            const double* __restrict__ kdiag, double os) {
   const int lane = threadIdx.x & 63;
   const int64_t cand = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cand >= Nc) return;
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(256) void bbh_rowreduce_kernel(const double* __rest
     sv += __shfl_down(sv, o, 64);
   }
   if (lane == 0) {
-    double pv = prior_base, mc = theta[1];  // k(x, x) without the task factor
+    double pv = kdiag ? os * kdiag[cand] : prior_base, mc = theta[1];  // k(x, x) without the task factor
     if (T > 1) {
       int tcand = (int)X[cand * ldx + task_col];
       tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
@@ -715,7 +728,8 @@ __global__ __launch_bounds__(256) void bbh_ext_epilogue_kernel(const double* __r
                                                                int64_t np, const double* __restrict__ theta, int dn,
                                                                double prior_base, int T, int task_col, int hoff, double ybar,
                                                                double ysd, int p, double* __restrict__ mean,
-                                                               double* __restrict__ var, double* __restrict__ cross) {
+                                                               double* __restrict__ var, double* __restrict__ cross,
+                                                               const double* __restrict__ kdiag, double os) {
   // one wave per candidate: O[c] = sum_i Kext[i] Bm[i][c] for the mean column c = 0 and the pending columns 1..p
   const int lane = threadIdx.x & 63;
   const int64_t cand = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(256) void bbh_ext_epilogue_kernel(const double* __r
     for (int c = 0; c < 16; c++) o[c] += __shfl_down(o[c], sh, 64);
   }
   if (lane == 0) {
-    double pv = prior_base, mc = theta[1];
+    double pv = kdiag ? os * kdiag[cand] : prior_base, mc = theta[1];
     if (T > 1) {
       int tcand = (int)X[cand * ldx + task_col];
       tcand = tcand < 0 ? 0 : (tcand >= T ? T - 1 : tcand);
@@ -763,13 +777,15 @@ int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_
   if (N <= 0) return 0;
   const int64_t np = h->np, ldk = np + 16;
   const int64_t chunk = N < 16384 ? bbh_round_up(N, 64) : 16384;  // (small candidate sets: a small workspace)
-  const size_t need = sizeof(double) * ((size_t)chunk * ldk + (size_t)chunk * np + 2 * h->dn);
+  const size_t need = sizeof(double) * ((size_t)chunk * ldk + (size_t)chunk * np + 2 * h->dn + (size_t)chunk);
   int rc = bbh_ensure_ws(h, need);
   if (rc) return rc;
   double* Kext = h->d_ws;
   double* V = Kext + chunk * ldk;
   double* d_lo = V + chunk * np;
   double* d_hi = d_lo + h->dn;
+  double* kdiag = bbh_has_dot_kind(h) ? d_hi + h->dn : nullptr;  // per-candidate k(x, x): Linear / Polynomial kernels
+  const double os_outer = h->desc.use_outputscale ? h->theta[2] : 1.0;
   hipStream_t s = h->stream;
   BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
   BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, s));
@@ -787,10 +803,13 @@ int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_
                        h->d_theta, h->d_numcol, d_lo, d_hi, h->p, (int64_t)16, h->dn, ks, h->T, h->desc.task_col, ldk,
                        Kext + np);
     if (var_dev) bbh_gemm(s, false, true, Ncpad, np, np, 1.0, Kext, ldk, 0, h->d_X, np, 0, 0.0, V, np, 0, 1);
+    if (kdiag && var_dev)
+      hipLaunchKernelGGL(bbh_kdiag_kernel, dim3((unsigned)((Nc + 255) / 256)), dim3(256), 0, s, Xc, Nc, ldx, h->d_theta, h->d_numcol, d_lo,
+                         d_hi, h->dn, ks, kdiag);
     hipLaunchKernelGGL(bbh_ext_epilogue_kernel, dim3((unsigned)((Nc + 3) / 4)), dim3(256), 0, s, var_dev ? V : nullptr, Kext, ldk,
                        h->d_meanB, Xc, ldx, Nc, np, h->d_theta, h->dn, bbh_prior_base(h), h->T, h->desc.task_col, bbh_hadamard_offset(h),
                        h->ybar, h->ysd, h->p, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr,
-                       cross_dev ? cross_dev + s0 * h->p : nullptr);
+                       cross_dev ? cross_dev + s0 * h->p : nullptr, var_dev ? kdiag : nullptr, os_outer);
   }
   BBH_HIP_TRY(h, hipGetLastError());
   h->last_form = 2;
@@ -800,23 +819,28 @@ int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_
 int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev) {
   const int64_t np = h->np;
   const int64_t chunk = 16384;
-  const size_t need = sizeof(double) * (2 * (size_t)chunk * np + 2 * h->dn);
+  const size_t need = sizeof(double) * (2 * (size_t)chunk * np + 2 * h->dn + (size_t)chunk);
   int rc = bbh_ensure_ws(h, need);
   if (rc) return rc;
   double* Kst = h->d_ws;
   double* V = Kst + chunk * np;
   double* d_lo = V + chunk * np;
   double* d_hi = d_lo + h->dn;
+  double* kdiag = bbh_has_dot_kind(h) ? d_hi + h->dn : nullptr;
+  const double os_outer = h->desc.use_outputscale ? h->theta[2] : 1.0;
   BBH_HIP_TRY(h, hipMemcpyAsync(d_lo, h->lo.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, h->stream));
   BBH_HIP_TRY(h, hipMemcpyAsync(d_hi, h->hi.data(), sizeof(double) * h->dn, hipMemcpyHostToDevice, h->stream));
   for (int64_t s0 = 0; s0 < N; s0 += chunk) {
     const int64_t Nc = (N - s0 < chunk) ? N - s0 : chunk;
     rc = bbh_unfused_chunk(h, X_dev + s0 * ldx, Nc, ldx, Kst, V, d_lo, d_hi);
     if (rc) return rc;
+    if (kdiag)
+      hipLaunchKernelGGL(bbh_kdiag_kernel, dim3((unsigned)((Nc + 255) / 256)), dim3(256), 0, h->stream, X_dev + s0 * ldx, Nc, ldx,
+                         h->d_theta, h->d_numcol, d_lo, d_hi, h->dn, bbh_kern_spec_of(h), kdiag);
     hipLaunchKernelGGL(bbh_rowreduce_kernel, dim3((unsigned)((Nc + 3) / 4)), dim3(256), 0, h->stream, Kst, V, h->d_alpha,
                        X_dev + s0 * ldx, ldx, Nc, np, h->d_theta, h->dn, bbh_prior_base(h), h->T, h->desc.task_col,
                        bbh_hadamard_offset(h),
-                       h->ybar, h->ysd, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr);
+                       h->ybar, h->ysd, mean_dev ? mean_dev + s0 : nullptr, var_dev ? var_dev + s0 : nullptr, kdiag, os_outer);
   }
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
@@ -908,10 +932,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
       double kc = ks.combine && ks.F > 1 ? 0.0 : 1.0;
       for (int f = 0; f < ks.F; f++) {
         double r2 = 0.0;
-        for (int c = 0; c < dn; c++) {
-          const double df = (pn[i * dn + c] - pn[j * dn + c]) / th[ks.ls_off[f] + c];
-          r2 += df * df;
-        }
+        for (int c = 0; c < dn; c++) r2 += bbh_metric_term(ks.kind[f], pn[i * dn + c], pn[j * dn + c], 1.0 / th[ks.ls_off[f] + c]);
         const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb, ks.alpha_off >= 0 ? th[ks.alpha_off + f] : 1.0);
         kc = (ks.combine && ks.F > 1) ? kc + u : kc * u;
       }
@@ -1248,11 +1269,8 @@ __global__ __launch_bounds__(256) void bbh_kqq_kernel(const double* __restrict__
     double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
     for (int j = 0; j < dn; j++) {
       const double rng = hi[j] - lo[j];
-      const double dx = (Xq[a * ldx + numcol[j]] - lo[j]) / rng - (Xq[b * ldx + numcol[j]] - lo[j]) / rng;
-      for (int f = 0; f < ks.F; f++) {
-        const double df = dx / theta[ks.ls_off[f] + j];
-        r2[f] += df * df;
-      }
+      const double xa = (Xq[a * ldx + numcol[j]] - lo[j]) / rng, xb = (Xq[b * ldx + numcol[j]] - lo[j]) / rng;
+      for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], xa, xb, 1.0 / theta[ks.ls_off[f] + j]);
     }
     v = bbh_kcomp(ks, theta, r2);
     if (ks.use_os) v *= theta[2];

@@ -31,6 +31,53 @@ def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))
 
 
+# Dot-product kernels (baybe/kernels/basic.py:20-46, 135-163): the device evaluates them on s = sum_j x_j x'_j / w_j^2 with the
+# weights w_j in the lengthscale slots of theta (include/baybe_hip.h, BBH_KERNEL_LINEAR ..).
+#   "linear" - gpytorch LinearKernel with ``ard_num_dims`` set (BasicKernel._get_dimensions, kernels/base.py:218-239, always sets
+#       it): one variance v_j = softplus(raw_variance_j) per active column, k = sum_j v_j x_j x'_j, hence w_j = v_j^-1/2.  Lengthscale
+#       constraint "linvar"; ``ls_prior`` / ``ls_init`` are the VARIANCE prior / initial value (LinearKernel.variance_prior, ..).
+#   "poly1" .. "poly4" - gpytorch PolynomialKernel(power): (x . x' + offset)^power, no per-column parameter: w_j = 1 (constraint
+#       "pinned"), offset = softplus(raw_offset) in the factor's alpha slot with ``alpha_prior`` / ``alpha_init``.
+DOT_KINDS = ("linear", "poly1", "poly2", "poly3", "poly4")
+ALPHA_KINDS = ("rq", "poly1", "poly2", "poly3", "poly4")  # kinds with one extra Positive() scalar (RQ alpha / polynomial offset)
+
+
+def dot_kind_constraint(kind: str) -> "str | None":
+    return "linvar" if kind == "linear" else ("pinned" if kind in DOT_KINDS else None)
+
+
+def _ls_nat_to_raw(c: str, ls):
+    ls = np.asarray(ls, dtype=np.float64)
+    if c == "box":
+        return ls
+    if c == "softplus":
+        return inv_softplus(ls)
+    if c == "linvar":
+        return inv_softplus(ls ** -2.0)
+    if c == "pinned":
+        return np.zeros_like(ls)
+    raise ValueError(c)
+
+
+def _ls_raw_to_nat(c: str, raw):
+    raw = np.asarray(raw, dtype=np.float64)
+    if c == "box":
+        return raw.copy()
+    if c == "softplus":
+        return softplus(raw)
+    if c == "linvar":
+        return softplus(raw) ** -0.5
+    if c == "pinned":
+        return np.ones_like(raw)
+    raise ValueError(c)
+
+
+def _ls_start(c: str, init) -> float:
+    """Natural value of a lengthscale slot at the start of a fit (``init`` = the kernel's ``*_initial_value``, None: raw 0)."""
+    v0 = float(init) if init is not None else float(softplus(0.0))
+    return 1.0 if c == "pinned" else (v0 ** -0.5 if c == "linvar" else v0)
+
+
 @dataclass
 class KernelFactor:
     """One stationary factor of a composite kernel (``baybe/kernels/composite.py:60-91``): ARD over all numerical
@@ -46,6 +93,8 @@ class KernelFactor:
     outputscale_prior: tuple | None = None
     outputscale_init: float | None = None
     active: "np.ndarray | None" = None  # bool [dn]: the numerical columns the factor acts on (``parameter_names``); None = all
+    alpha_prior: tuple | None = None  # polynomial kernels: prior / initial value of the offset (the factor's alpha slot)
+    alpha_init: float | None = None
 
 
 # Lengthscale of a numerical column a kernel does NOT act on (``BasicKernel.parameter_names``, kernels/base.py:198-240: gpytorch
@@ -85,6 +134,17 @@ class GPSpec:
     factors: "list[KernelFactor] | None" = None
     combine: str = "product"  # "product" (ProductKernel) | "sum" (AdditiveKernel)
     active: "np.ndarray | None" = None  # bool [dn]: columns the (first) kernel acts on (``parameter_names``); None = all
+    alpha_prior: tuple | None = None  # polynomial kernel: prior / initial value of the offset (KernelFactor.alpha_*)
+    alpha_init: float | None = None
+
+    def ls_constraint_of(self, k: int = 0) -> str:
+        return self.ls_constraint if (k == 0 or not self.factors) else self.factors[k].ls_constraint
+
+    def alpha_spec(self, k: int = 0):
+        """(prior, initial value) of factor ``k``'s alpha slot (RQ alpha: none / raw 0; polynomial offset: as given)."""
+        if k == 0 or not self.factors:
+            return self.alpha_prior, self.alpha_init
+        return self.factors[k].alpha_prior, self.factors[k].alpha_init
 
     def active_mask(self, k: int = 0) -> "np.ndarray | None":
         """Column mask of factor ``k`` (0 = the single kernel / first factor), None when it acts on every numerical column."""
@@ -105,9 +165,14 @@ class GPSpec:
 
     @property
     def has_rq(self) -> bool:
-        """A rational-quadratic kernel somewhere: theta ends with one alpha per factor (gpytorch ``RQKernel.raw_alpha``:
-        ``Positive()``, raw 0, no prior - BayBE's ``RQKernel`` exposes neither, kernels/basic.py:202-216)."""
-        return "rq" in self.factor_kinds
+        """A rational-quadratic or polynomial kernel somewhere: theta ends with one alpha per factor (gpytorch
+        ``RQKernel.raw_alpha``: ``Positive()``, raw 0, no prior - BayBE's ``RQKernel`` exposes neither, kernels/basic.py:202-216;
+        ``PolynomialKernel.raw_offset``: ``Positive()``, optional prior and initial value, kernels/basic.py:135-163)."""
+        return any(k in ALPHA_KINDS for k in self.factor_kinds)
+
+    @property
+    def has_dot_kind(self) -> bool:
+        return any(k in DOT_KINDS for k in self.factor_kinds)
 
     def set_factors(self, factors, combine: str = "product"):
         """Make this a composite-kernel model; the first factor takes over the single-kernel fields."""
@@ -120,6 +185,7 @@ class GPSpec:
         self.kernel, self.ls_constraint, self.ls_prior, self.ls_init = f0.kernel, f0.ls_constraint, f0.ls_prior, f0.ls_init
         self.ls_lower = f0.ls_lower if f0.ls_constraint == "box" else self.ls_lower
         self.active = f0.active
+        self.alpha_prior, self.alpha_init = f0.alpha_prior, f0.alpha_init
         self.factors, self.combine = factors, combine
         return self
 
@@ -271,7 +337,7 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
     """Prior modes for the default preset (presets/baybe.py:100-105, 134-142), softplus(0) for
     Positive()-constrained parameters.  Task factors start deterministically (W = 1/sqrt(T),
     v = softplus(0)); gpytorch's random start is not reproduced (parity notes)."""
-    ls0 = spec.ls_init if spec.ls_init is not None else float(softplus(0.0))
+    ls0 = _ls_start(spec.ls_constraint, spec.ls_init)
     nz0 = spec.noise_init if spec.noise_init is not None else 1e-2
     p = GPParams(
         lengthscale=np.full(spec.dn, ls0),
@@ -289,11 +355,12 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
             p.noise, p.mean = np.full(T, nz0), np.zeros(T)
     if spec.factors:
         sp0 = float(softplus(0.0))
-        p.factor_ls = [np.full(spec.dn, f.ls_init if f.ls_init is not None else sp0) for f in spec.factors[1:]]
+        p.factor_ls = [np.full(spec.dn, _ls_start(f.ls_constraint, f.ls_init)) for f in spec.factors[1:]]
         p.factor_os = np.array([(f.outputscale_init if f.outputscale_init is not None else sp0) if f.scaled else 1.0
                                 for f in spec.factors], dtype=np.float64)
     if spec.has_rq:
-        p.alpha = np.array([float(softplus(0.0)) if k == "rq" else 1.0 for k in spec.factor_kinds])
+        p.alpha = np.array([(float(spec.alpha_spec(m)[1]) if spec.alpha_spec(m)[1] is not None else float(softplus(0.0)))
+                            if k in ALPHA_KINDS else 1.0 for m, k in enumerate(spec.factor_kinds)])
     return _pin_inactive(spec, p)
 
 
@@ -331,7 +398,14 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
         raise ValueError(prior[0])
 
     p = initial_params(spec)
-    p.lengthscale = np.maximum(draw(spec.ls_prior, spec.dn, p.lengthscale[0]), spec.ls_lower if spec.ls_constraint == "box" else 1e-6)
+    def draw_ls(c, prior, start, lower):
+        if c == "pinned":
+            return np.ones(spec.dn)
+        if c == "linvar":  # the prior is over the variances v = w^-2
+            return np.maximum(draw(prior, spec.dn, start ** -2.0), 1e-6) ** -0.5
+        return np.maximum(draw(prior, spec.dn, start), lower if c == "box" else 1e-6)
+
+    p.lengthscale = draw_ls(spec.ls_constraint, spec.ls_prior, p.lengthscale[0], spec.ls_lower)
     if spec.hadamard:
         p.noise = np.maximum(draw(spec.noise_prior, spec.n_tasks, p.noise[0]), spec.noise_lower)
     else:
@@ -340,10 +414,14 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
         p.outputscale = float(max(draw(spec.outputscale_prior, 1, p.outputscale)[0], 1e-6))
     if spec.factors:
         for k, f in enumerate(spec.factors[1:]):
-            p.factor_ls[k] = np.maximum(draw(f.ls_prior, spec.dn, p.factor_ls[k][0]), f.ls_lower if f.ls_constraint == "box" else 1e-6)
+            p.factor_ls[k] = draw_ls(f.ls_constraint, f.ls_prior, p.factor_ls[k][0], f.ls_lower)
         for k, f in enumerate(spec.factors):
             if f.scaled:
                 p.factor_os[k] = float(max(draw(f.outputscale_prior, 1, p.factor_os[k])[0], 1e-6))
+    if spec.has_rq:
+        for m in range(spec.n_factors):
+            if spec.alpha_spec(m)[0] is not None:
+                p.alpha[m] = float(max(draw(spec.alpha_spec(m)[0], 1, p.alpha[m])[0], 1e-6))
     return _pin_inactive(spec, p)
 
 
@@ -371,15 +449,15 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
         parts.append(inv_softplus(np.array([p.outputscale])))
     if spec.factors and spec.factors[0].scaled:
         parts.append(inv_softplus(np.array([p.factor_os[0]])))
-    parts.append(p.lengthscale if spec.ls_constraint == "box" else inv_softplus(p.lengthscale))
+    parts.append(_ls_nat_to_raw(spec.ls_constraint, p.lengthscale))
     kinds = spec.factor_kinds
-    if kinds[0] == "rq":
+    if kinds[0] in ALPHA_KINDS:
         parts.append(inv_softplus(np.array([p.alpha[0]])))
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             parts.append(inv_softplus(np.array([p.factor_os[k + 1]])))
-        parts.append(p.factor_ls[k] if f.ls_constraint == "box" else inv_softplus(p.factor_ls[k]))
-        if f.kernel == "rq":
+        parts.append(_ls_nat_to_raw(f.ls_constraint, p.factor_ls[k]))
+        if f.kernel in ALPHA_KINDS:
             parts.append(inv_softplus(np.array([p.alpha[k + 1]])))
     if spec.n_tasks > 1:
         parts.append(inv_softplus(p.task_W).reshape(-1))
@@ -403,25 +481,26 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     if spec.factors and spec.factors[0].scaled:
         fos[0] = float(softplus(raw[i])); i += 1
     ls_raw = raw[i : i + spec.dn]; i += spec.dn
-    ls = ls_raw.copy() if spec.ls_constraint == "box" else softplus(ls_raw)
+    ls = _ls_raw_to_nat(spec.ls_constraint, ls_raw)
     kinds = spec.factor_kinds
     alpha = np.ones(len(kinds)) if spec.has_rq else None
-    if kinds[0] == "rq":
+    if kinds[0] in ALPHA_KINDS:
         alpha[0] = float(softplus(raw[i])); i += 1
     fls = [] if spec.factors else None
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             fos[k + 1] = float(softplus(raw[i])); i += 1
         r = raw[i : i + spec.dn]; i += spec.dn
-        fls.append(r.copy() if f.ls_constraint == "box" else softplus(r))
-        if f.kernel == "rq":
+        fls.append(_ls_raw_to_nat(f.ls_constraint, r))
+        if f.kernel in ALPHA_KINDS:
             alpha[k + 1] = float(softplus(raw[i])); i += 1
     W = v = None
     if spec.n_tasks > 1:
         T = spec.n_tasks
         W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
         v = softplus(raw[i : i + T]); i += T
-    return GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos, alpha)
+    p = GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos, alpha)
+    return _pin_inactive(spec, p) if (spec.has_subsets and spec.has_dot_kind) else p
 
 
 def raw_bounds(spec: GPSpec):
@@ -432,19 +511,21 @@ def raw_bounds(spec: GPSpec):
         b.append((None, None))
     if spec.factors and spec.factors[0].scaled:
         b.append((None, None))
-    def ls_bounds(k, lower, box):
+    def ls_bounds(k, lower, c):
         m = spec.active_mask(k)
-        pin = INACTIVE_LS if box else float(inv_softplus(np.array([INACTIVE_LS]))[0])  # raw value of a pinned slot
-        return [((pin, pin) if (m is not None and not m[j]) else ((lower, None) if box else (None, None))) for j in range(spec.dn)]
+        if c == "pinned":  # polynomial kernels: no per-column parameter at all
+            return [(0.0, 0.0)] * spec.dn
+        pin = float(_ls_nat_to_raw(c, np.array([INACTIVE_LS]))[0])  # raw value of a pinned slot
+        return [((pin, pin) if (m is not None and not m[j]) else ((lower, None) if c == "box" else (None, None))) for j in range(spec.dn)]
 
-    b += ls_bounds(0, spec.ls_lower, spec.ls_constraint == "box")
-    if spec.factor_kinds[0] == "rq":
+    b += ls_bounds(0, spec.ls_lower, spec.ls_constraint)
+    if spec.factor_kinds[0] in ALPHA_KINDS:
         b.append((None, None))
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             b.append((None, None))
-        b += ls_bounds(k + 1, f.ls_lower, f.ls_constraint == "box")
-        if f.kernel == "rq":
+        b += ls_bounds(k + 1, f.ls_lower, f.ls_constraint)
+        if f.kernel in ALPHA_KINDS:
             b.append((None, None))
     if spec.n_tasks > 1:
         b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
@@ -478,6 +559,26 @@ def _ls_prior_logp_and_grad(prior, ls, mask):
     g = np.zeros_like(ls)
     g[mask] = g_act
     return lp, g
+
+
+def _ls_chain(c, prior, ls, raw, g_theta, mask):
+    """(log prior, d objective / d raw) of one lengthscale block: the device's gradient in the theta slots chained through the
+    constraint ``c``, plus the prior term - for "linvar" both live on the variances v = w^-2 of the Linear kernel."""
+    ls = np.asarray(ls, dtype=np.float64)
+    if c == "pinned":
+        return 0.0, np.zeros_like(ls)
+    if c == "linvar":
+        act = np.ones(ls.shape, dtype=bool) if mask is None else mask
+        v = np.where(act, ls, 1.0) ** -2.0
+        lp, glp = _prior_logp_and_grad(prior, v[act])
+        g = g_theta * (-0.5) * v ** -1.5
+        g[act] += glp
+        return lp, np.where(act, g * sigmoid(raw), 0.0)
+    lp, glp = _ls_prior_logp_and_grad(prior, ls, mask)
+    g = g_theta + glp
+    if c != "box":
+        g = g * sigmoid(raw)
+    return lp, (g if mask is None else np.where(mask, g, 0.0))
 
 
 def _task_correlation_prior(prior, B):
@@ -517,12 +618,11 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         g_noise, g_mean = grad_theta[0:1], grad_theta[1:2]
     g_os = grad_theta[2]
     g_ls = grad_theta[3 : 3 + dn]
-    lp_ls, glp_ls = _ls_prior_logp_and_grad(spec.ls_prior, p.lengthscale, spec.active_mask(0))
     lp_nz, glp_nz = _prior_logp_and_grad(spec.noise_prior, np.atleast_1d(p.noise))
     lp_os, glp_os = 0.0, np.zeros(1)
     if spec.use_outputscale:
         lp_os, glp_os = _prior_logp_and_grad(spec.outputscale_prior, np.array([p.outputscale]))
-    total = value + lp_ls + lp_nz + lp_os
+    total = value + lp_nz + lp_os
     g_nz = g_noise + glp_nz
     if spec.noise_constraint != "box":
         g_nz = g_nz * sigmoid(raw[0:m])
@@ -544,31 +644,29 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
     if spec.factors and spec.factors[0].scaled:
         total += scale_slot(0, spec.factors[0], i)
         i += 1
-    gl = g_ls + glp_ls
-    if spec.ls_constraint != "box":
-        gl = gl * sigmoid(raw[i : i + dn])
-    if spec.active_mask(0) is not None:
-        gl = np.where(spec.active_mask(0), gl, 0.0)
+    def alpha_slot(m, i):  # RQ alpha / polynomial offset: softplus chain, prior only where the kernel declares one
+        lp, glp = _prior_logp_and_grad(spec.alpha_spec(m)[0], np.array([p.alpha[m]]))
+        g.append(np.array([(grad_theta[alpha_off + m] + glp[0]) * float(sigmoid(raw[i]))]))
+        return lp
+
+    lp_ls, gl = _ls_chain(spec.ls_constraint, spec.ls_prior, p.lengthscale, raw[i : i + dn], g_ls, spec.active_mask(0))
+    total += lp_ls
     g.append(gl)
     i += dn
-    if spec.factor_kinds[0] == "rq":  # softplus chain, no prior
-        g.append(np.array([grad_theta[alpha_off] * float(sigmoid(raw[i]))]))
+    if spec.factor_kinds[0] in ALPHA_KINDS:
+        total += alpha_slot(0, i)
         i += 1
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             total += scale_slot(k + 1, f, i)
             i += 1
-        lp_f, glp_f = _ls_prior_logp_and_grad(f.ls_prior, p.factor_ls[k], spec.active_mask(k + 1))
+        lp_f, gf = _ls_chain(f.ls_constraint, f.ls_prior, p.factor_ls[k], raw[i : i + dn],
+                             grad_theta[base + k * dn : base + (k + 1) * dn], spec.active_mask(k + 1))
         total += lp_f
-        gf = grad_theta[base + k * dn : base + (k + 1) * dn] + glp_f
-        if f.ls_constraint != "box":
-            gf = gf * sigmoid(raw[i : i + dn])
-        if spec.active_mask(k + 1) is not None:
-            gf = np.where(spec.active_mask(k + 1), gf, 0.0)
         g.append(gf)
         i += dn
-        if f.kernel == "rq":
-            g.append(np.array([grad_theta[alpha_off + k + 1] * float(sigmoid(raw[i]))]))
+        if f.kernel in ALPHA_KINDS:
+            total += alpha_slot(k + 1, i)
             i += 1
     if T > 1:
         S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)  # dL/dB of the (scaled) table the device multiplies with
@@ -595,7 +693,7 @@ class FastObjective:
 
     @staticmethod
     def applies(spec: GPSpec) -> bool:
-        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard and not spec.has_subsets
+        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard and not spec.has_subsets and not spec.has_dot_kind
 
     def __init__(self, spec: GPSpec, n: int):
         self.n = int(n)

@@ -1,7 +1,8 @@
 """Declarative kernel / prior specifications accepted by ``HipGaussianProcessSurrogate``
 (mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
 ``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
-device: Matérn(0.5|1.5|2.5) / RBF / RQ / PiecewisePolynomial(q) base kernels with ARD over all numerical columns, optionally
+device: Matérn(0.5|1.5|2.5) / RBF / RQ / PiecewisePolynomial(q) / Linear / Polynomial(power 1..4) base kernels with ARD over all
+numerical columns (or the columns of ``parameter_names``), optionally
 wrapped in a ScaleKernel, and ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``) of two to
 four such factors, each optionally in its own ScaleKernel, the whole optionally in an outer ScaleKernel).
 
@@ -70,6 +71,31 @@ class RQKernel:
 
 
 @define(frozen=True)
+class LinearKernel:
+    """``baybe.kernels.basic.LinearKernel`` (basic.py:20-46): sum_j v_j x_j x'_j with one variance per column (gpytorch
+    ``LinearKernel`` with ``ard_num_dims``, which ``BasicKernel._get_dimensions`` always sets)."""
+
+    variance_prior = field(default=None)
+    variance_initial_value: float | None = field(default=None, validator=optional(gt(0.0)))
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
+
+
+@define(frozen=True)
+class PolynomialKernel:
+    """``baybe.kernels.basic.PolynomialKernel`` (basic.py:135-163): (x . x' + offset)^power."""
+
+    power: int = field(validator=instance_of(int))
+    offset_prior = field(default=None)
+    offset_initial_value: float | None = field(default=None, validator=optional(gt(0.0)))
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
+
+    @power.validator
+    def _check_power(self, _, value):
+        if value < 0:
+            raise ValueError("'power' must be >= 0")
+
+
+@define(frozen=True)
 class ScaleKernel:
     base_kernel = field()
     outputscale_prior = field(default=None)
@@ -113,7 +139,28 @@ def _basic_kind(kernel) -> str | None:
         return f"piecewise{int(kernel.q)}"
     if name == "RQKernel":
         return "rq"
+    if name == "LinearKernel":
+        return "linear"
+    if name == "PolynomialKernel":
+        if not 1 <= int(kernel.power) <= 4:
+            raise IncompatibilityError(f"PolynomialKernel(power={kernel.power}): the HIP path evaluates powers 1 to 4.")
+        return f"poly{int(kernel.power)}"
     return None
+
+
+def _ls_fields(kernel, kind):
+    """(constraint, lower, prior, initial value) of the kernel's per-column parameter block and (prior, initial value) of its
+    extra scalar: lengthscales for the stationary kinds, ARD variances for the Linear kernel (``gp_spec.DOT_KINDS``), none for
+    the Polynomial kernel, whose offset takes the alpha slot."""
+    from baybe_amd.gp_spec import dot_kind_constraint
+
+    c = dot_kind_constraint(kind)
+    if c == "linvar":
+        return (c, 0.0, _prior_tuple(getattr(kernel, "variance_prior", None)), getattr(kernel, "variance_initial_value", None)), (None, None)
+    if c == "pinned":
+        return (c, 0.0, None, None), (_prior_tuple(getattr(kernel, "offset_prior", None)), getattr(kernel, "offset_initial_value", None))
+    return ("softplus", 0.0, _prior_tuple(getattr(kernel, "lengthscale_prior", None)),
+            getattr(kernel, "lengthscale_initial_value", None)), (None, None)
 
 
 def _active_mask(spec, kernel, searchspace):
@@ -181,22 +228,20 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
             kind = _basic_kind(member)
             if kind is None:
                 raise IncompatibilityError(
-                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial "
-                    f"factors, each optionally in a ScaleKernel, are)."
+                    f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial / "
+                    f"Linear / Polynomial factors, each optionally in a ScaleKernel, are)."
                 )
-            factors.append(KernelFactor(kind, "softplus", 0.0, _prior_tuple(getattr(member, "lengthscale_prior", None)),
-                                        getattr(member, "lengthscale_initial_value", None), scaled, os_prior, os_init,
-                                        _active_mask(spec, member, searchspace)))
+            (c, lower, ls_prior, ls_init), (a_prior, a_init) = _ls_fields(member, kind)
+            factors.append(KernelFactor(kind, c, lower, ls_prior, ls_init, scaled, os_prior, os_init,
+                                        _active_mask(spec, member, searchspace), a_prior, a_init))
         return spec.set_factors(factors, "product" if name == "ProductKernel" else "sum")
     kind = _basic_kind(kernel)
     if kind is None:
         raise IncompatibilityError(
-            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial, optionally in a "
-            f"ScaleKernel, and Product / Additive kernels of them are)."
+            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial / Linear / Polynomial, "
+            f"optionally in a ScaleKernel, and Product / Additive kernels of them are)."
         )
     spec.kernel = kind
     spec.active = _active_mask(spec, kernel, searchspace)
-    spec.ls_constraint = "softplus"
-    spec.ls_prior = _prior_tuple(getattr(kernel, "lengthscale_prior", None))
-    spec.ls_init = getattr(kernel, "lengthscale_initial_value", None)
+    (spec.ls_constraint, _, spec.ls_prior, spec.ls_init), (spec.alpha_prior, spec.alpha_init) = _ls_fields(kernel, kind)
     return spec

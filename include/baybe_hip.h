@@ -63,7 +63,19 @@ enum bbh_kernel_kind {
   BBH_KERNEL_PIECEWISE3 = 7,
   /* gpytorch RQKernel, baybe/kernels/basic.py:202-216: (1 + r^2 / (2 alpha))^-alpha with a learnable alpha per kernel
    * (theta: one slot per factor at the very end, present when any factor is an RQ kernel). */
-  BBH_KERNEL_RQ = 8
+  BBH_KERNEL_RQ = 8,
+  /* Dot-product kernels (baybe/kernels/basic.py:20-46, 135-163): functions of s = sum_j x_j x'_j / w_j^2 over the normalised
+   * inputs instead of a scaled squared distance; the lengthscale slots of theta carry the weights w_j (huge for columns the
+   * kernel does not act on), and bbh_fit_value_grad returns d/dw_j in those slots.
+   *   gpytorch LinearKernel with ARD variances v_j: k = sum_j v_j x_j x'_j, i.e. w_j = v_j^-1/2;
+   *   gpytorch PolynomialKernel(power p): (x . x' + offset)^p, p = 1 .. 4, w_j = 1, offset in the factor's alpha slot
+   *   (where an RQ kernel keeps its alpha).
+   * k(x, x) is not constant: these kinds are evaluated through the materialised-K* posterior path only. */
+  BBH_KERNEL_LINEAR = 9,
+  BBH_KERNEL_POLY1 = 10,
+  BBH_KERNEL_POLY2 = 11,
+  BBH_KERNEL_POLY3 = 12,
+  BBH_KERNEL_POLY4 = 13
 };
 
 enum bbh_criterion {

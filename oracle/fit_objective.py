@@ -23,6 +23,8 @@ parameters in ``mll.named_parameters()`` order; every piece of arithmetic comes 
 * user ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``: ``reduce(mul | add, gpytorch
   kernels)``): ``spec.members`` lists the base kernels (each ARD over all numerical columns, optionally inside its own
   ``ScaleKernel``); their Gram matrices are multiplied / added elementwise;
+* ``LinearKernel`` / ``PolynomialKernel`` (``baybe/kernels/basic.py:20-46, 135-163``): gpytorch's ``raw_variance``
+  [1, ard_num_dims] resp. ``raw_offset`` [1] in the place of a lengthscale, forward passes as in gpytorch's source;
 * ``(log-likelihood + sum of prior log-densities) / n``, negated; the **gradient is autograd's**.
 
 The product's host code (``baybe_amd/gp_spec.py``: hand-written chain rules and prior derivatives around the
@@ -95,6 +97,16 @@ def parameter_layout(spec) -> list[RawParameter]:
     if spec.use_outputscale:
         out.append(RawParameter(f"{base}.raw_outputscale", (), 0.0, True, _prior(spec.outputscale_prior)))
         base += ".base_kernel"
+    def base_kernel_parameters(leaf, kind, lower, transformed, prior, ndims, offset_prior, m):
+        if kind == "linear":  # gpytorch LinearKernel: raw_variance [1, ard_num_dims], Positive(), optional variance_prior
+            out.append(RawParameter(f"{leaf}.raw_variance", (1, ndims), 0.0, True, prior, m))
+        elif kind.startswith("poly"):  # gpytorch PolynomialKernel: raw_offset [1], Positive(), optional offset_prior; no lengthscale
+            out.append(RawParameter(f"{leaf}.raw_offset", (1,), 0.0, True, offset_prior, m))
+        else:
+            out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, ndims), lower, transformed, prior, m))
+            if kind == "rq":  # gpytorch RQKernel registers raw_alpha (Positive(), no prior) after the lengthscale
+                out.append(RawParameter(f"{leaf}.raw_alpha", (1,), 0.0, True, None, m))
+
     members = getattr(spec, "members", None)
     if members:  # ProductKernel / AdditiveKernel: .kernels.0, .kernels.1, ... each possibly a ScaleKernel
         for m, term in enumerate(members):
@@ -103,14 +115,11 @@ def parameter_layout(spec) -> list[RawParameter]:
                 out.append(RawParameter(f"{leaf}.raw_outputscale", (), 0.0, True, _prior(term.outputscale.prior), m))
                 leaf += ".base_kernel"
             h = term.lengthscale
-            out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, len(spec.dims_of(m))), h.lower, h.transformed, _prior(h.prior), m))
-            if term.kernel == "rq":  # gpytorch RQKernel registers raw_alpha (Positive(), no prior) after the lengthscale
-                out.append(RawParameter(f"{leaf}.raw_alpha", (1,), 0.0, True, None, m))
+            base_kernel_parameters(leaf, term.kernel, h.lower, h.transformed, _prior(h.prior), len(spec.dims_of(m)),
+                                   _prior(spec.offset_of(m).prior), m)
     else:
-        out.append(RawParameter(f"{base}.raw_lengthscale", (1, len(spec.dims_of(None))), spec.ls_lower if box_ls else 0.0, not box_ls,
-                                _prior(spec.ls_prior)))
-        if spec.kernel == "rq":
-            out.append(RawParameter(f"{base}.raw_alpha", (1,), 0.0, True, None))
+        base_kernel_parameters(base, spec.kernel, spec.ls_lower if box_ls else 0.0, not box_ls, _prior(spec.ls_prior),
+                               len(spec.dims_of(None)), _prior(spec.offset_of(None).prior), None)
     if T > 1:
         out.append(RawParameter("covar_module.kernels.1.raw_covar_factor", (T, T), 0.0, True, None))
         out.append(RawParameter("covar_module.kernels.1.raw_var", (T,), 0.0, True, None))
@@ -178,8 +187,16 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     """K(X, X) without noise on the normalised inputs: stationary ARD kernel (x outputscale) (x B[t, t'])."""
     Xnum = Xn[:, torch.as_tensor(np.asarray(spec.num_idx))]
 
-    def gram(kind, lengthscale, alpha=None, dims=None):  # dims: the kernel's active_dims (all numerical columns if None)
+    def gram(kind, m):  # base kernel m of a composite (None: the single kernel)
+        sfx = "" if m is None else f".{m}"
+        dims = getattr(spec, "active_dims", None) if m is None else spec.members[m].active_dims  # all numerical columns if None
         Xa = Xnum if dims is None else Xnum[:, torch.as_tensor(np.asarray(dims))]
+        if kind == "linear":  # gpytorch LinearKernel.forward: x1_ = x1 * variance.sqrt(); x1_ @ x1_^T
+            Xv = Xa * nat["variance" + sfx].reshape(1, -1).sqrt()
+            return Xv @ Xv.T
+        if kind.startswith("poly"):  # gpytorch PolynomialKernel.forward: (x1 @ x2^T + offset).pow(power)
+            return (Xa @ Xa.T + nat["offset" + sfx].reshape(())).pow(int(kind[-1]))
+        lengthscale, alpha = nat["lengthscale" + sfx], nat.get("alpha" + sfx)
         Xs = Xa / lengthscale.reshape(1, -1)
         diff = Xs[:, None, :] - Xs[None, :, :]
         return _base_kernel(kind, (diff * diff).sum(-1), Xa.shape[1], alpha)
@@ -188,12 +205,12 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
     if members:
         K = None
         for m, term in enumerate(members):
-            Km = gram(term.kernel, nat[f"lengthscale.{m}"], nat.get(f"alpha.{m}"), term.active_dims)
+            Km = gram(term.kernel, m)
             if term.outputscale is not None:
                 Km = Km * nat[f"outputscale.{m}"]
             K = Km if K is None else (K * Km if spec.composition == "product" else K + Km)
     else:
-        K = gram(spec.kernel, nat["lengthscale"], nat.get("alpha"), getattr(spec, "active_dims", None))
+        K = gram(spec.kernel, None)
     if spec.use_outputscale:
         K = K * nat["outputscale"]
     if spec.n_tasks > 1:

@@ -55,7 +55,15 @@ FAT_ALPHA_MAX = 2.0  # [UPSTREAM] botorch.utils.safe_math.fatmax alpha
 MIN_INFERRED_NOISE_LEVEL = 0.0001  # [UPSTREAM] botorch.models.utils.gpytorch_modules.MIN_INFERRED_NOISE_LEVEL
 MAX_BATCH_SIZE = 2048  # [UPSTREAM] optimize_acqf_discrete(max_batch_size=2048)
 
-KERNELS = ("matern12", "matern32", "matern52", "rbf", "piecewise0", "piecewise1", "piecewise2", "piecewise3", "rq")
+KERNELS = ("matern12", "matern32", "matern52", "rbf", "piecewise0", "piecewise1", "piecewise2", "piecewise3", "rq",
+           "linear", "poly1", "poly2", "poly3", "poly4")
+# Dot-product kernels (baybe/kernels/basic.py:20-46, 135-163 -> gpytorch LinearKernel / PolynomialKernel [UPSTREAM]):
+#   "linear": k = (x sqrt(v)) . (x' sqrt(v)) with one variance v_j per active column (``ard_num_dims`` is always passed,
+#             kernels/base.py:218-239); the term's ``lengthscale`` Hyper / parameter array IS that variance here;
+#   "polyP":  k = (x . x' + offset)^P; no per-column parameter, the offset (``KernelTerm.offset`` / ``GPSpec.offset``) is kept
+#             where an RQ kernel keeps its alpha (``GPParams.rq_alpha``).
+DOT_KERNELS = ("linear", "poly1", "poly2", "poly3", "poly4")
+SCALAR_KERNELS = ("rq", "poly1", "poly2", "poly3", "poly4")  # kernels with one extra Positive() scalar (alpha / offset)
 
 
 # --------------------------------------------------------------------------------------
@@ -94,6 +102,7 @@ class KernelTerm:
     outputscale: "Hyper | None" = None
     active_dims: "np.ndarray | None" = None  # positions among the numerical columns the kernel acts on (gpytorch active_dims
     # from ``BasicKernel.parameter_names``, baybe/kernels/base.py:198-240); its lengthscale has len(active_dims) entries
+    offset: "Hyper | None" = None  # polynomial kernels: the offset (PolynomialKernel.offset_prior / offset_initial_value)
 
 
 @dataclass
@@ -119,6 +128,11 @@ class GPSpec:
     members: "list[KernelTerm] | None" = None  # base kernels of a ProductKernel / AdditiveKernel (replaces `kernel`)
     composition: str = "product"  # "product" | "sum"
     active_dims: "np.ndarray | None" = None  # single kernel on a parameter subset (see KernelTerm.active_dims)
+    offset: "Hyper | None" = None  # single polynomial kernel: its offset (see KernelTerm.offset)
+
+    def offset_of(self, m: int | None = None) -> Hyper:
+        h = self.offset if (m is None or not self.members) else self.members[m].offset
+        return h if h is not None else Hyper()
 
     def dims_of(self, m: int | None = None) -> np.ndarray:
         """Positions (among the numerical columns) base kernel ``m`` - or the single kernel - acts on."""
@@ -227,7 +241,8 @@ def initial_params(spec, task_init=1.0):
         member_ls=[np.full(len(spec.dims_of(m)), t.lengthscale.start()) for m, t in enumerate(spec.members)] if spec.members else None,
         member_scale=np.array([1.0 if t.outputscale is None else t.outputscale.start() for t in spec.members])
         if spec.members else None,
-        rq_alpha=np.array([math.log(2.0) if k == "rq" else 1.0 for k in kernel_names(spec)]) if "rq" in kernel_names(spec) else None,
+        rq_alpha=np.array([math.log(2.0) if k == "rq" else (spec.offset_of(m).start() if k in SCALAR_KERNELS else 1.0)
+                           for m, k in enumerate(kernel_names(spec))]) if any(k in SCALAR_KERNELS for k in kernel_names(spec)) else None,
     )
 
 
@@ -265,6 +280,25 @@ def _scaled_sqdist(XA: np.ndarray, XB: np.ndarray, ls: np.ndarray) -> np.ndarray
     return d2
 
 
+def _metric(kernel: str, XA: np.ndarray, XB: np.ndarray, ls: np.ndarray) -> np.ndarray:
+    """What the base kernel is a function of: the scaled squared distance (stationary kernels), x sqrt(v) . x' sqrt(v) (gpytorch
+    LinearKernel.forward, ``ls`` = the variances) or x . x' (PolynomialKernel.forward)."""
+    if kernel == "linear":
+        return (XA * np.sqrt(ls)) @ (XB * np.sqrt(ls)).T
+    if kernel in DOT_KERNELS:
+        return XA @ XB.T
+    return _scaled_sqdist(XA, XB, ls)
+
+
+def _self_metric(kernel: str, XA: np.ndarray, ls: np.ndarray) -> np.ndarray:
+    """The metric of every row with itself (0 for the stationary kernels)."""
+    if kernel == "linear":
+        return (XA * XA * ls).sum(axis=1)
+    if kernel in DOT_KERNELS:
+        return (XA * XA).sum(axis=1)
+    return np.zeros(XA.shape[0])
+
+
 def _piecewise_terms(q: int, dims: int, r: np.ndarray):
     """gpytorch PiecewisePolynomialKernel [UPSTREAM, piecewise_polynomial_kernel.py]: exponent j = floor(D / 2) + q + 1 and
     the polynomial ``get_cov(r, j, q)`` with its derivative."""
@@ -283,6 +317,10 @@ def _piecewise_terms(q: int, dims: int, r: np.ndarray):
 def base_kernel_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None, alpha: float | None = None) -> np.ndarray:
     """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2 (``dims``: input dimension, piecewise family;
     ``alpha``: RQ kernel, ``(1 + r^2 / (2 alpha))^-alpha``)."""
+    if kernel == "linear":  # ``r2`` is the dot product of ``_metric`` here
+        return r2
+    if kernel in DOT_KERNELS:  # gpytorch PolynomialKernel: (x1 @ x2^T + offset).pow(power)
+        return (r2 + alpha) ** int(kernel[-1])
     if kernel == "rq":
         return (1.0 + r2 / (2.0 * alpha)) ** (-alpha)
     if kernel.startswith("piecewise"):
@@ -352,7 +390,7 @@ def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> lis
     out = []
     for m, t in enumerate(spec.members):
         c = spec.dims_of(m)
-        out.append(p.member_scale[m] * base_kernel_from_r2(t.kernel, _scaled_sqdist(A[:, c], B[:, c], p.member_ls[m]), len(c), _alpha_of(p, m)))
+        out.append(p.member_scale[m] * base_kernel_from_r2(t.kernel, _metric(t.kernel, A[:, c], B[:, c], p.member_ls[m]), len(c), _alpha_of(p, m)))
     return out
 
 
@@ -361,7 +399,7 @@ def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> 
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
     if not spec.members:
         c = spec.dims_of(None)
-        return base_kernel_from_r2(spec.kernel, _scaled_sqdist(A[:, c], B[:, c], p.lengthscale), len(c), _alpha_of(p, 0))
+        return base_kernel_from_r2(spec.kernel, _metric(spec.kernel, A[:, c], B[:, c], p.lengthscale), len(c), _alpha_of(p, 0))
     grams = member_grams(spec, p, A, B)
     out = grams[0].copy()
     for Km in grams[1:]:
@@ -388,10 +426,19 @@ def task_rows(spec: GPSpec, Xn: np.ndarray) -> np.ndarray:
 
 
 def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
-    """k(x,x) for each row (1 * outputscale * B[t,t])."""
+    """k(x,x) for each row (stationary kernels: 1 * outputscale * B[t,t]; dot-product kernels: a function of the row)."""
     v = np.full(Xn.shape[0], p.outputscale if spec.use_outputscale else 1.0)
+    Xs = Xn[:, spec.num_idx]
     if spec.members:  # k_m(x, x) = 1 for every stationary member
-        v = v * (np.prod(p.member_scale) if spec.composition == "product" else np.sum(p.member_scale))
+        diag = None
+        for m, t in enumerate(spec.members):
+            c = spec.dims_of(m)
+            km = p.member_scale[m] * base_kernel_from_r2(t.kernel, _self_metric(t.kernel, Xs[:, c], p.member_ls[m]), len(c), _alpha_of(p, m))
+            diag = km if diag is None else (diag * km if spec.composition == "product" else diag + km)
+        v = v * diag
+    elif spec.kernel in DOT_KERNELS:
+        c = spec.dims_of(None)
+        v = v * base_kernel_from_r2(spec.kernel, _self_metric(spec.kernel, Xs[:, c], p.lengthscale), len(c), _alpha_of(p, 0))
     if spec.task_idx is not None:
         B = p.task_B()
         t = Xn[:, spec.task_idx].astype(np.int64)
@@ -429,6 +476,8 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     if spec.active_dims is not None or any(t.active_dims is not None for t in (spec.members or [])):
         raise NotImplementedError("analytic data-term gradients are not restated for kernels on parameter subsets; "
                                   "use fit_objective (autograd)")
+    if any(k in DOT_KERNELS for k in kernel_names(spec)):
+        raise NotImplementedError("analytic data-term gradients are not restated for Linear / Polynomial kernels; use fit_objective")
     trow = task_rows(spec, Xn)
     Kf = cross_cov(spec, p, Xn, Xn)
     Ky = Kf + np.diag(p.noise_of(trow))
@@ -536,16 +585,17 @@ def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> Da
 # All of it is oracle/fit_objective.py (torch.distributions + autograd); these wrappers only translate between
 # GPParams and the gpytorch-named parameter dictionary.
 def _natural_dict(spec: GPSpec, p: GPParams) -> dict:
-    nat = {"noise": np.atleast_1d(p.noise), "constant": p.mean, "lengthscale": p.lengthscale}
+    nat = {"noise": np.atleast_1d(p.noise), "constant": p.mean, "lengthscale": p.lengthscale, "variance": p.lengthscale}
+    scalar = lambda k: "alpha" if k == "rq" else "offset"  # noqa: E731  (gpytorch's leaf names: raw_alpha / raw_offset)
     if spec.members:
         for m, t in enumerate(spec.members):
-            nat[f"lengthscale.{m}"] = p.member_ls[m]
+            nat[f"lengthscale.{m}"] = nat[f"variance.{m}"] = p.member_ls[m]
             if t.outputscale is not None:
                 nat[f"outputscale.{m}"] = p.member_scale[m]
-            if t.kernel == "rq":
-                nat[f"alpha.{m}"] = [p.rq_alpha[m]]
-    elif spec.kernel == "rq":
-        nat["alpha"] = [p.rq_alpha[0]]
+            if t.kernel in SCALAR_KERNELS:
+                nat[f"{scalar(t.kernel)}.{m}"] = [p.rq_alpha[m]]
+    elif spec.kernel in SCALAR_KERNELS:
+        nat[scalar(spec.kernel)] = [p.rq_alpha[0]]
     if spec.use_outputscale:
         nat["outputscale"] = p.outputscale
     if spec.n_tasks > 1:
@@ -565,18 +615,28 @@ def unpack_raw(spec, raw):
     from oracle import fit_objective as fo
 
     nat = {k: v.detach().numpy() for k, v in fo.split_raw(spec, torch.as_tensor(np.asarray(raw, dtype=np.float64))).items()}
-    mls = [nat[f"lengthscale.{m}"].reshape(-1).copy() for m in range(len(spec.members))] if spec.members else None
+    def percol(m):  # the per-column parameter of base kernel m: lengthscales / Linear variances / none (Polynomial: ones)
+        kind = kernel_names(spec)[0 if m is None else m]
+        suffix = "" if m is None else f".{m}"
+        if kind == "linear":
+            return nat["variance" + suffix].reshape(-1).copy()
+        if kind in DOT_KERNELS:
+            return np.ones(len(spec.dims_of(m)))
+        return nat["lengthscale" + suffix].reshape(-1).copy()
+
+    mls = [percol(m) for m in range(len(spec.members))] if spec.members else None
     msc = np.array([float(nat[f"outputscale.{m}"]) if t.outputscale is not None else 1.0
                     for m, t in enumerate(spec.members)]) if spec.members else None
     names = kernel_names(spec)
-    if "rq" in names:
-        key = (lambda m: f"alpha.{m}") if spec.members else (lambda m: "alpha")
-        alphas = np.array([float(nat[key(m)].reshape(-1)[0]) if k == "rq" else 1.0 for m, k in enumerate(names)])
+    if any(k in SCALAR_KERNELS for k in names):
+        leaf = lambda k: "alpha" if k == "rq" else "offset"  # noqa: E731
+        key = (lambda m, k: f"{leaf(k)}.{m}") if spec.members else (lambda m, k: leaf(k))
+        alphas = np.array([float(nat[key(m, k)].reshape(-1)[0]) if k in SCALAR_KERNELS else 1.0 for m, k in enumerate(names)])
     else:
         alphas = None
     return GPParams(
         rq_alpha=alphas,
-        lengthscale=mls[0] if spec.members else nat["lengthscale"].reshape(-1).copy(),
+        lengthscale=mls[0] if spec.members else percol(None),
         member_ls=mls,
         member_scale=msc,
         noise=nat["noise"].reshape(-1).copy() if spec.task_model == "per_task" else float(nat["noise"].reshape(-1)[0]),

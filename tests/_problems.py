@@ -60,10 +60,12 @@ def oracle_spec(spec):
         members=[go.KernelTerm(f.kernel,
                                go.Hyper(f.ls_lower if f.ls_constraint == "box" else 0.0, f.ls_constraint != "box", f.ls_prior, f.ls_init),
                                go.Hyper(0.0, True, f.outputscale_prior, f.outputscale_init) if f.scaled else None,
-                               None if spec.active_mask(k) is None else np.nonzero(spec.active_mask(k))[0])
+                               None if spec.active_mask(k) is None else np.nonzero(spec.active_mask(k))[0],
+                               go.Hyper(0.0, True, f.alpha_prior, f.alpha_init))
                  for k, f in enumerate(spec.factors)] if spec.factors else None,
         composition=spec.combine,
-        active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0])
+        active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0],
+        offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init))
 
 
 def oracle_params(spec, p):
@@ -74,6 +76,8 @@ def oracle_params(spec, p):
     def act(ls, k):
         m = spec.active_mask(k)
         ls = np.array(ls, dtype=float)
+        if spec.factor_kinds[k] == "linear":  # the product keeps weights w = v^-1/2 in the lengthscale slots, the oracle gpytorch's v
+            ls = ls ** -2.0
         return ls if m is None else ls[m]
 
     return go.GPParams(act(p.lengthscale, 0), p.noise, p.mean, p.outputscale,

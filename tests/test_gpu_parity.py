@@ -844,6 +844,65 @@ def test_kernels_on_parameter_subsets(gp, which):
     assert list(res.indices) == list(ref.indices) and np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL)
 
 
+@pytest.mark.parametrize("which", ["linear", "poly", "sum", "product_subsets"])
+def test_linear_and_polynomial_kernels(gp, which):
+    """``LinearKernel`` / ``PolynomialKernel`` (baybe/kernels/basic.py:20-46, 135-163; the reference iterates them alone and in sums,
+    tests/test_iterations.py:277-295).  On the device they are functions of s = sum_j x_j x'_j / w_j^2 (BBH_KERNEL_LINEAR ..): the
+    Linear kernel's ARD variances are v_j = w_j^-2, the Polynomial kernel's weights are pinned to 1 and its offset sits in the alpha
+    slot; k(x, x) varies per candidate, so the posterior goes through the materialised-K* path with a per-candidate prior variance.
+    Checked against the oracle (gpytorch's own parameterisation): fit objective + gradient, the whole fit, posterior, greedy batch."""
+    from _problems import oracle_params
+    from baybe_amd import gp_spec
+    from baybe_amd.kernels import (AdditiveKernel, GammaPrior, LinearKernel, MaternKernel, PolynomialKernel, ProductKernel, RBFKernel,
+                                   ScaleKernel, apply_kernel_spec)
+    from oracle import gp_oracle as go
+
+    d = 4
+
+    class Space:
+        comp_rep_columns = tuple(f"x{j}" for j in range(d))
+
+    X, Xt, y = make_problem(2500, d, 50, seed=57)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    kern = {"linear": ScaleKernel(LinearKernel(GammaPrior(2, 1)), GammaPrior(2, 0.5)),
+            "poly": PolynomialKernel(2, GammaPrior(2, 2)),
+            "sum": AdditiveKernel([RBFKernel(GammaPrior(3, 1)), ScaleKernel(LinearKernel(GammaPrior(3, 2))), PolynomialKernel(1, GammaPrior(2, 1))]),
+            "product_subsets": ProductKernel([MaternKernel(2.5, GammaPrior(3, 1), parameter_names=["x0", "x1"]),
+                                              ScaleKernel(PolynomialKernel(3, GammaPrior(2, 1), 1.5, parameter_names=["x1", "x2", "x3"]))])}[which]
+    apply_kernel_spec(spec, kern, Space())
+    ospec = _ospec(spec)
+    gp.set_model(spec, Xt, y)
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    rng = np.random.default_rng(9)
+    bounds = gp_spec.raw_bounds(spec)
+    free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+    raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+    raw = np.where(free, raw + 0.3 * rng.standard_normal(raw.shape), raw)
+    raw[0] = 0.03
+    p = gp_spec.unpack_raw(spec, raw)
+    val, g_theta = gp.data_term(p)
+    f_dev, g_dev = gp_spec.objective_from_data_term(spec, raw, len(y), val, g_theta)
+    raw_o = go.pack_raw(ospec, oracle_params(spec, p))
+    assert np.allclose(raw_o, raw[free], rtol=1e-12, atol=1e-12)
+    f_orc, g_orc = go.fit_objective(ospec, raw_o, Xn, ys)
+    assert math.isclose(f_dev, f_orc, rel_tol=1e-10), (f_dev, f_orc)
+    assert np.allclose(g_dev[free], g_orc, rtol=1e-7, atol=1e-9 * np.abs(g_orc).max()), (g_dev[free], g_orc)
+    assert (g_dev[~free] == 0.0).all()
+    fi = gp.fit()
+    fo = go.fit_hyperparameters(ospec, Xn, ys)
+    assert abs(fi.fun - fo.fun) <= 2e-5 * max(1.0, abs(fo.fun)), (fi.fun, fo.fun)
+    om = go.GPModel(ospec, oracle_params(spec, fi.params), Xt, y)
+    mo, vo = om.posterior(X)
+    m_, v_ = gp.posterior(X)
+    assert gp.posterior_kernel_form() == "materialised"
+    assert np.allclose(_np(m_), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v_), vo, rtol=VAR_RTOL, atol=1e-13)
+    assert np.ptp(go.prior_var(ospec, oracle_params(spec, fi.params), go.normalize_inputs(ospec, X))) > 0  # k(x, x) is not constant
+    cand = np.ascontiguousarray(X[:800])
+    res = gp.greedy_qlogei(cand, 3, seed=12)
+    ref = go.optimize_acqf_discrete_qlogei(om, cand, 3, seed=12)
+    assert list(res.indices) == list(ref.indices) and np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL)
+
+
 def test_joint_batches_beyond_sixteen_points(gp):
     """``optimize_acqf_discrete`` has no cap on batch_size + pending experiments (botorch/discrete.py:120-126); the register / LDS
     kernels hold 16 points.  Beyond that ``bbh_qlogei_pending_big`` keeps the per-candidate Cholesky factors in a global

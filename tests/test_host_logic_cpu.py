@@ -517,3 +517,96 @@ def test_parameter_subsets_pin_the_inactive_lengthscales():
                           ProductKernel([MaternKernel(2.5, parameter_names=["zz"]), RBFKernel()]), None)
     with pytest.raises(ValueError):
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(4, np.zeros(4), np.ones(4)), MaternKernel(2.5, parameter_names=["zz"]), Space())
+
+
+def _theta_layout_mll(spec, theta, Xn, ys):
+    """The MLL data term and its gradient in the DEVICE's theta layout (include/baybe_hip.h) from torch autograd - the stand-in
+    for ``bbh_fit_value_grad`` in the dot-product kernel test below (one task, plain likelihood): every factor is a function of
+    s = sum_j x_j x'_j / w_j^2 (dot kinds) or r^2 = sum_j (x_j - x'_j)^2 / l_j^2, both with the slot values as they stand."""
+    import torch
+
+    th = torch.tensor(theta, dtype=torch.float64, requires_grad=True)
+    X = torch.as_tensor(Xn[:, spec.num_idx], dtype=torch.float64)
+    y = torch.as_tensor(ys, dtype=torch.float64)
+    dn, F = spec.dn, spec.n_factors
+    base = 3 + dn
+    fos_off = base + (F - 1) * dn
+    alpha_off = base + ((F - 1) * dn + F if F > 1 else 0)
+    K = None
+    for f, kind in enumerate(spec.factor_kinds):
+        w = th[3 : 3 + dn] if f == 0 else th[base + (f - 1) * dn : base + f * dn]
+        Xs = X / w
+        if kind in gp_spec.DOT_KINDS:
+            s = Xs @ Xs.T
+            k = s if kind == "linear" else (s + th[alpha_off + f]) ** int(kind[-1])
+        else:
+            r2 = ((Xs[:, None, :] - Xs[None, :, :]) ** 2).sum(-1)
+            k = {"rbf": lambda: torch.exp(-0.5 * r2),
+                 "matern52": lambda: (1 + math.sqrt(5) * torch.sqrt(r2 + 1e-300) + 5.0 / 3.0 * r2) * torch.exp(-math.sqrt(5) * torch.sqrt(r2 + 1e-300))}[kind]()
+        if F > 1:
+            k = k * th[fos_off + f]
+        K = k if K is None else (K * k if spec.combine == "product" else K + k)
+    if spec.use_outputscale:
+        K = K * th[2]
+    n = len(y)
+    dist = torch.distributions.MultivariateNormal(th[1] * torch.ones(n, dtype=torch.float64), covariance_matrix=K + th[0] * torch.eye(n, dtype=torch.float64))
+    val = dist.log_prob(y)
+    (g,) = torch.autograd.grad(val, th)
+    return float(val.detach()), g.numpy()
+
+
+def test_linear_and_polynomial_kernels_against_the_autograd_oracle():
+    """LinearKernel / PolynomialKernel (baybe/kernels/basic.py:20-46, 135-163): the product keeps weights w_j = v_j^-1/2 (Linear
+    ARD variances) or pinned ones (Polynomial) in the lengthscale slots and the offset in the alpha slot; its raw vector has the
+    oracle's (= gpytorch's) free parameters in the same order plus pinned slots.  Value and gradient of the assembled objective
+    equal the oracle's on the free slots; pinned slots have zero gradient."""
+    from _problems import oracle_params
+    from baybe_amd.exceptions import IncompatibilityError
+    from baybe_amd.kernels import (AdditiveKernel, GammaPrior, LinearKernel, LogNormalPrior, MaternKernel, PolynomialKernel, ProductKernel,
+                                   RBFKernel, ScaleKernel, apply_kernel_spec)
+
+    class Space:
+        comp_rep_columns = ("a", "b", "c", "d")
+
+    d, n = 4, 24
+    rng = np.random.default_rng(5)
+    X, Xt, y = make_problem(100, d, n, seed=3)
+    kernels = (LinearKernel(), ScaleKernel(LinearKernel(GammaPrior(2, 1), 0.7), GammaPrior(2, 0.5)),
+               PolynomialKernel(2), ScaleKernel(PolynomialKernel(3, LogNormalPrior(0, 1), 0.5)),
+               LinearKernel(parameter_names=["a", "c"]), PolynomialKernel(1, GammaPrior(2, 2), parameter_names=["b", "c", "d"]),
+               AdditiveKernel([PolynomialKernel(1), PolynomialKernel(2), PolynomialKernel(3)]),  # reference tests/test_iterations.py:294
+               AdditiveKernel([RBFKernel(), ScaleKernel(LinearKernel(GammaPrior(3, 2))), PolynomialKernel(1, GammaPrior(2, 1))]),
+               ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(PolynomialKernel(2, None, 1.5))]))
+    for kern in kernels:
+        spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern, Space())
+        ospec = _ospec(spec)
+        assert spec.has_dot_kind and not gp_spec.FastObjective.applies(spec)
+        p0 = gp_spec.initial_params(spec)
+        raw, bounds = gp_spec.pack_raw(spec, p0), gp_spec.raw_bounds(spec)
+        free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+        assert np.allclose(raw[free], go.pack_raw(ospec, go.initial_params(ospec))) and free.sum() == len(go.raw_bounds(ospec))
+        raw = np.where(free, raw + 0.3 * rng.standard_normal(raw.shape), raw)
+        raw[0] = abs(raw[0]) + 0.05
+        q = gp_spec.unpack_raw(spec, raw)
+        assert np.allclose(gp_spec.pack_raw(spec, q), raw)
+        oq = oracle_params(spec, q)
+        assert np.allclose(go.pack_raw(ospec, oq), raw[free], rtol=1e-12, atol=1e-12)
+        theta = gp_spec.theta_from_params(spec, q)
+        Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+        # the theta-layout stand-in states the same covariance matrix as the oracle's numpy kernels
+        val, grad_theta = _theta_layout_mll(spec, theta, Xn, ys)
+        f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, val, grad_theta)
+        f0, g0 = go.fit_objective(ospec, raw[free], Xn, ys)
+        assert math.isclose(f0, f1, rel_tol=1e-10), (kern, f0, f1)
+        assert np.allclose(g0, g1[free], rtol=1e-8, atol=1e-11 * np.abs(g0).max()), (kern, g0, g1[free])
+        assert (g1[~free] == 0.0).all()
+        # prior variance: k(x, x) of the oracle equals the diagonal of its own cross covariance
+        Xc = go.normalize_inputs(ospec, X[:7])
+        assert np.allclose(go.prior_var(ospec, oq, Xc), np.diag(go.cross_cov(ospec, oq, Xc, Xc)), rtol=1e-13)
+        # restart points: drawn from the priors, pinned slots stay pinned
+        ps = gp_spec.sample_params_from_priors(spec, np.random.default_rng(1))
+        assert np.allclose(gp_spec.pack_raw(spec, ps)[~free], raw[~free])
+    with pytest.raises(IncompatibilityError):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), PolynomialKernel(5))
+    with pytest.raises(IncompatibilityError):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), PolynomialKernel(0))
