@@ -47,6 +47,7 @@ struct bbh_kern_spec {
   int use_os;                   // outer outputscale theta[2]
   int jb;                       // floor(dn / 2) + 1 (piecewise-polynomial kernels)
   int alpha_off;                // theta offset of the F alpha parameters (-1: no RQ factor)
+  int per_off;                  // theta offset of the F * dn period lengths (-1: no periodic factor)
 };
 // gpytorch PiecewisePolynomialKernel: k = (1 - r)_+^(j + q) P_q(r) with j = jb + q, jb = floor(dn / 2) + 1, and
 // g = -(dk/dr)/r = (1 - r)_+^(j + q - 1) Q_q(r) in closed form (no cancellation at r -> 0 for q >= 1)
@@ -78,17 +79,28 @@ __host__ __device__ inline double bbh_piecewise(int q, int jb, double r2, bool w
 // (not inlined: nine kinds with their libm calls, called once per factor and entry - inlined into the unrolled K* kernel it
 // made 23 000 instructions, far beyond the instruction cache)
 // dot-product kinds: the per-factor metric is s = sum_j (x_j / w_j)(x'_j / w_j) instead of a scaled squared distance
-#define BBH_KIND_IS_DOT(kind) ((kind) >= BBH_KERNEL_LINEAR)
-#define BBH_KIND_HAS_ALPHA(kind) ((kind) == BBH_KERNEL_RQ || (kind) >= BBH_KERNEL_POLY1)  // RQ alpha / polynomial offset slot
+#define BBH_KIND_IS_DOT(kind) ((kind) >= BBH_KERNEL_LINEAR && (kind) <= BBH_KERNEL_POLY4)
+#define BBH_KIND_IS_POLY(kind) ((kind) >= BBH_KERNEL_POLY1 && (kind) <= BBH_KERNEL_POLY4)
+#define BBH_KIND_HAS_ALPHA(kind) ((kind) == BBH_KERNEL_RQ || BBH_KIND_IS_POLY(kind))  // RQ alpha / polynomial offset slot
 // one dimension's contribution to a factor's metric
 __host__ __device__ __forceinline__ double bbh_metric_term(int kind, double xa, double xb, double invw) {
   if (BBH_KIND_IS_DOT(kind)) return (xa * invw) * (xb * invw);
   const double df = (xa - xb) * invw;
   return df * df;
 }
+// the same for factor f of a model: periodic factors read their period from theta's period block (invw = 1 / l_j there)
+__host__ __device__ __forceinline__ double bbh_metric_term_f(const bbh_kern_spec& ks, const double* theta, int f, int j, int dn,
+                                                             double xa, double xb, double invw) {
+  if (ks.kind[f] == BBH_KERNEL_PERIODIC) {
+    const double sn = sin(M_PI * (xa - xb) / theta[ks.per_off + f * dn + j]);
+    return sn * sn * invw;
+  }
+  return bbh_metric_term(ks.kind[f], xa, xb, invw);
+}
 __host__ __device__ __attribute__((noinline)) inline double bbh_kbase(int kind, double r2, int jb, double alpha = 1.0) {
-  if (kind == BBH_KERNEL_LINEAR) return r2;  // (the variance is the outputscale / factor scale)
-  if (kind >= BBH_KERNEL_POLY1) return bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1 + 1);
+  if (kind == BBH_KERNEL_LINEAR) return r2;  // (the ARD variances are the weights of the metric)
+  if (BBH_KIND_IS_POLY(kind)) return bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1 + 1);
+  if (kind == BBH_KERNEL_PERIODIC) return exp(-2.0 * r2);  // the metric is sum_j sin^2(pi Delta_j / p_j) / l_j
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
   if (kind == BBH_KERNEL_RQ) return exp(-alpha * log1p(r2 / (2.0 * alpha)));
   if (kind >= BBH_KERNEL_PIECEWISE0 && kind <= BBH_KERNEL_PIECEWISE3) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);

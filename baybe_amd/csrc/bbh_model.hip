@@ -20,7 +20,9 @@ __device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double a
   // dot-product kinds, k = f(s) with s = sum_j x_j x'_j / w_j^2: dk/dw_j = -2 f'(s) x_j x'_j / w_j^3, i.e. g = -2 f'(s) with the
   // product x_j x'_j in the place of Delta_j^2 (the Linear kernel's ARD variances are v_j = 1 / w_j^2)
   if (kind == BBH_KERNEL_LINEAR) return -2.0;
-  if (kind >= BBH_KERNEL_POLY1) return -2.0 * (double)(kind - BBH_KERNEL_POLY1 + 1) * bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1);
+  if (BBH_KIND_IS_POLY(kind)) return -2.0 * (double)(kind - BBH_KERNEL_POLY1 + 1) * bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1);
+  // periodic, k = exp(-2 sum_j sin^2(u_j) / l_j): dk/dl_j = 2 k sin^2(u_j) / l_j^2 - g = 2 k, the slot's term is assembled at the call
+  if (kind == BBH_KERNEL_PERIODIC) return 2.0 * exp(-2.0 * r2);
   if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
   if (kind == BBH_KERNEL_RQ) return exp(-(alpha + 1.0) * log1p(r2 / (2.0 * alpha)));  // (1 + u)^-(alpha + 1), u = r^2 / (2 alpha)
   if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, true);
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
   double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
     const double xa = xnT[(int64_t)j * np + a], xb = xnT[(int64_t)j * np + b];
-    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], xa, xb, s_invls[f * dn + j]);
+    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term_f(ks, theta, f, j, dn, xa, xb, s_invls[f * dn + j]);
   }
   double k = bbh_kcomp(ks, theta, r2);
   if (ks.use_os) k *= theta[TH_OS];
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
     const double xa = xnT[(int64_t)j * np + a], xb = xnT[(int64_t)j * np + bb];
-    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], xa, xb, 1.0 / theta[ks.ls_off[f] + j]);
+    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term_f(ks, theta, f, j, dn, xa, xb, 1.0 / theta[ks.ls_off[f] + j]);
   }
   const double os = ks.use_os ? theta[TH_OS] : 1.0;
   const double Bab = (T > 1) ? theta[TH_LS + dn + ta * T + tb] : 1.0;
@@ -248,10 +250,22 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
     for (int j = 0; j < dn; j++) {
       const double l = theta[ks.ls_off[f] + j];
       const double xa = xnT[(int64_t)j * np + a], xb = xnT[(int64_t)j * np + bb];
-      double v = Gg * (BBH_KIND_IS_DOT(ks.kind[f]) ? xa * xb : (xa - xb) * (xa - xb)) / (l * l * l);
+      double v, vp = 0.0;
+      if (ks.kind[f] == BBH_KERNEL_PERIODIC) {  // dk/dl_j = 2 k sin^2(u) / l^2,  dk/dp_j = (2 k / l) sin(2 u) pi Delta / p^2,  u = pi Delta / p
+        const double pl = theta[ks.per_off + f * dn + j], u = M_PI * (xa - xb) / pl, sn = sin(u);
+        v = Gg * sn * sn / (l * l);
+        vp = Gg * sin(2.0 * u) * M_PI * (xa - xb) / (l * pl * pl);
+      } else {
+        v = Gg * (BBH_KIND_IS_DOT(ks.kind[f]) ? xa * xb : (xa - xb) * (xa - xb)) / (l * l * l);
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
       if (lane == 0) prow[ks.ls_off[f] + j] = v;
+      if (ks.per_off >= 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vp += __shfl_down(vp, o, 64);
+        if (lane == 0) prow[ks.per_off + f * dn + j] = vp;
+      }
     }
     if (ks.F > 1) {  // d/d os_f = W_f k_f
       double v = G * os * Bab * wf[f] * kf[f];
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
       if (ks.kind[f] == BBH_KERNEL_RQ) {
         const double u = r2[f] / (2.0 * al[f]);
         v = G * os * Bab * wf[f] * fos * kf[f] * (u / (1.0 + u) - log1p(u));
-      } else if (ks.kind[f] >= BBH_KERNEL_POLY1) {  // d/d offset (s + offset)^p = p (s + offset)^(p - 1)
+      } else if (BBH_KIND_IS_POLY(ks.kind[f])) {  // d/d offset (s + offset)^p = p (s + offset)^(p - 1)
         const int pw = ks.kind[f] - BBH_KERNEL_POLY1 + 1;
         v = G * os * Bab * wf[f] * fos * (double)pw * bbh_powi(r2[f] + al[f], pw - 1);
       }
@@ -313,9 +327,17 @@ bool bbh_has_dot_kind(const bbh_handle* h) {
   return false;
 }
 
+static bool bbh_has_periodic(const bbh_handle* h) {
+  if (h->F <= 1) return h->desc.kernel_kind == BBH_KERNEL_PERIODIC;
+  for (int f = 0; f < h->F; f++)
+    if (h->desc.factor_kind[f] == BBH_KERNEL_PERIODIC) return true;
+  return false;
+}
+
 static int64_t bbh_theta_len_of(const bbh_handle* h) {
   return 3 + h->dn + (h->T > 1 ? (int64_t)h->T * h->T : 0) + (h->hadamard ? 2 * (int64_t)h->T : 0) +
-         (h->F > 1 ? (int64_t)(h->F - 1) * h->dn + h->F : 0) + (bbh_has_rq(h) ? h->F : 0);
+         (h->F > 1 ? (int64_t)(h->F - 1) * h->dn + h->F : 0) + (bbh_has_rq(h) ? h->F : 0) +
+         (bbh_has_periodic(h) ? (int64_t)h->F * h->dn : 0);
 }
 
 extern "C" int64_t bbh_theta_len(bbh_handle* h) {
@@ -337,6 +359,7 @@ bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h) {
   }
   ks.fos_off = h->F > 1 ? base + (h->F - 1) * h->dn : -1;
   ks.alpha_off = bbh_has_rq(h) ? base + (h->F > 1 ? (h->F - 1) * h->dn + h->F : 0) : -1;
+  ks.per_off = bbh_has_periodic(h) ? base + (h->F > 1 ? (h->F - 1) * h->dn + h->F : 0) + (bbh_has_rq(h) ? h->F : 0) : -1;
   return ks;
 }
 
@@ -392,7 +415,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->err = "bbh_set_model: bad arguments";
     return -1;
   }
-  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_POLY4 || desc->d < 1 || desc->n_tasks < 1 ||
+  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_PERIODIC || desc->d < 1 || desc->n_tasks < 1 ||
       (desc->n_tasks > 1 && (desc->task_col < 0 || desc->task_col >= desc->d)) ||
       (desc->criterion != BBH_CRITERION_MLL && desc->criterion != BBH_CRITERION_LOO)) {
     h->err = "bbh_set_model: invalid model description";
@@ -401,7 +424,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   if (desc->n_factors > 1) {
     bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1) &&
               desc->factor_kind[0] == desc->kernel_kind;
-    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_POLY4;
+    for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_PERIODIC;
     if (!ok) {
       h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1, factor_kind[0] == kernel_kind)";
       return -1;

@@ -196,7 +196,7 @@ static bool bbh_coopg_model(const bbh_handle* h) {
   if (h->nb > 4 * BBH_COOP_ROUNDS || h->nb % 4 != 0) return false;
   const bbh_kern_spec ks = bbh_kern_spec_of(h);
   for (int f = 0; f < ks.F; f++)
-    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0 || BBH_KIND_IS_DOT(ks.kind[f])) return false;
+    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0 || ks.kind[f] >= BBH_KERNEL_LINEAR) return false;
   return bbh_coopg_launch(h->kd, ks.F, dim3(0), 0, nullptr, CoopGArgs{});
 }
 
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void bbh_kstar_kernel(const double* __restrict
         const double xc = s_xc[c * dn + j];
 #pragma unroll
         for (int f = 0; f < BBH_MAX_FACTORS; f++)
-          if (f < ks.F) r2[c][f] += bbh_metric_term(ks.kind[f], xc, x, s_il[f * dn + j]);
+          if (f < ks.F) r2[c][f] += bbh_metric_term_f(ks, theta, f, j, dn, xc, x, s_il[f * dn + j]);
       }
     }
   const int ti = (T > 1 && i < n) ? task[i] : 0;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void bbh_kdiag_kernel(const double* __restrict
   double r2[BBH_MAX_FACTORS] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < dn; j++) {
     const double x = (X[i * ldx + numcol[j]] - lo[j]) / (hi[j] - lo[j]);
-    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], x, x, 1.0 / theta[ks.ls_off[f] + j]);
+    for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term_f(ks, theta, f, j, dn, x, x, 1.0 / theta[ks.ls_off[f] + j]);
   }
   out[i] = bbh_kcomp(ks, theta, r2);
 }
@@ -932,7 +932,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
       double kc = ks.combine && ks.F > 1 ? 0.0 : 1.0;
       for (int f = 0; f < ks.F; f++) {
         double r2 = 0.0;
-        for (int c = 0; c < dn; c++) r2 += bbh_metric_term(ks.kind[f], pn[i * dn + c], pn[j * dn + c], 1.0 / th[ks.ls_off[f] + c]);
+        for (int c = 0; c < dn; c++) r2 += bbh_metric_term_f(ks, th, f, c, dn, pn[i * dn + c], pn[j * dn + c], 1.0 / th[ks.ls_off[f] + c]);
         const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb, ks.alpha_off >= 0 ? th[ks.alpha_off + f] : 1.0);
         kc = (ks.combine && ks.F > 1) ? kc + u : kc * u;
       }
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void bbh_kqq_kernel(const double* __restrict__
     for (int j = 0; j < dn; j++) {
       const double rng = hi[j] - lo[j];
       const double xa = (Xq[a * ldx + numcol[j]] - lo[j]) / rng, xb = (Xq[b * ldx + numcol[j]] - lo[j]) / rng;
-      for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term(ks.kind[f], xa, xb, 1.0 / theta[ks.ls_off[f] + j]);
+      for (int f = 0; f < ks.F; f++) r2[f] += bbh_metric_term_f(ks, theta, f, j, dn, xa, xb, 1.0 / theta[ks.ls_off[f] + j]);
     }
     v = bbh_kcomp(ks, theta, r2);
     if (ks.use_os) v *= theta[2];

@@ -38,6 +38,9 @@ def sigmoid(x):
 #       constraint "linvar"; ``ls_prior`` / ``ls_init`` are the VARIANCE prior / initial value (LinearKernel.variance_prior, ..).
 #   "poly1" .. "poly4" - gpytorch PolynomialKernel(power): (x . x' + offset)^power, no per-column parameter: w_j = 1 (constraint
 #       "pinned"), offset = softplus(raw_offset) in the factor's alpha slot with ``alpha_prior`` / ``alpha_init``.
+#   "periodic" - gpytorch PeriodicKernel: exp(-2 sum_j sin^2(pi (x_j - x'_j) / p_j) / l_j); lengthscales l_j in the lengthscale
+#       slots as usual (Positive()), the periods p_j = softplus(raw_period_length_j) in a block of F * dn slots at the end of theta
+#       with ``period_prior`` / ``period_init`` (PeriodicKernel.period_length_prior, ..; kernels/basic.py:73-112).
 DOT_KINDS = ("linear", "poly1", "poly2", "poly3", "poly4")
 ALPHA_KINDS = ("rq", "poly1", "poly2", "poly3", "poly4")  # kinds with one extra Positive() scalar (RQ alpha / polynomial offset)
 
@@ -95,6 +98,8 @@ class KernelFactor:
     active: "np.ndarray | None" = None  # bool [dn]: the numerical columns the factor acts on (``parameter_names``); None = all
     alpha_prior: tuple | None = None  # polynomial kernels: prior / initial value of the offset (the factor's alpha slot)
     alpha_init: float | None = None
+    period_prior: tuple | None = None  # periodic kernels: prior / initial value of the period lengths
+    period_init: float | None = None
 
 
 # Lengthscale of a numerical column a kernel does NOT act on (``BasicKernel.parameter_names``, kernels/base.py:198-240: gpytorch
@@ -136,6 +141,18 @@ class GPSpec:
     active: "np.ndarray | None" = None  # bool [dn]: columns the (first) kernel acts on (``parameter_names``); None = all
     alpha_prior: tuple | None = None  # polynomial kernel: prior / initial value of the offset (KernelFactor.alpha_*)
     alpha_init: float | None = None
+    period_prior: tuple | None = None  # periodic kernel: prior / initial value of the period lengths (KernelFactor.period_*)
+    period_init: float | None = None
+
+    def period_spec(self, k: int = 0):
+        if k == 0 or not self.factors:
+            return self.period_prior, self.period_init
+        return self.factors[k].period_prior, self.factors[k].period_init
+
+    @property
+    def has_periodic(self) -> bool:
+        """A periodic kernel somewhere: theta ends with a block of F * dn period lengths (1 for the other factors)."""
+        return "periodic" in self.factor_kinds
 
     def ls_constraint_of(self, k: int = 0) -> str:
         return self.ls_constraint if (k == 0 or not self.factors) else self.factors[k].ls_constraint
@@ -186,6 +203,7 @@ class GPSpec:
         self.ls_lower = f0.ls_lower if f0.ls_constraint == "box" else self.ls_lower
         self.active = f0.active
         self.alpha_prior, self.alpha_init = f0.alpha_prior, f0.alpha_init
+        self.period_prior, self.period_init = f0.period_prior, f0.period_init
         self.factors, self.combine = factors, combine
         return self
 
@@ -321,6 +339,7 @@ class GPParams:
     factor_ls: "list[np.ndarray] | None" = None  # lengthscales of the factors 1.. of a composite kernel
     factor_os: "np.ndarray | None" = None  # [F] per-factor outputscales (1 for unscaled factors)
     alpha: "np.ndarray | None" = None  # [F] RQ alpha per factor (1 for the other kinds); None without an RQ kernel
+    period: "list[np.ndarray] | None" = None  # [F][dn] period lengths (1 for the other kinds / inactive columns); None without a periodic kernel
 
     def task_B_unscaled(self):
         if self.task_W is None:
@@ -361,6 +380,9 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
     if spec.has_rq:
         p.alpha = np.array([(float(spec.alpha_spec(m)[1]) if spec.alpha_spec(m)[1] is not None else float(softplus(0.0)))
                             if k in ALPHA_KINDS else 1.0 for m, k in enumerate(spec.factor_kinds)])
+    if spec.has_periodic:
+        p.period = [np.full(spec.dn, (float(spec.period_spec(m)[1]) if spec.period_spec(m)[1] is not None else float(softplus(0.0)))
+                            if k == "periodic" else 1.0) for m, k in enumerate(spec.factor_kinds)]
     return _pin_inactive(spec, p)
 
 
@@ -376,6 +398,8 @@ def _pin_inactive(spec: GPSpec, p: GPParams) -> GPParams:
                 p.lengthscale = arr
             else:
                 p.factor_ls[k - 1] = arr
+            if p.period is not None:
+                p.period[k] = np.where(m, p.period[k], 1.0)
     return p
 
 
@@ -422,6 +446,10 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
         for m in range(spec.n_factors):
             if spec.alpha_spec(m)[0] is not None:
                 p.alpha[m] = float(max(draw(spec.alpha_spec(m)[0], 1, p.alpha[m])[0], 1e-6))
+    if spec.has_periodic:
+        for m, k in enumerate(spec.factor_kinds):
+            if k == "periodic":
+                p.period[m] = np.maximum(draw(spec.period_spec(m)[0], spec.dn, p.period[m][0]), 1e-6)
     return _pin_inactive(spec, p)
 
 
@@ -437,6 +465,8 @@ def theta_from_params(spec: GPSpec, p: GPParams) -> np.ndarray:
         parts += [np.asarray(l, dtype=np.float64) for l in p.factor_ls] + [np.asarray(p.factor_os, dtype=np.float64)]
     if spec.has_rq:
         parts.append(np.asarray(p.alpha, dtype=np.float64))
+    if spec.has_periodic:
+        parts += [np.asarray(a, dtype=np.float64) for a in p.period]
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float64)
 
 
@@ -453,12 +483,16 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
     kinds = spec.factor_kinds
     if kinds[0] in ALPHA_KINDS:
         parts.append(inv_softplus(np.array([p.alpha[0]])))
+    if kinds[0] == "periodic":
+        parts.append(inv_softplus(p.period[0]))
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             parts.append(inv_softplus(np.array([p.factor_os[k + 1]])))
         parts.append(_ls_nat_to_raw(f.ls_constraint, p.factor_ls[k]))
         if f.kernel in ALPHA_KINDS:
             parts.append(inv_softplus(np.array([p.alpha[k + 1]])))
+        if f.kernel == "periodic":
+            parts.append(inv_softplus(p.period[k + 1]))
     if spec.n_tasks > 1:
         parts.append(inv_softplus(p.task_W).reshape(-1))
         parts.append(inv_softplus(p.task_v))
@@ -486,6 +520,9 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     alpha = np.ones(len(kinds)) if spec.has_rq else None
     if kinds[0] in ALPHA_KINDS:
         alpha[0] = float(softplus(raw[i])); i += 1
+    period = [np.ones(spec.dn) for _ in kinds] if spec.has_periodic else None
+    if kinds[0] == "periodic":
+        period[0] = softplus(raw[i : i + spec.dn]); i += spec.dn
     fls = [] if spec.factors else None
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
@@ -494,13 +531,15 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
         fls.append(_ls_raw_to_nat(f.ls_constraint, r))
         if f.kernel in ALPHA_KINDS:
             alpha[k + 1] = float(softplus(raw[i])); i += 1
+        if f.kernel == "periodic":
+            period[k + 1] = softplus(raw[i : i + spec.dn]); i += spec.dn
     W = v = None
     if spec.n_tasks > 1:
         T = spec.n_tasks
         W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
         v = softplus(raw[i : i + T]); i += T
-    p = GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos, alpha)
-    return _pin_inactive(spec, p) if (spec.has_subsets and spec.has_dot_kind) else p
+    p = GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos, alpha, period)
+    return _pin_inactive(spec, p) if (spec.has_subsets and (spec.has_dot_kind or spec.has_periodic)) else p
 
 
 def raw_bounds(spec: GPSpec):
@@ -518,15 +557,24 @@ def raw_bounds(spec: GPSpec):
         pin = float(_ls_nat_to_raw(c, np.array([INACTIVE_LS]))[0])  # raw value of a pinned slot
         return [((pin, pin) if (m is not None and not m[j]) else ((lower, None) if c == "box" else (None, None))) for j in range(spec.dn)]
 
+    def period_bounds(k):
+        m = spec.active_mask(k)
+        pin = float(inv_softplus(np.array([1.0]))[0])
+        return [((pin, pin) if (m is not None and not m[j]) else (None, None)) for j in range(spec.dn)]
+
     b += ls_bounds(0, spec.ls_lower, spec.ls_constraint)
     if spec.factor_kinds[0] in ALPHA_KINDS:
         b.append((None, None))
+    if spec.factor_kinds[0] == "periodic":
+        b += period_bounds(0)
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             b.append((None, None))
         b += ls_bounds(k + 1, f.ls_lower, f.ls_constraint)
         if f.kernel in ALPHA_KINDS:
             b.append((None, None))
+        if f.kernel == "periodic":
+            b += period_bounds(k + 1)
     if spec.n_tasks > 1:
         b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
     return b
@@ -649,6 +697,14 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         g.append(np.array([(grad_theta[alpha_off + m] + glp[0]) * float(sigmoid(raw[i]))]))
         return lp
 
+    per_off = alpha_off + (F if spec.has_rq else 0)  # [F][dn] period lengths, present when any factor is periodic
+
+    def period_block(m, i):  # softplus chain + optional prior over the active columns
+        lp, gp = _ls_chain("softplus", spec.period_spec(m)[0], p.period[m], raw[i : i + dn],
+                           grad_theta[per_off + m * dn : per_off + (m + 1) * dn], spec.active_mask(m))
+        g.append(gp)
+        return lp
+
     lp_ls, gl = _ls_chain(spec.ls_constraint, spec.ls_prior, p.lengthscale, raw[i : i + dn], g_ls, spec.active_mask(0))
     total += lp_ls
     g.append(gl)
@@ -656,6 +712,9 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
     if spec.factor_kinds[0] in ALPHA_KINDS:
         total += alpha_slot(0, i)
         i += 1
+    if spec.factor_kinds[0] == "periodic":
+        total += period_block(0, i)
+        i += dn
     for k, f in enumerate((spec.factors or [])[1:]):
         if f.scaled:
             total += scale_slot(k + 1, f, i)
@@ -668,6 +727,9 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         if f.kernel in ALPHA_KINDS:
             total += alpha_slot(k + 1, i)
             i += 1
+        if f.kernel == "periodic":
+            total += period_block(k + 1, i)
+            i += dn
     if T > 1:
         S = grad_theta[3 + dn : 3 + dn + T * T].reshape(T, T)  # dL/dB of the (scaled) table the device multiplies with
         Bu = p.task_B_unscaled()
@@ -693,7 +755,7 @@ class FastObjective:
 
     @staticmethod
     def applies(spec: GPSpec) -> bool:
-        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard and not spec.has_subsets and not spec.has_dot_kind
+        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard and not spec.has_subsets and not spec.has_dot_kind and not spec.has_periodic
 
     def __init__(self, spec: GPSpec, n: int):
         self.n = int(n)

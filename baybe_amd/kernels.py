@@ -1,7 +1,7 @@
 """Declarative kernel / prior specifications accepted by ``HipGaussianProcessSurrogate``
 (mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
 ``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
-device: Matérn(0.5|1.5|2.5) / RBF / RQ / PiecewisePolynomial(q) / Linear / Polynomial(power 1..4) base kernels with ARD over all
+device: Matérn(0.5|1.5|2.5) / RBF / RQ / PiecewisePolynomial(q) / Periodic / Linear / Polynomial(power 1..4) base kernels with ARD over all
 numerical columns (or the columns of ``parameter_names``), optionally
 wrapped in a ScaleKernel, and ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``) of two to
 four such factors, each optionally in its own ScaleKernel, the whole optionally in an outer ScaleKernel).
@@ -67,6 +67,18 @@ class RQKernel:
 
     lengthscale_prior = field(default=None)
     lengthscale_initial_value: float | None = field(default=None)
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
+
+
+@define(frozen=True)
+class PeriodicKernel:
+    """``baybe.kernels.basic.PeriodicKernel`` (basic.py:73-112): exp(-2 sum_j sin^2(pi |x_j - x'_j| / p_j) / l_j), one lengthscale
+    and one period length per column."""
+
+    lengthscale_prior = field(default=None)
+    lengthscale_initial_value: float | None = field(default=None)
+    period_length_prior = field(default=None)
+    period_length_initial_value: float | None = field(default=None, validator=optional(gt(0.0)))
     parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
 
 
@@ -139,6 +151,8 @@ def _basic_kind(kernel) -> str | None:
         return f"piecewise{int(kernel.q)}"
     if name == "RQKernel":
         return "rq"
+    if name == "PeriodicKernel":
+        return "periodic"
     if name == "LinearKernel":
         return "linear"
     if name == "PolynomialKernel":
@@ -161,6 +175,10 @@ def _ls_fields(kernel, kind):
         return (c, 0.0, None, None), (_prior_tuple(getattr(kernel, "offset_prior", None)), getattr(kernel, "offset_initial_value", None))
     return ("softplus", 0.0, _prior_tuple(getattr(kernel, "lengthscale_prior", None)),
             getattr(kernel, "lengthscale_initial_value", None)), (None, None)
+
+
+def _period_fields(kernel):
+    return _prior_tuple(getattr(kernel, "period_length_prior", None)), getattr(kernel, "period_length_initial_value", None)
 
 
 def _active_mask(spec, kernel, searchspace):
@@ -229,19 +247,20 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
             if kind is None:
                 raise IncompatibilityError(
                     f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial / "
-                    f"Linear / Polynomial factors, each optionally in a ScaleKernel, are)."
+                    f"Periodic / Linear / Polynomial factors, each optionally in a ScaleKernel, are)."
                 )
             (c, lower, ls_prior, ls_init), (a_prior, a_init) = _ls_fields(member, kind)
             factors.append(KernelFactor(kind, c, lower, ls_prior, ls_init, scaled, os_prior, os_init,
-                                        _active_mask(spec, member, searchspace), a_prior, a_init))
+                                        _active_mask(spec, member, searchspace), a_prior, a_init, *_period_fields(member)))
         return spec.set_factors(factors, "product" if name == "ProductKernel" else "sum")
     kind = _basic_kind(kernel)
     if kind is None:
         raise IncompatibilityError(
-            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial / Linear / Polynomial, "
+            f"Kernel '{name}' is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial / Periodic / Linear / Polynomial, "
             f"optionally in a ScaleKernel, and Product / Additive kernels of them are)."
         )
     spec.kernel = kind
     spec.active = _active_mask(spec, kernel, searchspace)
     (spec.ls_constraint, _, spec.ls_prior, spec.ls_init), (spec.alpha_prior, spec.alpha_init) = _ls_fields(kernel, kind)
+    spec.period_prior, spec.period_init = _period_fields(kernel)
     return spec

@@ -75,7 +75,11 @@ enum bbh_kernel_kind {
   BBH_KERNEL_POLY1 = 10,
   BBH_KERNEL_POLY2 = 11,
   BBH_KERNEL_POLY3 = 12,
-  BBH_KERNEL_POLY4 = 13
+  BBH_KERNEL_POLY4 = 13,
+  /* gpytorch PeriodicKernel (baybe/kernels/basic.py:73-112): exp(-2 sum_j sin^2(pi (x_j - x'_j) / p_j) / l_j) with one lengthscale
+   * l_j (lengthscale slots; note: not squared) and one period p_j per column.  theta: a block of F * dn periods at the very end
+   * (after the alpha slots), present when any factor is periodic; slots of the other factors are ignored.  Materialised-K* path. */
+  BBH_KERNEL_PERIODIC = 14
 };
 
 enum bbh_criterion {

@@ -97,7 +97,7 @@ def parameter_layout(spec) -> list[RawParameter]:
     if spec.use_outputscale:
         out.append(RawParameter(f"{base}.raw_outputscale", (), 0.0, True, _prior(spec.outputscale_prior)))
         base += ".base_kernel"
-    def base_kernel_parameters(leaf, kind, lower, transformed, prior, ndims, offset_prior, m):
+    def base_kernel_parameters(leaf, kind, lower, transformed, prior, ndims, offset_prior, period_prior, m):
         if kind == "linear":  # gpytorch LinearKernel: raw_variance [1, ard_num_dims], Positive(), optional variance_prior
             out.append(RawParameter(f"{leaf}.raw_variance", (1, ndims), 0.0, True, prior, m))
         elif kind.startswith("poly"):  # gpytorch PolynomialKernel: raw_offset [1], Positive(), optional offset_prior; no lengthscale
@@ -106,6 +106,8 @@ def parameter_layout(spec) -> list[RawParameter]:
             out.append(RawParameter(f"{leaf}.raw_lengthscale", (1, ndims), lower, transformed, prior, m))
             if kind == "rq":  # gpytorch RQKernel registers raw_alpha (Positive(), no prior) after the lengthscale
                 out.append(RawParameter(f"{leaf}.raw_alpha", (1,), 0.0, True, None, m))
+            if kind == "periodic":  # gpytorch PeriodicKernel: raw_period_length [1, ard_num_dims], Positive(), optional prior
+                out.append(RawParameter(f"{leaf}.raw_period_length", (1, ndims), 0.0, True, period_prior, m))
 
     members = getattr(spec, "members", None)
     if members:  # ProductKernel / AdditiveKernel: .kernels.0, .kernels.1, ... each possibly a ScaleKernel
@@ -116,10 +118,10 @@ def parameter_layout(spec) -> list[RawParameter]:
                 leaf += ".base_kernel"
             h = term.lengthscale
             base_kernel_parameters(leaf, term.kernel, h.lower, h.transformed, _prior(h.prior), len(spec.dims_of(m)),
-                                   _prior(spec.offset_of(m).prior), m)
+                                   _prior(spec.offset_of(m).prior), _prior(spec.period_of(m).prior), m)
     else:
         base_kernel_parameters(base, spec.kernel, spec.ls_lower if box_ls else 0.0, not box_ls, _prior(spec.ls_prior),
-                               len(spec.dims_of(None)), _prior(spec.offset_of(None).prior), None)
+                               len(spec.dims_of(None)), _prior(spec.offset_of(None).prior), _prior(spec.period_of(None).prior), None)
     if T > 1:
         out.append(RawParameter("covar_module.kernels.1.raw_covar_factor", (T, T), 0.0, True, None))
         out.append(RawParameter("covar_module.kernels.1.raw_var", (T,), 0.0, True, None))
@@ -196,6 +198,10 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
             return Xv @ Xv.T
         if kind.startswith("poly"):  # gpytorch PolynomialKernel.forward: (x1 @ x2^T + offset).pow(power)
             return (Xa @ Xa.T + nat["offset" + sfx].reshape(())).pow(int(kind[-1]))
+        if kind == "periodic":  # gpytorch PeriodicKernel.forward: x / (period / pi); diff.sin().pow(2).div(lengthscale).sum().mul(-2).exp()
+            Xp = Xa / (nat["period_length" + sfx].reshape(1, -1) / math.pi)
+            diff = Xp[:, None, :] - Xp[None, :, :]
+            return diff.sin().pow(2.0).div(nat["lengthscale" + sfx].reshape(1, 1, -1)).sum(-1).mul(-2.0).exp()
         lengthscale, alpha = nat["lengthscale" + sfx], nat.get("alpha" + sfx)
         Xs = Xa / lengthscale.reshape(1, -1)
         diff = Xs[:, None, :] - Xs[None, :, :]

@@ -56,7 +56,9 @@ MIN_INFERRED_NOISE_LEVEL = 0.0001  # [UPSTREAM] botorch.models.utils.gpytorch_mo
 MAX_BATCH_SIZE = 2048  # [UPSTREAM] optimize_acqf_discrete(max_batch_size=2048)
 
 KERNELS = ("matern12", "matern32", "matern52", "rbf", "piecewise0", "piecewise1", "piecewise2", "piecewise3", "rq",
-           "linear", "poly1", "poly2", "poly3", "poly4")
+           "linear", "poly1", "poly2", "poly3", "poly4", "periodic")
+# "periodic" (baybe/kernels/basic.py:73-112 -> gpytorch PeriodicKernel [UPSTREAM]): exp(-2 sum_j sin^2(pi |x_j - x'_j| / p_j) / l_j)
+# with a lengthscale AND a period length per active column (``KernelTerm.period`` / ``GPSpec.period``; ``GPParams.period``).
 # Dot-product kernels (baybe/kernels/basic.py:20-46, 135-163 -> gpytorch LinearKernel / PolynomialKernel [UPSTREAM]):
 #   "linear": k = (x sqrt(v)) . (x' sqrt(v)) with one variance v_j per active column (``ard_num_dims`` is always passed,
 #             kernels/base.py:218-239); the term's ``lengthscale`` Hyper / parameter array IS that variance here;
@@ -103,6 +105,7 @@ class KernelTerm:
     active_dims: "np.ndarray | None" = None  # positions among the numerical columns the kernel acts on (gpytorch active_dims
     # from ``BasicKernel.parameter_names``, baybe/kernels/base.py:198-240); its lengthscale has len(active_dims) entries
     offset: "Hyper | None" = None  # polynomial kernels: the offset (PolynomialKernel.offset_prior / offset_initial_value)
+    period: "Hyper | None" = None  # periodic kernels: the period lengths (period_length_prior / period_length_initial_value)
 
 
 @dataclass
@@ -129,6 +132,11 @@ class GPSpec:
     composition: str = "product"  # "product" | "sum"
     active_dims: "np.ndarray | None" = None  # single kernel on a parameter subset (see KernelTerm.active_dims)
     offset: "Hyper | None" = None  # single polynomial kernel: its offset (see KernelTerm.offset)
+    period: "Hyper | None" = None  # single periodic kernel: its period lengths (see KernelTerm.period)
+
+    def period_of(self, m: int | None = None) -> Hyper:
+        h = self.period if (m is None or not self.members) else self.members[m].period
+        return h if h is not None else Hyper()
 
     def offset_of(self, m: int | None = None) -> Hyper:
         h = self.offset if (m is None or not self.members) else self.members[m].offset
@@ -190,6 +198,7 @@ class GPParams:
     member_ls: "list[np.ndarray] | None" = None  # per base kernel of a composite: lengthscales [dn] (ALL members)
     member_scale: "np.ndarray | None" = None  # per base kernel: its own outputscale (1 where it has none)
     rq_alpha: "np.ndarray | None" = None  # RQ kernels: alpha per base kernel ([1] for a single kernel; 1 for other kinds)
+    period: "list | None" = None  # periodic kernels: period lengths per base kernel (None entries for the other kinds)
 
     def task_B(self) -> np.ndarray | None:
         if self.task_W is None:
@@ -210,7 +219,7 @@ class GPParams:
         return GPParams(dup(self.lengthscale), scal(self.noise), scal(self.mean), float(self.outputscale),
                         dup(self.task_W), dup(self.task_v), self.target_scaled,
                         None if self.member_ls is None else [dup(a) for a in self.member_ls], dup(self.member_scale),
-                        dup(self.rq_alpha))
+                        dup(self.rq_alpha), None if self.period is None else [dup(a) for a in self.period])
 
 
 def softplus(x):
@@ -243,6 +252,8 @@ def initial_params(spec, task_init=1.0):
         if spec.members else None,
         rq_alpha=np.array([math.log(2.0) if k == "rq" else (spec.offset_of(m).start() if k in SCALAR_KERNELS else 1.0)
                            for m, k in enumerate(kernel_names(spec))]) if any(k in SCALAR_KERNELS for k in kernel_names(spec)) else None,
+        period=[np.full(len(spec.dims_of(m if spec.members else None)), spec.period_of(m).start()) if k == "periodic" else None
+                for m, k in enumerate(kernel_names(spec))] if "periodic" in kernel_names(spec) else None,
     )
 
 
@@ -280,9 +291,15 @@ def _scaled_sqdist(XA: np.ndarray, XB: np.ndarray, ls: np.ndarray) -> np.ndarray
     return d2
 
 
-def _metric(kernel: str, XA: np.ndarray, XB: np.ndarray, ls: np.ndarray) -> np.ndarray:
+def _metric(kernel: str, XA: np.ndarray, XB: np.ndarray, ls: np.ndarray, period=None) -> np.ndarray:
     """What the base kernel is a function of: the scaled squared distance (stationary kernels), x sqrt(v) . x' sqrt(v) (gpytorch
-    LinearKernel.forward, ``ls`` = the variances) or x . x' (PolynomialKernel.forward)."""
+    LinearKernel.forward, ``ls`` = the variances), x . x' (PolynomialKernel.forward) or sum_j sin^2(pi (x_j - x'_j) / p_j) / l_j
+    (PeriodicKernel.forward: ``diff.sin().pow(2).div(lengthscale)`` summed over the dimensions)."""
+    if kernel == "periodic":
+        out = np.zeros((XA.shape[0], XB.shape[0]))
+        for j in range(XA.shape[1]):
+            out += np.sin(math.pi * (XA[:, j : j + 1] - XB[None, :, j]) / period[j]) ** 2 / ls[j]
+        return out
     if kernel == "linear":
         return (XA * np.sqrt(ls)) @ (XB * np.sqrt(ls)).T
     if kernel in DOT_KERNELS:
@@ -317,6 +334,8 @@ def _piecewise_terms(q: int, dims: int, r: np.ndarray):
 def base_kernel_from_r2(kernel: str, r2: np.ndarray, dims: int | None = None, alpha: float | None = None) -> np.ndarray:
     """Stationary kernels of gpytorch [UPSTREAM A3] as functions of r^2 (``dims``: input dimension, piecewise family;
     ``alpha``: RQ kernel, ``(1 + r^2 / (2 alpha))^-alpha``)."""
+    if kernel == "periodic":  # ``r2`` is the sum of ``_metric`` here: exp_term.mul(-2).exp()
+        return np.exp(-2.0 * r2)
     if kernel == "linear":  # ``r2`` is the dot product of ``_metric`` here
         return r2
     if kernel in DOT_KERNELS:  # gpytorch PolynomialKernel: (x1 @ x2^T + offset).pow(power)
@@ -385,12 +404,16 @@ def _alpha_of(p: GPParams, m: int):
     return None if p.rq_alpha is None else float(p.rq_alpha[m])
 
 
+def _period_of(p: GPParams, m: int):
+    return None if p.period is None else p.period[m]
+
+
 def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> list[np.ndarray]:
     """Scaled Gram matrix of every base kernel of a composite (numerical columns only)."""
     out = []
     for m, t in enumerate(spec.members):
         c = spec.dims_of(m)
-        out.append(p.member_scale[m] * base_kernel_from_r2(t.kernel, _metric(t.kernel, A[:, c], B[:, c], p.member_ls[m]), len(c), _alpha_of(p, m)))
+        out.append(p.member_scale[m] * base_kernel_from_r2(t.kernel, _metric(t.kernel, A[:, c], B[:, c], p.member_ls[m], _period_of(p, m)), len(c), _alpha_of(p, m)))
     return out
 
 
@@ -399,7 +422,7 @@ def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> 
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
     if not spec.members:
         c = spec.dims_of(None)
-        return base_kernel_from_r2(spec.kernel, _metric(spec.kernel, A[:, c], B[:, c], p.lengthscale), len(c), _alpha_of(p, 0))
+        return base_kernel_from_r2(spec.kernel, _metric(spec.kernel, A[:, c], B[:, c], p.lengthscale, _period_of(p, 0)), len(c), _alpha_of(p, 0))
     grams = member_grams(spec, p, A, B)
     out = grams[0].copy()
     for Km in grams[1:]:
@@ -476,8 +499,8 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     if spec.active_dims is not None or any(t.active_dims is not None for t in (spec.members or [])):
         raise NotImplementedError("analytic data-term gradients are not restated for kernels on parameter subsets; "
                                   "use fit_objective (autograd)")
-    if any(k in DOT_KERNELS for k in kernel_names(spec)):
-        raise NotImplementedError("analytic data-term gradients are not restated for Linear / Polynomial kernels; use fit_objective")
+    if any(k in DOT_KERNELS or k == "periodic" for k in kernel_names(spec)):
+        raise NotImplementedError("analytic data-term gradients are not restated for Linear / Polynomial / Periodic kernels; use fit_objective")
     trow = task_rows(spec, Xn)
     Kf = cross_cov(spec, p, Xn, Xn)
     Ky = Kf + np.diag(p.noise_of(trow))
@@ -594,8 +617,12 @@ def _natural_dict(spec: GPSpec, p: GPParams) -> dict:
                 nat[f"outputscale.{m}"] = p.member_scale[m]
             if t.kernel in SCALAR_KERNELS:
                 nat[f"{scalar(t.kernel)}.{m}"] = [p.rq_alpha[m]]
+            if t.kernel == "periodic":
+                nat[f"period_length.{m}"] = p.period[m]
     elif spec.kernel in SCALAR_KERNELS:
         nat[scalar(spec.kernel)] = [p.rq_alpha[0]]
+    elif spec.kernel == "periodic":
+        nat["period_length"] = p.period[0]
     if spec.use_outputscale:
         nat["outputscale"] = p.outputscale
     if spec.n_tasks > 1:
@@ -634,7 +661,12 @@ def unpack_raw(spec, raw):
         alphas = np.array([float(nat[key(m, k)].reshape(-1)[0]) if k in SCALAR_KERNELS else 1.0 for m, k in enumerate(names)])
     else:
         alphas = None
+    periods = None
+    if "periodic" in names:
+        pkey = (lambda m: f"period_length.{m}") if spec.members else (lambda m: "period_length")
+        periods = [nat[pkey(m)].reshape(-1).copy() if k == "periodic" else None for m, k in enumerate(names)]
     return GPParams(
+        period=periods,
         rq_alpha=alphas,
         lengthscale=mls[0] if spec.members else percol(None),
         member_ls=mls,

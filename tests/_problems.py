@@ -61,11 +61,11 @@ def oracle_spec(spec):
                                go.Hyper(f.ls_lower if f.ls_constraint == "box" else 0.0, f.ls_constraint != "box", f.ls_prior, f.ls_init),
                                go.Hyper(0.0, True, f.outputscale_prior, f.outputscale_init) if f.scaled else None,
                                None if spec.active_mask(k) is None else np.nonzero(spec.active_mask(k))[0],
-                               go.Hyper(0.0, True, f.alpha_prior, f.alpha_init))
+                               go.Hyper(0.0, True, f.alpha_prior, f.alpha_init), go.Hyper(0.0, True, f.period_prior, f.period_init))
                  for k, f in enumerate(spec.factors)] if spec.factors else None,
         composition=spec.combine,
         active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0],
-        offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init))
+        offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init), period=go.Hyper(0.0, True, spec.period_prior, spec.period_init))
 
 
 def oracle_params(spec, p):
@@ -85,4 +85,7 @@ def oracle_params(spec, p):
                        bool(getattr(p, "task_unit_scale", False)),
                        None if p.factor_ls is None else [act(p.lengthscale, 0)] + [act(a, k + 1) for k, a in enumerate(p.factor_ls)],
                        None if p.factor_os is None else np.array(p.factor_os, dtype=float),
-                       None if getattr(p, "alpha", None) is None else np.array(p.alpha, dtype=float))
+                       None if getattr(p, "alpha", None) is None else np.array(p.alpha, dtype=float),
+                       None if getattr(p, "period", None) is None else
+                       [(np.array(a, dtype=float) if spec.active_mask(k) is None else np.array(a, dtype=float)[spec.active_mask(k)])
+                        if spec.factor_kinds[k] == "periodic" else None for k, a in enumerate(p.period)])

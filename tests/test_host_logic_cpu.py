@@ -532,16 +532,22 @@ def _theta_layout_mll(spec, theta, Xn, ys):
     base = 3 + dn
     fos_off = base + (F - 1) * dn
     alpha_off = base + ((F - 1) * dn + F if F > 1 else 0)
+    per_off = alpha_off + (F if spec.has_rq else 0)
     K = None
     for f, kind in enumerate(spec.factor_kinds):
         w = th[3 : 3 + dn] if f == 0 else th[base + (f - 1) * dn : base + f * dn]
         Xs = X / w
-        if kind in gp_spec.DOT_KINDS:
+        if kind == "periodic":  # exp(-2 sum_j sin^2(pi Delta_j / p_j) / l_j): lengthscale slots l_j, period block p_j
+            per = th[per_off + f * dn : per_off + (f + 1) * dn]
+            u = math.pi * (X[:, None, :] - X[None, :, :]) / per
+            k = torch.exp(-2.0 * (torch.sin(u) ** 2 / w).sum(-1))
+        elif kind in gp_spec.DOT_KINDS:
             s = Xs @ Xs.T
             k = s if kind == "linear" else (s + th[alpha_off + f]) ** int(kind[-1])
         else:
             r2 = ((Xs[:, None, :] - Xs[None, :, :]) ** 2).sum(-1)
             k = {"rbf": lambda: torch.exp(-0.5 * r2),
+                 "rq": lambda: (1 + r2 / (2 * th[alpha_off + f])) ** (-th[alpha_off + f]),
                  "matern52": lambda: (1 + math.sqrt(5) * torch.sqrt(r2 + 1e-300) + 5.0 / 3.0 * r2) * torch.exp(-math.sqrt(5) * torch.sqrt(r2 + 1e-300))}[kind]()
         if F > 1:
             k = k * th[fos_off + f]
@@ -555,15 +561,16 @@ def _theta_layout_mll(spec, theta, Xn, ys):
     return float(val.detach()), g.numpy()
 
 
-def test_linear_and_polynomial_kernels_against_the_autograd_oracle():
-    """LinearKernel / PolynomialKernel (baybe/kernels/basic.py:20-46, 135-163): the product keeps weights w_j = v_j^-1/2 (Linear
-    ARD variances) or pinned ones (Polynomial) in the lengthscale slots and the offset in the alpha slot; its raw vector has the
+def test_linear_polynomial_and_periodic_kernels_against_the_autograd_oracle():
+    """LinearKernel / PolynomialKernel / PeriodicKernel (baybe/kernels/basic.py:20-46, 135-163, 73-112): the product keeps weights
+    w_j = v_j^-1/2 (Linear ARD variances) or pinned ones (Polynomial) in the lengthscale slots, the offset in the alpha slot and the
+    period lengths of a Periodic kernel in a block at the end of theta; its raw vector has the
     oracle's (= gpytorch's) free parameters in the same order plus pinned slots.  Value and gradient of the assembled objective
     equal the oracle's on the free slots; pinned slots have zero gradient."""
     from _problems import oracle_params
     from baybe_amd.exceptions import IncompatibilityError
-    from baybe_amd.kernels import (AdditiveKernel, GammaPrior, LinearKernel, LogNormalPrior, MaternKernel, PolynomialKernel, ProductKernel,
-                                   RBFKernel, ScaleKernel, apply_kernel_spec)
+    from baybe_amd.kernels import (AdditiveKernel, GammaPrior, LinearKernel, LogNormalPrior, MaternKernel, PeriodicKernel, PolynomialKernel,
+                                   ProductKernel, RBFKernel, RQKernel, ScaleKernel, apply_kernel_spec)
 
     class Space:
         comp_rep_columns = ("a", "b", "c", "d")
@@ -576,11 +583,16 @@ def test_linear_and_polynomial_kernels_against_the_autograd_oracle():
                LinearKernel(parameter_names=["a", "c"]), PolynomialKernel(1, GammaPrior(2, 2), parameter_names=["b", "c", "d"]),
                AdditiveKernel([PolynomialKernel(1), PolynomialKernel(2), PolynomialKernel(3)]),  # reference tests/test_iterations.py:294
                AdditiveKernel([RBFKernel(), ScaleKernel(LinearKernel(GammaPrior(3, 2))), PolynomialKernel(1, GammaPrior(2, 1))]),
-               ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(PolynomialKernel(2, None, 1.5))]))
+               ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(PolynomialKernel(2, None, 1.5))]),
+               PeriodicKernel(), ScaleKernel(PeriodicKernel(GammaPrior(3, 1), 0.8, LogNormalPrior(0, 0.5), 1.3), GammaPrior(2, 0.5)),
+               PeriodicKernel(GammaPrior(2, 1), None, GammaPrior(3, 3), parameter_names=["b", "d"]),
+               AdditiveKernel([ScaleKernel(PeriodicKernel(None, None, GammaPrior(2, 2))), RQKernel(), PolynomialKernel(1)]),
+               ProductKernel([RBFKernel(GammaPrior(3, 1), parameter_names=["a", "b"]),
+                              ScaleKernel(PeriodicKernel(GammaPrior(3, 1), 2.0, None, 0.6, parameter_names=["b", "c"]))]))
     for kern in kernels:
         spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern, Space())
         ospec = _ospec(spec)
-        assert spec.has_dot_kind and not gp_spec.FastObjective.applies(spec)
+        assert (spec.has_dot_kind or spec.has_periodic) and not gp_spec.FastObjective.applies(spec)
         p0 = gp_spec.initial_params(spec)
         raw, bounds = gp_spec.pack_raw(spec, p0), gp_spec.raw_bounds(spec)
         free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
