@@ -230,9 +230,18 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
     if name in ("ProductKernel", "AdditiveKernel"):
         from baybe_amd.gp_spec import KernelFactor
 
-        members = tuple(kernel.base_kernels)
+        def flatten(k):  # Product(Product(a, b), c) = Product(a, b, c), the same for sums: gpytorch multiplies / adds the members'
+            # Gram matrices (composite.py:75,91) and registers their parameters in this order; a ScaleKernel in between or a change of
+            # type is a different model (shared outputscale / sum of products) and stays unsupported
+            out = []
+            for m in k.base_kernels:
+                out.extend(flatten(m) if type(m).__name__ == name else [m])
+            return out
+
+        members = tuple(flatten(kernel))
         if not 2 <= len(members) <= 4:
-            raise IncompatibilityError(f"'{name}' with {len(members)} base kernels: the HIP path evaluates 2 to 4 factors.")
+            raise IncompatibilityError(f"'{name}' with {len(members)} base kernels (nested ones of the same type counted): the HIP path "
+                                       f"evaluates 2 to 4 factors.")
         factors = []
         for member in members:
             mname, scaled, os_prior, os_init = type(member).__name__, False, None, None

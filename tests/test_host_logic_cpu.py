@@ -250,9 +250,21 @@ def test_composite_kernel_parameterisation_against_the_autograd_oracle():
         f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
         f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
         assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
-    with pytest.raises(IncompatibilityError):  # nested composites are not flattened
+    with pytest.raises(IncompatibilityError):  # a sum inside a product is a different model class
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
                           ProductKernel([MaternKernel(2.5), AdditiveKernel([RBFKernel(), MaternKernel(1.5)])]))
+    with pytest.raises(IncompatibilityError):  # so is a scaled product inside a product (one outputscale over two factors)
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
+                          ProductKernel([MaternKernel(2.5), ScaleKernel(ProductKernel([RBFKernel(), MaternKernel(1.5)]))]))
+    # nesting of the same type flattens: same factors, same raw layout (gpytorch registers kernels.0.kernels.0, kernels.0.kernels.1,
+    # kernels.1 in this order)
+    nested = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
+                               AdditiveKernel([AdditiveKernel([ScaleKernel(MaternKernel(1.5)), RBFKernel(GammaPrior(3, 1))]), MaternKernel(0.5)]))
+    flat = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
+                             AdditiveKernel([ScaleKernel(MaternKernel(1.5)), RBFKernel(GammaPrior(3, 1)), MaternKernel(0.5)]))
+    assert nested.factor_kinds == flat.factor_kinds and nested.combine == flat.combine == "sum"
+    assert np.array_equal(gp_spec.pack_raw(nested, gp_spec.initial_params(nested)), gp_spec.pack_raw(flat, gp_spec.initial_params(flat)))
+    assert gp_spec.raw_bounds(nested) == gp_spec.raw_bounds(flat)
     with pytest.raises(IncompatibilityError):
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), ProductKernel([RBFKernel()] * 5))
 
