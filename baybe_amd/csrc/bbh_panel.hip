@@ -1057,6 +1057,166 @@ __global__ __launch_bounds__(256, 2) void bbh_fused_columns_kernel(const FusedAr
   }
 }
 
+// Cooperative variant for S >= 384 alternative columns: one workgroup per tile of 16 candidates, wave w contracts the tile's
+// kernel values with column group 4 G + w (128 columns) of a super-group of 512.  The kernel values are the expensive part (a
+// distance GEMM and a libm sqrt / exp per value: more pipe time than the 32 column MFMAs of a k-block) and the plain kernel above
+// recomputes them for every group of 128 columns; here the four waves take turns - k-block 4 g + w is produced by wave w - and
+// exchange them through a double-buffered 8 KB slot in LDS, one barrier per four k-blocks: every value is computed once per
+// candidate for 512 columns.
+// NT = candidate tiles (of 16) per workgroup: every column fragment that comes back from L2 feeds NT MFMAs (the column matrix is
+// re-read by every workgroup: 1.2 MB per 16 NT candidates at n = 288, S = 512 - L2 -> L1 bandwidth, not HBM).
+// SM (sample-major output [S, N]): the MFMAs run with swapped operands - the column fragment as A, the kernel values as B, the same
+// registers either way - so that the accumulators hold the transposed block (lane = candidate, register = column) and a store
+// instruction writes 16 consecutive candidates of a column (128 B) instead of 32 B pieces of 16 columns that lie N doubles apart.
+template <bool HAS_TBL, int KIND, int NT, bool SM>
+__global__ __launch_bounds__(256, 2) void bbh_coop_columns_kernel(const FusedArgs a, const double* __restrict__ colfrag, int64_t group0,
+                                                                  int64_t groups, int64_t nks, int64_t str_c, int64_t str_s,
+                                                                  int64_t s_total, double* __restrict__ tmat) {
+  extern __shared__ __attribute__((aligned(16))) double s_coopc[];  // candidate fragments [NT][kd][64] | kv [2][NT][4 k-blocks][4][64]
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cnd = l & 15, q = l >> 4;
+  const int64_t tile0 = (int64_t)blockIdx.x * 16 * NT;
+  double* kvx = s_coopc + NT * a.kd * 64;
+  int tc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int64_t row = (tile0 + 16 * t + cnd < a.N) ? tile0 + 16 * t + cnd : a.N - 1;
+    const double* xr = a.X + row * a.ldx;
+    double* candw = s_coopc + t * a.kd * 64;
+    if (w == t) {  // tile t's normalised candidate fragments, augmented as in the plain kernel (wave t builds them; NT <= 4)
+      double nbsum = 0.0;
+      for (int k0 = 0; k0 < a.kd; k0++) {
+        double v = 0.0;
+        if (4 * k0 + q < a.dn) {
+          v = fma(xr[a.numcol[4 * k0 + q]], a.scl[4 * k0 + q], a.ofs[4 * k0 + q]);
+          nbsum = fma(v, v, nbsum);
+        }
+        candw[k0 * 64 + l] = v;
+      }
+      nbsum += __shfl_xor(nbsum, 16, 64);
+      nbsum += __shfl_xor(nbsum, 32, 64);
+      const int k1 = a.dn >> 2, q1 = a.dn & 3;
+      if (q == q1) candw[k1 * 64 + l] = 1.0;
+      const int k2 = (a.dn + 1) >> 2, q2 = (a.dn + 1) & 3;
+      if (q == q2) candw[k2 * 64 + l] = nbsum;
+    }
+    tc[t] = 0;
+    if (HAS_TBL && a.task_col >= 0) {
+      tc[t] = (int)xr[a.task_col];
+      tc[t] = tc[t] < 0 ? 0 : (tc[t] >= a.T ? a.T - 1 : tc[t]);
+    }
+  }
+  __syncthreads();
+  WaveCtx c[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    c[t].tf = a.trainfrag + l;
+    c[t].candl = s_coopc + t * a.kd * 64 + l;
+    c[t].mb = a.meanB + l;
+    c[t].tbl = a.tasktbl;
+    c[t].taskext = a.taskext;
+    c[t].kvc = nullptr;
+    c[t].kvl = (bbh_lds_double*)nullptr;
+    c[t].nl = 0;
+    c[t].ncache = 0;
+    c[t].al = (const bbh_lds_double*)nullptr;
+    c[t].kd = a.kd;
+    c[t].kind = a.kind;
+    c[t].T = a.T;
+    c[t].tc = tc[t];
+    c[t].q = q;
+    c[t].l = l;
+    c[t].dn = a.dn;
+  }
+  const bool live = group0 + w < groups;  // (the last super-group may have fewer than four column groups: those waves only produce)
+  d4 acc[NT][8];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++) acc[t][cb] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* cf = colfrag + (live ? group0 + w : group0) * nks * 8 * 64 + l;
+  const int ngrp = (a.nb + 3) >> 2;
+  // Column fragments through a register ring of RD k-steps (8 fragments each), refilled right after the MFMAs that consumed a slot:
+  // the loads of k-step s + RD are in flight during the 8 NT (RD - 1) MFMAs in between (the fragments are static data: the ring runs
+  // ahead across the group barriers).  As plain loads at the head of every k-block the first MFMA of each block waited out the
+  // whole L2 latency: half the pipe time of this loop.
+  constexpr int RD = (NT == 1 && KIND >= 0) ? 8 : 4;  // (runtime kernel kinds: the deeper ring spills)
+  const int nsteps = 4 * a.nb;
+  double ring[RD][8];
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < RD; i++)
+      if (i < nsteps) {
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++) ring[i][cb] = cf[((int64_t)i * 8 + cb) * 64];
+      }
+  }
+  for (int g = 0; g < ngrp; g++) {
+    double* slot = kvx + (g & 1) * (NT * 1024);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      double kv[4] = {0.0, 0.0, 0.0, 0.0};
+      if (4 * g + w < a.nb) compute_kv<HAS_TBL, KIND>(c[t], 4 * g + w, kv);
+#pragma unroll
+      for (int r = 0; r < 4; r++) slot[t * 1024 + (w * 4 + r) * 64 + l] = kv[r];
+    }
+    __syncthreads();  // one barrier per group: the buffer written two groups later is only reached after the next barrier
+    if (live) {
+#pragma unroll
+      for (int blk = 0; blk < 16 / RD; blk++) {
+#pragma unroll
+        for (int i = 0; i < RD; i++) {
+          const int step = 16 * g + blk * RD + i;  // k-step 4 tb + r
+          if ((step >> 2) < a.nb) {  // wave-uniform
+            double kvv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) kvv[t] = slot[t * 1024 + ((blk * RD + i) & 15) * 64 + l];
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+              for (int cb = 0; cb < 8; cb++)
+                acc[t][cb] = SM ? mfma_f64(ring[i][cb], kvv[t], acc[t][cb]) : mfma_f64(kvv[t], ring[i][cb], acc[t][cb]);
+            if (step + RD < nsteps) {
+#pragma unroll
+              for (int cb = 0; cb < 8; cb++) ring[i][cb] = cf[((int64_t)(step + RD) * 8 + cb) * 64];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!live) return;
+  const int64_t col0 = 128 * (group0 + w);
+  if (SM) {  // acc[t][cb][r]: column col0 + 16 cb + q + 4 r of candidate tile0 + 16 t + cnd
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int64_t gi = tile0 + 16 * t + cnd;
+      const double mc = (HAS_TBL && a.taskmean) ? a.taskmean[tc[t]] : a.mean_const;  // (this lane's own row: tc[t] is candidate cnd's task)
+      if (gi < a.N) {
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (col0 + 16 * cb + q + 4 * r < s_total) tmat[gi * str_c + (col0 + 16 * cb + q + 4 * r) * str_s] = a.ybar + a.ysd * (mc + acc[t][cb][r]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t gi = tile0 + 16 * t + q + 4 * r;
+      const int tcm = __shfl(tc[t], q + 4 * r, 64);  // lane m (< 16) holds candidate m's task
+      const double mc = (HAS_TBL && a.taskmean) ? a.taskmean[tcm] : a.mean_const;
+      if (gi < a.N) {
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++)
+          if (col0 + 16 * cb + cnd < s_total) tmat[gi * str_c + (col0 + 16 * cb + cnd) * str_s] = a.ybar + a.ysd * (mc + acc[t][cb][r]);
+      }
+    }
+}
+
 // colfrag <- alpha columns A [np, spad] (row-major)
 __global__ void bbh_pack_colfrag_kernel(const double* __restrict__ A, int64_t spad, int64_t nks, double* __restrict__ out) {
   const int64_t g = blockIdx.z, ks = blockIdx.x, cb = blockIdx.y;
@@ -1232,7 +1392,35 @@ static int bbh_posterior_columns_impl(bbh_handle* h, const double* X_dev, int64_
   const int64_t S = h->ncols, spad = bbh_round_up(S, 128), groups = spad / 128;
   const int64_t nks = h->np / 4;
   const int64_t str_c = sample_major ? 1 : S, str_s = sample_major ? N : 1;
-  for (int64_t g = 0; g < groups; g++) {  // the last group may be partially padding: its columns >= S are not written
+  const char* cc_env = getenv("BBH_COLUMNS_COOP");  // A/B switch: 0 keeps the plain kernel for every column group
+  const bool coop_cols = !(cc_env && cc_env[0] == '0');
+  int64_t g = 0;
+  // super-groups of (up to) four column groups on the cooperative kernel while at least three remain (with fewer, three of its
+  // four waves would only produce kernel values: the plain kernel's four tiles per workgroup are the better use of the CU)
+  const char* nt_env = getenv("BBH_COLUMNS_NT");
+  const int cnt = nt_env ? atoi(nt_env) : 2;
+  for (; coop_cols && groups - g >= 3; g += 4) {
+    auto launch = [&](auto nt, auto sm) {
+      constexpr int NT = decltype(nt)::value;
+      constexpr bool SM = decltype(sm)::value;
+      dim3 cgrid((unsigned)((N + 16 * NT - 1) / (16 * NT)));
+      const size_t clds = sizeof(double) * ((size_t)NT * h->kd * 64 + 2 * NT * 1024);
+      if (has_tbl && m52)
+        hipLaunchKernelGGL((bbh_coop_columns_kernel<true, BBH_KERNEL_MATERN52, NT, SM>), cgrid, block, clds, h->stream, a, h->d_colfrag, g, groups, nks, str_c, str_s, S, tmat_dev);
+      else if (has_tbl)
+        hipLaunchKernelGGL((bbh_coop_columns_kernel<true, -1, NT, SM>), cgrid, block, clds, h->stream, a, h->d_colfrag, g, groups, nks, str_c, str_s, S, tmat_dev);
+      else if (m52)
+        hipLaunchKernelGGL((bbh_coop_columns_kernel<false, BBH_KERNEL_MATERN52, NT, SM>), cgrid, block, clds, h->stream, a, h->d_colfrag, g, groups, nks, str_c, str_s, S, tmat_dev);
+      else
+        hipLaunchKernelGGL((bbh_coop_columns_kernel<false, -1, NT, SM>), cgrid, block, clds, h->stream, a, h->d_colfrag, g, groups, nks, str_c, str_s, S, tmat_dev);
+    };
+    const bool two = !(cnt == 1 || !m52);  // (runtime kernel kinds: two tiles spill)
+    if (two && sample_major) launch(std::integral_constant<int, 2>{}, std::true_type{});
+    else if (two) launch(std::integral_constant<int, 2>{}, std::false_type{});
+    else if (sample_major) launch(std::integral_constant<int, 1>{}, std::true_type{});
+    else launch(std::integral_constant<int, 1>{}, std::false_type{});
+  }
+  for (; g < groups; g++) {  // the last group may be partially padding: its columns >= S are not written
     const double* cf = h->d_colfrag + g * nks * 8 * 64;
     const int64_t col0 = 128 * g;
     if (has_tbl && m52)
