@@ -21,6 +21,7 @@
 #endif
 
 // fatplus(x; tau) / tau = softplus(t) + 0.1 / (1 + t^2),  t = x / tau; torch softplus threshold 20
+template <int NEWTON = 2>
 __device__ __forceinline__ double bbh_fatplus_core(double t) {
   // softplus: t / tau_relu is huge in magnitude for almost every sample, so the log1p(exp) branch is rare.
   // It is entered through a wave-uniform test (ballot): a per-lane branch in unrolled callers is
@@ -36,7 +37,7 @@ __device__ __forceinline__ double bbh_fatplus_core(double t) {
   const double d = fma(t, t, 1.0);
   double y = __builtin_amdgcn_rcp(d);
   y = fma(fma(-d, y, 1.0), y, y);
-  y = fma(fma(-d, y, 1.0), y, y);
+  if (NEWTON > 1) y = fma(fma(-d, y, 1.0), y, y);  // (one step: <= 2^-46 relative - enough where the caller's own terms are single precision)
   y = (d < INFINITY) ? y : 0.0;  // |t| = inf (unbounded cell): the Newton step would produce inf * 0
   return fma(0.1, y, sp);
 }
@@ -1031,7 +1032,49 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_kernel(const NehviArgs a) {
 // issue rate; the slices bring the launch to >= 8 waves per SIMD.  All lanes of a wave work on the same samples, so the
 // cell data stays wave-uniform (scalar loads).  The slices' partial sums are combined in a fixed order by
 // bbh_qlognehvi_finish_kernel (sums of positive terms in the linear domain: no atomics, reproducible).
-template <int M>
+typedef float bbh_f2 __attribute__((ext_vector_type(2)));
+
+// delta = 1 - (1 + u^2)^(-tau_max) <= 0.007 of TWO (cell, target) terms at once, in packed single precision (v_pk_fma_f32 /
+// v_pk_mul_f32): the term is min(A, B) (1 - delta), so a relative error of ~1e-6 in delta is 7e-9 in the term - the same budget
+// the double-precision form below spends on its single-precision logarithms.  rho = min / max, x1 = 1 - rho (taken in double
+// precision, where it is exact next to rho = 1).  rho = 0 (cell unbounded above, or a ratio below the single-precision range):
+// log2 -> -inf, |li - ll| = inf, u = 0, delta = 0.
+__device__ __forceinline__ bbh_f2 bbh_fatmin_delta2(bbh_f2 rho, bbh_f2 x1) {
+  bbh_f2 ds = x1 * (1.0f / 7.0f) + (1.0f / 6.0f);
+  ds = ds * x1 + 0.2f;
+  ds = ds * x1 + 0.25f;
+  ds = ds * x1 + (1.0f / 3.0f);
+  ds = ds * x1 + 0.5f;
+  ds = ds * x1 + 1.0f;
+  ds = ds * x1;  // -log1p(-x1), x1 < 0.15
+  bbh_f2 dl;
+  dl.x = -0.6931471805599453f * __log2f(rho.x);
+  dl.y = -0.6931471805599453f * __log2f(rho.y);
+  bbh_f2 den;
+  den.x = (x1.x < 0.15f ? ds.x : dl.x) + (float)(2.0 * TAU_MAX);
+  den.y = (x1.y < 0.15f ? ds.y : dl.y) + (float)(2.0 * TAU_MAX);
+  bbh_f2 u;
+  u.x = __builtin_amdgcn_rcpf(den.x);
+  u.y = __builtin_amdgcn_rcpf(den.y);
+  u = u * (float)(2.0 * TAU_MAX);
+  const bbh_f2 w = u * u;
+  bbh_f2 lps = w * -0.25f + (1.0f / 3.0f);
+  lps = lps * w - 0.5f;
+  lps = lps * w + 1.0f;
+  lps = lps * w;  // log1p(w), w < 0.03
+  bbh_f2 lp;
+  lp.x = (w.x < 0.03f) ? lps.x : 0.6931471805599453f * __log2f(1.0f + w.x);
+  lp.y = (w.y < 0.03f) ? lps.y : 0.6931471805599453f * __log2f(1.0f + w.y);
+  const bbh_f2 x = lp * (float)TAU_MAX;  // in [0, 0.00694]
+  bbh_f2 d = x * (-1.0f / 24.0f) + (1.0f / 6.0f);
+  d = d * x - 0.5f;
+  d = d * x + 1.0f;
+  return d * x;  // 1 - exp(-x)
+}
+
+// PK: the (1 + u^2)^(-tau_max) factors in packed single precision, two cells at a time (default); PK = false is the double-precision
+// sequence (BBH_NEHVI_PK=0: A/B, tests)
+template <int M, bool PK>
 __global__ __launch_bounds__(256) void bbh_qlognehvi_lin_kernel(const NehviArgs a, const double* __restrict__ cell_len,
                                                                 double* __restrict__ partial) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1059,7 +1102,49 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_lin_kernel(const NehviArgs 
     for (int o = 0; o < M; o++) f[o] = sg[o] * fma(sd[o], a.zx[(int64_t)s * M + o], trow[o][s * tstride]);
     const int64_t c0 = a.cell_off[s], c1 = a.cell_off[s + 1];
     double ssum = 0.0;
-    for (int64_t c = c0; c < c1; c++) {
+    int64_t c = c0;
+    if (PK) {
+      for (; c < c1; c += 2) {
+        const int64_t cb = (c + 1 < c1) ? c + 1 : c;  // odd cell count: the last cell is paired with itself, its twin is not added
+        double pa = 1.0, pb = 1.0;
+#pragma unroll
+        for (int o = 0; o < M; o++) {
+          double mn2[2];
+          bbh_f2 rho, x1, rc;
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int64_t cc = h ? cb : c;
+            const double B = cell_len[cc * M + o];
+            const double A = TAU_RELU * bbh_fatplus_core<1>((f[o] - a.cell_lo[cc * M + o]) * inv_tau);
+            const double mn = fmin(A, B), mxv = fmax(A, B);
+            // rho = min / max and x1 = 1 - rho = (max - min) / max, each with its own relative accuracy (x1 next to rho = 1, where the
+            // term is sensitive; rho next to 0, where delta ~ 1e-8 would vanish in 1 - x1): the difference in double precision,
+            // the quotients in single precision - no double-precision reciprocal
+            const float gap = (float)(mxv - mn), mnf = (float)mn, mxf = (float)mxv;
+            mn2[h] = mn;
+            if (h) {
+              x1.y = gap;
+              rho.y = mnf;
+              rc.y = __builtin_amdgcn_rcpf(mxf);
+            } else {
+              x1.x = gap;
+              rho.x = mnf;
+              rc.x = __builtin_amdgcn_rcpf(mxf);
+            }
+          }
+          x1 = x1 * rc;  // max = inf (cell unbounded above): inf * 0 = NaN -> 1;  rho = min * 0 = 0
+          rho = rho * rc;
+          x1.x = (x1.x == x1.x) ? x1.x : 1.0f;
+          x1.y = (x1.y == x1.y) ? x1.y : 1.0f;
+          const bbh_f2 dl = bbh_fatmin_delta2(rho, x1);
+          pa *= fma(-mn2[0], (double)dl.x, mn2[0]);
+          pb *= fma(-mn2[1], (double)dl.y, mn2[1]);
+        }
+        ssum += pa;
+        if (c + 1 < c1) ssum += pb;
+      }
+    }
+    for (; !PK && c < c1; c++) {
       double prod = 1.0;
 #pragma unroll
       for (int o = 0; o < M; o++) {
@@ -1191,11 +1276,21 @@ static int bbh_qlognehvi_impl(bbh_handle* h, int32_t m, int64_t N, const double*
     rc = bbh_ensure_ws(h, sizeof(double) * (size_t)slices * (size_t)N);
     if (rc) return rc;
     dim3 sgrid(grid.x, (unsigned)slices);
-    switch (m) {
-      case 1: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<1>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-      case 2: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<2>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-      case 3: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<3>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-      default: hipLaunchKernelGGL(bbh_qlognehvi_lin_kernel<4>, sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+    const char* env_pk = getenv("BBH_NEHVI_PK");
+    if (env_pk && env_pk[0] == '0') {
+      switch (m) {
+        case 1: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<1, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 2: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<2, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 3: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<3, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        default: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<4, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      }
+    } else {
+      switch (m) {
+        case 1: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<1, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 2: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<2, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 3: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<3, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        default: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<4, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      }
     }
     hipLaunchKernelGGL(bbh_qlognehvi_finish_kernel, grid, block, 0, h->stream, h->d_ws, (int)slices, N, (int)S, alive_dev, scores_dev);
     BBH_HIP_TRY(h, hipGetLastError());
