@@ -21,7 +21,7 @@ if trace:
     PRE, WARM, STEPS = 8, 3, 20  # bench.py: extra["pre_warm_steps"], --warmup, --steps of scripts/profile_bench.sh
     rows = [r for r in csv.DictReader(open(trace[0])) if "posterior_kernel" in r["Kernel_Name"]]
     if any("qlognehvi" in r["Kernel_Name"] for r in csv.DictReader(open(trace[0]))):  # cfg5: three variance launches per step
-        rows = [r for r in csv.DictReader(open(trace[0])) if "qlognehvi_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(trace[0])) if "qlognehvi_lin_kernel" in r["Kernel_Name"] or "qlognehvi_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     timed = dur[PRE + WARM : PRE + WARM + STEPS]
