@@ -16,6 +16,10 @@
 #ifndef BBH_PENDING_LSE
 #define BBH_PENDING_LSE 0
 #endif
+typedef float bbh_f2 __attribute__((ext_vector_type(2)));
+#ifndef BBH_PENDING_PK
+#define BBH_PENDING_PK 1  // (with BBH_PENDING_FAST) the u_r^2 terms of the fat maximum in packed single precision, two points at a time
+#endif
 #ifndef BBH_PENDING_FAST
 #define BBH_PENDING_FAST 1  // joint q'-batch qLogEI kernels: reduced-precision logarithms where the power tau_max = 0.01 absorbs them
 #endif
@@ -324,6 +328,47 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
       fp[r] = bbh_fatplus_core(tt);
       fmx = fmax(fmx, fp[r]);
     }
+#if BBH_PENDING_PK
+    // The same in packed single precision, two points per instruction: rho_r = fp_r / fmx and x_r = (fmx - fp_r) / fmx as two
+    // single-precision quotients (the difference in double precision: exact next to rho = 1, where u^2 is sensitive) sharing one
+    // v_rcp_f32; series, log2, reciprocal and square on float2 values.  u^2 <= 1 to ~1e-7 relative: 1e-9 in the sample's term.
+    const float rcf = __builtin_amdgcn_rcpf((float)fmx);
+    bbh_f2 accp = {0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < Q; r += 2) {
+      const int r1 = (r + 1 < Q) ? r + 1 : r;
+      bbh_f2 x, rho;
+      x.x = (float)(fmx - fp[r]);
+      x.y = (float)(fmx - fp[r1]);
+      rho.x = (float)fp[r];
+      rho.y = (float)fp[r1];
+      x = x * rcf;
+      rho = rho * rcf;
+      bbh_f2 ds = x * (1.0f / 7.0f) + (1.0f / 6.0f);
+      ds = ds * x + 0.2f;
+      ds = ds * x + 0.25f;
+      ds = ds * x + (1.0f / 3.0f);
+      ds = ds * x + 0.5f;
+      ds = ds * x + 1.0f;
+      ds = ds * x;
+      bbh_f2 den;
+      den.x = ((x.x < 0.15f) ? ds.x : -0.6931471805599453f * __log2f(rho.x)) + (float)(2.0 * TAU_MAX);
+      den.y = ((x.y < 0.15f) ? ds.y : -0.6931471805599453f * __log2f(rho.y)) + (float)(2.0 * TAU_MAX);
+      bbh_f2 u;
+      u.x = __builtin_amdgcn_rcpf(den.x);  // den = inf (rho below the float range) -> 0
+      u.y = (r + 1 < Q) ? __builtin_amdgcn_rcpf(den.y) : 0.0f;  // odd Q: the last point's twin does not count
+      u = u * (float)(2.0 * TAU_MAX);
+      accp = u * u + accp;
+    }
+    const float accf = accp.x + accp.y;
+    const double w = (TAU_MAX * 0.6931471805599453) * (double)__log2f(accf);
+    double e = fma(w, 1.0 / 120.0, 1.0 / 24.0);
+    e = fma(e, w, 1.0 / 6.0);
+    e = fma(e, w, 0.5);
+    e = fma(e, w, 1.0);
+    e = fma(e, w, 1.0);
+    sum = fma(fmx, e, sum);
+#else
     double inv = __builtin_amdgcn_rcp(fmx);
     inv = fma(fma(-fmx, inv, 1.0), inv, inv);
     double acc = 0.0;
@@ -351,6 +396,7 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
     e = fma(e, w, 1.0);
     e = fma(e, w, 1.0);
     sum = fma(fmx, e, sum);
+#endif
   }
 #else
   for (int s = 0; s < S; s++) {
@@ -1032,8 +1078,6 @@ __global__ __launch_bounds__(256) void bbh_qlognehvi_kernel(const NehviArgs a) {
 // issue rate; the slices bring the launch to >= 8 waves per SIMD.  All lanes of a wave work on the same samples, so the
 // cell data stays wave-uniform (scalar loads).  The slices' partial sums are combined in a fixed order by
 // bbh_qlognehvi_finish_kernel (sums of positive terms in the linear domain: no atomics, reproducible).
-typedef float bbh_f2 __attribute__((ext_vector_type(2)));
-
 // delta = 1 - (1 + u^2)^(-tau_max) <= 0.007 of TWO (cell, target) terms at once, in packed single precision (v_pk_fma_f32 /
 // v_pk_mul_f32): the term is min(A, B) (1 - delta), so a relative error of ~1e-6 in delta is 7e-9 in the term - the same budget
 // the double-precision form below spends on its single-precision logarithms.  rho = min / max, x1 = 1 - rho (taken in double

@@ -348,6 +348,9 @@ def run(args):
                 "kernel": "bbh_qlogei_pending_q_kernel<2..%d>" % args.greedy, "bound": "fp64 vector pipe (mfma peak: matrix = vector)",
                 "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                 "flops_per_candidate": flops_p, "flops_formula": "sum over q' = Q of S (Q (Q + 1) + 87 Q + 47) + Q^3 / 3",
+                "note": "operation count of the reference's formulation (exp / log at 20 flops, a division at 8); the kernel reaches the same "
+                        "values (1e-10) with series and partly packed single-precision arithmetic, so this is throughput on the reference's count "
+                        "relative to the fp64 roof - it can exceed 1 and is not a utilisation figure",
                 "launches": p_n, "total_ms": p_ms,
                 "hbm_bytes_per_candidate_algorithmic": sum(8 * (2 + (Q - 1)) + 8 for Q in range(2, args.greedy + 1)),
             }
@@ -419,8 +422,11 @@ def run(args):
             "bound": "mfma",  # the fp64 pipe: matrix and vector fp64 share it and have the same peak (78.6 TFLOP/s)
             "achieved": recs[dom]["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": recs[dom]["frac"],
             "traffic": traffic_of(f"{rows_local}x{d}_n{n}_cfg5"),
-            "kernel": {"variance": kernel_names.get(form, form), "columns": "bbh_fused_columns_kernel", "cells": "bbh_qlognehvi_kernel"}[dom],
+            "kernel": {"variance": kernel_names.get(form, form), "columns": "bbh_coop_columns_kernel", "cells": "bbh_qlognehvi_lin_kernel"}[dom],
             "dominant_part": dom, "parts": recs,
+            "note": "cells: operation count by the maths of qLogNEHVI (exp / log at 20 flops, a division at 8) against the fp64 roof; "
+                    "about a third of the cell kernel's instructions execute as packed single precision (DESIGN.md 4.4), so its fraction "
+                    "is throughput on that count, not a utilisation bound",
             "whole_pass": {"flops_per_candidate": sum(v[0] for v in parts.values()),
                            "frac": rows_local * sum(v[0] for v in parts.values())
                                    / (sum(r["device_ms_per_step"] for r in recs.values()) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
