@@ -82,12 +82,12 @@ __global__ __launch_bounds__(256) void bbh_qlogei_q1_kernel(const double* __rest
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int s = 0;
   for (; s + 3 < S; s += 4) {
-    s0 += bbh_fatplus_core(fma(b, s_z[s], a));
-    s1 += bbh_fatplus_core(fma(b, s_z[s + 1], a));
-    s2 += bbh_fatplus_core(fma(b, s_z[s + 2], a));
-    s3 += bbh_fatplus_core(fma(b, s_z[s + 3], a));
+    s0 += bbh_fatplus_core<1>(fma(b, s_z[s], a));
+    s1 += bbh_fatplus_core<1>(fma(b, s_z[s + 1], a));
+    s2 += bbh_fatplus_core<1>(fma(b, s_z[s + 2], a));
+    s3 += bbh_fatplus_core<1>(fma(b, s_z[s + 3], a));
   }
-  for (; s < S; s++) s0 += bbh_fatplus_core(fma(b, s_z[s], a));
+  for (; s < S; s++) s0 += bbh_fatplus_core<1>(fma(b, s_z[s], a));
   const double sum = (s0 + s1) + (s2 + s3);
   scores[i] = log(TAU_RELU) + log(sum) - log((double)S);
 }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void bbh_qlogei_pending_q_kernel(
 #pragma unroll
       for (int c = 0; c <= r; c++) y = fma(L[r * (r + 1) / 2 + c], zr[c], y);
       const double tt = (sign * y - best_f) * inv_tau;
-      fp[r] = bbh_fatplus_core(tt);
+      fp[r] = bbh_fatplus_core<1>(tt);
       fmx = fmax(fmx, fp[r]);
     }
 #if BBH_PENDING_PK
