@@ -268,7 +268,8 @@ def test_user_product_and_additive_kernels_through_the_surrogate():
     the device like the oracle fits them, posterior statistics and a recommendation off the same model."""
     from _problems import oracle_spec
     from baybe_amd import gp_spec
-    from baybe_amd.kernels import AdditiveKernel, GammaPrior, MaternKernel, ProductKernel, RBFKernel, ScaleKernel, apply_kernel_spec
+    from baybe_amd.kernels import (AdditiveKernel, GammaPrior, LinearKernel, MaternKernel, PeriodicKernel, PolynomialKernel, ProductKernel,
+                                   RBFKernel, ScaleKernel, apply_kernel_spec)
     from baybe_amd.recommenders import HipBotorchRecommender
     from baybe_amd.surrogates import HipGaussianProcessSurrogate
     from oracle import gp_oracle as go
@@ -284,18 +285,36 @@ def test_user_product_and_additive_kernels_through_the_surrogate():
                                             RBFKernel(lengthscale_prior=GammaPrior(3, 1), lengthscale_initial_value=2.0)]),
                              outputscale_prior=GammaPrior(2, 0.15)),
                  AdditiveKernel([ScaleKernel(MaternKernel(nu=1.5, lengthscale_prior=GammaPrior(3, 1)), outputscale_prior=GammaPrior(2, 0.5)),
-                                 ScaleKernel(RBFKernel(lengthscale_prior=GammaPrior(3, 0.5)), outputscale_prior=GammaPrior(2, 0.5))])):
+                                 ScaleKernel(RBFKernel(lengthscale_prior=GammaPrior(3, 0.5)), outputscale_prior=GammaPrior(2, 0.5))]),
+                 # dot-product and periodic kernels (kernels/basic.py:20-46, 73-112, 135-163): alone and as members of a sum
+                 ScaleKernel(LinearKernel(variance_prior=GammaPrior(2, 1)), outputscale_prior=GammaPrior(2, 0.5)),
+                 AdditiveKernel([ScaleKernel(RBFKernel(lengthscale_prior=GammaPrior(3, 1)), outputscale_prior=GammaPrior(2, 0.5)),
+                                 PolynomialKernel(2, offset_prior=GammaPrior(2, 2))]),
+                 AdditiveKernel([ScaleKernel(PeriodicKernel(lengthscale_prior=GammaPrior(3, 2), period_length_prior=GammaPrior(4, 3),
+                                                            period_length_initial_value=1.2), outputscale_prior=GammaPrior(2, 0.5)),
+                                 ScaleKernel(MaternKernel(nu=2.5, lengthscale_prior=GammaPrior(3, 1)), outputscale_prior=GammaPrior(2, 0.5))])):
         sur = HipGaussianProcessSurrogate(kernel=kern)
         sur.fit(space, obj, meas)
         spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3)), kern)
-        assert sur.engine.spec.n_factors == 2 and sur.engine.spec.combine == spec.combine
+        assert sur.engine.spec.n_factors == spec.n_factors and sur.engine.spec.combine == spec.combine
+        assert sur.engine.spec.factor_kinds == spec.factor_kinds
         ospec = oracle_spec(spec)
-        fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
         fi = sur._fit_info
-        # products / sums have ridges (a factor's lengthscale against another's, scales against each other): two L-BFGS-B
-        # runs whose gradients differ in the last bits stop a few 1e-6 apart on them
-        assert np.isclose(fi.fun, fo.fun, rtol=2e-5), (kern, fi.fun, fo.fun)
-        mo, vo = go.GPModel(ospec, fo.params, Xt, y).posterior(space.transform(exp.iloc[:100]).to_numpy(dtype=float))
+        if spec.has_dot_kind or spec.has_periodic:
+            # (whole fits of these kernels against the oracle's own runs: test_gpu_parity.py::test_linear_polynomial_and_periodic_kernels;
+            # here the surrogate's end point is checked through the oracle's objective, and the posterior at that point)
+            from _problems import oracle_params
+
+            op = oracle_params(spec, fi.params)
+            f_at, g_at = go.fit_objective(ospec, go.pack_raw(ospec, op), go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+            assert np.isclose(f_at, fi.fun, rtol=1e-9, atol=1e-11) and np.abs(g_at).max() < 1e-2, (kern, f_at, fi.fun, np.abs(g_at).max())
+        else:
+            fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0])
+            # products / sums have ridges (a factor's lengthscale against another's, scales against each other): two L-BFGS-B
+            # runs whose gradients differ in the last bits stop a few 1e-6 apart on them
+            assert np.isclose(fi.fun, fo.fun, rtol=2e-5), (kern, fi.fun, fo.fun)
+            op = fo.params
+        mo, vo = go.GPModel(ospec, op, Xt, y).posterior(space.transform(exp.iloc[:100]).to_numpy(dtype=float))
         st = sur.posterior_stats(exp.iloc[:100], ("mean", "var"))
         assert np.allclose(st["yield_mean"], mo, rtol=5e-3, atol=5e-3) and np.allclose(st["yield_var"], vo, rtol=5e-2, atol=1e-6)
         got = HipBotorchRecommender(surrogate_model=HipGaussianProcessSurrogate(kernel=kern)).recommend(3, space, obj, meas)
