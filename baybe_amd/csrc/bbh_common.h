@@ -112,6 +112,27 @@ __host__ __device__ __attribute__((noinline)) inline double bbh_kbase(int kind, 
 // composite value from the per-factor squared distances: (prod | sum)_f os_f k_f(r2_f), without the outer scale.
 // (Reference to a fixed-size array and compile-time indices: with a pointer and a run-time loop bound the callers' r2
 // arrays went to scratch memory, and the K* kernel ran at 5 TFLOP/s.)
+// ---- stationary kernels as functions of the scaled squared distance -----------------------
+// g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3
+__device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double alpha) {
+  // dot-product kinds, k = f(s) with s = sum_j x_j x'_j / w_j^2: dk/dw_j = -2 f'(s) x_j x'_j / w_j^3, i.e. g = -2 f'(s) with the
+  // product x_j x'_j in the place of Delta_j^2 (the Linear kernel's ARD variances are v_j = 1 / w_j^2)
+  if (kind == BBH_KERNEL_LINEAR) return -2.0;
+  if (BBH_KIND_IS_POLY(kind)) return -2.0 * (double)(kind - BBH_KERNEL_POLY1 + 1) * bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1);
+  // periodic, k = exp(-2 sum_j sin^2(u_j) / l_j): dk/dl_j = 2 k sin^2(u_j) / l_j^2 - g = 2 k, the slot's term is assembled at the call
+  if (kind == BBH_KERNEL_PERIODIC) return 2.0 * exp(-2.0 * r2);
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  if (kind == BBH_KERNEL_RQ) return exp(-(alpha + 1.0) * log1p(r2 / (2.0 * alpha)));  // (1 + u)^-(alpha + 1), u = r^2 / (2 alpha)
+  if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, true);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (5.0 / 3.0) * (1.0 + BBH_SQRT5 * r) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return 3.0 * exp(-BBH_SQRT3 * r);
+  return r > 0.0 ? exp(-r) / r : 0.0;
+}
+
+// theta layout: [noise, mean, outputscale, ls[dn], B[T*T], (hadamard: noise_t[T], mean_t[T])]
+// hoff = offset of noise_t (mean_t follows at hoff + T), -1 = the scalar slots are in use
+
 __device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta,
                                             const double (&r2)[BBH_MAX_FACTORS]) {
   if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off] : 1.0);
@@ -206,6 +227,8 @@ struct bbh_handle {
   bool fit_overlap = true;        // env BBH_FIT_OVERLAP=0: the inverse of the factor strictly after the factorisation (A/B)
   hipStream_t side_stream = nullptr;  // second stream of the fit (rows of L^-1 next to the trailing updates)
   hipStream_t fit_stream = nullptr;   // stream the captured evaluation graph is replayed on
+  int fit_small = 1;  // env BBH_FIT_SMALL=0: evaluations of small models (np = 64, one task, one kernel, MLL) launch by launch instead of the fused one-workgroup kernel
+  bool fit_small_ready = false;
   bool potrf_tiles = true, tiles_ready = false;  // env BBH_POTRF_TILES=0: per-step launches instead of the one-launch tile-dataflow factorisation (np <= 1024)
   int tile_spin_limit = 1 << 17, tile_spin_limit_set = -1;  // env BBH_TILE_SPIN: polls (~1 us each) before a waiting tile gives up (a whole factorisation takes ~200 us)
   int tiles_per_device = 0;           // workgroups of the tile kernel the device holds at once (occupancy x CUs)
@@ -309,6 +332,7 @@ void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int
 // ---- model (bbh_model.hip) --------------------------------------------------------------
 int bbh_upload_theta(bbh_handle* h, const double* theta_host);
 void bbh_launch_gram(bbh_handle* h, double jitter);
+bool bbh_fit_small_launch(bbh_handle* h, double jitter, const double* theta_dev, double* out_dev, int* info_dev);  // whole objective evaluation of a small model in one workgroup; false: not eligible
 bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h);
 int bbh_hadamard_offset(const bbh_handle* h);
 double bbh_prior_base(const bbh_handle* h);

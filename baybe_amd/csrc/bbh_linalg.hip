@@ -669,6 +669,194 @@ static bool bbh_potrf_tiles(bbh_handle* h) {
   return true;
 }
 
+// =====================================================================================================================
+// One objective evaluation of a SMALL model in one workgroup: np = 64 (n <= 64 training points), one task, one kernel (any kind
+// but the periodic one), marginal log-likelihood.  BayBE campaigns start here (tens of measurements), and launch by launch such an
+// evaluation is ~13 operations of a few microseconds of work each - 0.13 ms, all of it launch latency (profiles/
+// r03_small_space_latency.json: fit 4.5 ms of an 8.5 ms recommend()).  Here: Gram matrix -> Cholesky factor and its inverse
+// (pd_factor_block) -> alpha, K^-1 = X^T X (MFMA) -> value -> the gradient sums over all pairs, everything in LDS, results
+// written in the layout of bbh_fit_enqueue (out[0] value, out[1 + slot] gradient; the Cholesky flag in *info).
+// Same arithmetic as the launch-by-launch kernels (bbh_gram_kernel, bbh_value_kernel, bbh_grad_pair_kernel); the sums are
+// taken in a different (fixed) order, so values agree to rounding, not bitwise.
+// =====================================================================================================================
+#define FS_MAXD 32
+__global__ __launch_bounds__(256) void bbh_fit_small_kernel(const double* __restrict__ xnT, const double* __restrict__ ystd,
+                                                            const double* __restrict__ nmask, const double* __restrict__ theta,
+                                                            int n, int dn, const bbh_kern_spec ks, double jitter, int tl,
+                                                            double* __restrict__ out, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double s_fs[];
+  double(*a)[PD_LD] = (double(*)[PD_LD])s_fs;          // K -> L -> X^T
+  double(*x)[PD_LD] = a + 64;                            // L^-1
+  double(*s)[PD_LD] = x + 64;                            // scratch -> M = K^-1
+  double* xs = (double*)(s + 64);                        // [dn][64] normalised training inputs
+  double* vec = xs + FS_MAXD * 64;                       // r[64] | t[64] | alpha[64] | invls[FS_MAXD] | theta[64] | red[4][FS_MAXD + 8]
+  double* rv = vec;
+  double* tv = vec + 64;
+  double* al = vec + 128;
+  double* invls = vec + 192;
+  double* th = invls + FS_MAXD;
+  double* red = th + 64;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int kind = ks.kind[0];
+  // theta / out / info may live in pinned HOST memory (bbh_fit_enqueue passes the staging buffers themselves: no copies around the
+  // launch): theta is read once, coalesced, into LDS
+  if (t < tl) th[t] = theta[t];
+  for (int e = t; e < dn * 64; e += 256) xs[e] = xnT[e];  // (np = 64: the rows of xnT are 64 long)
+  if (t == 0) *info = 0;
+  __syncthreads();
+  const double noise = th[0], mean = th[1], os = ks.use_os ? th[2] : 1.0;
+  const double kalpha = ks.alpha_off >= 0 ? th[ks.alpha_off] : 1.0;
+  if (t < dn) invls[t] = 1.0 / th[3 + t];
+  __syncthreads();
+  // ---- Gram matrix (identity on the padding), x = 0; every thread keeps the metric and the kernel value of its 16 entries for the
+  //      gradient sums below
+  double r2v[16], kbv[16];
+#pragma unroll
+  for (int k16 = 0; k16 < 16; k16++) {
+    const int e = t + 256 * k16;
+    const int i = e >> 6, j = e & 63;
+    double k;
+    r2v[k16] = 0.0;
+    kbv[k16] = 0.0;
+    if (i >= n || j >= n) {
+      k = (i == j) ? 1.0 : 0.0;
+    } else {
+      double r2 = 0.0;
+      for (int c = 0; c < dn; c++) r2 += bbh_metric_term(kind, xs[c * 64 + i], xs[c * 64 + j], invls[c]);
+      const double kb = bbh_kbase(kind, r2, ks.jb, kalpha);
+      r2v[k16] = r2;
+      kbv[k16] = kb;
+      k = kb * os;
+      if (i == j) k += noise * nmask[i] + jitter;
+    }
+    a[i][j] = k;
+    x[i][j] = 0.0;
+  }
+  __syncthreads();
+  pd_factor_block(a, x, s, 0, info);  // a = L (lower), x = L^-1; ends with a barrier
+  // ---- residual, t = X r, alpha = X^T t, log-determinant
+  if (t < 64) rv[t] = (t < n) ? ystd[t] - mean : 0.0;
+  __syncthreads();
+  const int row = t >> 2, part = t & 3;  // four threads per row / column, partial sums combined by two shuffles
+  {
+    double acc = 0.0;
+    for (int j = part; j <= row; j += 4) acc = fma(x[row][j], rv[j], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) tv[row] = acc;
+  }
+  __syncthreads();
+  double ld = 0.0, ra = 0.0, gmean = 0.0;
+  {
+    double acc = 0.0;
+    for (int j = row + part; j < 64; j += 4) acc = fma(x[j][row], tv[j], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) {
+      al[row] = acc;
+      if (row < n) {
+        ld = log(a[row][row]);
+        ra = rv[row] * acc;
+        gmean = acc;
+      }
+    }
+  }
+  __syncthreads();  // (a is read above for the last time)
+  // ---- a <- X^T, then M = X^T X = a a^T on the MFMA (into s)
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    a[i][j] = x[j][i];
+  }
+  __syncthreads();
+  pd_gemm64<true, false, PD_FULL>(s, a, a, 1.0);
+  __syncthreads();
+  // ---- gradient sums over all ordered pairs (a, b), a, b < n:  G = 0.5 (alpha_a alpha_b - M_ab)
+  double g_noise = 0.0, g_os = 0.0, g_al = 0.0, g_ls[FS_MAXD];
+#pragma unroll
+  for (int c = 0; c < FS_MAXD; c++) g_ls[c] = 0.0;
+  const bool dot = BBH_KIND_IS_DOT(kind);
+#pragma unroll
+  for (int k16 = 0; k16 < 16; k16++) {
+    const int e = t + 256 * k16;
+    const int i = e >> 6, j = e & 63;
+    if (i >= n || j >= n) continue;
+    const double G = 0.5 * (al[i] * al[j] - s[i][j]);
+    const double r2 = r2v[k16], kb = kbv[k16];
+    if (i == j) g_noise += G * nmask[i];
+    g_os += G * kb;
+    const double Gg = G * bbh_gfun(kind, r2, ks.jb, kalpha) * os;
+#pragma unroll
+    for (int c = 0; c < FS_MAXD; c++)
+      if (c < dn) {
+        const double xa = xs[c * 64 + i], xb = xs[c * 64 + j], il = invls[c];
+        g_ls[c] += Gg * (dot ? xa * xb : (xa - xb) * (xa - xb)) * (il * il * il);
+      }
+    if (ks.alpha_off >= 0) {
+      if (kind == BBH_KERNEL_RQ) {
+        const double u = r2 / (2.0 * kalpha);
+        g_al += G * os * kb * (u / (1.0 + u) - log1p(u));
+      } else if (BBH_KIND_IS_POLY(kind)) {
+        const int pw = kind - BBH_KERNEL_POLY1 + 1;
+        g_al += G * os * (double)pw * bbh_powi(r2 + kalpha, pw - 1);
+      }
+    }
+  }
+  // ---- block sums in a fixed order: wave shuffles, then the four waves
+  auto wave_sum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+  };
+  const int RW = FS_MAXD + 8;
+  double v0 = wave_sum(ld), v1 = wave_sum(ra), v2 = wave_sum(gmean), v3 = wave_sum(g_noise), v4 = wave_sum(g_os), v5 = wave_sum(g_al);
+  if (l == 0) {
+    red[w * RW + 0] = v0;
+    red[w * RW + 1] = v1;
+    red[w * RW + 2] = v2;
+    red[w * RW + 3] = v3;
+    red[w * RW + 4] = v4;
+    red[w * RW + 5] = v5;
+  }
+#pragma unroll
+  for (int c = 0; c < FS_MAXD; c++)
+    if (c < dn) {
+      const double v = wave_sum(g_ls[c]);
+      if (l == 0) red[w * RW + 8 + c] = v;
+    }
+  __syncthreads();
+  auto tot = [&](int k) { return (red[k] + red[RW + k]) + (red[2 * RW + k] + red[3 * RW + k]); };
+  for (int slot = t; slot < tl; slot += 256) out[1 + slot] = 0.0;
+  __syncthreads();
+  if (t == 0) {
+    out[0] = -0.5 * tot(1) - tot(0) - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    out[1 + 0] = tot(3);                        // noise
+    out[1 + 1] = tot(2);                        // constant mean
+    out[1 + 2] = ks.use_os ? tot(4) : 0.0;      // outputscale
+    if (ks.alpha_off >= 0) out[1 + ks.alpha_off] = tot(5);
+  }
+  if (t < dn) out[1 + 3 + t] = tot(8 + t);
+}
+
+bool bbh_fit_small_launch(bbh_handle* h, double jitter, const double* theta_dev, double* out_dev, int* info_dev) {
+  if (!h->fit_small || h->np != 64 || h->T != 1 || h->F > 1 || h->hadamard || h->desc.criterion != BBH_CRITERION_MLL ||
+      h->dn > FS_MAXD || h->desc.kernel_kind == BBH_KERNEL_PERIODIC || h->fit_graph_mode ||
+      (h->fit_stream && h->stream == h->fit_stream))
+    return false;
+  static const size_t lds = sizeof(double) * (3 * 64 * PD_LD + FS_MAXD * 64 + 192 + FS_MAXD + 64 + 4 * (FS_MAXD + 8));
+  if (!h->fit_small_ready) {
+    if (hipFuncSetAttribute((const void*)bbh_fit_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      h->fit_small = 0;
+      return false;
+    }
+    h->fit_small_ready = true;
+  }
+  if (bbh_theta_len(h) > 64) return false;
+  hipLaunchKernelGGL(bbh_fit_small_kernel, dim3(1), dim3(256), lds, h->stream, h->d_xnT, h->d_ystd, h->d_nmask, theta_dev, (int)h->n,
+                     h->dn, bbh_kern_spec_of(h), jitter, (int)bbh_theta_len(h), out_dev, info_dev);
+  return true;
+}
+
 void bbh_potrf_trtri(bbh_handle* h) {
   if (bbh_potrf_tiles(h)) return;
   hipStream_t s = h->stream;

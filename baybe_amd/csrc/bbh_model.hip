@@ -14,26 +14,7 @@
 
 #include "bbh_common.h"
 
-// ---- stationary kernels as functions of the scaled squared distance -----------------------
-// g(r) = -(dk/dr)/r, so that dk/dl_j = g(r) * Delta_j^2 / l_j^3
-__device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double alpha) {
-  // dot-product kinds, k = f(s) with s = sum_j x_j x'_j / w_j^2: dk/dw_j = -2 f'(s) x_j x'_j / w_j^3, i.e. g = -2 f'(s) with the
-  // product x_j x'_j in the place of Delta_j^2 (the Linear kernel's ARD variances are v_j = 1 / w_j^2)
-  if (kind == BBH_KERNEL_LINEAR) return -2.0;
-  if (BBH_KIND_IS_POLY(kind)) return -2.0 * (double)(kind - BBH_KERNEL_POLY1 + 1) * bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1);
-  // periodic, k = exp(-2 sum_j sin^2(u_j) / l_j): dk/dl_j = 2 k sin^2(u_j) / l_j^2 - g = 2 k, the slot's term is assembled at the call
-  if (kind == BBH_KERNEL_PERIODIC) return 2.0 * exp(-2.0 * r2);
-  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
-  if (kind == BBH_KERNEL_RQ) return exp(-(alpha + 1.0) * log1p(r2 / (2.0 * alpha)));  // (1 + u)^-(alpha + 1), u = r^2 / (2 alpha)
-  if (kind >= BBH_KERNEL_PIECEWISE0) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, true);
-  const double r = sqrt(r2);
-  if (kind == BBH_KERNEL_MATERN52) return (5.0 / 3.0) * (1.0 + BBH_SQRT5 * r) * exp(-BBH_SQRT5 * r);
-  if (kind == BBH_KERNEL_MATERN32) return 3.0 * exp(-BBH_SQRT3 * r);
-  return r > 0.0 ? exp(-r) / r : 0.0;
-}
-
-// theta layout: [noise, mean, outputscale, ls[dn], B[T*T], (hadamard: noise_t[T], mean_t[T])]
-// hoff = offset of noise_t (mean_t follows at hoff + T), -1 = the scalar slots are in use
+// (bbh_gfun: bbh_common.h)
 #define TH_NOISE 0
 #define TH_MEAN 1
 #define TH_OS 2
@@ -601,6 +582,15 @@ static int bbh_fit_enqueue(bbh_handle* h) {
   hipStream_t s = h->stream;
   const int64_t np = h->np, n = h->n;
   const int64_t tl = bbh_theta_len_of(h);
+  {  // small models: the whole evaluation in one workgroup (bbh_linalg.hip), reading theta from and writing the results to the
+     // pinned staging buffers themselves - one launch, no copies
+    void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
+    if (h->fit_small && h->np == 64 && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
+        hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess && hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess &&
+        bbh_fit_small_launch(h, 0.0, (const double*)th_dev, (double*)out_dev, (int*)info_dev))
+      return 0;
+    (void)hipGetLastError();
+  }
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_theta, h->pin_theta, sizeof(double) * tl, hipMemcpyHostToDevice, s));
   // One host synchronisation per evaluation: the Cholesky flag is fetched with the results at the end (after a failed
   // factorisation the remaining kernels run on NaNs, harmlessly, and the outcome is discarded).

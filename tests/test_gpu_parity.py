@@ -767,6 +767,77 @@ def test_fit_through_the_captured_graph_matches_the_launch_path(monkeypatch):
     assert np.allclose(out["0"][1].params.lengthscale, out["1"][1].params.lengthscale, rtol=1e-4)
 
 
+def test_small_model_evaluation_in_one_workgroup_matches_the_launch_path(monkeypatch):
+    """np = 64 (n <= 64), one task, one kernel, MLL: ``bbh_fit_small_kernel`` does a whole objective evaluation - Gram matrix,
+    factorisation and inverse, alpha, K^-1, value, every gradient slot - in one workgroup (``BBH_FIT_SMALL=0``: launch by launch).
+    Value and gradient at several points for every kernel kind the fused kernel accepts (incl. the alpha slot of RQ / Polynomial,
+    the weights of Linear, pinned slots of a subset), a failed factorisation, the whole fit against the launch path and against the
+    oracle; models it does not accept (two factors, n > 64) are unaffected."""
+    import time
+
+    from _problems import oracle_params
+    from baybe_amd import engine, gp_spec
+    from baybe_amd.kernels import (GammaPrior, LinearKernel, MaternKernel, PiecewisePolynomialKernel, PolynomialKernel, ProductKernel,
+                                   RBFKernel, RQKernel, ScaleKernel, apply_kernel_spec)
+    from oracle import gp_oracle as go
+
+    class Space:
+        comp_rep_columns = tuple(f"x{j}" for j in range(8))
+
+    rng = np.random.default_rng(3)
+    cases = [(None, 3, 20), (None, 8, 64), (ScaleKernel(RBFKernel(GammaPrior(3, 1)), GammaPrior(2, 0.5)), 8, 50),
+             (RQKernel(GammaPrior(3, 1)), 4, 33), (ScaleKernel(LinearKernel(GammaPrior(2, 1))), 4, 40), (PolynomialKernel(2, GammaPrior(2, 2)), 5, 45),
+             (PiecewisePolynomialKernel(2, GammaPrior(3, 1)), 3, 30), (MaternKernel(0.5, GammaPrior(3, 1)), 3, 25),
+             (ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1), parameter_names=["x0", "x2", "x3"])), 5, 37)]
+    for kern, d, n in cases:
+        X, Xt, y = make_problem(500, d, n, seed=100 + n)
+        spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+        if kern is not None:
+            apply_kernel_spec(spec, kern, Space())
+        bounds = gp_spec.raw_bounds(spec)
+        free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+        raw0 = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+        points = []
+        for _ in range(3):
+            raw = np.where(free, raw0 + 0.3 * rng.standard_normal(raw0.shape), raw0)
+            raw[0] = abs(raw[0]) + 0.01
+            points.append(gp_spec.unpack_raw(spec, raw))
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("BBH_FIT_SMALL", mode)
+            g = engine.HipGP(0)
+            g.set_model(spec, Xt, y)
+            evals = [g.data_term(p) for p in points]
+            t0 = time.perf_counter()
+            fi = g.fit()
+            out[mode] = (evals, fi, (time.perf_counter() - t0) * 1e3)
+            m_, v_ = g.posterior(X)  # the posterior path is untouched by the switch
+            out[mode] += (m_.cpu().numpy(), v_.cpu().numpy())
+            g.close()
+        for (v0, g0), (v1, g1) in zip(out["0"][0], out["1"][0]):
+            assert math.isclose(v0, v1, rel_tol=1e-11, abs_tol=1e-11), (kern, v0, v1)
+            assert np.allclose(g0, g1, rtol=1e-8, atol=1e-10 * np.abs(g0).max()), (kern, g0, g1)
+        f0, f1 = out["0"][1], out["1"][1]
+        assert abs(f0.fun - f1.fun) <= 2e-6 * max(1.0, abs(f0.fun)), (kern, f0.fun, f1.fun)
+        ospec = _ospec(spec)
+        Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+        f_at, _ = go.fit_objective(ospec, go.pack_raw(ospec, oracle_params(spec, f1.params)), Xn, ys)
+        assert math.isclose(f_at, f1.fun, rel_tol=1e-9, abs_tol=1e-11), (kern, f_at, f1.fun)
+        print(f"   {type(kern).__name__ if kern is not None else 'BAYBE preset'} d={d} n={n}: fit launch by launch {out['0'][2]:.2f} ms ({f0.nfev} evaluations), "
+              f"one workgroup {out['1'][2]:.2f} ms ({f1.nfev})")
+    # not positive definite: the flag comes back through the same channel (zero noise, duplicated rows)
+    monkeypatch.setenv("BBH_FIT_SMALL", "1")
+    X, Xt, y = make_problem(300, 3, 20, seed=5)
+    Xt[1] = Xt[0]
+    spec = gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
+    g = engine.HipGP(0)
+    g.set_model(spec, Xt, y)
+    assert g.data_term(gp_spec.GPParams(np.full(3, 1.0), 0.0, 0.0)) == (None, None)
+    fi = g.fit()  # the fit itself survives (the objective reports +inf there)
+    assert np.isfinite(fi.fun)
+    g.close()
+
+
 @pytest.mark.parametrize("which", ["single", "product", "sum_icm"])
 def test_kernels_on_parameter_subsets(gp, which):
     """``BasicKernel.parameter_names`` (baybe/kernels/base.py:198-240; gpytorch ``active_dims``): kernels acting on a subset of the
