@@ -2,7 +2,7 @@
 other people, importable here, unlike gpytorch / botorch) evaluates the same stationary ARD kernels, the same log marginal
 likelihood with its gradient, and the same exact-Cholesky posterior.  The oracle (``oracle/gp_oracle.py``) must agree with
 it to rounding on all three - kernel formulas (Matern-1/2, -3/2, -5/2, RBF, rational quadratic, products and sums with
-scales), likelihood value and gradient, posterior mean / variance / joint covariance.
+scales; linear, polynomial and periodic kernels), likelihood value and gradient, posterior mean / variance / joint covariance.
 
 What this does NOT pin: everything BoTorch-specific (priors and their constants, constraint transforms, the LOO criterion,
 fat-tailed qLogEI / qLogNEHVI, Sobol base samples, greedy semantics, the index kernel) - those parts of the oracle remain
@@ -122,6 +122,103 @@ def test_rational_quadratic_products_and_sums_against_scikit_learn():
                 assert np.allclose(val, dt.g_noise * 0.04, rtol=1e-7)
             else:
                 raise AssertionError(f"unexpected scikit-learn hyper-parameter {key}")
+
+
+def _autograd_lml_and_log_gradient(spec, p, Xn, ystd):
+    """Log marginal likelihood and its gradient w.r.t. the LOG of every positive hyper-parameter from the oracle's autograd
+    objective (oracle/fit_objective.py; priors must be absent): the quantities scikit-learn reports.  Keyed by the oracle's
+    parameter names."""
+    import torch
+
+    from oracle import fit_objective as fo
+
+    raw = go.pack_raw(spec, p)
+    f, g = go.fit_objective(spec, raw, Xn, ystd)
+    n = len(ystd)
+    out, i = {}, 0
+    nat = fo.split_raw(spec, torch.as_tensor(raw))
+    for prm in fo.parameter_layout(spec):
+        sl = slice(i, i + prm.size)
+        i += prm.size
+        grad_raw = -n * g[sl]  # the objective is -(log-likelihood) / n
+        val = nat[prm.key].detach().numpy().reshape(-1)
+        if prm.lower is None:  # the mean constant
+            out[prm.key] = grad_raw
+        else:  # value = lower + softplus(raw): d/dlog(value) = d/draw * value / sigmoid(raw)
+            sig = 1.0 / (1.0 + np.exp(-raw[sl]))
+            out[prm.key] = grad_raw / sig * val if prm.transformed else grad_raw * val
+    return -n * f, out
+
+
+def test_linear_polynomial_and_periodic_kernels_against_scikit_learn():
+    """The oracle's restatements of gpytorch's LinearKernel / PolynomialKernel / PeriodicKernel (baybe/kernels/basic.py:20-46,
+    135-163, 73-112) against scikit-learn's DotProduct, DotProduct ** p and ExpSineSquared: kernel matrices, log marginal
+    likelihood, its gradient (the oracle's is autograd), posterior.  Correspondences: Linear with equal variances v = ConstantKernel(v)
+    * DotProduct(sigma_0 -> 0); Polynomial(p) with offset c = DotProduct(sigma_0 = sqrt(c)) ** p; Periodic in one dimension with
+    gpytorch's lengthscale l (it divides by l, not l^2) = ExpSineSquared(length_scale = sqrt(l), periodicity)."""
+    from sklearn.gaussian_process.kernels import DotProduct, ExpSineSquared, Exponentiation
+
+    d = 3
+    Xt, X, y = _problem(n=30, N=50, d=d, seed=11)
+    ystd, ybar, ysd = go.standardize_targets(y)
+    noise, mean = 0.06, 0.1
+
+    def spec_of(kernel, dd=d, **kw):
+        return go.GPSpec(d=dd, num_idx=np.arange(dd), lo=np.zeros(dd), hi=np.ones(dd), kernel=kernel, lengthscale=go.Hyper(0.0, True, None, 0.5),
+                         noise=go.Hyper(1e-4, True, None, 0.05), outputscale=go.Hyper(0.0, True, None, 1.0), **kw)
+
+    # ---- linear: k = v x . x'
+    v = 0.8
+    spec = spec_of("linear")
+    p = go.GPParams(lengthscale=np.full(d, v), noise=noise, mean=mean)
+    k_sk = ConstantKernel(v) * DotProduct(sigma_0=1e-7, sigma_0_bounds="fixed")
+    assert np.allclose(go.cross_cov(spec, p, X, Xt), k_sk(X, Xt), rtol=1e-10, atol=1e-12)
+    full = k_sk + WhiteKernel(noise)
+    gpr = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xt, ystd - mean)
+    lml, grad_log = gpr.log_marginal_likelihood(full.theta, eval_gradient=True)
+    ours, g = _autograd_lml_and_log_gradient(spec, p, Xt, ystd)
+    assert math.isclose(ours, lml, rel_tol=1e-9)
+    # sklearn theta: [log v, log noise]; the ARD variances of the oracle add up to the single variance here
+    assert np.allclose([g["variance"].sum(), g["noise"].sum()], grad_log, rtol=1e-6, atol=1e-8 * np.abs(grad_log).max())
+    mu, var = go.GPModel(spec, p, Xt, y).posterior(X)
+    m_sk, s_sk = gpr.predict(X, return_std=True)
+    assert np.allclose(mu, ybar + ysd * (mean + m_sk), rtol=1e-8, atol=1e-10) and np.allclose(var, ysd**2 * (s_sk**2 - noise), rtol=1e-5, atol=1e-9)
+    assert np.ptp(go.prior_var(spec, p, X)) > 0 and np.allclose(go.prior_var(spec, p, X), v * (X * X).sum(1), rtol=1e-12)
+
+    # ---- polynomial: k = os (x . x' + c)^p
+    for power in (1, 2, 3):
+        c, os_ = 0.7, 1.4
+        spec = spec_of(f"poly{power}", use_outputscale=True)
+        p = go.GPParams(lengthscale=np.ones(d), noise=noise, mean=mean, outputscale=os_, rq_alpha=np.array([c]))
+        k_sk = ConstantKernel(os_) * Exponentiation(DotProduct(sigma_0=math.sqrt(c)), power)
+        assert np.allclose(go.cross_cov(spec, p, X, Xt), k_sk(X, Xt), rtol=1e-12, atol=1e-14)
+        full = k_sk + WhiteKernel(noise)
+        gpr = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xt, ystd - mean)
+        lml, grad_log = gpr.log_marginal_likelihood(full.theta, eval_gradient=True)
+        ours, g = _autograd_lml_and_log_gradient(spec, p, Xt, ystd)
+        assert math.isclose(ours, lml, rel_tol=1e-9)
+        # sklearn theta: [log os, log sigma_0, log noise]; c = sigma_0^2: d/dlog(sigma_0) = 2 d/dlog(c)
+        assert np.allclose([g["outputscale"].sum(), 2.0 * g["offset"].sum(), g["noise"].sum()], grad_log, rtol=1e-6,
+                           atol=1e-8 * np.abs(grad_log).max()), (power, g, grad_log)
+
+    # ---- periodic, one input dimension: k = os exp(-2 sin^2(pi |x - x'| / period) / l)
+    Xt1, X1 = Xt[:, :1], X[:, :1]
+    l, per, os_ = 0.6, 0.45, 1.2
+    spec = spec_of("periodic", dd=1, use_outputscale=True)
+    p = go.GPParams(lengthscale=np.array([l]), noise=noise, mean=mean, outputscale=os_, period=[np.array([per])])
+    k_sk = ConstantKernel(os_) * ExpSineSquared(length_scale=math.sqrt(l), periodicity=per)
+    assert np.allclose(go.cross_cov(spec, p, X1, Xt1), k_sk(X1, Xt1), rtol=1e-12, atol=1e-14)
+    full = k_sk + WhiteKernel(noise)
+    gpr = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xt1, ystd - mean)
+    lml, grad_log = gpr.log_marginal_likelihood(full.theta, eval_gradient=True)
+    ours, g = _autograd_lml_and_log_gradient(spec, p, Xt1, ystd)
+    assert math.isclose(ours, lml, rel_tol=1e-9)
+    # sklearn theta: [log os, log length_scale, log periodicity, log noise]; l = length_scale^2: d/dlog(length_scale) = 2 d/dlog(l)
+    assert np.allclose([g["outputscale"].sum(), 2.0 * g["lengthscale"].sum(), g["period_length"].sum(), g["noise"].sum()], grad_log,
+                       rtol=1e-6, atol=1e-8 * np.abs(grad_log).max()), (g, grad_log)
+    mu, var = go.GPModel(spec, p, Xt1, y).posterior(X1)
+    m_sk, s_sk = gpr.predict(X1, return_std=True)
+    assert np.allclose(mu, ybar + ysd * (mean + m_sk), rtol=1e-8, atol=1e-10) and np.allclose(var, ysd**2 * (s_sk**2 - noise), rtol=1e-5, atol=1e-9)
 
 
 def test_leave_one_out_criterion_against_brute_force_refits_with_scikit_learn():
