@@ -419,6 +419,14 @@ def sample_params_from_priors(spec: GPSpec, rng: np.random.Generator | None = No
             return rng.gamma(prior[1], 1.0 / prior[2], size=size)
         if prior[0] == "lognormal":
             return np.exp(prior[1] + prior[2] * rng.standard_normal(size))
+        if prior[0] == "halfcauchy":
+            return np.abs(prior[1] * np.tan(math.pi * (rng.random(size) - 0.5)))
+        if prior[0] == "normal":
+            return prior[1] + prior[2] * rng.standard_normal(size)
+        if prior[0] == "halfnormal":
+            return np.abs(prior[1] * rng.standard_normal(size))
+        if prior[0] == "smoothedbox":  # (restart points only: the box itself, without the thin tails)
+            return prior[1] + (prior[2] - prior[1]) * rng.random(size)
         raise ValueError(prior[0])
 
     p = initial_params(spec)
@@ -594,6 +602,27 @@ def _prior_logp_and_grad(prior, x):
         lx = np.log(x)
         lp = -lx - math.log(sd) - 0.5 * math.log(2 * math.pi) - 0.5 * ((lx - mu) / sd) ** 2
         return float(lp.sum()), (-1.0 - (lx - mu) / sd**2) / x
+    # the other priors of baybe/priors/basic.py (the reference iterates all of them over its kernels, tests/test_iterations.py:262-285);
+    # gpytorch's classes are torch.distributions' HalfCauchy / Normal / HalfNormal and its own SmoothedBoxPrior
+    if kind == "halfcauchy":  # 2 / (pi s (1 + (x / s)^2)), x >= 0
+        _, sc = prior
+        lp = math.log(2.0 / math.pi) - math.log(sc) - np.log1p((x / sc) ** 2)
+        return float(lp.sum()), -2.0 * x / (sc * sc + x * x)
+    if kind == "normal":
+        _, mu, sd = prior
+        z = (x - mu) / sd
+        lp = -0.5 * z * z - math.log(sd) - 0.5 * math.log(2 * math.pi)
+        return float(lp.sum()), -z / sd
+    if kind == "halfnormal":  # sqrt(2 / pi) / s exp(-x^2 / (2 s^2)), x >= 0
+        _, sc = prior
+        lp = 0.5 * math.log(2.0 / math.pi) - math.log(sc) - 0.5 * (x / sc) ** 2
+        return float(lp.sum()), -x / (sc * sc)
+    if kind == "smoothedbox":  # gpytorch SmoothedBoxPrior(a, b, sigma): N(0, sigma) tails outside [a, b], normalised by 1 + (b - a) / (sqrt(2 pi) sigma)
+        _, lo, hi, sg = prior
+        c, r = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        over = np.maximum(np.abs(x - c) - r, 0.0)
+        lp = -0.5 * (over / sg) ** 2 - math.log(sg) - 0.5 * math.log(2 * math.pi) - math.log1p((hi - lo) / (math.sqrt(2 * math.pi) * sg))
+        return float(lp.sum()), -over / (sg * sg) * np.sign(x - c)
     raise ValueError(f"unknown prior kind {kind!r}")
 
 
@@ -795,7 +824,8 @@ class FastObjective:
         if prior[0] == "lognormal":
             _, mu, sd = prior
             return ("lognormal", mu, sd, -math.log(sd) - 0.5 * math.log(2 * math.pi))
-        raise ValueError(f"unknown prior kind {prior[0]!r}")
+        _prior_logp_and_grad(prior, np.ones(1))  # (raises for an unknown family)
+        return ("general", prior, None, None)  # the rarer families go through the general function
 
     def theta(self, raw: np.ndarray):
         """(theta for the device, natural values per raw slot)."""
@@ -815,6 +845,10 @@ class FastObjective:
             if kind == "gamma":  # a = c - 1, b = rate
                 total += float((const + a * np.log(x) - b * x).sum())
                 g[sl] += a / x - b
+            elif kind == "general":
+                lp, glp = _prior_logp_and_grad(a, x)
+                total += lp
+                g[sl] += glp
             else:  # lognormal: a = mu, b = sd
                 lx = np.log(x)
                 z = (lx - a) / b

@@ -1,6 +1,6 @@
 """Declarative kernel / prior specifications accepted by ``HipGaussianProcessSurrogate``
 (mirror of ``baybe/kernels/basic.py:48-70,166-180``, ``baybe/kernels/composite.py:21-57`` and
-``baybe/priors/basic.py:17-65`` for the part of the kernel algebra the hot path evaluates on the
+``baybe/priors/basic.py:17-92`` for the part of the kernel algebra the hot path evaluates on the
 device: Matérn(0.5|1.5|2.5) / RBF / RQ / PiecewisePolynomial(q) / Periodic / Linear / Polynomial(power 1..4) base kernels with ARD over all
 numerical columns (or the columns of ``parameter_names``), optionally
 wrapped in a ScaleKernel, and ``ProductKernel`` / ``AdditiveKernel`` (``baybe/kernels/composite.py:60-91``) of two to
@@ -31,6 +31,36 @@ class GammaPrior:
 class LogNormalPrior:
     loc: float = field(converter=float)
     scale: float = field(converter=float, validator=gt(0.0))
+
+
+@define(frozen=True)
+class HalfCauchyPrior:
+    scale: float = field(converter=float, validator=gt(0.0))
+
+
+@define(frozen=True)
+class NormalPrior:
+    loc: float = field(converter=float)
+    scale: float = field(converter=float, validator=gt(0.0))
+
+
+@define(frozen=True)
+class HalfNormalPrior:
+    scale: float = field(converter=float, validator=gt(0.0))
+
+
+@define(frozen=True)
+class SmoothedBoxPrior:
+    """``baybe.priors.basic.SmoothedBoxPrior`` (basic.py:66-92): uniform on [a, b] with Gaussian tails of width sigma."""
+
+    a: float = field(converter=float)
+    b: float = field(converter=float)
+    sigma: float = field(default=0.01, converter=float, validator=gt(0.0))
+
+    @b.validator
+    def _check_order(self, _, value):
+        if value <= self.a:
+            raise ValueError("'b' must be larger than 'a'")
 
 
 def _names(v):
@@ -137,7 +167,16 @@ def _prior_tuple(prior):
         return ("gamma", float(prior.concentration), float(prior.rate))
     if name == "LogNormalPrior":
         return ("lognormal", float(prior.loc), float(prior.scale))
-    raise IncompatibilityError(f"Prior '{name}' is not available on the HIP path (Gamma / LogNormal are).")
+    if name == "HalfCauchyPrior":
+        return ("halfcauchy", float(prior.scale))
+    if name == "NormalPrior":
+        return ("normal", float(prior.loc), float(prior.scale))
+    if name == "HalfNormalPrior":
+        return ("halfnormal", float(prior.scale))
+    if name == "SmoothedBoxPrior":
+        return ("smoothedbox", float(prior.a), float(prior.b), float(prior.sigma))
+    raise IncompatibilityError(f"Prior '{name}' is not available on the HIP path (Gamma / LogNormal / HalfCauchy / Normal / HalfNormal / "
+                               f"SmoothedBox are).")
 
 
 def _basic_kind(kernel) -> str | None:

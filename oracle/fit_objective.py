@@ -38,7 +38,7 @@ from dataclasses import dataclass
 
 import numpy as np
 import torch
-from torch.distributions import Beta, Gamma, LogNormal, MultivariateNormal, Normal
+from torch.distributions import Beta, Gamma, HalfCauchy, HalfNormal, LogNormal, MultivariateNormal, Normal
 from torch.nn import functional as F
 
 F64 = torch.float64
@@ -69,12 +69,34 @@ class RawParameter:
 def _prior(desc):
     if desc is None:
         return None
+    family = desc[0]
+    if family == "halfcauchy":  # gpytorch HalfCauchyPrior = torch.distributions.HalfCauchy
+        return HalfCauchy(torch.tensor(desc[1], dtype=F64))
+    if family == "halfnormal":  # HalfNormalPrior = torch.distributions.HalfNormal
+        return HalfNormal(torch.tensor(desc[1], dtype=F64))
+    if family == "normal":  # NormalPrior = torch.distributions.Normal
+        return Normal(torch.tensor(desc[1], dtype=F64), torch.tensor(desc[2], dtype=F64))
+    if family == "smoothedbox":
+        return _SmoothedBox(*desc[1:])
     family, a, b = desc
     if family == "gamma":
         return Gamma(torch.tensor(a, dtype=F64), torch.tensor(b, dtype=F64))  # GammaPrior(concentration, rate)
     if family == "lognormal":
         return LogNormal(torch.tensor(a, dtype=F64), torch.tensor(b, dtype=F64))  # LogNormalPrior(loc, scale)
     raise ValueError(f"no torch distribution for prior family {family!r}")
+
+
+class _SmoothedBox:
+    """gpytorch ``SmoothedBoxPrior(a, b, sigma)`` [UPSTREAM, smoothed_box_prior.py]: ``tails = NormalPrior(0, sigma)``,
+    ``log_prob(x) = tails.log_prob(clamp(|x - (a + b) / 2| - (b - a) / 2, min = 0)) - log(1 + (b - a) / (sqrt(2 pi) sigma))``."""
+
+    def __init__(self, a, b, sigma):
+        self.c, self.r = 0.5 * (a + b), 0.5 * (b - a)
+        self.tails = Normal(torch.tensor(0.0, dtype=F64), torch.tensor(sigma, dtype=F64))
+        self.M = math.log(1.0 + (b - a) / (math.sqrt(2.0 * math.pi) * sigma))
+
+    def log_prob(self, x):
+        return self.tails.log_prob(torch.clamp(torch.abs(x - self.c) - self.r, min=0.0)) - self.M
 
 
 def parameter_layout(spec) -> list[RawParameter]:

@@ -634,3 +634,48 @@ def test_linear_polynomial_and_periodic_kernels_against_the_autograd_oracle():
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), PolynomialKernel(5))
     with pytest.raises(IncompatibilityError):
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), PolynomialKernel(0))
+
+
+@pytest.mark.parametrize("family", ["gamma", "halfcauchy", "halfnormal", "lognormal", "normal", "smoothedbox"])
+def test_every_prior_family_of_the_reference_on_every_kind_of_slot(family):
+    """baybe/priors/basic.py:17-92 - the reference iterates GammaPrior(3, 1), HalfCauchyPrior(0.5), HalfNormalPrior(0.5),
+    LogNormalPrior(1, 2), NormalPrior(1, 2), SmoothedBoxPrior(0, 3, 0.1) over its kernels and wraps them in
+    ``ScaleKernel(outputscale_prior=HalfCauchyPrior(1))`` (tests/test_iterations.py:262-285).  Priors are host arithmetic here
+    (``gp_spec._prior_logp_and_grad``: log-density and derivative by hand); the oracle takes them from ``torch.distributions`` with
+    autograd (gpytorch's HalfCauchyPrior / NormalPrior / HalfNormalPrior are those classes; SmoothedBoxPrior restated from its
+    source).  Lengthscales, outputscales, Linear variances, Polynomial offsets and period lengths each carry the prior once."""
+    from baybe_amd import kernels as K
+
+    prior = {"gamma": K.GammaPrior(3, 1), "halfcauchy": K.HalfCauchyPrior(0.5), "halfnormal": K.HalfNormalPrior(0.5),
+             "lognormal": K.LogNormalPrior(1, 2), "normal": K.NormalPrior(1, 2), "smoothedbox": K.SmoothedBoxPrior(0, 3, 0.1)}[family]
+    d, n = 3, 20
+    rng = np.random.default_rng(8)
+    X, Xt, y = make_problem(80, d, n, seed=6)
+    kernels = (K.ScaleKernel(K.MaternKernel(2.5, prior), K.HalfCauchyPrior(1.0)), K.ScaleKernel(K.RBFKernel(K.GammaPrior(3, 1)), prior),
+               K.ScaleKernel(K.LinearKernel(prior), K.HalfCauchyPrior(1.0)), K.ScaleKernel(K.PolynomialKernel(2, prior), K.HalfCauchyPrior(1.0)),
+               K.ScaleKernel(K.PeriodicKernel(prior, None, prior), K.HalfCauchyPrior(1.0)), K.RQKernel(prior))
+    for kern in kernels:
+        spec = K.apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern)
+        ospec = _ospec(spec)
+        bounds = gp_spec.raw_bounds(spec)
+        free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+        raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+        for trial in range(3):  # (trial 2 pushes the prior's argument beyond 3: the Gaussian tail of the smoothed box)
+            raw_t = np.where(free, raw + (0.4 if trial < 2 else 2.5) * np.abs(rng.standard_normal(raw.shape)) * (1 if trial else -1), raw)
+            raw_t[0] = abs(raw_t[0]) + 0.05
+            q = gp_spec.unpack_raw(spec, raw_t)
+            theta = gp_spec.theta_from_params(spec, q)
+            Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+            val, grad_theta = _theta_layout_mll(spec, theta, Xn, ys)
+            f1, g1 = gp_spec.objective_from_data_term(spec, raw_t, n, val, grad_theta)
+            f0, g0 = go.fit_objective(ospec, raw_t[free], Xn, ys)
+            assert math.isclose(f0, f1, rel_tol=1e-10), (family, kern, f0, f1)
+            assert np.allclose(g0, g1[free], rtol=1e-7, atol=1e-10 * np.abs(g0).max()), (family, kern, g0, g1[free])
+            if gp_spec.FastObjective.applies(spec):  # single stationary kernels: the vectorised assembly takes the same priors
+                fast = gp_spec.FastObjective(spec, n)
+                th_f, nat = fast.theta(raw_t)
+                assert np.allclose(th_f, theta, rtol=1e-14)
+                f2, g2 = fast.objective(raw_t, nat, val, grad_theta.copy())
+                assert math.isclose(f2, f1, rel_tol=1e-12) and np.allclose(g2, g1, rtol=1e-10, atol=1e-14)
+        ps = gp_spec.sample_params_from_priors(spec, np.random.default_rng(2))  # restart points exist for every family
+        assert np.all(np.isfinite(gp_spec.pack_raw(spec, ps)))
