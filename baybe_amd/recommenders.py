@@ -22,7 +22,7 @@ import attrs
 import numpy as np
 import pandas as pd
 from attrs import field
-from attrs.validators import ge, instance_of
+from attrs.validators import ge, gt, instance_of
 
 from baybe_amd import _lib
 from baybe_amd.acquisition import convert_acqf, qLogExpectedImprovement, qLogNoisyExpectedHypervolumeImprovement
@@ -481,6 +481,21 @@ class HipRecommenderImpl:
         return self._joint_value(comp)
 
 
+def _convert_hybrid_sampler(value):
+    """``DiscreteSamplingMethod`` (utils/sampling_algorithms.py:175-182) by value or member; None = no sampling."""
+    if value is None:
+        return None
+    name = str(getattr(value, "value", value))
+    if name not in ("Random", "FPS"):
+        raise ValueError(f"'{value}' is not a valid DiscreteSamplingMethod (Random, FPS)")
+    return value
+
+
+def _validate_percentage(_, attribute, value):
+    if not 0 <= value <= 1:  # botorch/core.py:123-135
+        raise ValueError(f"Hybrid sampling percentage needs to be between 0 and 1 but is {value}")
+
+
 def recommender_fields(with_base_fields: bool = True, surrogate_factory=HipGaussianProcessSurrogate) -> dict:
     """attrs fields of the recommender.  ``with_base_fields=False`` leaves out what BayBE's ``BayesianRecommender``
     declares itself (``acquisition_function``, ``_objective``; pure/bayesian/base.py:46-66); ``_surrogate_model`` is
@@ -488,6 +503,14 @@ def recommender_fields(with_base_fields: bool = True, surrogate_factory=HipGauss
     f = {
         "_surrogate_model": field(alias="surrogate_model", factory=surrogate_factory),
         "max_n_subsets": field(default=10, validator=[instance_of(int), ge(1)], kw_only=True),  # botorch/core.py:93-98
+        # The reference's options for continuous / hybrid optimisation (botorch/core.py:69-91), accepted with its defaults and
+        # validators so that constructor calls carry over; none of them affects purely discrete optimisation (the reference says so
+        # for n_restarts / n_raw_samples), which is the only kind of search space this recommender takes.
+        "sequential_continuous": field(default=True, validator=instance_of(bool), kw_only=True),
+        "hybrid_sampler": field(default=None, converter=_convert_hybrid_sampler, kw_only=True),
+        "sampling_percentage": field(default=1.0, validator=_validate_percentage, kw_only=True),
+        "n_restarts": field(default=10, validator=[instance_of(int), gt(0)], kw_only=True),
+        "n_raw_samples": field(default=64, validator=[instance_of(int), gt(0)], kw_only=True),
         # optional baybe_amd.distributed.RowShard: this process scores only its row range and joins one all-gather
         # per selection step (multi-GPU)
         "shard": field(default=None, eq=False, repr=False, kw_only=True),

@@ -46,6 +46,16 @@ def test_subclasses_construct_like_baybes_test_loops_do(classes):
     assert isinstance(r._surrogate_model, Sur) and r.acquisition_function is None and r._objective is None
     assert Rec.compatibility == "DISCRETE" and Rec.supports_discrete_subset_generating_constraints is True
     assert Rec(surrogate_model=Sur(preset="CHEN"), acquisition_function="qUCB", max_n_subsets=3).max_n_subsets == 3
+    # the reference's options for continuous / hybrid optimisation are accepted with its defaults and validators (botorch/core.py:69-135):
+    # constructor calls carry over, purely discrete optimisation ignores them as the reference does
+    assert (r.sequential_continuous, r.hybrid_sampler, r.sampling_percentage, r.n_restarts, r.n_raw_samples) == (True, None, 1.0, 10, 64)
+    assert Rec(hybrid_sampler="FPS", sampling_percentage=0.3, n_restarts=3, n_raw_samples=16, sequential_continuous=False).hybrid_sampler == "FPS"
+    with pytest.raises(ValueError, match="between 0 and 1"):
+        Rec(sampling_percentage=1.5)
+    with pytest.raises(ValueError):
+        Rec(hybrid_sampler="Farthest")
+    with pytest.raises(ValueError):
+        Rec(n_restarts=0)
     with pytest.raises(RuntimeError, match="deprecated"):
         Rec(allow_repeated_recommendations=True)  # the base's __attrs_post_init__ still runs
     with pytest.raises(TypeError):
