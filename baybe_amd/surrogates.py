@@ -141,27 +141,31 @@ class HipGPSurrogateImpl:
         bounds = np.asarray(searchspace.scaling_bounds.to_numpy(), dtype=np.float64)
         task_idx = getattr(searchspace, "task_idx", None)
         n_tasks = int(getattr(searchspace, "n_tasks", 1))
+        kernel = resolve_kernel_argument(self.kernel, self.kernel_or_factory, searchspace, train_x, train_y)
         if self.preset != "BAYBE":
             from baybe_amd.gp_spec import from_preset
 
-            if not isinstance(self.kernel, str) or self.kernel != "matern52" or self.use_outputscale:
+            if not isinstance(kernel, str) or kernel != "matern52" or self.use_outputscale:
                 raise ValueError("a preset fixes the kernel; pass either preset=... or kernel=...")
             spec = from_preset(self.preset, train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
                                edbo_encodings=_has_edbo_encoding(searchspace))
-        elif self.kernel == "matern52" and not self.use_outputscale and _has_substance_parameter(searchspace):
+        elif isinstance(kernel, str) and kernel == "matern52" and not self.use_outputscale and _has_substance_parameter(searchspace):
             # BayBE{Kernel,Mean,Likelihood}Factory delegate to the Chen components for chemical search spaces
             from baybe_amd.gp_spec import from_preset
 
             spec = from_preset("CHEN", train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks)
-        elif isinstance(self.kernel, str):
+        elif isinstance(kernel, str):
             spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks,
-                                        kernel=self.kernel)
+                                        kernel=kernel)
             spec.use_outputscale = bool(self.use_outputscale)
         else:
             from baybe_amd.kernels import apply_kernel_spec
 
             spec = GPSpec.baybe_default(train_x.shape[1], bounds[0], bounds[1], task_idx=task_idx, n_tasks=n_tasks)
-            apply_kernel_spec(spec, self.kernel, searchspace)
+            apply_kernel_spec(spec, kernel, searchspace)
+        criterion = resolve_fit_criterion(self.fit_criterion_or_factory, searchspace, train_x, train_y)
+        if criterion is not None:
+            spec.criterion = criterion
         if self._engine is None:
             self._engine = HipGP(self.device)
         self._engine.set_model(spec, train_x, train_y)
@@ -323,6 +327,48 @@ def _per_target(fixed, i):
     return fixed[i] if isinstance(fixed, (list, tuple)) else fixed
 
 
+def _only_default(name):
+    def check(_, attribute, value):
+        if value is not None:
+            raise IncompatibilityError(f"'{name}': custom mean / likelihood components are gpytorch objects; the HIP path evaluates the "
+                                       f"components of the GP presets (preset=...) only.")
+    return check
+
+
+_CRITERIA = {"MARGINAL_LOG_LIKELIHOOD": "mll", "MLL": "mll", "LEAVE_ONE_OUT_PSEUDOLIKELIHOOD": "loo", "LOO": "loo"}
+
+
+def resolve_kernel_argument(kernel, kernel_or_factory, searchspace, train_x, train_y):
+    """The kernel specification a fit uses: ``kernel_or_factory`` if given - a kernel object as is, a factory (any callable that is
+    not itself a kernel object: ``KernelFactoryProtocol.__call__(searchspace, train_x, train_y)``, components/kernel.py) called
+    with torch tensors - else ``kernel``.  gpytorch kernel objects (which the reference also accepts) are refused."""
+    if kernel_or_factory is None:
+        return kernel
+    k = kernel_or_factory
+    if callable(k) and not type(k).__name__.endswith("Kernel"):
+        import torch
+
+        k = k(searchspace, torch.as_tensor(train_x), torch.as_tensor(train_y).reshape(-1, 1))
+    if type(k).__module__.startswith("gpytorch"):
+        raise IncompatibilityError("gpytorch kernel objects are not evaluated on the HIP path; pass a BayBE kernel specification.")
+    return k
+
+
+def resolve_fit_criterion(value, searchspace, train_x, train_y):
+    """'mll' | 'loo' | None (keep the preset's choice) from a ``FitCriterion`` member / its name / a factory of one
+    (components/fit_criterion.py:18-40)."""
+    if value is None:
+        return None
+    if callable(value) and not hasattr(value, "value"):
+        import torch
+
+        value = value(searchspace, torch.as_tensor(train_x), torch.as_tensor(train_y).reshape(-1, 1))
+    name = str(getattr(value, "value", value)).upper()
+    if name not in _CRITERIA:
+        raise ValueError(f"unknown fit criterion {value!r}; available: MARGINAL_LOG_LIKELIHOOD, LEAVE_ONE_OUT_PSEUDOLIKELIHOOD")
+    return _CRITERIA[name]
+
+
 def gp_surrogate_fields(with_runtime_state: bool = True) -> dict:
     """attrs fields of the GP surrogate.  ``with_runtime_state=False`` leaves out the fields BayBE's ``Surrogate``
     base already declares (``surrogates/base.py:93-103``)."""
@@ -331,6 +377,14 @@ def gp_surrogate_fields(with_runtime_state: bool = True) -> dict:
         # Gamma priors), or a kernel specification object - baybe_amd.kernels or BayBE's own MaternKernel /
         # RBFKernel / ScaleKernel / ProductKernel - handled like Kernel.to_gpytorch
         "kernel": field(default="matern52"),
+        # The reference's constructor arguments (gaussian_process/core.py:149-207), accepted under their own names: a BayBE ``Kernel``
+        # object or a kernel factory ``(searchspace, train_x, train_y) -> Kernel`` (takes precedence over ``kernel``); a
+        # ``FitCriterion`` member / name or a factory of one.  Custom mean / likelihood components are gpytorch objects, which this
+        # path does not evaluate: anything but None is refused at construction.
+        "kernel_or_factory": field(default=None, kw_only=True),
+        "fit_criterion_or_factory": field(default=None, kw_only=True),
+        "mean_or_factory": field(default=None, kw_only=True, validator=_only_default("mean_or_factory")),
+        "likelihood_or_factory": field(default=None, kw_only=True, validator=_only_default("likelihood_or_factory")),
         # wrap the base kernel in a ScaleKernel (user kernels); the BAYBE preset has none
         "use_outputscale": field(default=False),
         # GaussianProcessPreset (presets/core.py:8-27): BAYBE | BOTORCH | CHEN | EDBO | EDBO_SMOOTHED | HVARFNER

@@ -148,3 +148,52 @@ def test_standalone_classes_share_the_implementation(classes):
     assert HipRecommenderImpl in Rec.__mro__ and HipRecommenderImpl in HipBotorchRecommender.__mro__
     assert Sur.fit is HipGaussianProcessSurrogate.fit and Rec._recommend_discrete is HipBotorchRecommender._recommend_discrete
     assert HipBotorchRecommender().max_n_subsets == 10 and HipBotorchRecommender.compatibility == "DISCRETE"
+
+
+def test_reference_constructor_arguments_of_the_gp_surrogate(classes):
+    """``GaussianProcessSurrogate(kernel_or_factory=..., fit_criterion_or_factory=..., mean_or_factory=..., likelihood_or_factory=...)``
+    (gaussian_process/core.py:149-207): kernel objects and kernel factories, fit criteria by member / name / factory; custom
+    mean / likelihood components (gpytorch objects) are refused at construction."""
+    from enum import Enum
+
+    from baybe_amd.kernels import GammaPrior, MaternKernel, ScaleKernel
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate, resolve_fit_criterion, resolve_kernel_argument
+
+    Sur, _, _ = classes
+    space, obj, meas = _context()
+    X, y = np.zeros((4, 2)), np.zeros(4)
+    kern = ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1)))
+    for cls in (Sur, HipGaussianProcessSurrogate):
+        s = cls(kernel_or_factory=kern)
+        assert s.kernel_or_factory is kern and s.kernel == "matern52" and s.fit_criterion_or_factory is None
+        with pytest.raises(IncompatibilityError, match="gpytorch objects"):
+            cls(mean_or_factory=object())
+        with pytest.raises(IncompatibilityError, match="gpytorch objects"):
+            cls(likelihood_or_factory=object())
+    assert resolve_kernel_argument("matern52", None, space, X, y) == "matern52"
+    assert resolve_kernel_argument("matern52", kern, space, X, y) is kern  # a kernel object is callable-free: taken as is
+    seen = {}
+
+    def factory(searchspace, train_x, train_y):  # KernelFactoryProtocol.__call__
+        seen["args"] = (searchspace, tuple(train_x.shape), tuple(train_y.shape))
+        return kern
+
+    assert resolve_kernel_argument("matern52", factory, space, X, y) is kern and seen["args"] == (space, (4, 2), (4, 1))
+
+    class FakeGpytorchKernel:
+        pass
+
+    FakeGpytorchKernel.__module__ = "gpytorch.kernels.matern_kernel"
+    with pytest.raises(IncompatibilityError, match="gpytorch kernel"):
+        resolve_kernel_argument("matern52", FakeGpytorchKernel(), space, X, y)
+
+    class FitCriterion(Enum):  # components/fit_criterion.py:18-24
+        MARGINAL_LOG_LIKELIHOOD = "MARGINAL_LOG_LIKELIHOOD"
+        LEAVE_ONE_OUT_PSEUDOLIKELIHOOD = "LEAVE_ONE_OUT_PSEUDOLIKELIHOOD"
+
+    assert resolve_fit_criterion(None, space, X, y) is None
+    assert resolve_fit_criterion(FitCriterion.MARGINAL_LOG_LIKELIHOOD, space, X, y) == "mll"
+    assert resolve_fit_criterion("LEAVE_ONE_OUT_PSEUDOLIKELIHOOD", space, X, y) == "loo"
+    assert resolve_fit_criterion(lambda sp, tx, ty: FitCriterion.LEAVE_ONE_OUT_PSEUDOLIKELIHOOD, space, X, y) == "loo"
+    with pytest.raises(ValueError, match="unknown fit criterion"):
+        resolve_fit_criterion("ELBO", space, X, y)
