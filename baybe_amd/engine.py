@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -63,6 +64,102 @@ def draw_sampler_seed() -> int:
     import torch
 
     return int(torch.randint(0, 1000000, (1,)).item())
+
+
+# ---- scipy's L-BFGS-B without scipy's per-evaluation wrappers -----------------------------------------------------------------
+# ``scipy.optimize.minimize(method="L-BFGS-B")`` is what ``botorch.fit.fit_gpytorch_mll`` runs, and the iterates have to stay
+# scipy's.  Its driver (``_minimize_lbfgsb``) is a short loop around the compiled reverse-communication routine ``setulb``;
+# around every objective evaluation it puts ``ScalarFunction`` / ``MemoizeJac`` bookkeeping (array comparisons, copies, lowest-value
+# tracking): ~25 us per evaluation - a quarter of an evaluation of a small model (0.09 ms on the device).  The loop
+# below is that driver with the evaluation called directly: same routine, same work arrays, same stopping logic, same messages -
+# bitwise the same iterates (``tests/test_host_logic_cpu.py::test_lean_lbfgsb_driver_is_scipys``).  ``setulb`` is a private
+# interface: the first use checks the lean driver against ``minimize`` on a small problem and falls back to ``minimize`` for good
+# if they differ in any bit or the call fails (another scipy version).
+_LEAN_LBFGSB = None  # None: unchecked, True / False after the first use
+
+
+class _OptResult:
+    __slots__ = ("x", "fun", "nit", "nfev", "status", "message")
+
+    def __init__(self, x, fun, nit, nfev, status, message):
+        self.x, self.fun, self.nit, self.nfev, self.status, self.message = x, fun, nit, nfev, status, message
+
+
+def _lbfgsb_lean(fun, x0, bounds, maxiter, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxls=20):
+    from scipy.optimize import _lbfgsb_py as lb
+
+    m = maxcor
+    factr = ftol / np.finfo(float).eps
+    x0 = np.asarray(x0, dtype=np.float64).ravel()
+    n = x0.shape[0]
+    nbd = np.zeros(n, np.int32)
+    low, up = np.zeros(n, np.float64), np.zeros(n, np.float64)
+    if bounds is not None:
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+        hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        if (lo > hi).any():
+            raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
+        x0 = np.clip(x0, lo, hi)
+        for i in range(n):
+            has_lo, has_hi = np.isfinite(lo[i]), np.isfinite(hi[i])
+            if has_lo:
+                low[i] = lo[i]
+            if has_hi:
+                up[i] = hi[i]
+            nbd[i] = (2 if has_hi else 1) if has_lo else (3 if has_hi else 0)
+    x = np.array(x0, dtype=np.float64)
+    f = np.array(0.0, dtype=np.int32)
+    g = np.zeros((n,), dtype=np.int32)
+    wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+    iwa = np.zeros(3 * n, dtype=np.int32)
+    task, ln_task = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)
+    lsave, isave, dsave = np.zeros(4, dtype=np.int32), np.zeros(44, dtype=np.int32), np.zeros(29, dtype=np.float64)
+    nit = nfev = 0
+    while True:
+        g = np.asarray(g, dtype=np.float64)
+        lb._lbfgsb.setulb(m, x, low, up, nbd, f, g, factr, gtol, wa, iwa, task, lsave, isave, dsave, maxls, ln_task)
+        if task[0] == 3:  # f and g at the current x
+            f, g = fun(np.copy(x))
+            nfev += 1
+        elif task[0] == 1:  # new iteration
+            nit += 1
+            if nit >= maxiter:
+                task[0], task[1] = 5, 504
+            elif nfev > maxfun:
+                task[0], task[1] = 5, 502
+        else:
+            break
+    status = 0 if task[0] == 4 else (1 if (nfev > maxfun or nit >= maxiter) else 2)
+    return _OptResult(x, f, nit, nfev, status, lb.status_messages[task[0]] + ": " + lb.task_messages[task[1]])
+
+
+def _lean_lbfgsb_usable() -> bool:
+    global _LEAN_LBFGSB
+    if _LEAN_LBFGSB is None:
+        try:
+            A = np.array([[3.0, 0.5, 0.1], [0.5, 2.0, 0.3], [0.1, 0.3, 1.5]])
+            b = np.array([1.0, -2.0, 0.5])
+
+            def probe(x):
+                return float(0.5 * x @ A @ x - b @ x + 0.1 * np.log1p(x @ x)), A @ x - b + 0.2 * x / (1.0 + x @ x)
+
+            bnd = [(None, None), (-0.1, None), (0.25, 0.25)]
+            x0 = np.array([0.7, -0.4, 0.2])
+            ref = sopt.minimize(probe, x0, jac=True, method="L-BFGS-B", bounds=bnd, options={"maxiter": 50})
+            got = _lbfgsb_lean(probe, x0, bnd, 50)
+            _LEAN_LBFGSB = bool(np.array_equal(ref.x, got.x) and ref.fun == got.fun and ref.nit == got.nit and ref.nfev == got.nfev
+                                and ref.status == got.status and str(ref.message) == got.message)
+        except Exception:  # noqa: BLE001  (another scipy: private interface changed)
+            _LEAN_LBFGSB = False
+    return _LEAN_LBFGSB
+
+
+def lbfgsb_minimize(fun, x0, bounds, maxiter):
+    """``scipy.optimize.minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": maxiter})`` - through the
+    lean driver above when it reproduces scipy bit for bit here (``BBH_LEAN_LBFGSB=0`` forces ``minimize``)."""
+    if os.environ.get("BBH_LEAN_LBFGSB", "1") != "0" and _lean_lbfgsb_usable():
+        return _lbfgsb_lean(fun, x0, bounds, maxiter)
+    return sopt.minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": maxiter})
 
 
 @dataclass
@@ -327,8 +424,7 @@ class HipGP:
         for attempt in range(max_attempts):
             start = p0 if (attempt == 0 and p0 is not None) else (
                 initial_params(spec) if attempt == 0 else sample_params_from_priors(spec))
-            res = sopt.minimize(fun, pack_raw(spec, start), jac=True, method="L-BFGS-B", bounds=raw_bounds(spec),
-                                options={"maxiter": maxiter})
+            res = lbfgsb_minimize(fun, pack_raw(spec, start), raw_bounds(spec), maxiter)
             last_msg = str(res.message)
             ok = np.all(np.isfinite(res.x)) and np.isfinite(res.fun) and "ABNORMAL" not in last_msg.upper()
             if not ok:

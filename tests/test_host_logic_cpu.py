@@ -679,3 +679,61 @@ def test_every_prior_family_of_the_reference_on_every_kind_of_slot(family):
                 assert math.isclose(f2, f1, rel_tol=1e-12) and np.allclose(g2, g1, rtol=1e-10, atol=1e-14)
         ps = gp_spec.sample_params_from_priors(spec, np.random.default_rng(2))  # restart points exist for every family
         assert np.all(np.isfinite(gp_spec.pack_raw(spec, ps)))
+
+
+def test_lean_lbfgsb_driver_is_scipys():
+    """``engine.lbfgsb_minimize`` drives scipy's compiled L-BFGS-B routine (``setulb``) without the per-evaluation wrappers of
+    ``scipy.optimize.minimize``; the iterates must be scipy's, bit for bit: end point, value, iteration / evaluation counts, status
+    and message - on the oracle's GP fit objective (box bounds, pinned slots, an infinite value on the way), on an iteration cap,
+    and when the very first evaluation fails."""
+    import scipy.optimize as sopt
+
+    from baybe_amd import engine
+    from baybe_amd.kernels import GammaPrior, MaternKernel, ScaleKernel, apply_kernel_spec
+
+    assert engine._lean_lbfgsb_usable()
+
+    def same(make_fun, x0, bounds, maxiter):  # (a fresh objective per run: the ones below count their calls)
+        ref = sopt.minimize(make_fun(), x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": maxiter})
+        got = engine.lbfgsb_minimize(make_fun(), x0, bounds, maxiter)
+        assert isinstance(got, engine._OptResult)  # (the lean driver ran, not the fallback)
+        assert np.array_equal(ref.x, got.x) and (ref.fun == got.fun or (np.isnan(ref.fun) and np.isnan(got.fun)))
+        assert (ref.nit, ref.nfev, ref.status, str(ref.message)) == (got.nit, got.nfev, got.status, got.message)
+        return got
+
+    class Space:
+        comp_rep_columns = ("a", "b", "c", "d")
+
+    X, Xt, y = make_problem(200, 4, 35, seed=12)
+    for kern in (None, ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1), parameter_names=["a", "c"]), GammaPrior(2, 0.5))):
+        spec = gp_spec.GPSpec.baybe_default(4, np.zeros(4), np.ones(4))
+        if kern is not None:
+            apply_kernel_spec(spec, kern, Space())
+        ospec = _ospec(spec)
+        Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+        bounds = gp_spec.raw_bounds(spec)
+        free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+        def make_fun(bad_call):
+            def factory():
+                calls = {"n": 0}
+
+                def fun(raw):  # the oracle's objective on the free slots, zero gradient in the pinned ones; one evaluation reports +inf
+                    calls["n"] += 1
+                    if calls["n"] == bad_call:
+                        return float("inf"), np.zeros_like(raw)
+                    f, g = go.fit_objective(ospec, raw[free], Xn, ys)
+                    full = np.zeros_like(raw)
+                    full[free] = g
+                    return f, full
+
+                return fun
+
+            return factory
+
+        x0 = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+        for maxiter, bad_call in ((15000, 0), (15000, 4), (5, 0)):
+            res = same(make_fun(bad_call), x0, bounds, maxiter)
+            assert (maxiter == 5) == (res.status == 1), (maxiter, res.status, res.message)
+    # the first evaluation fails (NaN value, zero gradient): the same outcome from both - the engine's retry logic looks at the value
+    res = same(lambda: (lambda x: (float("nan"), np.zeros_like(x))), np.ones(3), [(None, None)] * 3, 100)
+    assert np.isnan(res.fun)
