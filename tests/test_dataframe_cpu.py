@@ -123,3 +123,22 @@ def test_numerical_columns_are_normalised_to_float_like_the_reference():
         warnings.simplefilter("always")
         assert list(fuzzy_row_match(left, as_str, params)) == [1, 5]
     assert any("unexpected data types" in str(w.message) for w in rec)
+
+
+def test_measurements_key_of_the_fit_cache():
+    """``surrogates._frame_hash`` decides "unchanged context -> no refit" (surrogates/base.py:418-424): equal content gives equal keys
+    whatever the memory layout or the index; any edited value, an added row, a renamed column or a changed dtype gives another key."""
+    from baybe_amd.surrogates import _frame_hash
+
+    rng = np.random.default_rng(0)
+    df = pd.DataFrame({"a": rng.random(50), "b": rng.integers(0, 5, 50), "lab": rng.choice(["u", "v", "w"], 50), "y": rng.random(50)})
+    key = _frame_hash(df)
+    assert key == _frame_hash(df.copy()) == _frame_hash(df.reset_index(drop=True).set_index(pd.Index(range(100, 150))))
+    block = pd.DataFrame(np.asfortranarray(df[["a", "y"]].to_numpy()), columns=["a", "y"])  # another memory layout, same content
+    assert _frame_hash(block) == _frame_hash(pd.DataFrame({"a": df["a"].to_numpy(), "y": df["y"].to_numpy()}))
+    for edited in (df.assign(a=df["a"].where(df.index != 7, 0.123)), df.assign(lab=df["lab"].where(df.index != 3, "z")),
+                   pd.concat([df, df.iloc[:1]]), df.rename(columns={"y": "z"}), df.astype({"b": "float64"}), df.iloc[:-1]):
+        assert _frame_hash(edited) != key
+    nan = df.assign(y=df["y"].where(df.index != 0, np.nan))
+    assert _frame_hash(nan) == _frame_hash(nan.copy()) != key
+    assert isinstance(_frame_hash(pd.DataFrame()), int)
