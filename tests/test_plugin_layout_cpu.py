@@ -197,3 +197,69 @@ def test_reference_constructor_arguments_of_the_gp_surrogate(classes):
     assert resolve_fit_criterion(lambda sp, tx, ty: FitCriterion.LEAVE_ONE_OUT_PSEUDOLIKELIHOOD, space, X, y) == "loo"
     with pytest.raises(ValueError, match="unknown fit criterion"):
         resolve_fit_criterion("ELBO", space, X, y)
+
+
+class _StubEngine:
+    """Stands in for ``engine.HipGP`` in the host-logic tests below (no device): records the calls ``Surrogate.fit`` makes."""
+
+    created = 0
+
+    def __init__(self, device=0):
+        type(self).created += 1
+        self.device, self.calls, self.spec = device, [], None
+
+    def set_model(self, spec, X, y):
+        self.spec, self.n = spec, len(y)
+        self.calls.append(("set_model", X.shape, float(np.sum(y))))
+
+    def fit(self, p0=None, **kw):
+        from baybe_amd import gp_spec
+        from baybe_amd.engine import FitInfo
+
+        self.calls.append(("fit", p0 is not None))
+        return FitInfo(gp_spec.initial_params(self.spec), 0.0, 1, 1, 0, "ok")
+
+    def factorize(self, params):
+        self.calls.append(("factorize",))
+
+
+def test_surrogate_fit_host_logic_with_a_stub_engine(monkeypatch):
+    """``Surrogate.fit`` (surrogates/base.py:387-465) around the device calls: unchanged context -> no refit (the measurements are
+    keyed by content, not by identity, index or memory layout); any changed value, another objective or search-space encoding
+    refits; missing target values raise; ``kernel_or_factory`` / ``fit_criterion_or_factory`` reach the model description."""
+    import baybe_amd.engine as engine_mod
+    from baybe_amd.kernels import GammaPrior, MaternKernel, ScaleKernel
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate
+
+    monkeypatch.setattr(engine_mod, "HipGP", _StubEngine)
+    space, obj, meas = _context()
+    s = HipGaussianProcessSurrogate()
+    s.fit(space, obj, meas)
+    eng = s._engine
+    assert [c[0] for c in eng.calls] == ["set_model", "fit"] and eng.spec.kernel == "matern52" and eng.spec.criterion == "mll"
+    s.fit(space, obj, meas.copy())  # equal content, another object
+    s.fit(space, obj, meas.set_index(pd.Index([10, 11, 12, 13])))  # another index
+    assert len(eng.calls) == 2 and s._engine is eng
+    edited = meas.copy()
+    edited.loc[edited.index[0], "y"] += 0.5
+    s.fit(space, obj, edited)
+    assert [c[0] for c in eng.calls] == ["set_model", "fit", "set_model", "fit"] and s._engine is eng  # the same handle refits
+    s.fit(space, SingleTargetObjective(NumericalTarget("y", minimize=True)), edited)  # another objective: refit
+    assert len(eng.calls) == 6
+    with pytest.raises(ValueError, match="Missing target values"):
+        s.fit(space, obj, edited.assign(y=[0.1, np.nan, 0.3, 0.2]))
+    # warm starts hand the previous optimum to the next fit
+    w = HipGaussianProcessSurrogate(warm_start=True)
+    w.fit(space, obj, meas)
+    w.fit(space, obj, edited)
+    assert [c for c in w._engine.calls if c[0] == "fit"] == [("fit", False), ("fit", True)]
+    # the reference's constructor arguments
+    kern = ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1)), GammaPrior(2, 0.5))
+    k = HipGaussianProcessSurrogate(kernel_or_factory=lambda sp, tx, ty: kern, fit_criterion_or_factory="LEAVE_ONE_OUT_PSEUDOLIKELIHOOD")
+    k.fit(space, obj, meas)
+    assert k._engine.spec.kernel == "matern32" and k._engine.spec.use_outputscale and k._engine.spec.criterion == "loo"
+    with pytest.raises(ValueError, match="preset fixes the kernel"):
+        HipGaussianProcessSurrogate(preset="EDBO", kernel_or_factory=kern).fit(space, obj, meas)
+    fixed = HipGaussianProcessSurrogate(fixed_hyperparameters=object())
+    fixed.fit(space, obj, meas)
+    assert [c[0] for c in fixed._engine.calls] == ["set_model", "factorize"] and fixed._fit_info is None
