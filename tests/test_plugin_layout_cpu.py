@@ -263,3 +263,63 @@ def test_surrogate_fit_host_logic_with_a_stub_engine(monkeypatch):
     fixed = HipGaussianProcessSurrogate(fixed_hyperparameters=object())
     fixed.fit(space, obj, meas)
     assert [c[0] for c in fixed._engine.calls] == ["set_model", "factorize"] and fixed._fit_info is None
+
+
+def test_recommender_host_logic_with_a_stub_engine(monkeypatch):
+    """``Campaign.recommend`` -> ``recommend`` -> ``_recommend_with_discrete_parts`` around the device calls (pure/base.py:210-283,
+    botorch/core.py:143-186): the whole comp rep stays resident and is re-uploaded only when its CONTENT changes; the rows that are
+    candidates in a call travel as a mask; positions come back as index labels of the search space; measured / recommended /
+    pending rows are never among the candidates the engine sees."""
+    import torch
+
+    import baybe_amd.engine as engine_mod
+    from _baybe_shim import Campaign
+    from baybe_amd.engine import GreedyResult
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    seen = {"uploads": 0, "greedy": []}
+
+    class Engine(_StubEngine):
+        def best_f(self, *a, **k):
+            return 0.0
+
+        def greedy_qlogei(self, Xd, q, alive=None, X_pending=None, **kw):
+            live = np.arange(Xd.shape[0]) if alive is None else np.nonzero(alive.numpy())[0]
+            seen["greedy"].append((Xd.shape, None if alive is None else int(alive.sum()), None if X_pending is None else len(X_pending)))
+            return GreedyResult([int(i) for i in live[-q:]], [0.0] * q)  # (the LAST live rows: positions != labels below)
+
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):  # "upload": stay on the CPU, count the calls that move the candidate matrix
+        if self.ndim == 2:
+            seen["uploads"] += 1
+        return self
+
+    monkeypatch.setattr(engine_mod, "HipGP", Engine)
+    monkeypatch.setattr(engine_mod, "draw_sampler_seed", lambda: 7, raising=False)
+    monkeypatch.setattr(torch.Tensor, "to", to_cpu)
+    vals = np.arange(5) / 4.0
+    space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(2)])
+    exp = space.discrete.exp_rep
+    rec = HipBotorchRecommender()
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("y")), rec)
+    meas = exp.iloc[[0, 6, 12]].copy()
+    meas["y"] = [0.1, 0.5, 0.3]
+    camp.add_measurements(meas)
+    got = camp.recommend(2)
+    N = len(exp)
+    assert seen["uploads"] == 1 and seen["greedy"][-1] == ((N, 2), N - 3, None)  # 3 measured rows masked out, nothing pending
+    assert list(got.index) == [N - 2, N - 1] and got.equals(exp.loc[got.index])
+    got2 = camp.recommend(2)  # the two recommended rows are no candidates any more; same resident matrix
+    assert seen["uploads"] == 1 and seen["greedy"][-1][1] == N - 5 and list(got2.index) == [N - 4, N - 3]
+    pend = exp.iloc[[N - 5]]
+    got3 = camp.recommend(1, pending_experiments=pend)
+    assert seen["greedy"][-1][1:] == (N - 8, 1) and list(got3.index) == [N - 6] and seen["uploads"] == 1
+    # stand-alone call with a candidate frame that is a subset with its own labels
+    rec2 = HipBotorchRecommender()
+    sub = space.filtered(np.isin(np.arange(N), [3, 4, 9, 20]))
+    out = rec2.recommend(2, sub, camp.objective, camp.measurements)
+    assert list(out.index) == [9, 20]
+    with pytest.raises(Exception):  # more rows than candidates (NotEnoughPointsLeftError)
+        rec2.recommend(5, sub, camp.objective, camp.measurements)
+    monkeypatch.setattr(torch.Tensor, "to", real_to)
