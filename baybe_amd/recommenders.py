@@ -324,7 +324,7 @@ class HipRecommenderImpl:
                         f"RowShard was built for {self.shard.N_total} rows but the discrete subspace has {len(comp_rep)}"
                     )
                 X = X[self.shard.start : self.shard.stop]
-            self._cand_cache = (key, X.to(torch.device("cuda", self._engine.device)), comp_rep.index)
+            self._cand_cache = (key, X.to(self._engine._dev()), comp_rep.index)
         _, Xd, labels = self._cand_cache
         alive = None
         if keep_mask is not None:

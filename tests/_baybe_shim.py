@@ -1,8 +1,10 @@
-"""Minimal stand-ins for the BayBE data model (TEST INFRASTRUCTURE).
+"""Minimal stand-ins for the BayBE data model (TEST INFRASTRUCTURE) for boxes WITHOUT the reference tree.
 
-BayBE itself cannot be imported in this environment (cattrs / botorch / gpytorch are missing,
-SURVEY.md §0), so the drop-in tests drive the HIP recommender through objects that expose exactly
-the attributes the real classes expose on this path:
+The reference's own ``Campaign`` / ``SearchSpace`` run in the build container (``tests/_reference.py``;
+``tests/test_reference_campaign_cpu.py`` drives the plug-in with them and pins THIS file to them:
+``test_shim_campaign_makes_the_calls_the_real_campaign_makes``).  ``/root/reference`` does not exist on the GPU box, so
+the ``-m gpu`` drop-in tests drive the HIP recommender through objects that expose exactly the attributes the real
+classes expose on this path:
   SearchSpace      .discrete .continuous .parameters .transform() .scaling_bounds .task_idx .n_tasks
                    (baybe/searchspace/core.py:246-295, 469-515)
   SubspaceDiscrete .exp_rep .comp_rep .get_candidates() .n_subsets (baybe/searchspace/discrete.py:695-702)
@@ -159,11 +161,13 @@ class ParetoObjective:
 
 
 class Campaign:
-    """recommend() plumbing of baybe/campaign.py:495-642 for discrete spaces (default flags:
-    recommended, measured and pending rows are excluded from the candidates)."""
+    """recommend() plumbing of baybe/campaign.py:495-642 for discrete spaces.  Default flags as in the reference
+    (campaign.py:254-285): already RECOMMENDED and PENDING rows are excluded from the candidates of a discrete space,
+    already MEASURED rows are not (``allow_recommending_already_measured`` resolves to True)."""
 
-    def __init__(self, searchspace, objective, recommender):
+    def __init__(self, searchspace, objective, recommender, allow_recommending_already_measured=True):
         self.searchspace, self.objective, self.recommender = searchspace, objective, recommender
+        self.allow_recommending_already_measured = allow_recommending_already_measured
         n = len(searchspace.discrete.exp_rep)
         self.measurements = pd.DataFrame()
         self._meta = pd.DataFrame({"recommended": np.zeros(n, bool), "measured": np.zeros(n, bool)},
@@ -201,7 +205,9 @@ class Campaign:
         self._meta["excluded"] = self._meta.get("excluded", False) | hit if exclude else self._meta.get("excluded", False) & ~hit
 
     def recommend(self, batch_size, pending_experiments=None):
-        drop = self._meta["recommended"] | self._meta["measured"]
+        drop = self._meta["recommended"].copy()
+        if not self.allow_recommending_already_measured:
+            drop = drop | self._meta["measured"]
         if "excluded" in self._meta:
             drop = drop | self._meta["excluded"]
         if pending_experiments is not None:

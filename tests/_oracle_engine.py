@@ -1,0 +1,305 @@
+"""TEST INFRASTRUCTURE - a CPU double of the *device* under the product's own host driver.
+
+``OracleEngine`` subclasses ``baybe_amd.engine.HipGP`` and replaces exactly the methods that cross the C-ABI (``bbh_*`` calls) with
+the oracle's restatement of the same arithmetic (``oracle/gp_oracle.py``), on CPU tensors.  Everything above the C-ABI stays the
+PRODUCT's code: ``HipGP.fit`` (L-BFGS-B driver, prior terms, retries), ``HipGP.greedy_qlogei`` (sequential greedy, speculative
+cross-covariance columns and their hit / miss logic), ``baybe_amd.surrogates`` / ``baybe_amd.recommenders`` / ``baybe_amd.plugin``.
+
+Purpose: in the build container there is no GPU, but the reference's own Python is importable (``tests/_reference.py``).  With this
+double installed the REAL ``baybe.Campaign`` / ``SearchSpace`` / ``BayesianRecommender.recommend`` / ``simulate_experiment`` drive
+``make_baybe_classes()``'s subclasses end to end on the CPU (``tests/test_reference_*_cpu.py``), and the calls they make are recorded
+as fixtures that the GPU box replays through ``libbaybe_hip.so`` (``tests/golden/make_reference_traces.py``).
+
+It is never importable from the product (``tests/test_lib_cpu.py::test_product_code_never_imports_the_oracle``): the product path has
+no CPU fallback; this file is how the *tests* stand in for the hardware.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from _problems import oracle_params, oracle_spec
+from baybe_amd import engine as engine_mod
+from baybe_amd import gp_spec
+from baybe_amd.engine import GreedyResult, HipGP, ModelFittingError
+from oracle import gp_oracle as go
+
+
+class OracleEngine(HipGP):
+    """``HipGP`` with the device replaced by the oracle (see module docstring)."""
+
+    created = 0
+    instances: list = []
+
+    def __init__(self, device: int = 0):  # no library, no handle
+        type(self).created += 1
+        type(self).instances.append(self)
+        self._libobj = None
+        self._handle = None
+        self._pool_key = None
+        self.device = int(device)
+        self.spec = self.params = None
+        self.n, self.ybar, self.ysd, self.jitter = 0, 0.0, 1.0, 0.0
+        self._comm = None
+        self._model_args = None
+        self._X_train = self._y_train = None
+        self._model = None  # oracle GPModel once factorised
+        self._pend = None
+        self.calls: list = []  # (name, detail) of every would-be C-ABI call, for the tests
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------------------
+    def close(self):
+        self._model = None
+
+    def __getstate__(self):
+        st = super().__getstate__()
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._model, self._pend, self.calls = None, None, []
+        self._restorable = False
+        if self.spec is not None and self._X_train is not None:
+            params = self.params
+            mask, std = self._model_args or (None, None)
+            self.set_model(self.spec, self._X_train, self._y_train, noise_mask=mask, standardization=std)
+            if params is not None:
+                self.factorize(params)
+
+    def _dev(self):
+        return torch.device("cpu")
+
+    def use_current_torch_stream(self):
+        pass
+
+    def timing(self, enable):
+        pass
+
+    def _as_dev(self, X):
+        if isinstance(X, np.ndarray):
+            X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64))
+        if X.dim() != 2 or X.shape[1] < self.spec.d:
+            raise ValueError("candidates must be [N, d]")
+        return X.to(torch.float64)
+
+    def _np(self, X):
+        return np.ascontiguousarray(self._as_dev(X).numpy()[:, : self.spec.d])
+
+    # ---- model ------------------------------------------------------------------------------------------------------------
+    def set_model(self, spec, X_train, y_train, noise_mask=None, standardization=None):
+        X = np.ascontiguousarray(X_train, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y_train, dtype=np.float64).reshape(-1))
+        if X.ndim != 2 or X.shape[1] != spec.d or X.shape[0] != y.shape[0]:
+            raise ValueError("X_train must be [n, d] and y_train [n]")
+        if noise_mask is not None or standardization is not None:
+            raise NotImplementedError("the CPU double has no extended (noise-masked) models; see OracleNEHVI")
+        self.spec, self.n, self.params, self._model = spec, X.shape[0], None, None
+        self._ospec = oracle_spec(spec)
+        self._X_train, self._y_train, self._model_args = X, y, (None, None)
+        self._Xn = go.normalize_inputs(self._ospec, X)
+        self._ystd, self.ybar, self.ysd = go.standardize_targets(y)
+        self.calls.append(("set_model", X.shape))
+
+    def data_term(self, params):
+        op = oracle_params(self.spec, params)
+        try:
+            dt = go.data_term(self._ospec, op, self._Xn, self._ystd)
+        except Exception:  # noqa: BLE001  (train covariance not positive definite)
+            return None, None
+        if dt is None or not np.isfinite(dt.value):
+            return None, None
+        spec = self.spec
+        if spec.factors or spec.hadamard or spec.has_rq or spec.has_periodic or spec.has_dot_kind:
+            raise NotImplementedError("the CPU double covers single-kernel (+ task kernel) models")
+        parts = [[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls]
+        if spec.n_tasks > 1:
+            parts.append(dt.g_task_B.reshape(-1))
+        self.calls.append(("fit_value_grad", None))
+        return dt.value, np.concatenate(parts)
+
+    def fit(self, p0=None, maxiter: int = 15000, max_attempts: int = 5):
+        """The product's own fit driver; only the vectorised host objective (``FastObjective``, which feeds theta vectors to the
+        device call directly) is switched off so that every evaluation passes through ``data_term`` above."""
+        applies = gp_spec.FastObjective.applies
+        engine_mod.FastObjective.applies = staticmethod(lambda spec: False)
+        try:
+            return super().fit(p0=p0, maxiter=maxiter, max_attempts=max_attempts)
+        finally:
+            engine_mod.FastObjective.applies = applies
+
+    def factorize(self, params):
+        try:
+            self._model = go.GPModel(self._ospec, oracle_params(self.spec, params), self._X_train, self._y_train)
+        except Exception as ex:  # noqa: BLE001
+            raise ModelFittingError(str(ex)) from ex
+        self.params, self.jitter = params, self._model.jitter
+        self.calls.append(("factorize", None))
+
+    # ---- posterior ----------------------------------------------------------------------------------------------------------
+    def posterior(self, X, unfused: bool = False):
+        mu, var = self._model.posterior(self._np(X))
+        self.calls.append(("posterior", len(mu)))
+        return torch.from_numpy(mu), torch.from_numpy(var)
+
+    def posterior_joint(self, Xq):
+        Xq = np.ascontiguousarray(np.atleast_2d(Xq), dtype=np.float64)
+        return self._model.posterior_joint(Xq)
+
+    def train_posterior_mean(self):
+        return self._model.posterior(self._X_train)[0]
+
+    # ---- acquisition ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _mask(scores: np.ndarray, alive):
+        if alive is not None:
+            scores = np.where(alive.numpy().astype(bool), scores, -np.inf)
+        return torch.from_numpy(np.ascontiguousarray(scores))
+
+    def qlogei(self, mean, var, z, best_f, sign=1.0, alive=None):
+        return self.mc_acq("qLogEI", mean, var, z, best_f, sign, alive=alive)
+
+    def mc_acq(self, kind, mean, var, z, best_f=0.0, sign=1.0, beta=0.2, alive=None, cross=None):
+        mu, v = mean.numpy(), var.numpy()
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if cross is None:
+            self.calls.append(("mc_acq_q1", kind))
+            return self._mask(go.mc_acq_q1(kind, mu, v, z.reshape(-1), best_f, sign, beta), alive)
+        mp, cpp = self._pend_stats
+        self.calls.append(("mc_acq_pending", kind))
+        return self._joint_scores(kind, mu, v, cross.numpy(), mp, cpp, z, best_f, sign, beta, alive)
+
+    def _joint_scores(self, kind, mu, v, cross, mp, cpp, z, best_f, sign, beta, alive):
+        N, p = len(mu), len(mp)
+        live = np.ones(N, bool) if alive is None else alive.numpy().astype(bool)
+        out = np.full(N, -np.inf)
+        cov = np.empty((1 + p, 1 + p))
+        cov[1:, 1:] = cpp
+        mean = np.empty(1 + p)
+        mean[1:] = mp
+        for i in np.nonzero(live)[0]:
+            cov[0, 0], cov[0, 1:], cov[1:, 0], mean[0] = v[i], cross[i], cross[i], mu[i]
+            out[i] = go.mc_acq_joint(kind, mean, cov, z, best_f, sign, beta)
+        return torch.from_numpy(out)
+
+    def analytic_acq(self, kind, mean, var, best_f=0.0, sign=1.0, beta=0.2, maximize=True, alive=None):
+        return self._mask(np.asarray(go.analytic_acq(kind, mean.numpy(), var.numpy(), best_f, sign, beta, maximize)), alive)
+
+    def score_qlogei(self, X, z, best_f, sign=1.0, alive=None, want_posterior=True):
+        mean, var = self.posterior(X)
+        return self.qlogei(mean, var, z, best_f, sign, alive), mean, var
+
+    def set_pending(self, X_pending):
+        if X_pending is None or len(X_pending) == 0:
+            self._pend, self._pend_stats = None, None
+            return None, None
+        P = np.ascontiguousarray(X_pending, dtype=np.float64)
+        if P.shape[0] > engine_mod.MAX_PENDING:
+            raise ValueError(f"at most {engine_mod.MAX_PENDING} pending points are supported by the HIP path")
+        self._pend, self._p = P, P.shape[0]
+        self._pend_stats = self._model.posterior_joint(P)
+        self.calls.append(("pending_set", P.shape[0]))
+        return self._pend_stats
+
+    def cross_cov(self, X):
+        """Posterior covariances of every candidate with every pending point [N, p] (original target scale)."""
+        m = self._model
+        Xcn = go.normalize_inputs(m.spec, self._np(X))
+        Pn = go.normalize_inputs(m.spec, self._pend)
+        import scipy.linalg as sla
+
+        Vc = sla.solve_triangular(m.L, go.cross_cov(m.spec, m.params, Xcn, m.Xn).T, lower=True)
+        Vp = sla.solve_triangular(m.L, go.cross_cov(m.spec, m.params, Pn, m.Xn).T, lower=True)
+        self.calls.append(("cross_cov", self._pend.shape[0]))
+        return torch.from_numpy(np.ascontiguousarray(m.ysd**2 * (go.cross_cov(m.spec, m.params, Xcn, Pn) - Vc.T @ Vp)))
+
+    def qlogei_pending_big(self, mean, var, cross, X_pending, z, best_f, sign=1.0, alive=None, stats=None):
+        P = np.ascontiguousarray(np.atleast_2d(X_pending), dtype=np.float64)
+        mp, cpp = stats if stats is not None else self._model.posterior_joint(P)
+        self.calls.append(("qlogei_pending_big", P.shape[0]))
+        return self._joint_scores("qLogEI", mean.numpy(), var.numpy(), cross.numpy(), np.asarray(mp), np.asarray(cpp),
+                                  np.ascontiguousarray(z, dtype=np.float64), best_f, sign, 0.2, alive)
+
+    qlogei_pending = None  # (not used by the host code)
+
+    # ---- selection ----------------------------------------------------------------------------------------------------------
+    def argmax(self, scores):
+        s = scores.numpy()
+        i = int(np.argmax(s))  # first index on ties
+        return float(s[i]), i
+
+    def topk(self, scores, k):
+        s = scores.numpy()
+        order = go.topk_first_index(s, k)
+        vals, idx = np.full(k, -np.inf), np.full(k, -1, dtype=np.int64)
+        vals[: len(order)], idx[: len(order)] = s[order], order
+        return vals, idx
+
+
+class OracleNEHVI:
+    """CPU double of ``baybe_amd.nehvi.HipNEHVI`` on ``oracle/nehvi_oracle.py`` (same constructor / ``greedy`` / ``prepare`` /
+    ``score`` surface; pending points and picks join the baseline as in BoTorch's ``cache_pending``)."""
+
+    def __init__(self, engines, signs, X_baseline, ref_point, n_mc_samples=128, prune_baseline=True, device=0):
+        from types import SimpleNamespace
+
+        self.engines, self.signs = list(engines), np.asarray(signs, dtype=np.float64)
+        self.outputs = [SimpleNamespace(engine=e, ext=e, sign=float(s)) for e, s in zip(engines, signs)]
+        self.X_baseline = np.ascontiguousarray(np.atleast_2d(X_baseline), dtype=np.float64)
+        self.ref, self.S, self.prune = np.asarray(ref_point, dtype=np.float64), int(n_mc_samples), bool(prune_baseline)
+        self._pruned = None
+        self._oracle = None
+
+    def prepare(self, seed, extra_baseline=None, prune_seed=None):
+        from oracle import nehvi_oracle as no
+
+        models = [e._model for e in self.engines]
+        if self._pruned is None:
+            Xb0 = self.X_baseline
+            if self.prune and len(Xb0):
+                Xb0 = Xb0[no.prune_baseline(models, self.signs, Xb0, self.ref,
+                                            engine_mod.draw_sampler_seed() if prune_seed is None else prune_seed)]
+            self._pruned = Xb0
+        Xb = self._pruned
+        if extra_baseline is not None and len(extra_baseline):
+            Xb = np.vstack([Xb, np.atleast_2d(extra_baseline)])
+        z = no.sobol_normal_base_samples_nd(self.S, len(Xb) + 1, len(models), seed)
+        self._oracle = no.NEHVIOracle(models, self.signs, Xb, self.ref, z)
+
+    def score(self, X_dev, alive=None):
+        X = self.engines[0]._np(X_dev)
+        live = np.ones(len(X), bool) if alive is None else alive.numpy().astype(bool)
+        out = np.full(len(X), -np.inf)
+        out[live] = self._oracle.values(X[live])
+        return torch.from_numpy(out)
+
+    def greedy(self, X_dev, q, seed=None, prune_seed=None, X_pending=None, alive=None, shard=None):
+        X_dev = self.engines[0]._as_dev(X_dev)
+        d = self.engines[0].spec.d
+        seed = engine_mod.draw_sampler_seed() if seed is None else seed
+        alive = torch.ones(X_dev.shape[0], dtype=torch.uint8) if alive is None else alive.clone()
+        picks = [np.atleast_2d(np.asarray(X_pending, dtype=np.float64))] if X_pending is not None and len(X_pending) else []
+        indices, values = [], []
+        for _ in range(q):
+            self.prepare(seed, np.vstack(picks) if picks else None, prune_seed)
+            scores = self.score(X_dev, alive).numpy()
+            idx = int(np.argmax(scores))
+            indices.append(idx), values.append(float(scores[idx]))
+            alive[idx] = 0
+            picks.append(X_dev[idx, :d].numpy().reshape(1, d))
+        return GreedyResult(indices, values)
+
+
+def install(monkeypatch):
+    """Route the product's host code to the CPU double: ``engine.HipGP`` -> ``OracleEngine``, ``nehvi.HipNEHVI`` ->
+    ``OracleNEHVI``, and ``_lib.is_available()`` -> True.  Returns the ``OracleEngine`` class (call log: ``.instances``)."""
+    import baybe_amd._lib as lib_mod
+    import baybe_amd.nehvi as nehvi_mod
+
+    OracleEngine.created, OracleEngine.instances = 0, []
+    monkeypatch.setattr(engine_mod, "HipGP", OracleEngine)
+    monkeypatch.setattr(nehvi_mod, "HipNEHVI", OracleNEHVI)
+    monkeypatch.setattr(lib_mod, "is_available", lambda: True)
+    return OracleEngine

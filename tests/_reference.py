@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE - import the reference's own Python (``/root/reference/baybe``) where it exists.
+
+BayBE is pure Python; what keeps ``import baybe`` from working in the build image is the missing third-party ``cattrs`` package
+(``baybe/campaign.py:12``).  ``tests/_stubs/cattrs`` is a stand-in for the few calls made at import time and by attribute
+converters; with it on ``sys.path`` the reference's ``Campaign`` / ``SearchSpace`` / recommenders / ``simulate_*`` run unchanged.
+BoTorch / GPyTorch stay absent: every code path that reaches them (the reference's own ``BotorchRecommender``) still fails, which is
+the point - only the plug-in classes of ``baybe_amd.plugin.make_baybe_classes()`` do arithmetic here.
+
+``/root/reference`` does not exist on the GPU box, so tests that call ``reference_baybe()`` skip there; what they establish travels as
+fixtures (``tests/golden/reference_traces.npz``, written by ``tests/golden/make_reference_traces.py``).
+"""
+
+from __future__ import annotations
+
+import importlib
+import sys
+from pathlib import Path
+
+REFERENCE_ROOT = Path("/root/reference")
+_STUBS = Path(__file__).resolve().parent / "_stubs"
+
+
+def reference_available() -> bool:
+    return (REFERENCE_ROOT / "baybe" / "__init__.py").exists()
+
+
+def reference_baybe():
+    """The imported reference package (``pytest.skip`` where the reference tree is absent)."""
+    import pytest
+
+    if not reference_available():
+        pytest.skip("the reference tree (/root/reference) is not present on this box")
+    try:
+        import cattrs  # noqa: F401  (a real cattrs wins if one is ever installed)
+    except ImportError:
+        if str(_STUBS) not in sys.path:
+            sys.path.insert(0, str(_STUBS))
+    if str(REFERENCE_ROOT) not in sys.path:
+        sys.path.insert(0, str(REFERENCE_ROOT))
+    return importlib.import_module("baybe")

@@ -1,0 +1,71 @@
+"""TEST INFRASTRUCTURE - replays the ``recommend()`` calls recorded from the reference's own objects (``tests/golden/
+make_reference_traces.py``) where the reference tree does not exist (the GPU box).  The objects below expose, from the recorded arrays,
+exactly the attributes the recommender reads from ``baybe.searchspace.SearchSpace`` / ``SubspaceDiscrete`` / ``Objective`` on this
+path; the experimental representation of the replay IS the recorded computational representation (``transform`` selects columns)."""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pandas as pd
+
+TRACES = Path(__file__).resolve().parent / "golden" / "reference_traces.npz"
+
+
+class _Discrete:
+    n_subsets = 0
+    parameters = ()
+
+    def __init__(self, comp: pd.DataFrame, mask):
+        self.exp_rep = self.comp_rep = comp
+        self.mask_keep = mask
+
+    def get_candidates(self):
+        return self.exp_rep.loc[self.mask_keep], self.comp_rep.loc[self.mask_keep]
+
+
+class ReplaySpace:
+    def __init__(self, comp: pd.DataFrame, mask, bounds, task_idx, n_tasks):
+        self.discrete = _Discrete(comp, mask)
+        self.continuous = SimpleNamespace(is_empty=True)
+        self.parameters = ()
+        self.comp_rep_columns = tuple(comp.columns)
+        self.scaling_bounds = pd.DataFrame(bounds, index=["min", "max"], columns=comp.columns)
+        self.task_idx, self.n_tasks = task_idx, n_tasks
+
+    def transform(self, df, allow_extra=False):
+        return df[list(self.comp_rep_columns)].astype(float)
+
+
+def load_traces():
+    data = np.load(TRACES)
+    return json.loads(bytes(data["meta"]).decode()), data
+
+
+def replay(recommender, calls, data, on_call=None):
+    """Feed the recorded calls of one scenario to ``recommender`` (torch's RNG state restored before each); returns
+    [(recorded labels, returned labels)]."""
+    import torch
+
+    out = []
+    frames = {}
+    for c in calls:
+        k = c["key"]
+        comp_values = data[k + "_comp"]
+        fkey = (comp_values.shape, comp_values.tobytes())
+        if fkey not in frames:  # one DataFrame object per distinct search space, as in a campaign
+            frames[fkey] = pd.DataFrame(comp_values, columns=c["columns"])
+        space = ReplaySpace(frames[fkey], data[k + "_mask"], data[k + "_bounds"], c["task_idx"], c["n_tasks"])
+        targets = tuple(SimpleNamespace(name=n, minimize=m, transformation=None) for n, m in zip(c["targets"], c["minimize"]))
+        objective = SimpleNamespace(targets=targets, is_multi_output=c["multi_output"])
+        meas = pd.DataFrame(np.hstack([data[k + "_meas_x"], data[k + "_meas_y"]]), columns=c["columns"] + c["targets"])
+        pend = pd.DataFrame(data[k + "_pend"], columns=c["columns"]) if c["has_pending"] else None
+        torch.set_rng_state(torch.from_numpy(data[k + "_rng"].copy()))
+        got = recommender.recommend(c["batch_size"], space, objective, meas, pend)
+        if on_call is not None:
+            on_call(c, got)
+        out.append((data[k + "_out"].tolist(), list(got.index)))
+    return out

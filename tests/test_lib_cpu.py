@@ -47,3 +47,6 @@ def test_product_code_never_imports_the_oracle():
     for path in (ROOT / "baybe_amd").rglob("*.py"):
         src = path.read_text()
         assert "import oracle" not in src and "from oracle" not in src, path
+        # nor the test-only stand-ins (tests/_stubs: cattrs, botorch objective wrappers) or the CPU double of the device
+        for name in ("_stubs", "_oracle_engine", "_reference", "_replay"):
+            assert name not in src, (path, name)

@@ -65,7 +65,7 @@ def test_campaign_recommend_is_a_drop_in(minimize):
     torch.manual_seed(1337)
     got = camp.recommend(3)
     assert list(got.columns) == ["x0", "x1", "x2"] and len(got) == 3
-    cand = exp.loc[~camp._meta["measured"]]
+    cand = exp  # (measured rows stay candidates: allow_recommending_already_measured resolves to True, campaign.py:254-259)
     ref_idx, _ = _oracle_greedy(space, meas, cand, 3, seed, -1.0 if minimize else 1.0)
     assert got.index.tolist() == ref_idx.tolist()
     assert camp._meta.loc[got.index, "recommended"].all()
@@ -388,7 +388,7 @@ def test_surrogate_presets_recommend_like_the_oracle(preset):
     got = camp.recommend(3)
     spec = _ospec(gp_spec.from_preset(preset, 3, np.zeros(3), np.ones(3)))
     m = go.fit_gp(spec, space.transform(meas).to_numpy(dtype=float), meas["yield"].to_numpy(dtype=float))
-    cand = exp.loc[~camp._meta["measured"]]
+    cand = exp
     ref = go.optimize_acqf_discrete_qlogei(m, space.transform(cand).to_numpy(dtype=float), 3, seed=seed)
     assert got.index.tolist() == cand.index[ref.indices].tolist()
     with pytest.raises(ValueError):

@@ -222,6 +222,11 @@ class _StubEngine:
     def factorize(self, params):
         self.calls.append(("factorize",))
 
+    def _dev(self):
+        import torch
+
+        return torch.device("cpu")
+
 
 def test_surrogate_fit_host_logic_with_a_stub_engine(monkeypatch):
     """``Surrogate.fit`` (surrogates/base.py:387-465) around the device calls: unchanged context -> no refit (the measurements are
@@ -302,7 +307,7 @@ def test_recommender_host_logic_with_a_stub_engine(monkeypatch):
     space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(2)])
     exp = space.discrete.exp_rep
     rec = HipBotorchRecommender()
-    camp = Campaign(space, SingleTargetObjective(NumericalTarget("y")), rec)
+    camp = Campaign(space, SingleTargetObjective(NumericalTarget("y")), rec, allow_recommending_already_measured=False)
     meas = exp.iloc[[0, 6, 12]].copy()
     meas["y"] = [0.1, 0.5, 0.3]
     camp.add_measurements(meas)
