@@ -50,7 +50,7 @@ CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15  # pending points per cross-covariance pass / in the handle's pending state (BBH_MAX_PENDING)
 MAX_PENDING_BIG = 63  # joint q'-batches through bbh_qlogei_pending_big: q' = 1 + pending <= 64 (qLogEI)
 MAX_OBJECTIVES = 4
-TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2, "columns": 3, "nehvi": 4, "q1": 5}  # enum bbh_timed_family
+TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2, "columns": 3, "nehvi": 4, "q1": 5, "select": 6}  # enum bbh_timed_family
 ACQ_KINDS = {"qLogEI": 0, "qEI": 1, "qPI": 2, "qSR": 3, "qUCB": 4, "qPSTD": 5,
              "PM": 10, "PSTD": 11, "UCB": 12, "EI": 13, "LogEI": 14, "PI": 15}
 
@@ -86,6 +86,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double, C.c_double,
          C.c_void_p, C.c_void_p],
+    ),
+    "bbh_qlogei_q1_topk": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p, C.c_int64, C.c_double, C.c_double,
+         C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p],
     ),
     "bbh_score_qlogei": (
         C.c_int,

@@ -577,6 +577,11 @@ static int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
   return 0;
 }
 
+int bbh_qlogei_q1_sliced(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N, const double* z_host, int64_t S,
+                         double best_f, double sign, const uint8_t* alive_dev, double* scores_dev);  // bbh_select.hip
+int bbh_qlogei_q1_rounds(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N, const double* z_host, int64_t S,
+                         double best_f, double sign, const uint8_t* alive_dev, double* scores_dev);
+
 extern "C" int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N,
                              const double* z_host, int64_t S, double best_f, double sign, const uint8_t* alive_dev,
                              double* scores_dev) {
@@ -587,6 +592,16 @@ extern "C" int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double
   }
   if (N == 0) return 0;
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  if (h->q1_sliced) {  // sample-sliced form (bbh_select.hip); 1 = does not apply (S beyond its LDS tables)
+    const int rc = bbh_qlogei_q1_sliced(h, mean_dev, var_dev, N, z_host, S, best_f, sign, alive_dev, scores_dev);
+    if (rc <= 0) return rc;
+  }
+  return bbh_qlogei_q1_rounds(h, mean_dev, var_dev, N, z_host, S, best_f, sign, alive_dev, scores_dev);
+}
+
+// one thread per candidate over all S samples (any S; A/B partner of the sliced form: BBH_Q1_SLICED=0)
+int bbh_qlogei_q1_rounds(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N, const double* z_host, int64_t S,
+                         double best_f, double sign, const uint8_t* alive_dev, double* scores_dev) {
   int rc = bbh_upload_z(h, z_host, (size_t)S);
   if (rc) return rc;
   bbh_timed_scope timed(h, BBH_TIMED_Q1);
@@ -798,8 +813,8 @@ extern "C" int bbh_qlogei_pending_big(bbh_handle* h, const double* mean_dev, con
   return 0;
 }
 
-extern "C" int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,
-                          int64_t* best_idx_host) {
+int bbh_argmax_rounds(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,
+                      int64_t* best_idx_host) {
   if (!h) return -1;
   if (!scores_dev || N < 1 || !best_val_host || !best_idx_host) {
     h->err = "bbh_argmax: bad arguments";
@@ -902,8 +917,9 @@ __global__ __launch_bounds__(256) void bbh_topk_stage2(double* __restrict__ pv, 
   }
 }
 
-// k best scores on the device: *vals_dev / *idx_dev point into the handle's workspace (valid until its next use)
-int bbh_topk_device(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double** vals_dev, int64_t** idx_dev) {
+// k best scores on the device by k rounds of workgroup argmax (the form before bbh_select.hip; BBH_SELECT=0 routes bbh_topk /
+// bbh_argmax here for A/B): *vals_dev / *idx_dev point into the handle's workspace (valid until its next use)
+int bbh_topk_rounds_device(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double** vals_dev, int64_t** idx_dev) {
   if (!scores_dev || N < 1 || k < 1 || k > N || k > TOPK_MAXK) {
     h->err = "bbh_topk: bad arguments (1 <= k <= min(N, 64))";
     return -1;
@@ -925,8 +941,8 @@ int bbh_topk_device(bbh_handle* h, const double* scores_dev, int64_t N, int64_t 
   return 0;
 }
 
-extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
-                        int64_t* idx_host) {
+int bbh_topk_rounds(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
+                    int64_t* idx_host) {
   if (!h) return -1;
   if (!vals_host || !idx_host) {
     h->err = "bbh_topk: bad arguments (1 <= k <= min(N, 64))";
@@ -934,7 +950,7 @@ extern "C" int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int6
   }
   double* outv = nullptr;
   int64_t* outi = nullptr;
-  int rc = bbh_topk_device(h, scores_dev, N, k, &outv, &outi);
+  int rc = bbh_topk_rounds_device(h, scores_dev, N, k, &outv, &outi);
   if (rc) return rc;
   BBH_HIP_TRY(h, hipMemcpyAsync(vals_host, outv, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
   BBH_HIP_TRY(h, hipMemcpyAsync(idx_host, outi, sizeof(int64_t) * k, hipMemcpyDeviceToHost, h->stream));

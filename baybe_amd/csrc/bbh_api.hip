@@ -40,6 +40,8 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_COOP")) h->coop_mode = atoi(e);
   if (const char* e = getenv("BBH_POTRF_REG")) h->potrf_register_form = (e[0] != '0');
   if (const char* e = getenv("BBH_FIT_OVERLAP")) h->fit_overlap = (e[0] != '0');
+  if (const char* e = getenv("BBH_Q1_SLICED")) h->q1_sliced = (e[0] != '0');
+  if (const char* e = getenv("BBH_SELECT")) h->select_on = (e[0] != '0');
   *out = h;
   return 0;
 }
@@ -56,6 +58,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
     hipEventDestroy(sp.e1);
   }
   bbh_comm_destroy(h);
+  bbh_select_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
   if (h->fit_stream) {

@@ -280,6 +280,9 @@ struct bbh_handle {
   double* d_red = nullptr;        // argmax partials
   int64_t* d_redi = nullptr;
   void* comm_state = nullptr;     // RCCL communicator + exchange buffers (bbh_comm.hip), null until bbh_comm_init
+  void* select_state = nullptr;   // chunk keys, result block and base-sample tables of the selection kernels (bbh_select.hip)
+  bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
+  bool select_on = true;          // env BBH_SELECT=0: top-k / argmax by k rounds of workgroup argmax (A/B)
   // timing
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -349,4 +352,5 @@ int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ld
                        double* var_dev);
 
 int bbh_ensure_ws(bbh_handle* h, size_t bytes);
+void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
 void bbh_free_model_public(bbh_handle* h);

@@ -140,6 +140,28 @@ class RowShard:
         g = self._all_gather(self._payload_to_backend(buf.reshape(-1), device)).cpu().numpy().reshape(-1, 2)
         return self.merge_topk(g, k)
 
+    def global_topk_rows(self, vals: np.ndarray, lidx: np.ndarray, k: int, X_local, d: int):
+        """Global top-k WITH the comp-rep rows of its members: every rank contributes its local top-k as (score, global index,
+        row [d]) - one all-gather of k (2 + d) doubles per rank - and every rank returns the same (values [m], global indices [m],
+        rows [m, d]), m <= k, ties to the lower global index.  Used once per greedy batch, for the speculative columns."""
+        buf = np.zeros((k, 2 + d))
+        buf[:, 0], buf[:, 1] = -math.inf, -1.0
+        m = min(k, len(vals))
+        if m:
+            import torch
+
+            li = np.asarray(lidx[:m], dtype=np.int64)
+            ok = li >= 0
+            buf[:m, 0] = np.where(ok, vals[:m], -math.inf)
+            buf[:m, 1] = np.where(ok, li + self.start, -1)
+            if ok.any():
+                rows = X_local[torch.as_tensor(li[ok], device=X_local.device), :d].cpu().numpy()  # one D2H of <= k rows
+                buf[:m][ok, 2:] = rows
+        g = self._all_gather(self._payload_to_backend(buf.reshape(-1), X_local.device)).cpu().numpy().reshape(-1, 2 + d)
+        g = g[g[:, 1] >= 0]
+        order = np.lexsort((g[:, 1], -g[:, 0]))[:k]
+        return g[order, 0], g[order, 1].astype(np.int64), g[order, 2:].copy()
+
     @staticmethod
     def merge_topk(gathered: np.ndarray, k: int):
         """Rows (score, global index) of all ranks -> the k best, ties to the lower global index."""

@@ -462,13 +462,16 @@ class HipGP:
             X = X.contiguous()
         return X
 
-    def posterior(self, X, unfused: bool = False):
-        """Marginal posterior (mean, var) of N candidates as device tensors [N] (fp64)."""
+    def posterior(self, X, unfused: bool = False, out=None):
+        """Marginal posterior (mean, var) of N candidates as device tensors [N] (fp64); ``out`` = (mean, var) tensors to write into."""
         torch = self._torch()
         X = self._as_dev(X)
         N = X.shape[0]
-        mean = torch.empty(N, dtype=torch.float64, device=X.device)
-        var = torch.empty(N, dtype=torch.float64, device=X.device)
+        if out is not None:
+            mean, var = out
+        else:
+            mean = torch.empty(N, dtype=torch.float64, device=X.device)
+            var = torch.empty(N, dtype=torch.float64, device=X.device)
         fn = self._lib.bbh_posterior_unfused if unfused else self._lib.bbh_posterior
         self._check(fn(self._h, X.data_ptr(), N, X.stride(0), mean.data_ptr(), var.data_ptr()), "bbh_posterior")
         return mean, var
@@ -523,6 +526,26 @@ class HipGP:
             "bbh_qlogei_q1",
         )
         return scores
+
+    def qlogei_topk(self, mean, var, z: np.ndarray, best_f: float, sign: float = 1.0, k: int = 1, alive=None, scores=None):
+        """q' = 1 qLogEI scores AND their k best in one call (``bbh_qlogei_q1_topk``: scores kernel, one selection kernel, results
+        in host-mapped memory, one synchronisation): (scores [N] device tensor, values [k], indices [k]); entries beyond the
+        number of scored candidates are (-inf, -1).  ``scores``: an fp64 device tensor [N] to write into (a step loop's buffer)."""
+        torch = self._torch()
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1)
+        N = mean.shape[0]
+        if scores is None:
+            scores = torch.empty(N, dtype=torch.float64, device=mean.device)
+        k = int(min(k, N))
+        vals, idx = np.empty(k), np.empty(k, dtype=np.int64)
+        self._check(
+            self._lib.bbh_qlogei_q1_topk(
+                self._h, mean.data_ptr(), var.data_ptr(), N, _dp(z), z.shape[0], float(best_f), float(sign),
+                alive.data_ptr() if alive is not None else None, scores.data_ptr(), k, _dp(vals), idx.ctypes.data_as(_lib.c_int64_p),
+            ),
+            "bbh_qlogei_q1_topk",
+        )
+        return scores, vals, idx
 
     def mc_acq(self, kind: str, mean, var, z: np.ndarray, best_f: float = 0.0, sign: float = 1.0, beta: float = 0.2,
                alive=None, cross=None):
@@ -770,6 +793,7 @@ class HipGP:
         # step whose pending points are all among them gathers its columns (bit-identical values: a column is an independent
         # dot product) instead of launching its own pass, any other step falls back to its own pass.
         spec_rows, spec_pos, cross_spec, big_cross, spec_stats = None, {}, None, None, None
+        first_vals = first_top = None
         b0 = base.shape[0]
         for _step in range(q):
             pend = np.vstack([base] + chosen_rows) if chosen_rows else base
@@ -779,7 +803,12 @@ class HipGP:
                 if mean is None:  # first step: posterior of every candidate, cached for the later steps
                     self.set_pending(None)
                     mean, var = self.posterior(X)
-                scores = self.mc_acq(kind, mean, var, z[:, 0], best_f, sign, beta, alive)
+                if kind == "qLogEI" and shard is None and N > 0:
+                    # scores, the winner and (for later steps) the head of the ranking in ONE call
+                    m_spec = min(MAX_PENDING - b0, N, 4 * q) if (q > 1 and speculate and N > 1 and b0 < MAX_PENDING) else 1
+                    scores, first_vals, first_top = self.qlogei_topk(mean, var, z[:, 0], best_f, sign, max(1, m_spec), alive)
+                else:
+                    scores = self.mc_acq(kind, mean, var, z[:, 0], best_f, sign, beta, alive)
             else:
                 if mean is None:
                     mean, var = self.posterior(X)
@@ -817,18 +846,37 @@ class HipGP:
                         scores = self.mc_acq(kind, mean, var, z, best_f, sign, beta, alive, cross=cross)
                     if p == MAX_PENDING:
                         big_cross = cross  # the next step continues from these columns
-            if _step == 0 and q > 1 and shard is None and speculate and N > 1 and b0 < MAX_PENDING:
-                m_spec = min(MAX_PENDING - b0, N, 4 * q)
-                tv, top = self.topk(scores, m_spec)
-                top = [int(t) for t, v in zip(top, tv) if t >= 0 and v > -math.inf]  # live candidates only
+            step0_global = None
+            if _step == 0 and q > 1 and speculate and b0 < MAX_PENDING and (N > 1 or shard is not None):
+                if shard is None:
+                    m_spec = min(MAX_PENDING - b0, N, 4 * q)
+                    tv, top = (first_vals, first_top) if first_top is not None and len(first_top) == m_spec else self.topk(scores, m_spec)
+                    keep = [j for j, (t, v) in enumerate(zip(top, tv)) if t >= 0 and v > -math.inf]  # live candidates only
+                    top = [int(top[j]) for j in keep]
+                    spec_rows = X[torch.as_tensor(top, device=X.device), :d].cpu().numpy() if top else None
+                else:
+                    # row shards: the head of the GLOBAL ranking with its rows - one all-gather of each rank's local head; its
+                    # first entry is this step's winner, so the step needs no collective of its own
+                    m_spec = min(MAX_PENDING - b0, shard.N_total, 4 * q)
+                    lv, li = self.topk(scores, min(m_spec, N)) if N > 0 else (np.empty(0), np.empty(0, dtype=np.int64))
+                    tv, top, rows = shard.global_topk_rows(lv, li, m_spec, X, d)
+                    if len(top):
+                        step0_global = (float(tv[0]), int(top[0]), rows[0].copy())
+                    keep = [j for j, v in enumerate(tv) if v > -math.inf]
+                    top = [int(top[j]) for j in keep]
+                    spec_rows = rows[keep] if keep else None
                 if top:
-                    spec_rows = X[torch.as_tensor(top, device=X.device), :d].cpu().numpy()
                     spec_stats = self.set_pending(np.vstack([base, spec_rows]))  # (mean, cov) of base + speculative points
-                    cross_spec = self.cross_cov(X)
+                    cross_spec = self.cross_cov(X) if N > 0 else torch.empty((0, b0 + len(top)), dtype=torch.float64, device=X.device)
                     spec_pos = {ix: b0 + j for j, ix in enumerate(top)}
             if _step + 1 < q:  # host-side Sobol scrambling of the next step overlaps the device work of this one
                 z_next = get_z(2 + p)
-            if shard is not None and shard.rccl_bound(self):  # payload built on the device, one ncclAllGather
+            if step0_global is not None:  # (sharded first step: the winner came with the speculative head)
+                val, gidx, row = step0_global
+                if shard.owns(gidx):
+                    alive[shard.to_local(gidx)] = 0
+                idx = gidx
+            elif shard is not None and shard.rccl_bound(self):  # payload built on the device, one ncclAllGather
                 val, gidx, row = self.allgather_argmax(scores, shard.start, X)
                 if shard.owns(gidx):
                     alive[shard.to_local(gidx)] = 0
@@ -840,7 +888,10 @@ class HipGP:
                     alive[shard.to_local(gidx)] = 0
                 idx = gidx
             else:
-                val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
+                if _step == 0 and first_top is not None:
+                    val, idx = float(first_vals[0]), int(first_top[0])
+                else:
+                    val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
                 row = X[idx, :d].cpu().numpy()
                 alive[idx] = 0
             indices.append(int(idx))

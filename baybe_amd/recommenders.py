@@ -99,25 +99,27 @@ def _check_objective(objective, acqf) -> None:
     single-output in the reference (scalarised, optimised with qLogEI, ``objectives/desirability.py:222-265``) -
     treating it as Pareto because it has several targets would answer a different question."""
     kind = type(objective).__name__
-    if kind == "DesirabilityObjective" or (len(objective.targets) > 1 and not _is_multi_output(objective)):
+    from baybe_amd.surrogates import _target_sign, modeled_quantities
+
+    quantities = modeled_quantities(objective)
+    if len(quantities) > 1 and not _is_multi_output(objective):
+        # one model per target + a per-sample scalarisation objective (objectives/desirability.py:229-265): not a device path
         raise IncompatibilityError(
-            f"Objectives of type '{kind}' scalarise several targets; the HIP path supports single-target and Pareto "
-            f"objectives. Use BotorchRecommender, or 'DesirabilityObjective(as_pre_transformation=True)' upstream of a "
-            f"single-target objective."
+            f"Objectives of type '{kind}' scalarise several modeled targets per posterior sample; the HIP path supports "
+            f"single-target and Pareto objectives and 'DesirabilityObjective(as_pre_transformation=True)', which scalarises the "
+            f"measurements before fitting. Use BotorchRecommender otherwise."
         )
     if _is_multi_output(objective) and not acqf.supports_multi_output:
         raise IncompatibleAcquisitionFunctionError(
             f"You attempted to use a single-output acquisition function in a "
-            f"{len(objective.targets)}-target multi-output context."
+            f"{len(quantities)}-target multi-output context."
         )
     if not _is_multi_output(objective) and acqf.supports_multi_output:
         raise IncompatibleAcquisitionFunctionError(
             f"The acquisition function '{type(acqf).__name__}' needs a multi-output objective, but a single-target "
             f"objective was given."
         )
-    from baybe_amd.surrogates import _target_sign
-
-    for target in objective.targets:  # identity transformations (+ minimisation) only: raises IncompatibilityError
+    for target in quantities:  # identity transformations (+ minimisation) only: raises IncompatibilityError
         _target_sign(target)
 
 
@@ -434,17 +436,31 @@ class HipRecommenderImpl:
             if len(pend):
                 raise IncompatibleAcquisitionFunctionError("Analytic acquisition functions score single points only.")
             return float(self._analytic_scores(eng, acqf, mean, var, surrogate.sign).cpu().numpy()[0])
+        s = self._mc_scores_with_pending(eng, acqf, comp[:1], mean, var, pend, seed, surrogate.sign)
+        return float(s.cpu().numpy()[0])
+
+    def _mc_scores_with_pending(self, eng, acqf, comp, mean, var, pend, seed, sign):
+        """MC acquisition values of the t-batches [x_i ; pend] for the read-back APIs.  Up to 15 pending rows ride on the handle's
+        pending state; beyond that (qLogEI only, up to 63 - the same limit ``_check_batch_size`` admits for recommend()) the
+        columns come from ``cross_cov_many`` and the joint kernel takes the pending statistics explicitly, as in the greedy loop."""
         beta = getattr(acqf, "beta", 0.2)
         if len(pend) == 0:
             z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]
-            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta)
+            return eng.mc_acq(acqf.kind, mean, var, z, self._best_f, sign, beta)
+        z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(pend), seed)
+        if len(pend) > _lib.MAX_PENDING:
+            if acqf.kind != "qLogEI" or len(pend) > _lib.MAX_PENDING_BIG:
+                raise IncompatibilityError(
+                    f"{len(pend)} pending / batch rows exceed the largest joint q-batch of the HIP kernels for '{type(acqf).__name__}' "
+                    f"({_lib.MAX_PENDING_BIG + 1} points for qLogEI, {_lib.MAX_PENDING + 1} otherwise).")
+            cross = eng.cross_cov_many(comp, pend)
+            s = eng.qlogei_pending_big(mean, var, cross, pend, z, self._best_f, sign)
         else:
             eng.set_pending(pend)
-            cross = eng.cross_cov(comp[:1])
-            z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(pend), seed)
-            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta, cross=cross)
-            eng.set_pending(None)
-        return float(s.cpu().numpy()[0])
+            cross = eng.cross_cov(comp)
+            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, sign, beta, cross=cross)
+        eng.set_pending(None)
+        return s
 
     def acquisition_values(self, candidates: pd.DataFrame, searchspace, objective, measurements,
                            pending_experiments=None, acquisition_function=None) -> pd.Series:
@@ -460,17 +476,8 @@ class HipRecommenderImpl:
         if acqf.is_analytic:
             s = self._analytic_scores(eng, acqf, mean, var, surrogate.sign)
             return pd.Series(s.cpu().numpy(), index=candidates.index)
-        seed = self._sampler_seed()
-        beta = getattr(acqf, "beta", 0.2)
-        if self._pending_comp is None:
-            z = sobol_normal_base_samples(acqf.n_mc_samples, 1, seed)[:, 0]
-            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta)
-        else:
-            eng.set_pending(self._pending_comp)
-            cross = eng.cross_cov(comp)
-            z = sobol_normal_base_samples(acqf.n_mc_samples, 1 + len(self._pending_comp), seed)
-            s = eng.mc_acq(acqf.kind, mean, var, z, self._best_f, surrogate.sign, beta, cross=cross)
-            eng.set_pending(None)
+        pend = self._pending_comp if self._pending_comp is not None else np.zeros((0, comp.shape[1]))
+        s = self._mc_scores_with_pending(eng, acqf, comp, mean, var, pend, self._sampler_seed(), surrogate.sign)
         return pd.Series(s.cpu().numpy(), index=candidates.index)
 
     def joint_acquisition_value(self, candidates: pd.DataFrame, searchspace, objective, measurements,

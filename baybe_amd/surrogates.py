@@ -44,18 +44,21 @@ def _frame_hash(df: pd.DataFrame):
         import joblib
 
         return joblib.hash(df)
+    # every part is an xxh3 digest or a plain integer - no ``hash()`` of strings, which is salted per process (PYTHONHASHSEED): the
+    # key of a pickled surrogate has to match in the process that loads it, or its first fit there would needlessly retrain
     dtypes = tuple(str(t) for t in df.dtypes)
-    parts = [df.shape, tuple(map(str, df.columns)), dtypes]
+    head = xxhash.xxh3_64_intdigest(repr((tuple(map(str, df.columns)), dtypes)).encode())
+    parts = [df.shape[0], df.shape[1], head]
     if df.size and len(set(dtypes)) == 1 and dtypes[0] != "object":  # one numeric block: a single buffer
         parts.append(xxhash.xxh3_64_intdigest(memoryview(np.ascontiguousarray(df.to_numpy())).cast("B")))
-        return hash(tuple(parts))
+        return tuple(parts)
     for j in range(df.shape[1]):
         a = df.iloc[:, j].to_numpy()
-        if a.dtype == object:
-            parts.append(hash(tuple(a.tolist())))
+        if a.dtype == object:  # labels (strings), or anything else with a stable repr; unhashable values are fine here
+            parts.append(xxhash.xxh3_64_intdigest("\x1f".join(map(repr, a.tolist())).encode()))
         elif a.size:
             parts.append(xxhash.xxh3_64_intdigest(memoryview(np.ascontiguousarray(a)).cast("B")))
-    return hash(tuple(parts))
+    return tuple(parts)
 
 
 def _has_substance_parameter(searchspace) -> bool:
@@ -107,6 +110,30 @@ def _target_sign(target) -> float:
     return -1.0 if getattr(target, "minimize", False) else 1.0
 
 
+def modeled_quantities(objective) -> tuple:
+    """The quantities the surrogate models (``Objective._modeled_quantities``, objectives/base.py:55-63): the targets themselves,
+    except for ``DesirabilityObjective(as_pre_transformation=True)``, whose ONE modeled quantity is the desirability score computed
+    from all targets before fitting (objectives/desirability.py:155-172)."""
+    mq = getattr(objective, "_modeled_quantities", None)
+    return tuple(mq) if mq is not None else tuple(objective.targets)
+
+
+def pre_transformed(objective, measurements: pd.DataFrame) -> pd.DataFrame:
+    """``objective._pre_transform(measurements, allow_extra=True)`` (surrogates/base.py:454): the columns the model is trained on, named
+    after the modeled quantities.  The default pipes the target columns through (objectives/base.py:161-176); the desirability
+    objective scalarises them on the host (objectives/desirability.py:322-346) - after which the path IS the single-target one."""
+    fn = getattr(objective, "_pre_transform", None)
+    return measurements if fn is None else fn(measurements, allow_extra=True)
+
+
+def _objective_key(objective) -> tuple:
+    """What of the objective the trained model depends on (part of the fit-cache key)."""
+    targets = tuple((t.name, bool(getattr(t, "minimize", False)), repr(getattr(t, "transformation", None)))
+                    for t in objective.targets)
+    return (type(objective).__name__, targets, getattr(objective, "as_pre_transformation", None),
+            repr(getattr(objective, "weights", None)), str(getattr(objective, "scalarizer", None)))
+
+
 class HipGPSurrogateImpl:
     """Behaviour of the GP surrogate evaluated on an MI355X (no fields: see the module docstring)."""
 
@@ -124,7 +151,8 @@ class HipGPSurrogateImpl:
 
     # ---- SurrogateProtocol ---------------------------------------------------------------------
     def fit(self, searchspace, objective, measurements: pd.DataFrame) -> None:
-        n_targets = len(objective.targets)
+        quantities = modeled_quantities(objective)
+        n_targets = len(quantities)
         if n_targets > 1 and not self.supports_multi_output and self._target_index is None:
             raise IncompatibleSurrogateError(
                 f"You attempted to train a single-output surrogate in a {n_targets}-target multi-output "
@@ -138,7 +166,7 @@ class HipGPSurrogateImpl:
             np.asarray(searchspace.scaling_bounds.to_numpy(), dtype=np.float64).tobytes(),
             getattr(searchspace, "task_idx", None),
             int(getattr(searchspace, "n_tasks", 1)),
-            tuple((t.name, bool(getattr(t, "minimize", False))) for t in objective.targets),
+            _objective_key(objective),
             self._target_index,
             self.preset,
             _frame_hash(measurements),
@@ -146,17 +174,22 @@ class HipGPSurrogateImpl:
         if self._engine is not None and mhash == self._measurements_hash:
             self._searchspace, self._objective = searchspace, objective
             return
-        target = objective.targets[self._tix]
-        names = [t.name for t in objective.targets]
-        if pd.isna(measurements[target.name].to_numpy()).any():  # (on the column's array: the frame-level reduction costs 0.6 ms)
+        target = quantities[self._tix]
+        # the raw target columns this model's quantity is computed from (all of them for a pre-transformed desirability score)
+        needs = getattr(objective, "_model_quantities_to_target_names", None)
+        names = list(needs[target.name]) if needs is not None else [target.name]
+        missing = np.zeros(len(measurements), dtype=bool)
+        for nm in names:  # (on the columns' arrays: the frame-level reduction costs 0.6 ms)
+            missing |= pd.isna(measurements[nm].to_numpy())
+        if missing.any():
             if n_targets == 1:
-                raise ValueError(f"Missing target values are not supported: {names}")  # handle_missing_values
-            measurements = measurements.dropna(subset=[target.name])  # composite.py:101-123 per-target filter
+                raise ValueError(f"Missing target values are not supported: {[t.name for t in objective.targets]}")  # handle_missing_values
+            measurements = measurements.loc[~missing]  # composite.py:101-123 per-target filter
         from baybe_amd.engine import HipGP
 
         comp = searchspace.transform(measurements, allow_extra=True)
         train_x = np.ascontiguousarray(comp.to_numpy(dtype=np.float64))
-        train_y = measurements[target.name].to_numpy(dtype=np.float64)
+        train_y = pre_transformed(objective, measurements)[target.name].to_numpy(dtype=np.float64)  # surrogates/base.py:454
         bounds = np.asarray(searchspace.scaling_bounds.to_numpy(), dtype=np.float64)
         task_idx = getattr(searchspace, "task_idx", None)
         n_tasks = int(getattr(searchspace, "n_tasks", 1))
@@ -227,7 +260,7 @@ class HipGPSurrogateImpl:
 
     @property
     def sign(self) -> float:
-        return _target_sign(self._objective.targets[self._tix])
+        return _target_sign(modeled_quantities(self._objective)[self._tix])
 
     def posterior_mean_var(self, candidates_comp):
         """(mean, var) device tensors [N] for comp-rep candidates (numpy or torch)."""
@@ -245,7 +278,7 @@ class HipGPSurrogateImpl:
         comp = self._searchspace.transform(candidates, allow_extra=True)
         mean, var = eng.posterior(np.ascontiguousarray(comp.to_numpy(dtype=np.float64)))
         mean, var = mean.cpu().numpy(), np.maximum(var.cpu().numpy(), 0.0)
-        name = self._objective.targets[self._tix].name
+        name = modeled_quantities(self._objective)[self._tix].name  # (``_modeled_quantity_names``, surrogates/base.py:345-352)
         out = pd.DataFrame(index=candidates.index)
         for s in stats:
             if isinstance(s, float):
@@ -315,14 +348,13 @@ class HipCompositeImpl:
     is_available = _availability_property()
 
     def fit(self, searchspace, objective, measurements: pd.DataFrame) -> None:
-        m = len(objective.targets)
+        m = len(modeled_quantities(objective))
         if len(self._models) != m:
+            # one copy of the template per target with EVERY constructor argument carried over (the reference deep-copies the
+            # template, surrogates/composite.py:54-60): kernel / kernel_or_factory / fit_criterion_or_factory / preset / ...
             t = self.template
-            self._models = [
-                type(t)(kernel=t.kernel, use_outputscale=t.use_outputscale, preset=t.preset, device=t.device,
-                        warm_start=t.warm_start, fixed_hyperparameters=_per_target(t.fixed_hyperparameters, i), target_index=i)
-                for i in range(m)
-            ]
+            self._models = [attrs.evolve(t, target_index=i, fixed_hyperparameters=_per_target(t.fixed_hyperparameters, i))
+                            for i in range(m)]
         for model in self._models:
             model.fit(searchspace, objective, measurements)
         self._objective = objective

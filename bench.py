@@ -71,6 +71,72 @@ def synth_pareto_targets(Xt: np.ndarray):
     return [fo + 0.05 * np.random.default_rng(30 + o).standard_normal(len(Xt)) for o, fo in enumerate(f)]
 
 
+class _BenchSpace:
+    """What ``HipBotorchRecommender.recommend`` reads from ``baybe.searchspace.SearchSpace`` for a purely discrete, all-numerical
+    space (attribute names of searchspace/core.py, searchspace/discrete.py): the N x d grid is both representations."""
+
+    class _Discrete:
+        n_subsets, parameters = 0, ()
+
+        def __init__(self, frame):
+            self.exp_rep = self.comp_rep = frame
+            self.mask_keep = np.ones(len(frame), dtype=bool)
+
+        def get_candidates(self):
+            return self.exp_rep.loc[self.mask_keep], self.comp_rep.loc[self.mask_keep]
+
+    class _Continuous:
+        is_empty = True
+
+    def __init__(self, X):
+        import pandas as pd
+
+        cols = [f"x{j}" for j in range(X.shape[1])]
+        self.discrete, self.continuous, self.parameters = self._Discrete(pd.DataFrame(X, columns=cols)), self._Continuous(), ()
+        self.comp_rep_columns, self.task_idx, self.n_tasks = tuple(cols), None, 1
+        self.scaling_bounds = pd.DataFrame([np.zeros(len(cols)), np.ones(len(cols))], index=["min", "max"], columns=cols)
+
+    def transform(self, df, allow_extra=False):
+        return df[list(self.comp_rep_columns)]
+
+
+def time_recommend_e2e(X, Xt, y, d, batch):
+    """``recommend(batch)`` of the plug-in recommender on the bench's own grid and measurements, wall clock in ms: the first call
+    (comp rep hashed and uploaded, hyper-parameters fitted), a call with unchanged measurements (resident matrix, cached fit: the
+    hot path plus the pandas boundary) and a call after one more measurement (refit)."""
+    import pandas as pd
+    import torch
+    from types import SimpleNamespace
+
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    space = _BenchSpace(X)
+    cols = list(space.comp_rep_columns)
+    meas = pd.DataFrame(Xt, columns=cols)
+    meas["y"] = y
+    objective = SimpleNamespace(targets=(SimpleNamespace(name="y", minimize=False, transformation=None),), is_multi_output=False)
+    rec = HipBotorchRecommender()
+    out = {}
+
+    def timed(label, m):
+        torch.manual_seed(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = rec.recommend(batch, space, objective, m)
+        torch.cuda.synchronize()
+        out[label] = (time.perf_counter() - t0) * 1e3
+        return got
+
+    timed("first_call_upload_and_fit", meas)
+    timed("unchanged_measurements", meas)
+    got = timed("unchanged_measurements_again", meas)
+    more = pd.concat([meas, got.assign(y=float(np.mean(y)))], ignore_index=True)
+    timed("after_new_measurements_refit", more)
+    out["batch_size"] = batch
+    out["rows"], out["n_train"] = int(X.shape[0]), int(len(y))
+    return out
+
+
 CONFIGS = {  # BASELINE.json configs -> (rows per GPU, d, n_train); the default is the configuration the metric is quoted on
     "cfg3": (1_000_000, 20, 512),
     "cfg2": (100_000, 15, 256),
@@ -96,6 +162,8 @@ def parse_args(argv=None):
                     help="time a device hyper-parameter fit outside the timed region (extra.fit_ms); default: on for single-task "
                          "configurations on one GPU (second of two fits: the first pays the allocations), --fit 0 switches it off")
     ap.add_argument("--greedy", type=int, default=5, help="also time a greedy batch of this size (extra; 0 = skip)")
+    ap.add_argument("--e2e", type=int, default=-1, help="time recommend() through the plug-in surface (extra.recommend_e2e_ms); default: on "
+                                                        "for the single-target configurations on one GPU, --e2e 0 switches it off")
     args = ap.parse_args(argv)
     rows, d, n = CONFIGS[args.config]
     args.rows = rows if args.rows is None else args.rows
@@ -251,22 +319,32 @@ def run(args):
         if not use_rccl:
             shard.use_rccl = False  # (a rank whose own set-up succeeded must not take the library path alone)
 
-    def step():
-        # two kernels: measured 1.5 % faster than the single fused posterior+qLogEI kernel
-        # (scripts/gpu_ab_fused_acq.py: 5.64 vs 5.73 ms/step): the epilogue's VALU work costs the shared fp64
-        # pipe the same either way, but a separate launch runs it at full occupancy and leaves the fused
-        # kernel's LDS to the kernel-value cache
-        if nehvi is not None:  # extended-model variance pass + S conditional means per target, then the cell kernel
-            scores = nehvi.score(Xd)
-            return gp.topk(scores, TOPK)
-        mean, var = gp.posterior(Xd)
-        scores = gp.qlogei(mean, var, z, best_f, 1.0)
-        if use_rccl:
-            return gp.allgather_topk(scores, shard.start, TOPK)
-        vals, idx = gp.topk(scores, TOPK)
-        if shard is not None:
-            vals, idx = shard.global_topk(vals, idx, TOPK, device=Xd.device)
-        return vals, idx
+    def make_step(Xs, row_start):
+        """One selection step over the resident rows ``Xs`` (global rows ``row_start ...``): three launches - posterior, qLogEI with
+        sample slices (which leaves the chunk keys), selection - whose k results land in host-mapped memory; output buffers are the
+        step loop's own."""
+        bufs = [torch.empty(Xs.shape[0], dtype=torch.float64, device=Xs.device) for _ in range(3)]
+
+        def step():
+            # posterior and qLogEI as two kernels: measured 1.5 % faster than the single fused posterior+qLogEI kernel
+            # (scripts/gpu_ab_fused_acq.py: 5.64 vs 5.73 ms/step): the epilogue's VALU work costs the shared fp64 pipe the same
+            # either way, but a separate launch runs it at full occupancy and leaves the fused kernel's LDS to the kernel-value cache
+            if nehvi is not None:  # extended-model variance pass + S conditional means per target, then the cell kernel
+                scores = nehvi.score(Xs)
+                return gp.topk(scores, TOPK)
+            mean, var = gp.posterior(Xs, out=(bufs[0], bufs[1]))
+            if shard is None:
+                _, vals, idx = gp.qlogei_topk(mean, var, z, best_f, 1.0, TOPK, scores=bufs[2])
+                return vals, idx
+            scores = gp.qlogei(mean, var, z, best_f, 1.0)
+            if use_rccl:
+                return gp.allgather_topk(scores, row_start, TOPK)
+            vals, idx = gp.topk(scores, TOPK)
+            return shard.global_topk(vals, idx, TOPK, device=Xs.device)
+
+        return step
+
+    step = make_step(Xd, shard.start if shard is not None else 0)
 
     def fence():
         torch.cuda.synchronize()
@@ -282,7 +360,7 @@ def run(args):
         step()
     for _ in range(args.warmup):
         step()
-    FAMILIES = ("posterior", "cross", "pending", "columns", "nehvi", "q1")
+    FAMILIES = ("posterior", "cross", "pending", "columns", "nehvi", "q1", "select")
     for g in timed_engines:
         g.timing(True)
         for fam in FAMILIES:
@@ -305,6 +383,7 @@ def run(args):
         g.timing(False)
     fused_ms, fused_launches = fam_step["posterior"]
     extra["ms_per_step_median"] = float(np.median(step_ms))
+    extra["ms_per_step_mean"] = float(np.mean(step_ms))
     extra["device_ms_per_step"] = {fam: v[0] / args.steps for fam, v in fam_step.items() if v[1]}
     form = timed_engines[0].posterior_kernel_form()
     if dist_on:
@@ -312,8 +391,41 @@ def run(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    ms_per_step = dt / args.steps * 1e3
+    # value: the K timed steps against the fenced wall clock (max over ranks), as the contract asks; ms_per_step: the median step
+    #  - the mean, which is dt / K, sits in extra next to it
+    ms_per_step = extra["ms_per_step_median"]
+    if dist_on:
+        mt = torch.tensor([ms_per_step], dtype=torch.float64, device="cpu" if single_dev else "cuda")
+        dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+        ms_per_step = float(mt.item())
     value = total_rows * args.steps / dt
+
+    # ---- extra: the strong-scaled form of BASELINE configs[2] (a 1e6-row grid split over the ranks) next to the weak line ----------
+    if dist_on and cfg == "cfg3" and not args.strong and nehvi is None:
+        g_rows = CONFIGS["cfg3"][0]
+        a_s, b_s = shard_bounds(g_rows, rank, world)
+        Xs = torch.from_numpy(np.ascontiguousarray(synth_problem(g_rows, d, n, 0)[0][a_s:b_s])).cuda()
+        keep = (shard.start, shard.stop)
+        shard.start, shard.stop = a_s, b_s
+        sstep = make_step(Xs, a_s)
+        for _ in range(3):
+            sstep()
+        fence()
+        ts_ms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            svals, sidx = sstep()
+            ts_ms.append((time.perf_counter() - ts) * 1e3)
+        fence()
+        sdt = time.perf_counter() - t0
+        tt = torch.tensor([sdt, float(np.median(ts_ms))], dtype=torch.float64, device="cpu" if single_dev else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        shard.start, shard.stop = keep
+        extra["strong_cfg3"] = {"global_rows": g_rows, "rows_per_rank": b_s - a_s, "ms_per_step": float(tt[1].item()),
+                                "value": g_rows * args.steps / float(tt[0].item()), "unit": "candidates/s", "scaling": "strong",
+                                "top_indices": [int(i) for i in sidx]}
+        del Xs
 
     # ---- extra: one greedy batch (optimize_acqf_discrete, q = --greedy) on the same shard, timed per kernel family ----
     pending_roofline = None
@@ -354,6 +466,10 @@ def run(args):
                 "launches": p_n, "total_ms": p_ms,
                 "hbm_bytes_per_candidate_algorithmic": sum(8 * (2 + (Q - 1)) + 8 for Q in range(2, args.greedy + 1)),
             }
+
+    # ---- extra: end-to-end recommend() through the plug-in surface ("report additionally ... end-to-end recommend()") ----
+    if (args.e2e == 1 or (args.e2e < 0 and world == 1 and cfg in ("cfg3", "cfg2"))) and nehvi is None and not dist_on:
+        extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, y, d, args.greedy if args.greedy > 0 else 5)
 
     # ---- roofline of the dominant kernel, algorithmic flops ----
     def traffic_of(key):  # PMC-derived L2<->fabric bytes per launch for this exact workload (collected offline, profiles/)

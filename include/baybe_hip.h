@@ -200,6 +200,13 @@ int bbh_qlogei_q1(bbh_handle* h, const double* mean_dev, const double* var_dev, 
                   const double* z_host, int64_t S, double best_f, double sign,
                   const uint8_t* alive_dev, double* scores_dev);
 
+/* The same scores AND their k best (descending, ties -> lower index first; (-inf, -1) beyond the number of scored candidates) in
+ * one call: the whole tail of a selection step of optimize_acqf_discrete (baybe/recommenders/pure/bayesian/botorch/
+ * discrete.py:120-126) - scores kernel, one selection kernel whose results land in host-mapped memory, one synchronisation. */
+int bbh_qlogei_q1_topk(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N,
+                       const double* z_host, int64_t S, double best_f, double sign,
+                       const uint8_t* alive_dev, double* scores_dev, int64_t k, double* vals_host, int64_t* idx_host);
+
 /* Fused scoring pass (the hot call of optimize_acqf_discrete's first greedy step): posterior AND
  * q'=1 qLogEI in one kernel.  mean_dev / var_dev may be NULL (scores only). */
 int bbh_score_qlogei(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, const double* z_host,
@@ -329,7 +336,8 @@ enum bbh_timed_family {
   BBH_TIMED_COLUMNS = 3,  /* bbh_posterior_columns: conditional means under S target columns (qLogNEHVI) */
   BBH_TIMED_NEHVI = 4,    /* bbh_qlognehvi: the scoring kernel over the cells of the box decompositions */
   BBH_TIMED_Q1 = 5,       /* q' = 1 acquisition kernels (bbh_qlogei_q1, bbh_mc_acq_q1) */
-  BBH_TIMED_FAMILIES = 6
+  BBH_TIMED_SELECT = 6,   /* chunk keys + the selection kernel (bbh_topk, bbh_argmax, bbh_qlogei_q1_topk) */
+  BBH_TIMED_FAMILIES = 7
 };
 int bbh_timing_read_family(bbh_handle* h, int32_t family, double* ms_total, int64_t* launches, int reset);
 

@@ -161,6 +161,11 @@ class OracleEngine(HipGP):
     def qlogei(self, mean, var, z, best_f, sign=1.0, alive=None):
         return self.mc_acq("qLogEI", mean, var, z, best_f, sign, alive=alive)
 
+    def qlogei_topk(self, mean, var, z, best_f, sign=1.0, k=1, alive=None, scores=None):
+        s = self.qlogei(mean, var, z, best_f, sign, alive)
+        vals, idx = self.topk(s, int(min(k, len(s))))
+        return s, vals, idx
+
     def mc_acq(self, kind, mean, var, z, best_f=0.0, sign=1.0, beta=0.2, alive=None, cross=None):
         mu, v = mean.numpy(), var.numpy()
         z = np.ascontiguousarray(z, dtype=np.float64)

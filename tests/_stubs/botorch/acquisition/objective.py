@@ -30,6 +30,15 @@ class GenericMCObjective(MCAcquisitionObjective):
             return self.objective(samples)
 
 
+class LinearMCObjective(MCAcquisitionObjective):
+    def __init__(self, weights):
+        super().__init__()
+        self.weights = weights
+
+    def forward(self, samples, X=None):
+        return samples @ self.weights.to(samples)
+
+
 class PosteriorTransform(torch.nn.Module):
     pass
 

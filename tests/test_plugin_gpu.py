@@ -423,7 +423,7 @@ def test_backtesting_loop_matches_an_oracle_driven_loop():
 
     # the same loop with the oracle in the recommender's place
     torch.manual_seed(99)
-    meas, taken, ref_rows = init.copy(), set(space.discrete.exp_rep.index[camp._match(init)]), []
+    meas, taken, ref_rows = init.copy(), set(), []  # (measured rows stay candidates by default, campaign.py:254-259; recommended ones do not)
     spec = go.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
     for _ in range(4):
         seed = int(torch.randint(0, 1000000, (1,)).item())

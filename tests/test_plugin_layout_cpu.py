@@ -328,3 +328,52 @@ def test_recommender_host_logic_with_a_stub_engine(monkeypatch):
     with pytest.raises(Exception):  # more rows than candidates (NotEnoughPointsLeftError)
         rec2.recommend(5, sub, camp.objective, camp.measurements)
     monkeypatch.setattr(torch.Tensor, "to", real_to)
+
+
+def test_replicated_surrogate_carries_every_constructor_argument(monkeypatch):
+    """``HipCompositeImpl.fit`` (surrogates/composite.py:54-60, 101-123: deep copies of the template): a multi-target fit of a template
+    built with ``kernel_or_factory`` / ``fit_criterion_or_factory`` / a preset reaches the model description of EVERY target with
+    those choices (they were dropped and every target silently fitted the default Matern-5/2 + MLL)."""
+    import baybe_amd.engine as engine_mod
+    from baybe_amd.kernels import GammaPrior, MaternKernel, ScaleKernel
+    from baybe_amd.surrogates import HipGaussianProcessSurrogate
+
+    monkeypatch.setattr(engine_mod, "HipGP", _StubEngine)
+    space, obj, meas = _context()
+    meas = meas.assign(y2=[0.4, 0.1, 0.2, 0.3])
+
+    class _Obj:
+        is_multi_output = True
+        targets = (NumericalTarget("y"), NumericalTarget("y2", minimize=True))
+
+    kern = ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1)), GammaPrior(2, 0.5))
+    comp = HipGaussianProcessSurrogate(kernel_or_factory=kern, fit_criterion_or_factory="LEAVE_ONE_OUT_PSEUDOLIKELIHOOD",
+                                       warm_start=True).replicate()
+    comp.fit(space, _Obj(), meas)
+    assert len(comp.models) == 2
+    for i, m in enumerate(comp.models):
+        assert m._target_index == i and m.warm_start
+        assert m._engine.spec.kernel == "matern32" and m._engine.spec.use_outputscale and m._engine.spec.criterion == "loo"
+    edbo = HipGaussianProcessSurrogate(preset="EDBO").replicate()
+    edbo.fit(space, _Obj(), meas)
+    assert all(m.preset == "EDBO" and m._engine.spec.use_outputscale for m in edbo.models)
+
+
+def test_measurement_key_is_process_independent():
+    """The fit-cache key of the measurements (``_frame_hash``) holds no salted ``hash()`` of strings: the same frame keys identically
+    in another interpreter (a pickled surrogate must not retrain on its first fit after loading); unhashable cell values are fine."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    ROOT = Path(__file__).resolve().parents[1]
+    code = ("import pandas as pd, sys; sys.path.insert(0, %r); from baybe_amd.surrogates import _frame_hash; "
+            "print(_frame_hash(pd.DataFrame({'a': [1.0, 2.0], 'lab': ['u', 'v'], 'y': [0.5, 0.25]})))") % str(ROOT)
+    outs = {subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                           env={**__import__("os").environ, "PYTHONHASHSEED": seed}).stdout for seed in ("1", "2", "3")}
+    assert len(outs) == 1
+    from baybe_amd.surrogates import _frame_hash
+
+    a = pd.DataFrame({"x": [1.0, 2.0], "lists": [[1, 2], [3]]})
+    b = pd.DataFrame({"x": [1.0, 2.0], "lists": [[1, 2], [4]]})
+    assert _frame_hash(a) == _frame_hash(a.copy()) and _frame_hash(a) != _frame_hash(b)

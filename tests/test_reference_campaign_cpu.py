@@ -550,3 +550,122 @@ def test_shim_campaign_makes_the_calls_the_real_campaign_makes(ref):
     assert len(masks["real"]) == 3
     for k, (a, b) in enumerate(zip(masks["real"], masks["shim"])):
         assert np.array_equal(a, b), (k, np.nonzero(a != b)[0])
+
+
+# ---- joint q-batches beyond 16 points in the subset and read-back paths ----------------------------------------------------
+def test_batches_beyond_sixteen_points_on_a_subset_constrained_space(ref):
+    """batch_size = 17 with a ``DiscreteBatchConstraint``: the greedy passes AND the joint value of every subset's batch
+    (botorch/discrete.py:60-75) take the explicit-statistics kernel path; ``acquisition_values`` / ``joint_acquisition_value`` with
+    more than 15 pending / batch rows do too.  Values equal the oracle's joint qLogEI."""
+    baybe, S, C, R, Eng = ref
+    from baybe import Campaign
+    from baybe.constraints import DiscreteBatchConstraint
+    from baybe.parameters import CategoricalParameter, NumericalDiscreteParameter
+    from baybe.searchspace import SearchSpace
+    from baybe.targets import NumericalTarget
+    from oracle import gp_oracle as go
+
+    vals = np.arange(7) / 6
+    space = SearchSpace.from_product(
+        [NumericalDiscreteParameter("x0", vals), NumericalDiscreteParameter("x1", vals), CategoricalParameter("plate", ["p", "q"])],
+        constraints=[DiscreteBatchConstraint(parameters=["plate"])])
+    rng = np.random.default_rng(21)
+    exp = space.discrete.exp_rep
+    meas = exp.iloc[rng.choice(len(exp), 8, replace=False)].copy()
+    X = meas[["x0", "x1"]].to_numpy(dtype=float)
+    meas["yield"] = -((X - 0.5) ** 2).sum(1) + 0.2 * (meas["plate"] == "q")
+    camp = Campaign(space, NumericalTarget("yield").to_objective(), R())
+    camp.add_measurements(meas)
+    got = camp.recommend(17)
+    assert len(got) == 17 and got["plate"].nunique() == 1 and got.index.is_unique
+    # read-backs with 16 other points in the q-batch / 16 pending rows
+    eng = Eng.instances[0]
+    seed = _next_sampler_seed(9)
+    jv = camp.joint_acquisition_value(got)
+    comp = space.transform(got).to_numpy(dtype=float)
+    mj, cj = eng._model.posterior_joint(comp)
+    want = go.qlogei_joint(mj, cj, go.sobol_normal_base_samples(512, 17, seed), go.best_f_from_model(eng._model))
+    assert np.isclose(jv, want, rtol=1e-9, atol=1e-10)
+    seed = _next_sampler_seed(10)
+    others = exp.drop(index=got.index).iloc[:6]
+    acq = camp.acquisition_values(others, pending_experiments=got.iloc[:16])
+    z = go.sobol_normal_base_samples(512, 17, seed)
+    pend = space.transform(got.iloc[:16]).to_numpy(dtype=float)
+    for i, (_, row) in enumerate(others.iterrows()):
+        m_, c_ = eng._model.posterior_joint(np.vstack([space.transform(others.iloc[[i]]).to_numpy(dtype=float), pend]))
+        assert np.isclose(acq.iloc[i], go.qlogei_joint(m_, c_, z, go.best_f_from_model(eng._model)), rtol=1e-9, atol=1e-10)
+
+
+# ---- Objective._pre_transform in the fit (surrogates/base.py:454) ----------------------------------------------------------------------
+def test_desirability_as_pre_transformation_is_the_single_target_path(ref):
+    """``DesirabilityObjective(as_pre_transformation=True)`` (objectives/desirability.py:155-172, 222-227, 322-346): the targets are
+    scalarised on the host BEFORE fitting, one model is trained on the 'Desirability' column, and recommend() is the single-target
+    qLogEI path - the picks equal the oracle's on the scalarised column; posterior statistics are named after the modeled quantity.
+    The default desirability (one model per target, per-sample scalarisation) is refused with a message naming the alternative."""
+    baybe, S, C, R, Eng = ref
+    from baybe import Campaign
+    from baybe.exceptions import IncompatibilityError
+    from baybe.objectives import DesirabilityObjective
+    from baybe.targets import NumericalTarget
+
+    rng = np.random.default_rng(31)
+    space = _space3(6)
+    exp = space.discrete.exp_rep
+    meas = exp.iloc[rng.choice(216, 14, replace=False)].copy()
+    X = meas.to_numpy()
+    meas["gain"] = 100.0 * np.exp(-((X - 0.4) ** 2).sum(1))
+    meas["cost"] = 3.0 + 5.0 * X.sum(1)
+    targets = [NumericalTarget.normalized_ramp("gain", cutoffs=(20, 100)),
+               NumericalTarget.normalized_ramp("cost", cutoffs=(3, 18), descending=True)]
+    objective = DesirabilityObjective(targets, weights=[2.0, 1.0], scalarizer="GEOM_MEAN", as_pre_transformation=True)
+    assert not objective.is_multi_output and [t.name for t in objective._modeled_quantities] == ["Desirability"]
+    camp = Campaign(space, objective, R())
+    camp.add_measurements(meas)
+    seed = _next_sampler_seed(77)
+    got = camp.recommend(3)
+    desir = objective.transform(meas[["gain", "cost"]], allow_extra=False)["Desirability"].to_numpy()
+    assert desir.min() >= 0.0 and desir.max() <= 1.0 and np.ptp(desir) > 0.1
+    eng = Eng.instances[0]
+    assert np.allclose(eng._y_train, desir, rtol=0, atol=1e-15)
+    r, m = _oracle_greedy(meas[["x0", "x1", "x2"]].to_numpy(), desir, exp.to_numpy(), 3, seed)
+    assert got.index.tolist() == exp.index[r.indices].tolist()
+    stats = camp.posterior_stats(exp.iloc[:4])
+    assert list(stats.columns) == ["Desirability_mean", "Desirability_std"]
+    assert np.allclose(stats["Desirability_mean"], m.posterior(exp.iloc[:4].to_numpy())[0], rtol=1e-6, atol=1e-9)
+    with pytest.raises(ValueError, match="Missing target values"):
+        S().fit(space, objective, meas.assign(cost=[np.nan] + [1.0] * 13))
+    per_sample = DesirabilityObjective(targets, weights=[2.0, 1.0], as_pre_transformation=False)
+    with pytest.raises(IncompatibilityError, match="as_pre_transformation=True"):
+        R().recommend(2, space, per_sample, meas)
+
+
+# ---- a lookup-table benchmark domain on real data (benchmarks/domains/direct_arylation/convergence.py, scenario "Categorical") --------------
+@pytest.mark.parametrize("seed", [1337, 1338])
+def test_direct_arylation_converges_to_the_table_optimum(ref, seed):
+    """The reference's direct-arylation domain with one-hot encodings over its own lookup table (1 728 measured reactions), through the
+    reference's ``simulate_experiment`` (simulation/core.py:21-239) with the plug-in as the Bayesian phase: 30 iterations of batch 2
+    find the table optimum (yield 100) and measure three times the mean yield of a random recommender on the same seed."""
+    baybe, S, C, R, Eng = ref
+    import importlib.util
+
+    from baybe import Campaign
+    from baybe.recommenders import RandomRecommender, TwoPhaseMetaRecommender
+    from baybe.simulation.core import simulate_experiment
+    from baybe.targets import NumericalTarget
+
+    from _replay import TRACES
+
+    spec = importlib.util.spec_from_file_location("make_da", TRACES.parent / "make_direct_arylation_fixture.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    data, space, arrays = mod.build()
+    stored = np.load(TRACES.parent / "direct_arylation_comp.npz")
+    assert np.array_equal(stored["comp"], arrays["comp"]) and np.array_equal(stored["y"], arrays["y"])  # the GPU box's fixture is current
+    objective = NumericalTarget("yield").to_objective()
+    bo = Campaign(space, objective, TwoPhaseMetaRecommender(initial_recommender=RandomRecommender(), recommender=R()))
+    res = simulate_experiment(bo, data, batch_size=2, n_doe_iterations=30, random_seed=seed, impute_mode="error")
+    rnd = simulate_experiment(Campaign(space, objective, RandomRecommender()), data, batch_size=2, n_doe_iterations=30, random_seed=seed)
+    assert len(res) == 30 and res["yield_CumBest"].iloc[-1] == data["yield"].max() == 100.0
+    mean_bo = np.mean(sum(res["yield_Measurements"].tolist(), []))
+    mean_rnd = np.mean(sum(rnd["yield_Measurements"].tolist(), []))
+    assert mean_bo > 45.0 and mean_bo > 2.5 * mean_rnd
