@@ -655,7 +655,7 @@ static int bbh_qlogei_pending_impl(bbh_handle* h, const double* mean_dev, const 
   int slices = 1;
 #if BBH_PENDING_FAST && !BBH_PENDING_LSE
   if (fits && !h->pending_lds_form && p + 1 <= 14) {
-    int64_t want = ((int64_t)16 * 4 * h->num_cu * 64) / N;
+    int64_t want = ((int64_t)16 * 4 * h->num_cu * 64) / (h->slice_rows > 0 ? h->slice_rows : N);
     if (const char* e = getenv("BBH_PENDING_SLICES")) want = atoi(e);
     if (want > S / 32) want = S / 32;
     slices = (int)(want < 1 ? 1 : (want > 32 ? 32 : want));
@@ -1328,7 +1328,8 @@ static int bbh_qlognehvi_impl(bbh_handle* h, int32_t m, int64_t N, const double*
   if (!(env_log && env_log[0] == '1')) {  // linear-domain sums (default)
     const double* len = h->d_z + S * m + 2 * ncells * m;
     // sample slices: ~16 waves per SIMD (4 SIMDs per CU; 11.3 / 10.4 / 10.0 / 9.8 ms for 6 / 12 / 24 / 48 slices at 1e5 candidates), each slice at least 8 samples
-    int64_t slices = ((int64_t)16 * 4 * h->num_cu * 64 + N - 1) / N;
+    const int64_t srows = h->slice_rows > 0 ? h->slice_rows : N;
+    int64_t slices = ((int64_t)16 * 4 * h->num_cu * 64 + srows - 1) / srows;
     if (const char* e = getenv("BBH_NEHVI_SLICES")) slices = atoi(e);
     if (slices > S / 8) slices = S / 8;
     if (slices > 64) slices = 64;

@@ -42,6 +42,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_FIT_OVERLAP")) h->fit_overlap = (e[0] != '0');
   if (const char* e = getenv("BBH_Q1_SLICED")) h->q1_sliced = (e[0] != '0');
   if (const char* e = getenv("BBH_SELECT")) h->select_on = (e[0] != '0');
+  if (const char* e = getenv("BBH_SMALL")) h->small_on = (e[0] != '0');
   *out = h;
   return 0;
 }
@@ -72,6 +73,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   for (auto& e : h->side_events)
     if (e) hipEventDestroy(e);
   if (h->d_rstream) hipFree(h->d_rstream);
+  if (h->d_rsmall) hipFree(h->d_rsmall);
   if (h->d_tileflags) hipFree(h->d_tileflags);
   if (h->d_kvcache) hipFree(h->d_kvcache);
   if (h->d_slab_flags) hipFree(h->d_slab_flags);
@@ -209,6 +211,12 @@ extern "C" int bbh_train_posterior_mean(bbh_handle* h, double* mean_host) {
   if (own) hipFree(own);
   if (rc) return rc;
   BBH_HIP_TRY(h, e);
+  return 0;
+}
+
+extern "C" int bbh_set_slice_rows(bbh_handle* h, int64_t rows) {
+  if (!h || rows < 0) return -1;
+  h->slice_rows = rows;
   return 0;
 }
 

@@ -280,6 +280,10 @@ struct bbh_handle {
   double* d_red = nullptr;        // argmax partials
   int64_t* d_redi = nullptr;
   void* comm_state = nullptr;     // RCCL communicator + exchange buffers (bbh_comm.hip), null until bbh_comm_init
+  double* d_rsmall = nullptr;     // register-resident small-model form (bbh_small.h): fragments of the lower triangle of L^-T
+  int small_nb = 0;               // its training blocks ceil(n / 16) <= 4 once the operands are packed (0: form not available)
+  bool small_on = true;           // env BBH_SMALL=0: keep the cooperative form for n <= 64 (A/B)
+  int64_t slice_rows = 0;         // bbh_set_slice_rows: row count the sample-slice heuristics use instead of the local N (0: local)
   void* select_state = nullptr;   // chunk keys, result block and base-sample tables of the selection kernels (bbh_select.hip)
   bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
   bool select_on = true;          // env BBH_SELECT=0: top-k / argmax by k rounds of workgroup argmax (A/B)

@@ -29,6 +29,7 @@
 // bbh_fused_kd{0,2,4,6,8,12,16}.hip); this file holds operand packing, launch logic and the related kernels.
 #include "bbh_coop2.h"
 #include "bbh_coopg.h"
+#include "bbh_small.h"
 
 // ---- operand packing ------------------------------------------------------------------------
 // R fragments of one pass: for tb in [0, j1), r in 0..3, jb in [max(j0, tb), j1):
@@ -259,6 +260,17 @@ int bbh_pack_operands(bbh_handle* h) {
       hipLaunchKernelGGL(bbh_pack_rfrag_kernel, dim3((unsigned)(j0 + W), 4), dim3(64), 0, s, h->d_X, np, j0, W,
                          h->d_rfrag + pass_off[ps]);
       j0 += W;
+    }
+  }
+  // ---- register-resident small-model form (n <= 64): the lower triangle of L^-T as fragments, bbh_small.h ----
+  h->small_nb = 0;
+  if (h->small_on && h->use_pipeline && nb == 4 && h->n >= 1) {
+    const int NB = (int)((h->n + 15) / 16);
+    const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
+    if (bbh_small_launch(h->kd, h->desc.kernel_kind, has_tbl0, NB, 0, h->num_cu, nullptr, SmallArgs{})) {
+      if (!h->d_rsmall) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rsmall, sizeof(double) * 10 * 4 * 64));
+      hipLaunchKernelGGL(bbh_pack_small_kernel, dim3((unsigned)NB, (unsigned)NB, 4), dim3(64), 0, s, h->d_X, np, NB, h->d_rsmall);
+      h->small_nb = NB;
     }
   }
   // ---- operand slices of the cooperative form (n <= 512, instantiated models only) ----
@@ -511,6 +523,20 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (2 * 4 * 256 + 128));
     bbh_coopg_launch(h->kd, ks.F, dim3((unsigned)((N + 15) / 16)), clds, h->stream, g);
     h->last_form = 4;
+    BBH_HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
+  // Register-resident form (n <= 64, variance pass without pending columns): persistent waves, the model in registers / LDS
+  if (h->small_nb > 0 && h->small_on && with_var && h->p == 0 && !cross_dev && !a.qz && h->use_mean_valu) {
+    SmallArgs sa;
+    sa.f = a;
+    sa.rsmall = h->d_rsmall;
+    const int NB = h->small_nb;
+    if (!bbh_small_launch(h->kd, a.kind, has_tbl, NB, (N + 15) / 16, h->num_cu, h->stream, sa)) {
+      h->err = "register-resident posterior form: no instantiation for this model although its operands were packed";
+      return -6;
+    }
+    h->last_form = 5;
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;
   }

@@ -23,6 +23,7 @@
 //                           resolve to the lowest index exactly as torch.argmax / the oracle do.  NaN never wins.  The k results go
 //                           to device memory or straight to a host-mapped buffer (no copy engine in the step).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(256) void bbh_select_kernel(const double* __restric
     const double v = s_lv[e];
     const int64_t id = s_li[e];
     int r = 0;
-    for (int j = 0; j < c1; j++) r += sel_beats(s_lv[j], s_li[j], v, id) ? 1 : 0;
+#pragma unroll 8
+    for (int j = 0; j < c1; j++) r += sel_beats(s_lv[j], s_li[j], v, id) ? 1 : 0;  // (unrolled: the LDS reads of a batch are in flight together)
     if (r < kk) {
       s_selv[r] = v;
       s_selc[r] = id;
@@ -344,19 +346,21 @@ __global__ __launch_bounds__(256) void bbh_select_kernel(const double* __restric
     }
   }
   __syncthreads();
-  // (5) elements >= the threshold element, over the flat index space (selected chunk, offset)
-  const int64_t total = (int64_t)kk * chunk;
-  for (int64_t e0 = tid; e0 < total; e0 += 256 * SEL_BATCH) {
+  // (5) elements >= the threshold element, over the flat index space (selected chunk, offset); 32-bit index arithmetic (a 64-bit
+  // division by the run-time chunk size is ~100 instructions, sixteen of them per thread were a quarter of the kernel)
+  const uint32_t total = (uint32_t)kk * (uint32_t)chunk;  // <= 64 * 64 * ceil(N / 262144): fits for N < 2^43
+  for (uint32_t e0 = tid; e0 < total; e0 += 256 * SEL_BATCH) {
     double bx[SEL_BATCH];
     int64_t bg[SEL_BATCH];
 #pragma unroll
     for (int u = 0; u < SEL_BATCH; u++) {
-      const int64_t e = e0 + u * 256;
+      const uint32_t e = e0 + u * 256;
       bx[u] = NAN;
       bg[u] = -1;
       if (e < total) {
-        const int64_t cid = s_selc[e / chunk] >> 32;
-        const int64_t g = cid * chunk + e % chunk;
+        const uint32_t sl = e / (uint32_t)chunk;
+        const int64_t cid = s_selc[sl] >> 32;
+        const int64_t g = cid * chunk + (e - sl * (uint32_t)chunk);
         if (!(cid & SEL_NANFLAG) && g < N) {
           bx[u] = scores[g];
           bg[u] = g;
@@ -387,9 +391,10 @@ __global__ __launch_bounds__(256) void bbh_select_kernel(const double* __restric
     for (int r = 0; r < k; r++) {
       double bv = -INFINITY;
       int64_t bi = -1;
-      for (int64_t e = tid; e < total; e += 256) {
-        const int64_t cid = s_selc[e / chunk] >> 32;
-        const int64_t g = cid * chunk + e % chunk;
+      for (uint32_t e = tid; e < total; e += 256) {
+        const uint32_t sl = e / (uint32_t)chunk;
+        const int64_t cid = s_selc[sl] >> 32;
+        const int64_t g = cid * chunk + (e - sl * (uint32_t)chunk);
         if ((cid & SEL_NANFLAG) || g >= N) continue;
         const double x = scores[g];
         if (x == x && (pi < 0 || sel_beats(pv, pi, x, g)) && (bi < 0 || sel_beats(x, g, bv, bi))) {
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(256) void bbh_select_kernel(const double* __restric
     const double v = s_lv[e];
     const int64_t id = s_li[e];
     int r = 0;
+#pragma unroll 8
     for (int j = 0; j < c2; j++) r += sel_beats(s_lv[j], s_li[j], v, id) ? 1 : 0;
     if (r < k) {
       outv[r] = v;
@@ -465,7 +471,11 @@ static int sel_ensure(bbh_handle* h, bbh_select_state* st) {
   BBH_HIP_TRY(h, hipMalloc((void**)&st->d_out_v, sizeof(double) * 64));
   BBH_HIP_TRY(h, hipMalloc((void**)&st->d_out_i, sizeof(int64_t) * 64));
   // results straight to the host: the select kernel's stores travel over the link, one stream synchronisation ends the step
-  if (hipHostMalloc(&st->h_res, 16 + 64 * 16, hipHostMallocMapped) == hipSuccess) {
+  // (BBH_SELECT_MAPPED=0: device buffer + copy, for A/B)
+  const char* mp = getenv("BBH_SELECT_MAPPED");
+  if (mp && mp[0] == '0') {
+    st->h_res = nullptr;
+  } else if (hipHostMalloc(&st->h_res, 16 + 64 * 16, hipHostMallocMapped) == hipSuccess) {
     if (hipHostGetDevicePointer(&st->h_res_dev, st->h_res, 0) != hipSuccess) {
       hipHostFree(st->h_res);
       st->h_res = st->h_res_dev = nullptr;

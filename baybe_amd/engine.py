@@ -726,7 +726,8 @@ class HipGP:
     # ---- instrumentation ------------------------------------------------------------------
     def posterior_kernel_form(self) -> str:
         """Which form of the fused posterior kernel the last variance pass ran as."""
-        return {0: "windowed", 1: "cooperative", 2: "materialised", 3: "cooperative-2sweep", 4: "cooperative-generic"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
+        return {0: "windowed", 1: "cooperative", 2: "materialised", 3: "cooperative-2sweep", 4: "cooperative-generic",
+                5: "register-resident"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
 
     def timing(self, enable: bool):
         self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")

@@ -298,6 +298,12 @@ int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_
 int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, double* vals_host,
              int64_t* idx_host);
 
+/* The joint q'-batch and qLogNEHVI kernels split the MC samples into slices when a candidate set alone would not fill the chip; the
+ * slice count - and with it the order in which a candidate's partial sums are added - follows the number of candidate rows.
+ * rows > 0 fixes the row count the heuristic sees (a row shard passes the GLOBAL count: every rank then adds in the order the
+ * unsharded pass uses, so scores are bit-identical across shard layouts); 0 = the rows of each call (default). */
+int bbh_set_slice_rows(bbh_handle* h, int64_t rows);
+
 /* ---- row-sharded selection over the GPUs of one node (RCCL over xGMI) ---------------------------
  * No reference call site (BayBE is single-process): these belong to the argmax / top-k of
  * optimize_acqf_discrete (baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126) once the candidate rows are

@@ -51,4 +51,5 @@ def run(tag, env):
 
 
 run("sliced+select", {})
+run("sliced+select, results via device buffer + copy", {"BBH_SELECT_MAPPED": "0"})
 run("per-candidate+rounds", {"BBH_Q1_SLICED": "0", "BBH_SELECT": "0"})
