@@ -41,6 +41,10 @@ class RowShard:
         self.N_total = int(N_total)
         self.start, self.stop = shard_bounds(N_total, self.rank, self.world)
         self.use_rccl = False  # True: selections go through the library's own communicator (bbh_allgather_*)
+        # True: the joint q'-batch kernels add a candidate's MC partial sums in the order of the UNSHARDED pass (slice count from the
+        # global row count): scores bit-identical to a single-device run whatever the shard sizes, so exact ties resolve alike;
+        # default off - per-shard slice counts fill the device better, and scores then agree to the last ulp or two only
+        self.reproducible = False
 
     def bind_rccl(self, engine) -> None:
         """Create the library-side RCCL communicator of ``engine`` (a ``HipGP`` handle) for this shard layout: rank 0's

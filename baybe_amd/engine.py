@@ -723,6 +723,13 @@ class HipGP:
         )
         return val.value, gidx.value, row
 
+    def set_slice_rows(self, rows: int):
+        """Row count the sample-slice heuristics of the joint q'-batch / qLogNEHVI kernels use instead of each call's own N
+        (``bbh_set_slice_rows``; 0 = per call).  A row shard passes the GLOBAL count to add every candidate's partial sums in the
+        order the unsharded pass uses: scores are then bit-identical across shard layouts, at the price of fewer slices (less
+        parallelism) per rank."""
+        self._check(self._lib.bbh_set_slice_rows(self._h, int(rows)), "bbh_set_slice_rows")
+
     # ---- instrumentation ------------------------------------------------------------------
     def posterior_kernel_form(self) -> str:
         """Which form of the fused posterior kernel the last variance pass ran as."""
@@ -770,6 +777,8 @@ class HipGP:
         X = self._as_dev(X)
         N = X.shape[0]
         d = self.spec.d
+        if shard is not None and getattr(shard, "reproducible", False):
+            self.set_slice_rows(shard.N_total)
         if seed is None and z_by_q is None:
             seed = draw_sampler_seed()
         if best_f is None:
@@ -899,4 +908,6 @@ class HipGP:
             values.append(float(val))
             chosen_rows.append(np.asarray(row, dtype=np.float64).reshape(1, d))
         self.set_pending(None if (base.shape[0] == 0 or base.shape[0] > MAX_PENDING) else base)
+        if shard is not None and getattr(shard, "reproducible", False):
+            self.set_slice_rows(0)
         return GreedyResult(indices, values)

@@ -78,6 +78,9 @@ class OracleEngine(HipGP):
     def timing(self, enable):
         pass
 
+    def set_slice_rows(self, rows):
+        pass
+
     def _as_dev(self, X):
         if isinstance(X, np.ndarray):
             X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64))

@@ -163,3 +163,37 @@ def test_speculative_hit_then_miss_on_the_device():
         assert np.allclose(on.values, ref.values, rtol=0, atol=1e-8) and np.allclose(off.values, ref.values, rtol=0, atol=1e-8)
     assert abs(X[on.indices[0], 0] - 0.2) < 0.05 and abs(X[on.indices[1], 0] - 0.8) < 0.05
     g.close()
+
+
+def test_slice_row_hint_makes_shard_scores_bit_identical():
+    """the joint q'-batch kernel picks its number of sample slices from the candidate count, so a shard of another size
+    adds a candidate's partial sums in another order (last-ulp differences, which can flip exact ties across ranks).  With the GLOBAL
+    row count as the hint (``bbh_set_slice_rows``, ``RowShard.reproducible``) every shard reproduces the unsharded scores bit for bit."""
+    import torch
+
+    from _problems import make_problem
+    from baybe_amd import engine, gp_spec
+
+    X, Xt, y = make_problem(60_000, 6, 40, seed=3)
+    g = engine.HipGP(0)
+    spec = gp_spec.GPSpec.baybe_default(6, np.zeros(6), np.ones(6))
+    g.set_model(spec, Xt, y)
+    g.factorize(gp_spec.initial_params(spec))
+    z = engine.sobol_normal_base_samples(512, 3, 7)
+    Xd = torch.from_numpy(X).cuda()
+    pend = X[[5, 17]]
+
+    def scores(rows):
+        mean, var = g.posterior(rows)
+        g.set_pending(pend)
+        cross = g.cross_cov(rows)
+        s = g.qlogei_pending(mean, var, cross, z, 0.1).cpu().numpy()
+        g.set_pending(None)
+        return s
+
+    full = scores(Xd)
+    g.set_slice_rows(len(X))
+    parts = [scores(Xd[a:b]) for a, b in ((0, 7_001), (7_001, 30_000), (30_000, 60_000))]
+    g.set_slice_rows(0)
+    assert np.array_equal(np.concatenate(parts), full)
+    g.close()
