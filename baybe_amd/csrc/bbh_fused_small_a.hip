@@ -19,12 +19,14 @@
   if (kd == 8) BBH_SMALL_KVF(8, NBV)
 
 bool bbh_small_launch_b(int kd, int kind, bool has_tbl, int NB, int64_t tiles, int num_cu, hipStream_t s, const SmallArgs& a);
+bool bbh_small_launch_c(int kd, int kind, bool has_tbl, int NB, int64_t tiles, int num_cu, hipStream_t s, const SmallArgs& a);
 
 bool bbh_small_launch(int kd, int kind, bool has_tbl, int NB, int64_t tiles, int num_cu, hipStream_t s, const SmallArgs& a) {
   if (kind != BBH_KERNEL_MATERN52 && kind != BBH_KERNEL_MATERN32 && kind != BBH_KERNEL_RBF) return false;
   if (kind == BBH_KERNEL_MATERN32 && has_tbl) return false;  // (no such instantiation in any form)
   if (kd != 2 && kd != 4 && kd != 6 && kd != 8) return false;
-  if (NB < 1 || NB > 4) return false;
+  if (NB < 1 || NB > 8) return false;
+  if (NB >= 5) return bbh_small_launch_c(kd, kind, has_tbl, NB, tiles, num_cu, s, a);
   if (tiles == 0) return true;
   if (NB >= 3) return bbh_small_launch_b(kd, kind, has_tbl, NB, tiles, num_cu, s, a);
   if (NB == 1) { BBH_SMALL_KD(1) }

@@ -262,13 +262,13 @@ int bbh_pack_operands(bbh_handle* h) {
       j0 += W;
     }
   }
-  // ---- register-resident small-model form (n <= 64): the lower triangle of L^-T as fragments, bbh_small.h ----
+  // ---- register-resident small-model form (n <= 128): the lower triangle of L^-T as fragments, bbh_small.h ----
   h->small_nb = 0;
-  if (h->small_on && h->use_pipeline && nb == 4 && h->n >= 1) {
+  if (h->small_on && h->use_pipeline && nb <= 8 && h->n >= 1) {
     const int NB = (int)((h->n + 15) / 16);
     const bool has_tbl0 = (T > 1) || h->desc.use_outputscale;
     if (bbh_small_launch(h->kd, h->desc.kernel_kind, has_tbl0, NB, 0, h->num_cu, nullptr, SmallArgs{})) {
-      if (!h->d_rsmall) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rsmall, sizeof(double) * 10 * 4 * 64));
+      if (!h->d_rsmall) BBH_HIP_TRY(h, hipMalloc((void**)&h->d_rsmall, sizeof(double) * 36 * 4 * 64));
       hipLaunchKernelGGL(bbh_pack_small_kernel, dim3((unsigned)NB, (unsigned)NB, 4), dim3(64), 0, s, h->d_X, np, NB, h->d_rsmall);
       h->small_nb = NB;
     }
@@ -526,8 +526,14 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;
   }
-  // Register-resident form (n <= 64, variance pass without pending columns): persistent waves, the model in registers / LDS
-  if (h->small_nb > 0 && h->small_on && with_var && h->p == 0 && !cross_dev && !a.qz && h->use_mean_valu) {
+  // Register-resident form (n <= 128, variance pass without pending columns): persistent waves, the model in registers / LDS
+  // (64 < n <= 128: the operand fragments are 45 - 74 KB of LDS that every workgroup fills first - ahead of the cooperative form
+  // only once the candidate set amortises that: measured cross-overs, profiles/r04_ab_small_form.log; BBH_SMALL_FORCE=1 lifts the rule)
+  const char* sf_env = getenv("BBH_SMALL_FORCE");
+  const bool small_force = sf_env && sf_env[0] == '1';
+  const int64_t small_min_rows[9] = {0, 0, 0, 0, 0, 20000, 60000, 120000, 300000};
+  if (h->small_nb > 0 && h->small_on && with_var && h->p == 0 && !cross_dev && !a.qz && h->use_mean_valu &&
+      (small_force || N >= small_min_rows[h->small_nb])) {
     SmallArgs sa;
     sa.f = a;
     sa.rsmall = h->d_rsmall;

@@ -1,4 +1,4 @@
-// Register-resident form of the fused posterior kernel for small models: n <= 64 training points (where BayBE campaigns start and
+// Register-resident form of the fused posterior kernel for small models: n <= 128 training points (operands in LDS beyond 32) (where BayBE campaigns start and
 // where its backtesting loops live: simulation/core.py:144-201 calls recommend() thousands of times at n = 10 ... 100).
 //
 // Why another form.  The cooperative form (bbh_coop.h) deals 16-candidate tiles to workgroups of four waves and streams L^-T from
@@ -42,26 +42,30 @@ static __global__ void bbh_pack_small_kernel(const double* __restrict__ X, int64
 #ifndef BBH_SMALL_RLDS
 #define BBH_SMALL_RLDS 1
 #endif
-// register budget as waves per SIMD: the table variants carry the per-lane task lookups of four kernel values on top
+// register budget as waves per SIMD: the table variants carry the per-lane task lookups of four kernel values on top.
+// 64 < n <= 128 (NB = 5 ... 8): the operand fragments are 45 - 74 KB of LDS, one workgroup per CU - of eight waves, so that every
+// SIMD still holds two.
 __host__ __device__ constexpr int small_waves(int KD, int KVF, int NB) {
-  return (KVF & 1) ? (KD >= 6 ? 2 : 3) : (NB <= 2 ? (KD >= 6 ? 3 : 4) : (BBH_SMALL_RLDS ? 3 : 2));
+  return NB >= 5 ? 2 : (KVF & 1) ? (KD >= 6 ? 2 : 3) : (NB <= 2 ? (KD >= 6 ? 3 : 4) : (BBH_SMALL_RLDS ? 3 : 2));
 }
+__host__ __device__ constexpr int small_threads(int NB) { return NB >= 5 ? 512 : 256; }
 template <int KD, int KVF, int NB>
-__global__ __launch_bounds__(256, small_waves(KD, KVF, NB)) void bbh_small_posterior_kernel(const SmallArgs sa) {
+__global__ __launch_bounds__(small_threads(NB), small_waves(KD, KVF, NB)) void bbh_small_posterior_kernel(const SmallArgs sa) {
   const FusedArgs& a = sa.f;
   constexpr int NP = NB * (NB + 1) / 2;
-  constexpr bool RLDS = BBH_SMALL_RLDS && NB >= 3;
+  constexpr bool RLDS = (BBH_SMALL_RLDS && NB >= 3) || NB >= 5;
+  constexpr int NT = small_threads(NB), NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) double s_mem[];  // training fragments [NB][KD][64] | alpha [16 NB] | (RLDS) operand fragments [NP][4][64]
   double* s_tf = s_mem;
   double* s_alpha = s_mem + NB * KD * 64;
   double* s_r = s_alpha + 16 * NB;
   const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cnd = l & 15, q = l >> 4;
-  for (int e = threadIdx.x; e < NB * KD * 64; e += 256) s_tf[e] = a.trainfrag[e];
-  for (int e = threadIdx.x; e < 16 * NB; e += 256) s_alpha[e] = a.meanB[(int64_t)e * 16];
+  for (int e = threadIdx.x; e < NB * KD * 64; e += NT) s_tf[e] = a.trainfrag[e];
+  for (int e = threadIdx.x; e < 16 * NB; e += NT) s_alpha[e] = a.meanB[(int64_t)e * 16];
   double rfr[RLDS ? 1 : NP * 4];
   if constexpr (RLDS) {
-    for (int e = threadIdx.x; e < NP * 4 * 64; e += 256) s_r[e] = sa.rsmall[e];
+    for (int e = threadIdx.x; e < NP * 4 * 64; e += NT) s_r[e] = sa.rsmall[e];
   } else {
 #pragma unroll
     for (int i = 0; i < NP * 4; i++) rfr[i] = sa.rsmall[(int64_t)i * 64 + l];
@@ -77,8 +81,8 @@ __global__ __launch_bounds__(256, small_waves(KD, KVF, NB)) void bbh_small_poste
     xofs[k] = a.ofs[dimc];
   }
   const int64_t ntiles = (a.N + 15) / 16;
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t tile = (int64_t)blockIdx.x * 4 + w;
+  const int64_t stride = (int64_t)gridDim.x * NW;
+  int64_t tile = (int64_t)blockIdx.x * NW + w;
   double xv[KD], xtask = 0.0;
   {
     const int64_t row = (tile * 16 + cnd < a.N) ? tile * 16 + cnd : a.N - 1;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, small_waves(KD, KVF, NB)) void bbh_small_poste
 }
 
 __host__ inline size_t small_lds_bytes(int kd, int NB) {
-  return sizeof(double) * ((size_t)NB * kd * 64 + 16 * (size_t)NB + ((BBH_SMALL_RLDS && NB >= 3) ? (size_t)NB * (NB + 1) / 2 * 4 * 64 : 0));
+  return sizeof(double) * ((size_t)NB * kd * 64 + 16 * (size_t)NB + (((BBH_SMALL_RLDS && NB >= 3) || NB >= 5) ? (size_t)NB * (NB + 1) / 2 * 4 * 64 : 0));
 }
 
 // Persistent launch: exactly as many workgroups as the device holds at once (a queued workgroup would start when the others are
@@ -213,12 +217,15 @@ static void small_go(int64_t tiles, int num_cu, hipStream_t s, const SmallArgs& 
   const size_t lds = small_lds_bytes(KD, NB);
   if (!per_cu) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bbh_small_posterior_kernel<KD, KVF, NB>, 256, lds) != hipSuccess || n < 1) n = 2;
+    constexpr int NT = small_threads(NB);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)bbh_small_posterior_kernel<KD, KVF, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bbh_small_posterior_kernel<KD, KVF, NB>, NT, lds) != hipSuccess || n < 1) n = 1;
     per_cu = n > 2 ? n - 1 : n;
   }
-  int64_t blocks = (tiles + 3) / 4;
+  constexpr int NW = small_threads(NB) / 64;
+  int64_t blocks = (tiles + NW - 1) / NW;
   if (blocks > (int64_t)per_cu * num_cu) blocks = (int64_t)per_cu * num_cu;
-  hipLaunchKernelGGL((bbh_small_posterior_kernel<KD, KVF, NB>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bbh_small_posterior_kernel<KD, KVF, NB>), dim3((unsigned)blocks), dim3(small_threads(NB)), lds, s, a);
 }
 
 // false: no instantiation for this model; tiles == 0 only asks

@@ -18,7 +18,7 @@ def handle(small, d, Xt, y):
     return g
 
 
-for (d, n) in ((10, 64), (14, 48), (6, 32), (3, 20), (6, 16)):
+for (d, n) in ((15, 128), (15, 100), (10, 80), (10, 64), (14, 48), (6, 32), (3, 20), (6, 16)):
     Xall, Xt, y = synth_problem(1_000_000, d, n, 0)
     gs = {f: handle(f, d, Xt, y) for f in ("1", "0")}
     for N in (10_000, 100_000, 1_000_000):
