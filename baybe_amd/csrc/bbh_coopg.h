@@ -1,6 +1,7 @@
 // Cooperative form of the fused posterior kernel with a GENERIC kernel-value production: composite kernels (ProductKernel /
 // AdditiveKernel of up to four stationary ARD factors, baybe/kernels/composite.py:60-91) and the single kernels that have no
-// software-pipelined instantiation (rational quadratic, piecewise polynomial; baybe/kernels/basic.py:115-131,203-216), n <= 512.
+// software-pipelined instantiation (rational quadratic, piecewise polynomial, Linear, Polynomial, Periodic; baybe/kernels/basic.py:
+// 20-46, 73-163, 203-216), n <= 512.
 //
 // These models used to take the materialised-K* path for every posterior-shaped call: [K(X*, X)] written to and re-read
 // from HBM per 16384-candidate chunk (8 n bytes per candidate and pass, ~47 x the algorithmic traffic), an elementwise
@@ -16,16 +17,32 @@
 #pragma once
 #include "bbh_coop.h"
 
+// One entry of a factor's candidate-side feature map: feature e = 4 k + q of the factor's GEMM operand is
+//   op 0  x[src] * scl + ofs           (scaled coordinate; its square enters the factor's |b|^2)
+//   op 1  cos(x[src] * scl + ofs)      op 2  sin(...)      (periodic factors: angle 2 pi xn / p)
+//   op 3  the constant ofs             op 4  |b|^2 of the factor            op 5  0
+// The metric of a factor is ONE dot product of such features with the factor's training fragments:
+//   distance kinds   |a|^2 + |b|^2 - 2 a.b   train [-2 a, |a|^2, 1]            candidate [b, 1, |b|^2]
+//   dot kinds        a.b (Linear, Polynomial; a = xn / w)   train [a, 0, 0]     candidate [b, 1, |b|^2]  (|b|^2 is k(x, x)'s argument)
+//   periodic         sum_j sin^2(pi (xn_j - xn'_j) / p_j) / l_j = sum_j (1 - cos al_j cos be_j - sin al_j sin be_j) / (2 l_j)
+//                    train [-cos al / 2l, -sin al / 2l, sum_j 1 / 2l_j]         candidate [cos be, sin be, 1]
+// (padding rows of the training fragments carry 1e8 in the slot that meets the candidate's constant 1: metric 1e8 -> value 0)
+struct CoopGFeat {
+  double scl, ofs;
+  int src, op;
+};
+
 struct CoopGArgs {
   CoopArgs c;
   int F, combine, has_tbl, jb;
   int kind[BBH_MAX_FACTORS];
   double fos[BBH_MAX_FACTORS];    // per-factor scales (1 for a single kernel)
-  double alpha[BBH_MAX_FACTORS];  // RQ alpha per factor
+  double alpha[BBH_MAX_FACTORS];  // RQ alpha / polynomial offset per factor
   const double* trainfrag_f;      // [F][nb + 1][KD][64]
   int64_t tf_stride;              // doubles per factor
-  const double* sclofs_f;         // [F][2][dn]
-  double prior_k0;                // k(x, x) without the table / outputscale: prod_f fos_f or sum_f fos_f
+  const CoopGFeat* feat;          // [F][4 KD]
+  double prior_k0;                // k(x, x) without the table / outputscale when no factor is a dot kind: prod_f fos_f or sum_f fos_f
+  int has_dot;                    // some factor is Linear / Polynomial: k(x, x) is per candidate
 };
 
 // one k-block's kernel values (4 per lane) for all factors, combined
@@ -54,12 +71,20 @@ __device__ __forceinline__ void coopg_produce(const CoopGArgs& g, const WaveCtx&
       kv_all<2>(c, tb, da, db, kv);
     } else if (kind == BBH_KERNEL_MATERN32) {
       kv_all<4>(c, tb, da, db, kv);
+    } else if (BBH_KIND_IS_DOT(kind)) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double sdot = da[r] + db[r];
+        kv[r] = (kind == BBH_KERNEL_LINEAR) ? sdot : bbh_powi(sdot + g.alpha[f], kind - BBH_KERNEL_POLY1 + 1);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const double r2 = fmax(da[r] + db[r], 0.0);
         if (kind == BBH_KERNEL_RQ)
           kv[r] = exp(-g.alpha[f] * log1p(r2 / (2.0 * g.alpha[f])));
+        else if (kind == BBH_KERNEL_PERIODIC)
+          kv[r] = exp(-2.0 * r2);
         else
           kv[r] = bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, g.jb, r2, false);
       }
@@ -91,39 +116,36 @@ __global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopG
   double* s_red = s_kv + BBH_COOP_KV_TILE;
   const int64_t tile0 = (int64_t)blockIdx.x * 16;
 
-  // candidate fragments per factor: b = x * scl_f + ofs_f, augmented with [1, |b|^2]
+  // candidate fragments per factor through the factor's feature map (see CoopGFeat)
   const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
   const double* xr = a.X + row * a.ldx;
-  double xval[KD];
-#pragma unroll
-  for (int k = 0; k < KD; k++) {
-    const int dimc = (4 * k + q < a.dn) ? 4 * k + q : a.dn - 1;
-    xval[k] = xr[a.numcol_identity ? dimc : a.numcol[dimc]];
-  }
   for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
   double cf[F][KD];
+  double kself = g.combine ? 0.0 : 1.0;  // k(x, x) of candidate cnd without table / outputscale (dot kinds: not a constant)
 #pragma unroll
   for (int f = 0; f < F; f++) {
-    const double* scl = g.sclofs_f + (int64_t)f * 2 * a.dn;
-    const double* ofs = scl + a.dn;
     double nbsum = 0.0;
+    int ops[KD];
 #pragma unroll
     for (int k = 0; k < KD; k++) {
-      const int dim = 4 * k + q;
-      double v = 0.0;
-      if (dim < a.dn) {
-        v = fma(xval[k], scl[dim], ofs[dim]);
-        nbsum = fma(v, v, nbsum);
-      }
+      const CoopGFeat ft = g.feat[(f * KD + k) * 4 + q];
+      const double x = (ft.src >= 0) ? xr[a.numcol_identity ? ft.src : a.numcol[ft.src]] : 0.0;
+      double v = fma(x, ft.scl, ft.ofs);
+      if (ft.op == 0) nbsum = fma(v, v, nbsum);
+      if (ft.op == 1) v = cos(v);
+      if (ft.op == 2) v = sin(v);
+      if (ft.op >= 4) v = 0.0;
       cf[f][k] = v;
+      ops[k] = ft.op;
     }
     nbsum += __shfl_xor(nbsum, 16, 64);
     nbsum += __shfl_xor(nbsum, 32, 64);
 #pragma unroll
-    for (int k = 0; k < KD; k++) {
-      if (4 * k + q == a.dn) cf[f][k] = 1.0;
-      if (4 * k + q == a.dn + 1) cf[f][k] = nbsum;
-    }
+    for (int k = 0; k < KD; k++)
+      if (ops[k] == 4) cf[f][k] = nbsum;
+    const int kindf = g.kind[f];
+    const double ks = BBH_KIND_IS_DOT(kindf) ? ((kindf == BBH_KERNEL_LINEAR) ? nbsum : bbh_powi(nbsum + g.alpha[f], kindf - BBH_KERNEL_POLY1 + 1)) : 1.0;
+    kself = g.combine ? kself + g.fos[f] * ks : kself * (g.fos[f] * ks);
   }
   int tc = 0;
   if (g.has_tbl && a.task_col >= 0) {
@@ -224,9 +246,10 @@ __global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopG
     const int64_t gidx = tile0 + m;
     const double sv = (red_v[m] + red_v[16 + m]) + (red_v[32 + m] + red_v[48 + m]);
     const double sm = (red_m[m] + red_m[16 + m]) + (red_m[32 + m] + red_m[48 + m]);
-    double pv = a.prior_scale * g.prior_k0, mc = a.mean_const;
+    const double k0 = g.has_dot ? kself : g.prior_k0;  // (lane m of wave 0: candidate m's own k(x, x))
+    double pv = a.prior_scale * k0, mc = a.mean_const;
     if (g.has_tbl) {
-      pv = a.tasktbl[tc * a.T + tc] * g.prior_k0;
+      pv = a.tasktbl[tc * a.T + tc] * k0;
       if (a.taskmean) mc = a.taskmean[tc];
     }
     if (gidx < a.N) {

@@ -192,13 +192,96 @@ static void host_pack_trainfrag(const bbh_handle* h, const double* pts, int64_t 
 // path whose factors are Matérn-5/2, -3/2, RBF, rational quadratic or piecewise polynomial with q >= 1 (Matérn-1/2 and the
 // q = 0 piecewise polynomial (1 - r)^j are not smooth at r = 0: the |a|^2 + |b|^2 - 2ab distances lose sqrt(eps) there, so they
 // need the direct-difference distances and keep that path), n <= 512, d <= 30.
+// k-steps of the generic form's metric GEMM: ceil((dn + 2) / 4) for distance / dot factors, ceil((2 dn + 1) / 4) once a periodic
+// factor is present (cos and sin features), rounded up to an instantiated count; 0: none fits
+static int bbh_coopg_kd(const bbh_handle* h) {
+  const bbh_kern_spec ks = bbh_kern_spec_of(h);
+  int feats = h->dn + 2;
+  for (int f = 0; f < ks.F; f++)
+    if (ks.kind[f] == BBH_KERNEL_PERIODIC && 2 * h->dn + 1 > feats) feats = 2 * h->dn + 1;
+  const int kd = (feats + 3) / 4;
+  for (int c : {2, 4, 6, 8})
+    if (kd <= c) return c;
+  return 0;
+}
+
 static bool bbh_coopg_model(const bbh_handle* h) {
   if (!bbh_materialised_only(h) || h->coop_mode <= 0 || !h->use_pipeline) return false;
   if (h->nb > 4 * BBH_COOP_ROUNDS || h->nb % 4 != 0) return false;
   const bbh_kern_spec ks = bbh_kern_spec_of(h);
   for (int f = 0; f < ks.F; f++)
-    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0 || ks.kind[f] >= BBH_KERNEL_LINEAR) return false;
-  return bbh_coopg_launch(h->kd, ks.F, dim3(0), 0, nullptr, CoopGArgs{});
+    if (ks.kind[f] == BBH_KERNEL_MATERN12 || ks.kind[f] == BBH_KERNEL_PIECEWISE0) return false;
+  const int kd = bbh_coopg_kd(h);
+  return kd > 0 && bbh_coopg_launch(kd, ks.F, dim3(0), 0, nullptr, CoopGArgs{});
+}
+
+// Training fragments of factor f of the generic form (see CoopGFeat in bbh_coopg.h): frag[tb][k][l] = A[16 tb + (l & 15)][4 k + (l >> 4)]
+static void host_pack_trainfrag_generic(const bbh_handle* h, const bbh_kern_spec& ks, int f, int kd, int64_t nblocks, std::vector<double>& out) {
+  const int dn = h->dn, kind = ks.kind[f];
+  const double* th = h->theta.data();
+  const double* ls = th + ks.ls_off[f];
+  out.assign((size_t)nblocks * kd * 64, 0.0);
+  std::vector<double> row((size_t)4 * kd);
+  for (int64_t tb = 0; tb < nblocks; tb++)
+    for (int c16 = 0; c16 < 16; c16++) {
+      const int64_t i = tb * 16 + c16;
+      const bool real = i < h->n;
+      std::fill(row.begin(), row.end(), 0.0);
+      const double* x = real ? h->xn_host.data() + i * dn : nullptr;
+      if (kind == BBH_KERNEL_PERIODIC) {
+        double c0 = 0.0;
+        for (int j = 0; j < dn; j++) c0 += 0.5 / ls[j];
+        if (real)
+          for (int j = 0; j < dn; j++) {
+            const double al = 2.0 * M_PI * x[j] / th[ks.per_off + f * dn + j];
+            row[j] = -cos(al) * 0.5 / ls[j];
+            row[dn + j] = -sin(al) * 0.5 / ls[j];
+          }
+        row[2 * dn] = real ? c0 : 1e8;
+      } else if (BBH_KIND_IS_DOT(kind)) {
+        if (real)
+          for (int j = 0; j < dn; j++) row[j] = x[j] / ls[j];
+        row[dn] = real ? 0.0 : 1e8;
+      } else {
+        double na = 0.0;
+        if (real)
+          for (int j = 0; j < dn; j++) {
+            const double a = (x[j] - h->xcenter[j]) / ls[j];
+            row[j] = -2.0 * a;
+            na += a * a;
+          }
+        row[dn] = real ? na : 1e8;
+        row[dn + 1] = real ? 1.0 : 0.0;
+      }
+      for (int k = 0; k < kd; k++)
+        for (int qq = 0; qq < 4; qq++) out[((size_t)tb * kd + k) * 64 + qq * 16 + c16] = row[4 * k + qq];
+    }
+}
+
+// ... and the matching candidate-side feature map [4 kd]
+static void host_feature_map(const bbh_handle* h, const bbh_kern_spec& ks, int f, int kd, CoopGFeat* out) {
+  const int dn = h->dn, kind = ks.kind[f];
+  const double* th = h->theta.data();
+  const double* ls = th + ks.ls_off[f];
+  for (int e = 0; e < 4 * kd; e++) out[e] = CoopGFeat{0.0, 0.0, -1, 5};
+  for (int j = 0; j < dn; j++) {
+    const double rng = h->hi[j] - h->lo[j];
+    if (kind == BBH_KERNEL_PERIODIC) {
+      const double per = th[ks.per_off + f * dn + j];
+      out[j] = CoopGFeat{2.0 * M_PI / (rng * per), -2.0 * M_PI * h->lo[j] / (rng * per), j, 1};
+      out[dn + j] = CoopGFeat{2.0 * M_PI / (rng * per), -2.0 * M_PI * h->lo[j] / (rng * per), j, 2};
+    } else if (BBH_KIND_IS_DOT(kind)) {
+      out[j] = CoopGFeat{1.0 / (rng * ls[j]), -h->lo[j] / (rng * ls[j]), j, 0};
+    } else {
+      out[j] = CoopGFeat{1.0 / (rng * ls[j]), -(h->lo[j] / rng + h->xcenter[j]) / ls[j], j, 0};
+    }
+  }
+  if (kind == BBH_KERNEL_PERIODIC) {
+    out[2 * dn] = CoopGFeat{0.0, 1.0, -1, 3};
+  } else {
+    out[dn] = CoopGFeat{0.0, 1.0, -1, 3};
+    out[dn + 1] = CoopGFeat{0.0, 0.0, -1, 4};
+  }
 }
 
 int bbh_pack_operands(bbh_handle* h) {
@@ -308,29 +391,26 @@ int bbh_pack_operands(bbh_handle* h) {
     hipLaunchKernelGGL(bbh_pack_coop_kernel, dim3(16, (unsigned)(BBH_COOP_ROUNDS - g0), 4), dim3(64), 0, s, h->d_X, np, g0, frags,
                        h->d_rstream);
     h->coop_g0 = g0;
-    const int64_t per = (nb + 1) * (int64_t)kd * 64;
+    const int kdg = bbh_coopg_kd(h);
+    const int64_t per = (nb + 1) * (int64_t)kdg * 64;
     if (!h->d_trainfrag_f || h->tf_f_elems != per * ks.F) {
       if (h->d_trainfrag_f) hipFree(h->d_trainfrag_f);
       if (h->d_sclofs_f) hipFree(h->d_sclofs_f);
       h->d_trainfrag_f = h->d_sclofs_f = nullptr;
       BBH_HIP_TRY(h, hipMalloc((void**)&h->d_trainfrag_f, sizeof(double) * per * ks.F));
-      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_sclofs_f, sizeof(double) * 2 * dn * BBH_MAX_FACTORS));
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_sclofs_f, sizeof(CoopGFeat) * 4 * 8 * BBH_MAX_FACTORS));  // the feature maps [F][4 kd]
       h->tf_f_elems = per * ks.F;
     }
-    std::vector<double> tff, sof((size_t)2 * dn * ks.F);
+    std::vector<double> tff;
+    std::vector<CoopGFeat> feat((size_t)ks.F * 4 * kdg);
     for (int f = 0; f < ks.F; f++) {
-      const double* ls = th + ks.ls_off[f];
       std::vector<double> one;
-      host_pack_trainfrag(h, h->xn_host.data(), h->n, 0, nb + 1, one, ls);
+      host_pack_trainfrag_generic(h, ks, f, kdg, nb + 1, one);
       tff.insert(tff.end(), one.begin(), one.end());
-      for (int j = 0; j < dn; j++) {
-        const double rng = h->hi[j] - h->lo[j];
-        sof[(size_t)f * 2 * dn + j] = 1.0 / (rng * ls[j]);
-        sof[(size_t)f * 2 * dn + dn + j] = -(h->lo[j] / rng + h->xcenter[j]) / ls[j];
-      }
+      host_feature_map(h, ks, f, kdg, feat.data() + (size_t)f * 4 * kdg);
     }
     BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag_f, tff.data(), sizeof(double) * tff.size(), hipMemcpyHostToDevice, s));
-    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_sclofs_f, sof.data(), sizeof(double) * sof.size(), hipMemcpyHostToDevice, s));
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_sclofs_f, feat.data(), sizeof(CoopGFeat) * feat.size(), hipMemcpyHostToDevice, s));
     BBH_HIP_TRY(h, hipStreamSynchronize(s));  // the staging vectors go out of scope
     h->coopg_ready = true;
   }
@@ -511,17 +591,20 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     g.has_tbl = has_tbl ? 1 : 0;
     g.jb = ks.jb;
     g.prior_k0 = (ks.F > 1 && ks.combine) ? 0.0 : 1.0;
+    g.has_dot = 0;
     for (int f = 0; f < BBH_MAX_FACTORS; f++) {
       g.kind[f] = ks.kind[f < ks.F ? f : 0];
       g.fos[f] = (ks.F > 1 && f < ks.F) ? th[ks.fos_off + f] : 1.0;
       g.alpha[f] = (ks.alpha_off >= 0 && f < ks.F) ? th[ks.alpha_off + f] : 1.0;
       if (ks.F > 1 && f < ks.F) g.prior_k0 = ks.combine ? g.prior_k0 + g.fos[f] : g.prior_k0 * g.fos[f];
+      if (f < ks.F && BBH_KIND_IS_DOT(ks.kind[f])) g.has_dot = 1;
     }
+    const int kdg = bbh_coopg_kd(h);
     g.trainfrag_f = h->d_trainfrag_f;
-    g.tf_stride = (h->nb + 1) * (int64_t)h->kd * 64;
-    g.sclofs_f = h->d_sclofs_f;
+    g.tf_stride = (h->nb + 1) * (int64_t)kdg * 64;
+    g.feat = (const CoopGFeat*)h->d_sclofs_f;
     const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (2 * 4 * 256 + 128));
-    bbh_coopg_launch(h->kd, ks.F, dim3((unsigned)((N + 15) / 16)), clds, h->stream, g);
+    bbh_coopg_launch(kdg, ks.F, dim3((unsigned)((N + 15) / 16)), clds, h->stream, g);
     h->last_form = 4;
     BBH_HIP_TRY(h, hipGetLastError());
     return 0;

@@ -969,8 +969,12 @@ def test_linear_polynomial_and_periodic_kernels(gp, which):
     om = go.GPModel(ospec, oracle_params(spec, fi.params), Xt, y)
     mo, vo = om.posterior(X)
     m_, v_ = gp.posterior(X)
-    assert gp.posterior_kernel_form() == "materialised"
+    # fused: the cooperative form with the generic production - dot products / the cos-sin expansion of the periodic metric through
+    # the same MFMA as the distances (csrc/bbh_coopg.h); the materialised-K* path stays as the second opinion
+    assert gp.posterior_kernel_form() == "cooperative-generic"
     assert np.allclose(_np(m_), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v_), vo, rtol=VAR_RTOL, atol=1e-13)
+    mu_, vu_ = gp.posterior(X, unfused=True)
+    assert np.allclose(_np(mu_), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(vu_), vo, rtol=VAR_RTOL, atol=1e-13)
     if spec.has_dot_kind:
         assert np.ptp(go.prior_var(ospec, oracle_params(spec, fi.params), go.normalize_inputs(ospec, X))) > 0  # k(x, x) is not constant
     cand = np.ascontiguousarray(X[:800])
