@@ -39,7 +39,7 @@ def make_baybe_classes(surrogate_base=None, recommender_base=None, discrete_comp
     if discrete_compatibility is None:
         from baybe.searchspace.core import SearchSpaceType
 
-        discrete_compatibility = SearchSpaceType.DISCRETE
+        discrete_compatibility = SearchSpaceType.HYBRID  # discrete, hybrid and (through the hybrid fallback) continuous spaces
 
     surrogate = attrs.make_class("HipGaussianProcessSurrogate", gp_surrogate_fields(with_runtime_state=False),
                                  bases=(HipGPSurrogateImpl, surrogate_base), slots=True)

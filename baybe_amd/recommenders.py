@@ -123,6 +123,17 @@ def _check_objective(objective, acqf) -> None:
         _target_sign(target)
 
 
+def _check_continuous_part(cont) -> None:
+    """What of ``SubspaceContinuous`` the HIP path's search handles: box-bounded parameters.  Linear / nonlinear / cardinality /
+    interpoint constraints need the reference's constrained optimiser."""
+    for name in ("constraints_lin_eq", "constraints_lin_ineq", "constraints_nonlin", "constraints_cardinality"):
+        if len(getattr(cont, name, ()) or ()):
+            raise IncompatibilityError(
+                f"The continuous subspace carries '{name}'; the HIP path searches box-bounded continuous parameters only. "
+                f"Use BotorchRecommender."
+            )
+
+
 class HipRecommenderImpl:
     """Behaviour of the Bayesian recommender scoring the full discrete candidate set on an MI355X.  No fields: they
     are attached by ``attrs.make_class`` - below for the stand-alone class, in ``baybe_amd.plugin`` on top of BayBE's
@@ -195,10 +206,7 @@ class HipRecommenderImpl:
         """Native counterpart of ``_setup_botorch_acqf``: fit (cached), best_f, pending rows."""
         cont = getattr(searchspace, "continuous", None)
         if cont is not None and not getattr(cont, "is_empty", True):
-            raise IncompatibilityError(
-                "HipBotorchRecommender handles purely discrete search spaces; use BotorchRecommender for "
-                "continuous / hybrid spaces."
-            )
+            _check_continuous_part(cont)  # hybrid / continuous spaces: box-bounded continuous parameters only
         self._objective = objective
         acqf = self._get_acquisition_function(objective, acquisition_function)
         _check_objective(objective, acqf)
@@ -272,6 +280,12 @@ class HipRecommenderImpl:
     def _recommend_with_discrete_parts(self, searchspace, batch_size, pending_experiments=None) -> pd.DataFrame:
         sd = searchspace.discrete
         self._check_batch_size(batch_size)
+        cont = getattr(searchspace, "continuous", None)
+        if cont is not None and not getattr(cont, "is_empty", True):  # hybrid space (pure/base.py:268-303)
+            if getattr(sd, "is_empty", False):
+                return self._recommend_hybrid(searchspace, pd.DataFrame(), batch_size)
+            candidates_exp, _ = sd.get_candidates()
+            return self._recommend_hybrid(searchspace, candidates_exp, batch_size)
         mask = getattr(sd, "mask_keep", None)  # FilteredSubspaceDiscrete (searchspace/_filtered.py:14-44)
         if (isinstance(mask, np.ndarray) and mask.dtype == bool and len(mask) == len(sd.exp_rep)
                 and getattr(sd, "n_subsets", 0) == 0):
@@ -413,6 +427,126 @@ class HipRecommenderImpl:
             raise _E("No feasible subset with enough candidates was found.")
         return best[0]
 
+    # ---- hybrid and continuous spaces --------------------------------------------------------------
+    def _recommend_hybrid(self, searchspace, candidates_exp: pd.DataFrame, batch_size: int) -> pd.DataFrame:
+        """``recommend_hybrid_without_subsets`` (botorch/hybrid.py:30-163) as a data-parallel search.  The reference hands BoTorch's
+        ``optimize_acqf_mixed`` one fixed-feature dictionary per discrete row and runs a multi-start gradient optimiser over the
+        continuous parameters for each - "a brute-force calculation ... computationally expensive" (its own docstring).  Here the
+        brute force is one scoring pass: every discrete candidate row is crossed with ``n_raw_samples`` scrambled-Sobol points of
+        the continuous box (the raw samples of BoTorch's initialiser), all rows are scored on the device, and the ``n_restarts`` best
+        rows are refined in their continuous coordinates by a compass search (2 d_c probes per start and iteration, all starts in
+        one pass, step halved when no probe improves) - no acquisition gradients exist on this path.  Batches are built greedily with
+        the chosen points pending, as ``optimize_acqf_mixed`` does.  Same options (``hybrid_sampler`` "Random",
+        ``sampling_percentage``, ``n_restarts``, ``n_raw_samples``), same return frame (discrete part in experimental representation,
+        indexed by the discrete candidate, plus the continuous columns); purely continuous spaces arrive here through
+        ``PureRecommender._recommend_continuous`` with an empty discrete part.  Not a parity path: both sides are stochastic
+        multi-start searches, compared by the acquisition value they reach (tests/test_hybrid_*.py)."""
+        import torch
+
+        from baybe_amd.engine import GreedyResult  # noqa: F401
+
+        cont, disc = searchspace.continuous, searchspace.discrete
+        _check_continuous_part(cont)
+        acqf, surrogate = self._acqf_in_use, self._surrogate_model
+        if self._nehvi is not None:
+            raise IncompatibilityError("Multi-output objectives in hybrid / continuous spaces are not on the HIP path; use BotorchRecommender.")
+        if batch_size > 1 and not acqf.supports_batching:
+            raise IncompatibleAcquisitionFunctionError(
+                f"The '{self.__class__.__name__}' only works with Monte Carlo acquisition functions for batch sizes > 1.")
+        if getattr(disc, "n_subsets", 0) > 0:
+            raise IncompatibilityError("Discrete subset-generating constraints in hybrid spaces are not on the HIP path.")
+        eng = surrogate.engine
+        cnames = list(cont.comp_rep_bounds.columns)
+        cb = cont.comp_rep_bounds.to_numpy(dtype=np.float64)  # [2, d_c]
+        dc = len(cnames)
+        has_disc = candidates_exp is not None and len(candidates_exp.columns) > 0 and len(candidates_exp) > 0
+        if has_disc:
+            Dcomp = disc.comp_rep.loc[candidates_exp.index]
+            n_keep = int(np.ceil(self.sampling_percentage * len(Dcomp)))
+            if self.hybrid_sampler is not None and n_keep < len(Dcomp):
+                name = str(getattr(self.hybrid_sampler, "value", self.hybrid_sampler))
+                if name != "Random":
+                    raise IncompatibilityError("hybrid_sampler='FPS' is not on the HIP path; use 'Random' or sampling_percentage=1.")
+                Dcomp = Dcomp.iloc[np.sort(np.random.choice(len(Dcomp), n_keep, replace=False))]
+            D = np.ascontiguousarray(Dcomp.to_numpy(dtype=np.float64))
+            labels = Dcomp.index
+        else:
+            D = np.zeros((1, 0))
+            labels = pd.RangeIndex(1)
+        Nd, dd = D.shape
+        # raw samples of the continuous box: scrambled Sobol, as many per discrete row as a few million rows allow
+        R = int(max(1, min(self.n_raw_samples, 4_000_000 // max(Nd, 1))))
+        sob = torch.quasirandom.SobolEngine(dimension=max(dc, 1), scramble=True, seed=self._sampler_seed())
+        U = sob.draw(R, dtype=torch.float64).numpy()[:, :dc]
+        Craw = cb[0] + U * (cb[1] - cb[0])
+        dev = eng._dev()
+        Dd, Cd = torch.from_numpy(D).to(dev), torch.from_numpy(np.ascontiguousarray(Craw)).to(dev)
+        X = torch.cat([Dd.repeat_interleave(R, dim=0), Cd.repeat(Nd, 1)], dim=1).contiguous()  # row i R + r = [disc i | cont r]
+        base = self._pending_comp if self._pending_comp is not None else np.zeros((0, dd + dc))
+        seed = self._sampler_seed()
+        mean, var = eng.posterior(X)
+        picks, pick_labels = [], []
+        for _step in range(batch_size):
+            pend = np.vstack([base] + picks) if picks else base
+            scores = self._mc_or_analytic(eng, acqf, X, mean, var, pend, seed, surrogate.sign)
+            k = int(min(self.n_restarts, X.shape[0]))
+            _, top = eng.topk(scores, k)
+            top = [int(t) for t in top if t >= 0]
+            starts = X[torch.as_tensor(top, device=X.device)].cpu().numpy()
+            best_row, _ = self._compass_refine(eng, acqf, starts, dd, cb, pend, seed, surrogate.sign)
+            picks.append(best_row.reshape(1, -1))
+            if has_disc:  # the label of the refined winner's discrete part (copied bit for bit from its start row)
+                pick_labels.append(labels[int(np.nonzero((D == best_row[:dd]).all(axis=1))[0][0])])
+        out_cont = pd.DataFrame(np.vstack(picks)[:, dd:], columns=[str(c) for c in cnames])
+        if has_disc:
+            rec_disc = disc.exp_rep.loc[pd.Index(pick_labels)]
+            out_cont.index = rec_disc.index
+            return pd.concat([rec_disc, out_cont], axis=1)
+        return out_cont
+
+    def _mc_or_analytic(self, eng, acqf, X, mean, var, pend, seed, sign):
+        if acqf.is_analytic:
+            if len(pend):
+                raise IncompatibleAcquisitionFunctionError("Analytic acquisition functions score single points only.")
+            return self._analytic_scores(eng, acqf, mean, var, sign)
+        return self._mc_scores_with_pending(eng, acqf, X, mean, var, pend, seed, sign)
+
+    def _compass_refine(self, eng, acqf, starts: np.ndarray, dd: int, cb: np.ndarray, pend, seed, sign, iters: int = 24):
+        """Compass (pattern) search on the continuous coordinates of ``starts`` [k, d], all starts advancing together: per
+        iteration 2 d_c probes per start (plus and minus the start's step along every continuous axis, clipped to the box) are
+        scored in ONE device pass; a start moves to its best improving probe, otherwise its step halves.  Returns the best row and
+        its value.  (Same base samples for every evaluation: the MC acquisition is a deterministic function of the point.)"""
+        k, d = starts.shape
+        dc = d - dd
+        cur = starts.copy()
+        span = cb[1] - cb[0]
+        if dc == 0:
+            m, v = eng.posterior(cur)
+            val = self._mc_or_analytic(eng, acqf, cur, m, v, pend, seed, sign).cpu().numpy()
+            i = int(np.argmax(val))
+            return cur[i], float(val[i])
+        step = np.full(k, 0.125)  # fraction of the box, per start
+        m, v = eng.posterior(cur)
+        val = self._mc_or_analytic(eng, acqf, cur, m, v, pend, seed, sign).cpu().numpy()
+        for _ in range(iters):
+            probes = np.repeat(cur, 2 * dc, axis=0)  # [k * 2 dc, d]: start s, axis a, sign
+            for a in range(dc):
+                for sg, off in ((+1.0, 0), (-1.0, 1)):
+                    rows = np.arange(k) * 2 * dc + 2 * a + off
+                    probes[rows, dd + a] = np.clip(cur[:, dd + a] + sg * step * span[a], cb[0, a], cb[1, a])
+            pm, pv = eng.posterior(probes)
+            pval = self._mc_or_analytic(eng, acqf, probes, pm, pv, pend, seed, sign).cpu().numpy().reshape(k, 2 * dc)
+            j = pval.argmax(axis=1)
+            better = pval[np.arange(k), j] > val
+            rows = np.arange(k) * 2 * dc + j
+            cur[better] = probes[rows[better]]
+            val[better] = pval[np.arange(k), j][better]
+            step[~better] *= 0.5
+            if (step < 1e-6).all():
+                break
+        i = int(np.argmax(val))
+        return cur[i], float(val[i])
+
     def _analytic_scores(self, eng, acqf, mean, var, sign, alive=None):
         return eng.analytic_acq(acqf.kind, mean, var, self._best_f, sign, getattr(acqf, "beta", 0.2),
                                 getattr(acqf, "maximize", True), alive)
@@ -537,4 +671,4 @@ HipBotorchRecommender = attrs.make_class("HipBotorchRecommender", recommender_fi
                                          kw_only=True, slots=False)
 HipBotorchRecommender.__doc__ = "Bayesian recommender scoring the full discrete candidate set on an MI355X (stand-alone)."
 HipBotorchRecommender.__module__ = __name__
-HipBotorchRecommender.compatibility = "DISCRETE"
+HipBotorchRecommender.compatibility = "HYBRID"

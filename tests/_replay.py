@@ -69,3 +69,25 @@ def replay(recommender, calls, data, on_call=None):
             on_call(c, got)
         out.append((data[k + "_out"].tolist(), list(got.index)))
     return out
+
+
+class HybridSpace:
+    """A hybrid search space from arrays, for boxes without the reference tree: all-numerical discrete rows (experimental =
+    computational representation) plus box-bounded continuous parameters - the attributes ``HipBotorchRecommender`` reads from
+    ``baybe.searchspace.SearchSpace`` / ``SubspaceContinuous`` (searchspace/core.py:234-251, continuous.py:365-376)."""
+
+    def __init__(self, disc: pd.DataFrame, cont_bounds: pd.DataFrame):
+        n = len(disc)
+        self.discrete = _Discrete(disc, np.ones(n, dtype=bool))
+        self.discrete.is_empty = n == 0
+        self.continuous = SimpleNamespace(is_empty=False, comp_rep_bounds=cont_bounds, constraints_lin_eq=(), constraints_lin_ineq=(),
+                                          constraints_nonlin=(), constraints_cardinality=())
+        self.parameters = ()
+        self.comp_rep_columns = tuple(disc.columns) + tuple(cont_bounds.columns)
+        lo = [disc[c].min() if n else 0.0 for c in disc.columns] + list(cont_bounds.loc["min"])
+        hi = [disc[c].max() if n else 1.0 for c in disc.columns] + list(cont_bounds.loc["max"])
+        self.scaling_bounds = pd.DataFrame([lo, hi], index=["min", "max"], columns=list(self.comp_rep_columns))
+        self.task_idx, self.n_tasks = None, 1
+
+    def transform(self, df, allow_extra=False):
+        return df[list(self.comp_rep_columns)].astype(float)
