@@ -74,7 +74,12 @@ def test_continuous_space_and_unsupported_constraints(ref):
     S, C, R, Eng = ref
     from baybe import Campaign
     from baybe.constraints import ContinuousLinearConstraint
-    from baybe.exceptions import IncompatibilityError
+    import baybe.exceptions
+    import baybe_amd.exceptions
+
+    # (``baybe_amd.exceptions`` re-exports BayBE's classes when BayBE is importable at ITS import time - in a test process that
+    # imported the product first it holds the stand-ins, so both spellings are accepted here)
+    IncompatibilityError = (baybe.exceptions.IncompatibilityError, baybe_amd.exceptions.IncompatibilityError)
     from baybe.parameters import NumericalContinuousParameter
     from baybe.searchspace import SearchSpace
     from baybe.targets import NumericalTarget

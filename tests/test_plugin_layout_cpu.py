@@ -147,7 +147,7 @@ def test_standalone_classes_share_the_implementation(classes):
     assert HipGPSurrogateImpl in Sur.__mro__ and HipGPSurrogateImpl in HipGaussianProcessSurrogate.__mro__
     assert HipRecommenderImpl in Rec.__mro__ and HipRecommenderImpl in HipBotorchRecommender.__mro__
     assert Sur.fit is HipGaussianProcessSurrogate.fit and Rec._recommend_discrete is HipBotorchRecommender._recommend_discrete
-    assert HipBotorchRecommender().max_n_subsets == 10 and HipBotorchRecommender.compatibility == "DISCRETE"
+    assert HipBotorchRecommender().max_n_subsets == 10 and HipBotorchRecommender.compatibility == "HYBRID"
 
 
 def test_reference_constructor_arguments_of_the_gp_surrogate(classes):

@@ -604,7 +604,12 @@ def test_desirability_as_pre_transformation_is_the_single_target_path(ref):
     The default desirability (one model per target, per-sample scalarisation) is refused with a message naming the alternative."""
     baybe, S, C, R, Eng = ref
     from baybe import Campaign
-    from baybe.exceptions import IncompatibilityError
+    import baybe.exceptions
+    import baybe_amd.exceptions
+
+    # (``baybe_amd.exceptions`` re-exports BayBE's classes when BayBE is importable at ITS import time - in a test process that
+    # imported the product first it holds the stand-ins, so both spellings are accepted here)
+    IncompatibilityError = (baybe.exceptions.IncompatibilityError, baybe_amd.exceptions.IncompatibilityError)
     from baybe.objectives import DesirabilityObjective
     from baybe.targets import NumericalTarget
 
