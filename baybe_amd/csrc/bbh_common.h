@@ -153,6 +153,7 @@ struct bbh_handle {
 
   // ---- model description ----
   bbh_model_desc desc{};
+  std::string model_sig;  // shape signature of the current model: a refit with the same one keeps every device buffer
   bool have_model = false;
   bool factorized = false;
   int64_t n = 0;      // training points

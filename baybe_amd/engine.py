@@ -460,6 +460,10 @@ class HipGP:
             raise ValueError("candidates must be [N, d]")
         if X.stride(1) != 1:
             X = X.contiguous()
+        if X.shape[0] == 1 and X.stride(0) < X.shape[1]:
+            # a single row that came from a column-major block (``frame.iloc[[i]].to_numpy()``) counts as contiguous with a row
+            # stride of 1: give it the row stride the C-ABI asks for (ldx >= d)
+            X = X.as_strided(X.shape, (X.shape[1], 1))
         return X
 
     def posterior(self, X, unfused: bool = False, out=None):

@@ -71,6 +71,16 @@ def synth_pareto_targets(Xt: np.ndarray):
     return [fo + 0.05 * np.random.default_rng(30 + o).standard_normal(len(Xt)) for o, fo in enumerate(f)]
 
 
+def issue_frac_of(cfg_name, kernel_prefix):
+    """{kernel: issue_frac} from the committed PMC summary of this configuration (profiles/r04_<cfg>_issue.json), or None."""
+    try:
+        ij = json.loads((ROOT / "profiles" / f"r04_{cfg_name}_issue.json").read_text())
+        got = {k: round(v["issue_frac"], 4) for k, v in ij["kernels"].items() if k.startswith(kernel_prefix)}
+        return got or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 class _BenchSpace:
     """What ``HipBotorchRecommender.recommend`` reads from ``baybe.searchspace.SearchSpace`` for a purely discrete, all-numerical
     space (attribute names of searchspace/core.py, searchspace/discrete.py): the N x d grid is both representations."""
@@ -458,11 +468,14 @@ def run(args):
             ach = rows_local * flops_p / (p_ms * 1e-3) / 1e12
             pending_roofline = {
                 "kernel": "bbh_qlogei_pending_q_kernel<2..%d>" % args.greedy, "bound": "fp64 vector pipe (mfma peak: matrix = vector)",
-                "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                # NOT a roofline fraction: the reference formulation's operation count (exp / log at 20 flops, a division at 8) over the
+                # fp64 peak; the kernel reaches the same values (1e-10) with series and partly packed single precision, so it can exceed 1
+                "throughput_vs_fp64_formulation": ach / FP64_MFMA_PEAK_TFLOPS,
+                # the utilisation statement: issued wave-instructions x cycles of their class over SIMD-cycles, from the PMC passes of
+                # scripts/profile_config.sh (SQ_INSTS_VALU, GRBM_GUI_ACTIVE) and the kernels' static class mix (profiles/r04_isa_class_mix.json)
+                "issue_frac": issue_frac_of(cfg, "bbh_qlogei_pending_q_kernel"),
                 "flops_per_candidate": flops_p, "flops_formula": "sum over q' = Q of S (Q (Q + 1) + 87 Q + 47) + Q^3 / 3",
-                "note": "operation count of the reference's formulation (exp / log at 20 flops, a division at 8); the kernel reaches the same "
-                        "values (1e-10) with series and partly packed single-precision arithmetic, so this is throughput on the reference's count "
-                        "relative to the fp64 roof - it can exceed 1 and is not a utilisation figure",
                 "launches": p_n, "total_ms": p_ms,
                 "hbm_bytes_per_candidate_algorithmic": sum(8 * (2 + (Q - 1)) + 8 for Q in range(2, args.greedy + 1)),
             }
@@ -533,10 +546,15 @@ def run(args):
             recs[name] = {"flops_per_candidate": fl, "device_ms_per_step": per_step, "launches_per_step": cnt / args.steps,
                           "achieved": rows_local * fl / (per_step * 1e-3) / 1e12 if per_step > 0 else 0.0}
             recs[name]["frac"] = recs[name]["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        # the cell kernel is VALU-issue-bound and a third of its instructions are packed single precision: its figure on the fp64
+        # formulation's operation count is a throughput, its utilisation is the issue fraction
+        recs["cells"]["throughput_vs_fp64_formulation"] = recs["cells"].pop("frac")
+        recs["cells"]["issue_frac"] = issue_frac_of(cfg, "bbh_qlognehvi_lin_kernel")
         dom = max(recs, key=lambda k: recs[k]["device_ms_per_step"])
         roofline = {
             "bound": "mfma",  # the fp64 pipe: matrix and vector fp64 share it and have the same peak (78.6 TFLOP/s)
-            "achieved": recs[dom]["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": recs[dom]["frac"],
+            "achieved": recs[dom]["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": recs[dom].get("frac", (recs[dom].get("issue_frac") or {}).get("bbh_qlognehvi_lin_kernel<3, true>")),
             "traffic": traffic_of(f"{rows_local}x{d}_n{n}_cfg5"),
             "kernel": {"variance": kernel_names.get(form, form), "columns": "bbh_coop_columns_kernel", "cells": "bbh_qlognehvi_lin_kernel"}[dom],
             "dominant_part": dom, "parts": recs,

@@ -61,6 +61,43 @@ import json
 
 with open(os.path.join(dst, f"{tag}_traffic.json"), "w") as f:
     json.dump(_traffic(acc), f, indent=1)
+
+# ---- pipe-level issue fraction of the VALU-bound kernels ------------------------------------------------------
+# issue_frac = (VALU wave-instructions x mean cycles of the kernel's static class mix + MFMA x 64) / (SIMDs x clock x duration), with
+# SQ_INSTS_VALU taken to INCLUDE the MFMA instructions (they are subtracted), the clock from GRBM_GUI_ACTIVE (summed over the 8 XCDs)
+# over the traced duration of the same dispatches, and 1024 SIMDs.
+mix_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r04_isa_class_mix.json")
+if os.path.exists(mix_file):
+    mix = json.load(open(mix_file))
+    cnt, dur = defaultdict(lambda: defaultdict(list)), defaultdict(list)
+    for d in sorted(glob.glob(os.path.join(out, "pmcg_*"))):
+        if not os.path.isdir(d):
+            continue
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(fn)):
+                cnt[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for fn in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(fn)):
+                dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    issue = {}
+    for shown, rec in mix["kernels"].items():
+        for kname, c in cnt.items():
+            if shown not in kname or "SQ_INSTS_VALU" not in c:
+                continue
+            mean = lambda v: sum(v) / len(v)
+            valu_all, mfma = mean(c["SQ_INSTS_VALU"]), mean(c.get("SQ_INSTS_MFMA", [0.0]))
+            t_ns = mean(dur[kname]) if dur.get(kname) else None
+            if not t_ns:
+                continue
+            clock = mean(c["GRBM_GUI_ACTIVE"]) / 8.0 / (t_ns * 1e-9) if "GRBM_GUI_ACTIVE" in c else 2.4e9
+            cyc = (valu_all - mfma) * rec["mean_cycles_per_valu_instruction"] + mfma * 64.0
+            issue[shown] = {"dispatches": len(c["SQ_INSTS_VALU"]), "valu_wave_instructions_excl_mfma": valu_all - mfma, "mfma_wave_instructions": mfma,
+                            "mean_cycles_per_valu_instruction_static_mix": rec["mean_cycles_per_valu_instruction"],
+                            "duration_us_under_pmc": t_ns / 1e3, "clock_ghz_from_grbm_gui_active": clock / 1e9,
+                            "issue_frac": cyc / (1024.0 * clock * t_ns * 1e-9)}
+    with open(os.path.join(dst, f"{tag}_issue.json"), "w") as f:
+        json.dump({"_comment": "pipe-level issue fraction of the VALU-bound kernels: see scripts/profile_summarize.py and profiles/r04_isa_class_mix.json",
+                   "kernels": issue}, f, indent=1)
 line = os.path.join(out, "bench_line.json")
 if os.path.exists(line):
     try:

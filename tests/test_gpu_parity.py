@@ -506,7 +506,7 @@ def test_multitask_botorch_presets_data_term_posterior_and_fit(gp, preset, n_per
         assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL, atol=1e-14)
     if n_per_task * T <= 512:
         gp.posterior(X)
-        assert gp.posterior_kernel_form() == "cooperative"
+        assert gp.posterior_kernel_form() in ("cooperative", "register-resident")  # (n <= 128: the small-model form, bbh_small.h)
     mj, cj = gp.posterior_joint(X[:7])
     moj, coj = om.posterior_joint(X[:7])
     assert np.allclose(mj, moj, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(cj, coj, rtol=1e-7, atol=1e-12)
