@@ -365,9 +365,24 @@ def run(args):
     # The device comes out of idle at ramping clocks: the posterior kernel of the first launches after set-up runs 6.0, 5.5,
     # 5.2, 5.0, 4.85, 4.76 ms before it settles at 4.73 (rocprofv3 trace of this command, profiles/r02_bench_kernel_stats.csv).
     # A fixed number of untimed passes before the W warm-up steps takes the ramp out of the timed region whatever W is.
-    extra["pre_warm_steps"] = 8
-    for _ in range(extra["pre_warm_steps"]):
-        step()
+    # Round 4: at least 8 passes AND at least 100 ms of them - on a 125 000-row shard eight passes are 6 ms and the ramp reached
+    # through the whole timed region (rocprofv3 trace of that run: the posterior kernel fell from 0.69 to 0.64 ms over the 20 timed
+    # steps and is 0.597 ms in back-to-back launches, profiles/r04_cfg3_125k_bench_posterior_launches.csv, r04_ramp_probe.log).
+    def pre_warm(fn, first):  # the same number of passes on every rank (a pass ends in a collective)
+        t_pw = time.perf_counter()
+        for _ in range(first):
+            fn()
+        el = time.perf_counter() - t_pw
+        more = int(min(2000, math.ceil(max(0.0, 0.1 - el) / max(el / first, 1e-6))))
+        if dist_on:
+            mt = torch.tensor([more], dtype=torch.int64, device="cpu" if single_dev else "cuda")
+            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+            more = int(mt.item())
+        for _ in range(more):
+            fn()
+        return first + more
+
+    extra["pre_warm_steps"] = pre_warm(step, 8)
     for _ in range(args.warmup):
         step()
     FAMILIES = ("posterior", "cross", "pending", "columns", "nehvi", "q1", "select")
@@ -418,8 +433,7 @@ def run(args):
         keep = (shard.start, shard.stop)
         shard.start, shard.stop = a_s, b_s
         sstep = make_step(Xs, a_s)
-        for _ in range(3):
-            sstep()
+        pre_warm(sstep, 3)
         fence()
         ts_ms = []
         t0 = time.perf_counter()
