@@ -72,6 +72,7 @@ SIGNATURES = {
          C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_double],
     ),
     "bbh_set_slice_rows": (C.c_int, [C.c_void_p, C.c_int64]),
+    "bbh_trim": (C.c_int, [C.c_void_p, C.c_int64]),
     "bbh_theta_len": (C.c_int64, [C.c_void_p]),
     "bbh_get_standardization": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "bbh_fit_value_grad": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),

@@ -6,7 +6,10 @@
 // baybe/objectives/base.py:99-105).  Maths restated in oracle/gp_oracle.py (log_fatplus, fatmax,
 // logmeanexp, psd_safe_cholesky jitter).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include "bbh_common.h"
 
@@ -703,6 +706,7 @@ static int bbh_qlogei_pending_impl(bbh_handle* h, const double* mean_dev, const 
 // Memory-bound on the factor (q'^2 / 2 loads per sample): ~0.1 s per 1e5 candidates at q' = 32 - a correctness path for the
 // rare large batch, not a tuned one.
 #define QBIG_MAX 64
+#define QBIG_WS_BYTES ((size_t)512 << 20)  // workspace bound of bbh_qlogei_pending_big (env BBH_QBIG_WS_MB for tests)
 __global__ __launch_bounds__(64) void bbh_qlogei_pending_big_kernel(
     const double* __restrict__ mean, const double* __restrict__ var, const double* __restrict__ cross, int64_t N, int p,
     const double* __restrict__ mean_p, const double* __restrict__ cov_pp, const double* __restrict__ z, int S,
@@ -802,13 +806,25 @@ extern "C" int bbh_qlogei_pending_big(bbh_handle* h, const double* mean_dev, con
   memcpy(buf.data() + S * q + p, cov_pp_host, sizeof(double) * p * p);
   int rc = bbh_upload_z(h, buf.data(), buf.size());
   if (rc) return rc;
-  rc = bbh_ensure_ws(h, sizeof(double) * (size_t)(q * (q + 1) / 2) * (size_t)N);
+  // The per-candidate factor workspace is q'(q' + 1) / 2 doubles: 16 GB for 1e6 candidates at q' = 64.  The candidates are walked in
+  // chunks whose workspace stays below QBIG_WS_BYTES (the handle's grow-only workspace outlives the call, also in the handle pool);
+  // chunks are multiples of 64 rows, every chunk addresses its own rows from 0.
+  const int64_t tri_q = q * (q + 1) / 2;
+  size_t ws_bound = QBIG_WS_BYTES;
+  if (const char* e = getenv("BBH_QBIG_WS_MB")) ws_bound = (size_t)std::max(1LL, atoll(e)) << 20;
+  int64_t chunk = (int64_t)(ws_bound / (sizeof(double) * (size_t)tri_q)) / 64 * 64;
+  if (chunk < 64) chunk = 64;
+  if (chunk > N) chunk = N;
+  rc = bbh_ensure_ws(h, sizeof(double) * (size_t)tri_q * (size_t)chunk);
   if (rc) return rc;
   const double* dz = h->d_z;
   bbh_timed_scope timed(h, BBH_TIMED_PENDING);
-  hipLaunchKernelGGL(bbh_qlogei_pending_big_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), sizeof(double) * q * 64, h->stream,
-                     mean_dev, var_dev, cross_dev, N, (int)p, dz + S * q, dz + S * q + p, dz, (int)S, best_f, sign, alive_dev,
-                     scores_dev, h->d_ws);
+  for (int64_t c0 = 0; c0 < N; c0 += chunk) {
+    const int64_t nc = std::min(chunk, N - c0);
+    hipLaunchKernelGGL(bbh_qlogei_pending_big_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), sizeof(double) * q * 64, h->stream,
+                       mean_dev + c0, var_dev + c0, cross_dev + c0 * p, nc, (int)p, dz + S * q, dz + S * q + p, dz, (int)S, best_f, sign,
+                       alive_dev ? alive_dev + c0 : nullptr, scores_dev + c0, h->d_ws);
+  }
   BBH_HIP_TRY(h, hipGetLastError());
   return 0;
 }

@@ -35,7 +35,6 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
   if (const char* e = getenv("BBH_KV_LDS")) h->kv_lds_blocks = atoi(e);
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');
-  if (const char* e = getenv("BBH_COOP_PREFETCH")) h->coop_prefetch = (e[0] != '0');
   if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
   if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
   if (const char* e = getenv("BBH_COOP")) h->coop_mode = atoi(e);
@@ -218,6 +217,27 @@ extern "C" int bbh_train_posterior_mean(bbh_handle* h, double* mean_host) {
 extern "C" int bbh_set_slice_rows(bbh_handle* h, int64_t rows) {
   if (!h || rows < 0) return -1;
   h->slice_rows = rows;
+  return 0;
+}
+
+// Idle handles are kept in a pool by the host side (engine.py); their grow-only buffers would pin HBM for as long as they sit there.
+// Everything above keep_bytes goes: the scratch workspace, the global kernel-value cache, and the model (its buffers are re-created by
+// the next bbh_set_model) when its matrices exceed the bound.  Small campaign models - what the pool is for - keep everything.
+extern "C" int bbh_trim(bbh_handle* h, int64_t keep_bytes) {
+  if (!h || keep_bytes < 0) return -1;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->d_ws && h->ws_bytes > (size_t)keep_bytes) {
+    hipFree(h->d_ws);
+    h->d_ws = nullptr;
+    h->ws_bytes = 0;
+  }
+  if (h->d_kvcache && h->kvcache_bytes > (size_t)keep_bytes) {
+    hipFree(h->d_kvcache);
+    h->d_kvcache = nullptr;
+    h->kvcache_bytes = 0;
+  }
+  if (h->have_model && sizeof(double) * (size_t)h->np * (size_t)h->np * 6 > (size_t)keep_bytes) bbh_free_model_public(h);
   return 0;
 }
 

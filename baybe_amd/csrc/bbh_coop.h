@@ -87,7 +87,6 @@ struct CoopArgs {
   const double* rstream;  // [4 waves][frags][64] operand slices
   int64_t frags;          // fragments per wave
   int g0;                 // first group that exists: 8 - nb / 4
-  int prefetch;           // 1: the launch's first workgroups touch the operand stream once, a share each (cold L2 at kernel start)
 };
 
 // fragments of the groups before G (in the full 8-round numbering)
@@ -242,18 +241,6 @@ __global__ __launch_bounds__(256, (GMIN >= 6 ? 5 : GMIN >= 4 ? 4 : BBH_COOP_WAVE
   // is 8 us of which the MFMA work is 5)
   double tfv0[KD];
   kvp_load<KD>(a.trainfrag + l, w, tfv0);
-  // Every XCD's L2 starts a kernel cold, and the workgroups of the first round walk the operand stream in lock step: each of
-  // its 128-byte lines is then a miss that all of them wait for, one after the other (a ring of BBH_COOP_PAIRS requests per
-  // wave in flight).  The first workgroups of the launch therefore request a 1/64 share of the whole stream each (workgroups go
-  // round-robin over the 8 XCDs: blockIdx / 8 is the position within the XCD), one line per thread, before anything else waits;
-  // the value is consumed after the set-up's own waits, which cover these older requests.
-  double pf_touch = 0.0;
-  if (ca.prefetch && blockIdx.x < 1024) {
-    const int64_t lines = ca.frags * (4 * 64 * 8 / 128);
-    const int64_t per = (lines + 63) >> 6;
-    const int64_t ln = (int64_t)((blockIdx.x >> 3) & 63) * per + threadIdx.x;
-    if (threadIdx.x < per && ln < lines) pf_touch = ca.rstream[ln * 16];
-  }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const int64_t row = (tile0 + 16 * t + cnd < a.N) ? tile0 + 16 * t + cnd : a.N - 1;
@@ -324,7 +311,6 @@ __global__ __launch_bounds__(256, (GMIN >= 6 ? 5 : GMIN >= 4 ? 4 : BBH_COOP_WAVE
     c[t].dn = a.dn;
   }
 
-  asm volatile("" ::"v"(pf_touch));
   bbh_lds_double* kvb = (bbh_lds_double*)(s_kv + l);  // [tile][buffer][k-block of the group][4 values x 64 lanes]
   const bbh_lds_double* alq = (const bbh_lds_double*)(s_alpha + q);  // alpha[16 tb + 4 r + q]
   const int g0 = ca.g0;

@@ -264,10 +264,12 @@ __device__ __forceinline__ void pd_static_for(F&& f) {
 // Factor and invert the 64 x 64 SPD block held in LDS array a (in place: lower factor L, strict upper zeroed) into x =
 // L^-1 (lower); s is scratch.  256 threads, all LDS arrays [64][PD_LD]; x must be zero on entry.  row0: global index of
 // the block's first row (failure reports row0 + pivot + 1 through *info).
+// nbk < 4 (one-workgroup fit evaluation of a model with n <= 16 nbk rows): the sub-blocks from nbk on are identity in a AND in x on
+// entry and are left alone.
 __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[PD_LD], double (*s)[PD_LD], int64_t row0, int* info,
-                                                int* early_flag = nullptr, int epoch = 0) {
+                                                int* early_flag = nullptr, int epoch = 0, int nbk = 4) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  for (int jb = 0; jb < 4; jb++) {
+  for (int jb = 0; jb < nbk; jb++) {
     // (tile-dataflow caller: stores issued before this call have landed by now - publish them without a stall)
     if (jb == 1 && early_flag) {
       __threadfence();
@@ -351,7 +353,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
     __syncthreads();
     // panel: L_IJ = A_IJ T_J^T for the sub-blocks below the diagonal one, one wave each, in place (a wave's LDS
     // operations complete in order: its operand reads precede its writes)
-    for (int ib = jb + 1 + w; ib < 4; ib += 4) {
+    for (int ib = jb + 1 + w; ib < nbk; ib += 4) {
       const d4 c = pd_mul_nt(a, 16 * ib, o, x, o, o, l);
 #pragma unroll
       for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][o + (l & 15)] = c[r];
@@ -359,7 +361,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
     __syncthreads();
     // trailing update: A_IK -= L_IJ L_KJ^T for jb < K <= I (at most 6 sub-blocks, dealt to the waves)
     int cnt = 0;
-    for (int ib = jb + 1; ib < 4; ib++)
+    for (int ib = jb + 1; ib < nbk; ib++)
       for (int kb = jb + 1; kb <= ib; kb++, cnt++) {
         if ((cnt & 3) != w) continue;
         const d4 c = pd_mul_nt(a, 16 * ib, o, a, 16 * kb, o, l);
@@ -377,7 +379,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
   // L^-1 by block columns: X_IJ = -T_I (sum_{K=J}^{I-1} L_IK X_KJ), wave J owns block column J (rows I = J+1..3 in turn)
   {
     const int jb = w, oj = 16 * jb;
-    for (int ib = jb + 1; ib < 4; ib++) {
+    for (int ib = jb + 1; ib < nbk; ib++) {
       d4 c = {0.0, 0.0, 0.0, 0.0};
       for (int kb = jb; kb < ib; kb++) c = pd_mul_nn(a, 16 * ib, 16 * kb, x, 16 * kb, oj, l, c);
 #pragma unroll
@@ -680,6 +682,7 @@ static bool bbh_potrf_tiles(bbh_handle* h) {
 // taken in a different (fixed) order, so values agree to rounding, not bitwise.
 // =====================================================================================================================
 #define FS_MAXD 32
+#define FS_ENT 9  // pairs j <= i < 64 per thread: 2080 / 256, rounded up
 __global__ __launch_bounds__(256) void bbh_fit_small_kernel(const double* __restrict__ xnT, const double* __restrict__ ystd,
                                                             const double* __restrict__ nmask, const double* __restrict__ theta,
                                                             int n, int dn, const bbh_kern_spec ks, double jitter, int tl,
@@ -696,46 +699,64 @@ __global__ __launch_bounds__(256) void bbh_fit_small_kernel(const double* __rest
   double* invls = vec + 192;
   double* th = invls + FS_MAXD;
   double* red = th + 64;
+  double* nm = red + 4 * (FS_MAXD + 8);                  // noise mask [64]
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int kind = ks.kind[0];
   // theta / out / info may live in pinned HOST memory (bbh_fit_enqueue passes the staging buffers themselves: no copies around the
-  // launch): theta is read once, coalesced, into LDS
+  // launch): theta is read once, coalesced, into LDS.  Everything the evaluation reads from memory is requested here, at once.
   if (t < tl) th[t] = theta[t];
   for (int e = t; e < dn * 64; e += 256) xs[e] = xnT[e];  // (np = 64: the rows of xnT are 64 long)
+  if (t < 64) {
+    nm[t] = nmask[t];
+    rv[t] = (t < n) ? ystd[t] : 0.0;
+  }
   if (t == 0) *info = 0;
+  // a = identity, x = identity on the sub-blocks the factorisation skips (rows >= 16 nbk are padding), 0 elsewhere
+  const int nbk = (n + 15) >> 4;
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    a[i][j] = (i == j) ? 1.0 : 0.0;
+    x[i][j] = (i == j && i >= 16 * nbk) ? 1.0 : 0.0;
+  }
   __syncthreads();
   const double noise = th[0], mean = th[1], os = ks.use_os ? th[2] : 1.0;
   const double kalpha = ks.alpha_off >= 0 ? th[ks.alpha_off] : 1.0;
   if (t < dn) invls[t] = 1.0 / th[3 + t];
   __syncthreads();
-  // ---- Gram matrix (identity on the padding), x = 0; every thread keeps the metric and the kernel value of its 16 entries for the
-  //      gradient sums below
-  double r2v[16], kbv[16];
+  // ---- Gram matrix.  Only the n (n + 1) / 2 pairs j <= i < n are evaluated (the matrix is symmetric, the padding is the identity
+  //      written above), dealt round-robin to the threads: at most FS_ENT each - 9 for n = 64, 3 for n = 33, 1 for n <= 22 (every
+  //      thread walking its 16 entries of the full 64 x 64 square was 16 kernel-function evaluations in a row whatever n is).  A thread
+  //      keeps the metric and the kernel value of its pairs for the gradient sums below.
+  const int npairs = n * (n + 1) / 2;
+  double r2v[FS_ENT], kbv[FS_ENT];
+  int pij[FS_ENT];
 #pragma unroll
-  for (int k16 = 0; k16 < 16; k16++) {
-    const int e = t + 256 * k16;
-    const int i = e >> 6, j = e & 63;
-    double k;
-    r2v[k16] = 0.0;
-    kbv[k16] = 0.0;
-    if (i >= n || j >= n) {
-      k = (i == j) ? 1.0 : 0.0;
-    } else {
+  for (int k = 0; k < FS_ENT; k++) {
+    const int idx = t + 256 * k;
+    r2v[k] = 0.0;
+    kbv[k] = 0.0;
+    pij[k] = -1;
+    if (idx < npairs) {
+      int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > idx) i--;
+      while ((i + 1) * (i + 2) / 2 <= idx) i++;
+      const int j = idx - i * (i + 1) / 2;
       double r2 = 0.0;
       for (int c = 0; c < dn; c++) r2 += bbh_metric_term(kind, xs[c * 64 + i], xs[c * 64 + j], invls[c]);
       const double kb = bbh_kbase(kind, r2, ks.jb, kalpha);
-      r2v[k16] = r2;
-      kbv[k16] = kb;
-      k = kb * os;
-      if (i == j) k += noise * nmask[i] + jitter;
+      r2v[k] = r2;
+      kbv[k] = kb;
+      pij[k] = (i << 8) | j;
+      double kv = kb * os;
+      if (i == j) kv += noise * nm[i] + jitter;
+      a[i][j] = kv;
+      a[j][i] = kv;
     }
-    a[i][j] = k;
-    x[i][j] = 0.0;
   }
   __syncthreads();
-  pd_factor_block(a, x, s, 0, info);  // a = L (lower), x = L^-1; ends with a barrier
+  pd_factor_block(a, x, s, 0, info, nullptr, 0, nbk);  // a = L (lower), x = L^-1; ends with a barrier
   // ---- residual, t = X r, alpha = X^T t, log-determinant
-  if (t < 64) rv[t] = (t < n) ? ystd[t] - mean : 0.0;
+  if (t < n) rv[t] -= mean;
   __syncthreads();
   const int row = t >> 2, part = t & 3;  // four threads per row / column, partial sums combined by two shuffles
   {
@@ -770,19 +791,19 @@ __global__ __launch_bounds__(256) void bbh_fit_small_kernel(const double* __rest
   __syncthreads();
   pd_gemm64<true, false, PD_FULL>(s, a, a, 1.0);
   __syncthreads();
-  // ---- gradient sums over all ordered pairs (a, b), a, b < n:  G = 0.5 (alpha_a alpha_b - M_ab)
+  // ---- gradient sums over all ordered pairs (a, b), a, b < n:  G = 0.5 (alpha_a alpha_b - M_ab); every term is symmetric in (a, b),
+  //      so the thread's pairs j < i count twice
   double g_noise = 0.0, g_os = 0.0, g_al = 0.0, g_ls[FS_MAXD];
 #pragma unroll
   for (int c = 0; c < FS_MAXD; c++) g_ls[c] = 0.0;
   const bool dot = BBH_KIND_IS_DOT(kind);
 #pragma unroll
-  for (int k16 = 0; k16 < 16; k16++) {
-    const int e = t + 256 * k16;
-    const int i = e >> 6, j = e & 63;
-    if (i >= n || j >= n) continue;
-    const double G = 0.5 * (al[i] * al[j] - s[i][j]);
-    const double r2 = r2v[k16], kb = kbv[k16];
-    if (i == j) g_noise += G * nmask[i];
+  for (int k = 0; k < FS_ENT; k++) {
+    if (pij[k] < 0) continue;
+    const int i = pij[k] >> 8, j = pij[k] & 255;
+    const double G = (i == j ? 0.5 : 1.0) * (al[i] * al[j] - s[i][j]);
+    const double r2 = r2v[k], kb = kbv[k];
+    if (i == j) g_noise += G * nm[i];
     g_os += G * kb;
     const double Gg = G * bbh_gfun(kind, r2, ks.jb, kalpha) * os;
 #pragma unroll
@@ -842,7 +863,7 @@ bool bbh_fit_small_launch(bbh_handle* h, double jitter, const double* theta_dev,
       h->dn > FS_MAXD || h->desc.kernel_kind == BBH_KERNEL_PERIODIC || h->fit_graph_mode ||
       (h->fit_stream && h->stream == h->fit_stream))
     return false;
-  static const size_t lds = sizeof(double) * (3 * 64 * PD_LD + FS_MAXD * 64 + 192 + FS_MAXD + 64 + 4 * (FS_MAXD + 8));
+  static const size_t lds = sizeof(double) * (3 * 64 * PD_LD + FS_MAXD * 64 + 192 + FS_MAXD + 64 + 4 * (FS_MAXD + 8) + 64);
   if (!h->fit_small_ready) {
     if (hipFuncSetAttribute((const void*)bbh_fit_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();

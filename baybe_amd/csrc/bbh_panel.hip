@@ -645,7 +645,6 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     ca.rstream = h->d_rstream;
     ca.frags = h->rstream_frags;
     ca.g0 = h->coop_g0;
-    ca.prefetch = h->coop_prefetch;
     // (Two candidate tiles per workgroup - every operand fragment feeding two MFMAs, half the vector-memory traffic per MFMA -
     // was built and measured in round 2: 4.72 vs 4.68 ms on the bench shape, profiles/r02_libs_nt2.log.  What the MFMA pipe
     // loses is per candidate, not per operand fragment; the variant was removed from the library, coop_group keeps its NT
@@ -666,7 +665,6 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     ca.rstream = h->d_rstream;
     ca.frags = h->rstream_frags;
     ca.g0 = h->coop_g0;
-    ca.prefetch = 0;
     const int ra = BBH_COOP_ROUNDS - ca.g0;  // archived k-block groups (at least the 16 KB sweep B's exchange slots need)
     const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (size_t)(ra > 2 ? ra : 2) * 4 * 256 + 128);
     bbh_coop2_launch(kdc, a.kind, has_tbl, dim3((unsigned)((N + 15) / 16)), clds, h->stream, ca);

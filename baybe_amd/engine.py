@@ -187,6 +187,7 @@ class ModelFittingError(RuntimeError):
 # handle keeps its streams, events, workspaces and grow-only device buffers instead of paying hipMalloc / hipFree per case.
 _HANDLE_POOL: dict = {}
 _HANDLE_POOL_MAX = 8  # idle handles kept per device
+_POOL_KEEP_BYTES = 64 << 20  # per buffer of an idle handle (bbh_trim)
 pool_stats = {"created": 0, "reused": 0}
 
 
@@ -266,9 +267,10 @@ class HipGP:
             key = self._pool_key
             if self._comm is not None or len(_HANDLE_POOL.setdefault(key, [])) >= _HANDLE_POOL_MAX:
                 self._lib.bbh_destroy(self._handle)  # a handle that owns a communicator is not handed on
-            else:  # back to its defaults: legacy stream, no timing
+            else:  # back to its defaults: legacy stream, no timing; buffers above 64 MB are released (an idle handle must not pin HBM)
                 self._lib.bbh_set_stream(self._handle, None)
                 self._lib.bbh_timing_enable(self._handle, 0)
+                self._lib.bbh_trim(self._handle, _POOL_KEEP_BYTES)
                 _HANDLE_POOL[key].append(self._handle)
             self._handle = None
         self._restorable = False

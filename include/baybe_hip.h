@@ -304,6 +304,11 @@ int bbh_topk(bbh_handle* h, const double* scores_dev, int64_t N, int64_t k, doub
  * unsharded pass uses, so scores are bit-identical across shard layouts); 0 = the rows of each call (default). */
 int bbh_set_slice_rows(bbh_handle* h, int64_t rows);
 
+/* Release what an idle handle holds above keep_bytes per buffer: the scratch workspace (bbh_qlogei_pending_big, the materialised
+ * K* path), the global kernel-value cache, and the model's matrices (6 np^2 doubles; the next bbh_set_model re-creates them).  No
+ * reference counterpart (BayBE holds no device state); called by the host side when a handle goes back to its pool. */
+int bbh_trim(bbh_handle* h, int64_t keep_bytes);
+
 /* ---- row-sharded selection over the GPUs of one node (RCCL over xGMI) ---------------------------
  * No reference call site (BayBE is single-process): these belong to the argmax / top-k of
  * optimize_acqf_discrete (baybe/recommenders/pure/bayesian/botorch/discrete.py:120-126) once the candidate rows are

@@ -65,19 +65,26 @@ if __name__ == "__main__":
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "small_space_latency.json").write_text(json.dumps(rows, indent=1))
     import cProfile, pstats
-    rng = np.random.default_rng(1)
-    vals = np.arange(10) / 9.0
-    space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(3)])
-    exp = space.discrete.exp_rep
-    meas = exp.iloc[rng.choice(len(exp), 20, replace=False)].copy(); meas["yield"] = f(meas.to_numpy(dtype=float))
-    rec = HipBotorchRecommender(); camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), rec)
-    camp.add_measurements(meas); camp.recommend(3)
-    got = camp.recommend(3); new = got.copy(); new["yield"] = f(new.to_numpy(dtype=float)); camp.add_measurements(new)
-    pr = cProfile.Profile(); pr.enable(); camp.recommend(3); pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
-    # the same in microseconds (print_stats rounds to milliseconds): own time and cumulative time of the 40 most expensive functions
-    st = pstats.Stats(pr).stats
-    rows_ = sorted(((tt, ct, nc, f"{Path(k[0]).name}:{k[1]}({k[2]})") for k, (cc, nc, tt, ct, _) in st.items()), reverse=True)[:40]
-    print("own_us   cum_us  calls  function")
-    for tt, ct, nc, name in rows_:
-        print(f"{tt * 1e6:7.0f} {ct * 1e6:8.0f} {nc:6d}  {name}")
+
+    def profile_one(levels, d, n0, batch, warm):
+        rng = np.random.default_rng(1)
+        vals = np.arange(levels) / (levels - 1.0)
+        space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(d)])
+        exp = space.discrete.exp_rep
+        meas = exp.iloc[rng.choice(len(exp), n0, replace=False)].copy(); meas["yield"] = f(meas.to_numpy(dtype=float))
+        rec = HipBotorchRecommender(); camp = Campaign(space, SingleTargetObjective(NumericalTarget("yield")), rec)
+        camp.add_measurements(meas); camp.recommend(batch)
+        for _ in range(warm):
+            got = camp.recommend(batch); new = got.copy(); new["yield"] = f(new.to_numpy(dtype=float)); camp.add_measurements(new)
+        pr = cProfile.Profile(); pr.enable(); camp.recommend(batch); torch.cuda.synchronize(); pr.disable()
+        print(f"---- profile of one recommend({batch}) after new measurements: {len(exp)} candidates, n = {len(camp.measurements)}")
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+        # the same in microseconds (print_stats rounds to milliseconds): own time and cumulative time of the most expensive functions
+        st = pstats.Stats(pr).stats
+        rows_ = sorted(((tt, ct, nc, f"{Path(k[0]).name}:{k[1]}({k[2]})") for k, (cc, nc, tt, ct, _) in st.items()), reverse=True)[:40]
+        print("own_us   cum_us  calls  function")
+        for tt, ct, nc, name in rows_:
+            print(f"{tt * 1e6:7.0f} {ct * 1e6:8.0f} {nc:6d}  {name}")
+
+    profile_one(10, 3, 20, 3, 1)
+    profile_one(18, 4, 100, 5, 2)

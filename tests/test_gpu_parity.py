@@ -6,6 +6,7 @@ Tolerances (fp64 everywhere): posterior mean/variance 1e-9 relative here (north_
 """
 
 import math
+import os
 from pathlib import Path
 
 import numpy as np
@@ -1010,6 +1011,27 @@ def test_joint_batches_beyond_sixteen_points(gp):
     gp.set_pending(P[15:]); rest = _np(gp.cross_cov(X))
     gp.set_pending(None)
     assert np.array_equal(many, np.hstack([first, rest]))
+    # the factor workspace is bounded (16 GB at 1e6 candidates and q' = 64): candidates go through it in chunks, and the
+    # scores do not depend on the chunking (BBH_QBIG_WS_MB=1: 512-row chunks at q' = 22, masked rows and the ragged last chunk included)
+    import torch
+
+    from baybe_amd import engine
+
+    rng = np.random.default_rng(5)
+    Xl = np.ascontiguousarray(rng.random((3003, d)))
+    P21 = X[res.indices[:18]].tolist() + pend.tolist()
+    P21 = np.asarray(P21)
+    z = engine.sobol_normal_base_samples(64, len(P21) + 1, 3)
+    m, v = gp.posterior(Xl)
+    cr = gp.cross_cov_many(Xl, P21)
+    alive = torch.from_numpy((rng.random(3003) > 0.1).astype(np.uint8)).to(m.device)
+    one = _np(gp.qlogei_pending_big(m, v, cr, P21, z, gp.best_f(1.0), alive=alive))
+    os.environ["BBH_QBIG_WS_MB"] = "1"
+    try:
+        many_chunks = _np(gp.qlogei_pending_big(m, v, cr, P21, z, gp.best_f(1.0), alive=alive))
+    finally:
+        del os.environ["BBH_QBIG_WS_MB"]
+    assert np.array_equal(one, many_chunks) and np.isfinite(one[_np(alive).astype(bool)]).all() and np.isneginf(one[~_np(alive).astype(bool)]).all()
     with pytest.raises(ValueError):
         gp.greedy_qlogei(X, 5, S=64, seed=1, X_pending=X[:62])  # 62 + 4 picks > 63 pending points
     with pytest.raises(ValueError):
