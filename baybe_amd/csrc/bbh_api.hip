@@ -35,6 +35,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
   if (const char* e = getenv("BBH_KV_LDS")) h->kv_lds_blocks = atoi(e);
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');
+  if (const char* e = getenv("BBH_COOPG_CROSS")) h->coopg_cross_on = (e[0] != '0');
   if (const char* e = getenv("BBH_KVCACHE")) h->use_kvcache = (e[0] != '0');
   if (const char* e = getenv("BBH_PIPELINE")) h->use_pipeline = (e[0] != '0');  // A/B switch, default on
   if (const char* e = getenv("BBH_COOP")) h->coop_mode = atoi(e);

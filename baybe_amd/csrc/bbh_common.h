@@ -217,6 +217,7 @@ struct bbh_handle {
   double* d_kvcache = nullptr;    // kernel-value cache of the multi-pass fused kernel (grow-only)
   size_t kvcache_bytes = 0;
   int* d_slab_flags = nullptr;    // claim flags of the cache slabs (zero = free)
+  bool coopg_cross_on = true;     // env BBH_COOPG_CROSS=0: composite models' mean-only / cross passes through the materialised path (A/B)
   bool use_mean_valu = true;      // env BBH_MEAN_VALU=0: mean contraction through the MFMA form (A/B)
   bool use_kvcache = true;        // env BBH_KVCACHE=0: recompute kernel values in every pass (A/B)
   size_t lds_per_block = 65536;   // LDS a workgroup may use (device property; 160 KB on gfx950)

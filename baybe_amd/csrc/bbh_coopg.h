@@ -259,6 +259,96 @@ __global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopG
   }
 }
 
+// ---- mean / cross-covariance pass with the generic production (round 4) ---------------------------------------------------------
+// Steps >= 2 of a greedy batch need, per candidate, the posterior mean and the cross-covariances with the p <= 15 pending points:
+//   [mean | cross_1 .. cross_p] = K*(x, [X ; P]) . [alpha | -beta_1 .. -beta_p ; 0 | e_1 .. e_p]      (d_meanB, rows np.. = unit vectors)
+// i.e. one 16-column contraction of the kernel values - no variance GEMM.  Composite / non-stationary models used to materialise
+// K* for it (23 ms per 1e6 candidates and step at n = 512); here one wave takes 16 candidates, walks the nb (+1 pending) k-blocks,
+// produces each block's kernel values with coopg_produce (the pending points sit in block nb of every factor's training fragments,
+// written by bbh_pending_set) and feeds four MFMAs per block.  Same epilogue as the windowed form's mean-only pass (bbh_fused.h).
+template <int KD, int F>
+__global__ __launch_bounds__(256, 2) void bbh_coopg_cross_kernel(const CoopGArgs g) {
+  const FusedArgs& a = g.c.f;
+  const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cnd = l & 15, q = l >> 4;
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+  if (tile0 >= a.N) return;
+  const int64_t row = (tile0 + cnd < a.N) ? tile0 + cnd : a.N - 1;
+  const double* xr = a.X + row * a.ldx;
+  double cf[F][KD];
+#pragma unroll
+  for (int f = 0; f < F; f++) {
+    double nbsum = 0.0;
+    int ops[KD];
+#pragma unroll
+    for (int k = 0; k < KD; k++) {
+      const CoopGFeat ft = g.feat[(f * KD + k) * 4 + q];
+      const double x = (ft.src >= 0) ? xr[a.numcol_identity ? ft.src : a.numcol[ft.src]] : 0.0;
+      double v = fma(x, ft.scl, ft.ofs);
+      if (ft.op == 0) nbsum = fma(v, v, nbsum);
+      if (ft.op == 1) v = cos(v);
+      if (ft.op == 2) v = sin(v);
+      if (ft.op >= 4) v = 0.0;
+      cf[f][k] = v;
+      ops[k] = ft.op;
+    }
+    nbsum += __shfl_xor(nbsum, 16, 64);
+    nbsum += __shfl_xor(nbsum, 32, 64);
+#pragma unroll
+    for (int k = 0; k < KD; k++)
+      if (ops[k] == 4) cf[f][k] = nbsum;
+  }
+  int tc = 0;
+  if (g.has_tbl && a.task_col >= 0) {
+    tc = (int)xr[a.task_col];
+    tc = tc < 0 ? 0 : (tc >= a.T ? a.T - 1 : tc);
+  }
+  WaveCtx c;
+  c.tf = a.trainfrag + l;
+  c.candl = nullptr;
+  c.mb = a.meanB + l;
+  c.tbl = a.tasktbl;
+  c.taskext = a.taskext;
+  c.kvc = nullptr;
+  c.kvl = (bbh_lds_double*)nullptr;
+  c.nl = 0;
+  c.ncache = 0;
+  c.al = (const bbh_lds_double*)nullptr;
+  c.kd = KD;
+  c.kind = a.kind;
+  c.T = a.T;
+  c.tc = tc;
+  c.q = q;
+  c.l = l;
+  c.dn = a.dn;
+  d4 accm = {0.0, 0.0, 0.0, 0.0};
+  for (int tb = 0; tb < a.nb_ext; tb++) {
+    double mbv[4], kv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) mbv[r] = c.mb[(int64_t)(4 * tb + r) * 64];
+    coopg_produce<KD, F>(g, c, cf, tb, kv);
+#pragma unroll
+    for (int r = 0; r < 4; r++) accm = mfma_f64(kv[r], mbv[r], accm);
+  }
+  // epilogue: lane (q, cnd), reg r  <->  candidate q + 4 r, column cnd
+  const double s2 = a.ysd * a.ysd;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = q + 4 * r;
+    const int tcm = __shfl(tc, m, 64);
+    const int64_t gi = tile0 + m;
+    const double mc = (g.has_tbl && a.taskmean) ? a.taskmean[tcm] : a.mean_const;
+    if (gi < a.N) {
+      if (cnd == 0) {
+        if (a.mean) a.mean[gi] = a.ybar + a.ysd * (mc + accm[r]);
+      } else if (cnd <= a.p && a.cross) {
+        a.cross[gi * a.p + (cnd - 1)] = s2 * accm[r];
+      }
+    }
+  }
+}
+
 // Instantiations (bbh_fused_coopg.hip): 2, 4, 6, 8 k-steps of the distance GEMM (d <= 30), 1 - 4 factors.
 // false: no instantiation for this model; grid.x == 0 only asks.
 bool bbh_coopg_launch(int kd, int F, dim3 grid, size_t lds, hipStream_t s, const CoopGArgs& a);
+bool bbh_coopg_cross_launch(int kd, int F, dim3 grid, hipStream_t s, const CoopGArgs& a);

@@ -216,18 +216,24 @@ static bool bbh_coopg_model(const bbh_handle* h) {
 }
 
 // Training fragments of factor f of the generic form (see CoopGFeat in bbh_coopg.h): frag[tb][k][l] = A[16 tb + (l & 15)][4 k + (l >> 4)]
-static void host_pack_trainfrag_generic(const bbh_handle* h, const bbh_kern_spec& ks, int f, int kd, int64_t nblocks, std::vector<double>& out) {
+// pts: normalised rows [cnt, dn] (nullptr: the training rows); rows beyond cnt are padding
+static void host_pack_trainfrag_generic(const bbh_handle* h, const bbh_kern_spec& ks, int f, int kd, int64_t nblocks, std::vector<double>& out,
+                                        const double* pts = nullptr, int64_t cnt = -1) {
   const int dn = h->dn, kind = ks.kind[f];
   const double* th = h->theta.data();
   const double* ls = th + ks.ls_off[f];
+  if (!pts) {
+    pts = h->xn_host.data();
+    cnt = h->n;
+  }
   out.assign((size_t)nblocks * kd * 64, 0.0);
   std::vector<double> row((size_t)4 * kd);
   for (int64_t tb = 0; tb < nblocks; tb++)
     for (int c16 = 0; c16 < 16; c16++) {
       const int64_t i = tb * 16 + c16;
-      const bool real = i < h->n;
+      const bool real = i < cnt;
       std::fill(row.begin(), row.end(), 0.0);
-      const double* x = real ? h->xn_host.data() + i * dn : nullptr;
+      const double* x = real ? pts + i * dn : nullptr;
       if (kind == BBH_KERNEL_PERIODIC) {
         double c0 = 0.0;
         for (int j = 0; j < dn; j++) c0 += 0.5 / ls[j];
@@ -469,7 +475,9 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
   // composite / RQ / piecewise kernels: the cooperative form with the generic production for variance passes without pending
   // columns (bbh_coopg.h), otherwise the materialised-K* path (fused qLogEI: applied by the caller)
   const bool coopg = h->coopg_ready && with_var && h->p == 0 && !cross_dev && !h->fuse_qz && h->use_mean_valu;
-  if (bbh_materialised_only(h) && !coopg)
+  // ... and their mean-only / cross-covariance passes (steps >= 2 of a greedy batch) on bbh_coopg_cross_kernel (BBH_COOPG_CROSS=0: A/B)
+  const bool coopg_cross = h->coopg_ready && !with_var && !h->fuse_qz && h->coopg_cross_on;
+  if (bbh_materialised_only(h) && !coopg && !coopg_cross)
     return bbh_launch_unfused_ext(h, X_dev, N, ldx, mean_dev, with_var ? var_dev : nullptr, cross_dev);
   FusedArgs a;
   a.X = X_dev;
@@ -577,7 +585,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     a.slab_flags = h->d_slab_flags;
   }
   bbh_timed_scope timed(h, with_var ? BBH_TIMED_POSTERIOR : BBH_TIMED_CROSS);
-  if (coopg) {
+  if (coopg || coopg_cross) {
     const bbh_kern_spec ks = bbh_kern_spec_of(h);
     const double* th = h->theta.data();
     CoopGArgs g;
@@ -603,6 +611,14 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     g.trainfrag_f = h->d_trainfrag_f;
     g.tf_stride = (h->nb + 1) * (int64_t)kdg * 64;
     g.feat = (const CoopGFeat*)h->d_sclofs_f;
+    if (coopg_cross) {
+      if (!bbh_coopg_cross_launch(kdg, ks.F, dim3((unsigned)((N + 63) / 64)), h->stream, g)) {
+        h->err = "generic cross-covariance pass: no instantiation for this model although its operands were packed";
+        return -6;
+      }
+      BBH_HIP_TRY(h, hipGetLastError());
+      return 0;
+    }
     const size_t clds = sizeof(double) * (16 * (size_t)h->nb + (2 * 4 * 256 + 128));
     bbh_coopg_launch(kdg, ks.F, dim3((unsigned)((N + 15) / 16)), clds, h->stream, g);
     h->last_form = 4;
@@ -999,6 +1015,21 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
   host_pack_trainfrag(h, pn.data(), p, nb, nb + 1, tf);
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag + nb * h->kd * 64, tf.data(), sizeof(double) * tf.size(),
                                 hipMemcpyHostToDevice, s));
+  std::vector<double> tfg;  // (outlives the copies below: the stream is synchronised before this function returns)
+  if (h->coopg_ready) {  // generic production (bbh_coopg.h): the pending block of every factor's training fragments
+    const bbh_kern_spec ksg = bbh_kern_spec_of(h);
+    const int kdg = bbh_coopg_kd(h);
+    const int64_t per = (nb + 1) * (int64_t)kdg * 64;
+    tfg.reserve((size_t)ksg.F * kdg * 64);
+    for (int f = 0; f < ksg.F; f++) {
+      std::vector<double> one;
+      host_pack_trainfrag_generic(h, ksg, f, kdg, 1, one, p > 0 ? pn.data() : &h->ybar, p);  // (p = 0: any non-null pointer, all padding)
+      tfg.insert(tfg.end(), one.begin(), one.end());
+    }
+    for (int f = 0; f < ksg.F; f++)
+      BBH_HIP_TRY(h, hipMemcpyAsync(h->d_trainfrag_f + f * per + nb * kdg * 64, tfg.data() + (size_t)f * kdg * 64, sizeof(double) * kdg * 64,
+                                    hipMemcpyHostToDevice, s));
+  }
   std::vector<int> te(16, 0);
   for (int64_t j = 0; j < p; j++) te[j] = pt[j];
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_taskext + np, te.data(), sizeof(int) * 16, hipMemcpyHostToDevice, s));

@@ -597,7 +597,7 @@ def test_composite_kernels_data_term_posterior_and_greedy(gp, name, tl):
         assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL, atol=1e-14)
     gp.posterior(X)
     # variance passes: the cooperative kernel with the generic production (bbh_coopg.h) unless a Matérn-1/2 factor is present
-    # (direct-difference distances near r = 0: materialised-K* path); cross-covariance passes are materialised either way
+    # (direct-difference distances near r = 0: materialised-K* path)
     assert gp.posterior_kernel_form() == ("materialised" if name in ("scaled_sum", "product4") else "cooperative-generic")
     mj, cj = gp.posterior_joint(X[:6])
     moj, coj = om.posterior_joint(X[:6])
@@ -609,6 +609,29 @@ def test_composite_kernels_data_term_posterior_and_greedy(gp, name, tl):
     ref = go.optimize_acqf_discrete_qlogei(om, cand, 3, seed=5)
     assert list(res.indices) == list(ref.indices)
     assert np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL)
+    # mean-only / cross-covariance passes (steps >= 2 of a greedy batch; round 4: bbh_coopg_cross_kernel where the generic production
+    # applies): against the oracle's joint posterior, and against the materialised-K* path on a handle created under BBH_COOPG_CROSS=0
+    from baybe_amd import engine
+
+    P = cand[[5, 77, 300]]
+    gp.set_pending(P)
+    cr = _np(gp.cross_cov(cand[:600]))
+    gp.set_pending(None)
+    for i in (0, 17, 599):
+        _, cov = om.posterior_joint(np.vstack([cand[i:i + 1], P]))
+        assert np.allclose(cr[i], cov[0, 1:], rtol=1e-7, atol=1e-12), (i, cr[i], cov[0, 1:])
+    os.environ["BBH_COOPG_CROSS"] = "0"
+    try:
+        g2 = engine.HipGP(0)
+        g2.set_model(spec, Xt, y)
+        g2.factorize(p)
+        g2.set_pending(P)
+        cr2 = _np(g2.cross_cov(cand[:600]))
+        assert np.allclose(g2.train_posterior_mean(), gp.train_posterior_mean(), rtol=1e-11, atol=1e-13)
+        g2.close()
+    finally:
+        del os.environ["BBH_COOPG_CROSS"]
+    assert np.allclose(cr, cr2, rtol=1e-9, atol=1e-13), np.abs(cr - cr2).max()
 
 
 @pytest.mark.parametrize("q", [0, 1, 2, 3])
@@ -982,6 +1005,14 @@ def test_linear_polynomial_and_periodic_kernels(gp, which):
     res = gp.greedy_qlogei(cand, 3, seed=12)
     ref = go.optimize_acqf_discrete_qlogei(om, cand, 3, seed=12)
     assert list(res.indices) == list(ref.indices) and np.allclose(res.values, ref.values, rtol=0, atol=SCORE_ATOL)
+    # the cross-covariance columns of steps >= 2 (bbh_coopg_cross_kernel: same feature maps, pending points in block nb) vs the oracle
+    P = cand[[3, 410]]
+    gp.set_pending(P)
+    cr = _np(gp.cross_cov(cand[:300]))
+    gp.set_pending(None)
+    for i in (0, 151, 299):
+        _, cov = om.posterior_joint(np.vstack([cand[i:i + 1], P]))
+        assert np.allclose(cr[i], cov[0, 1:], rtol=1e-7, atol=1e-11), (i, cr[i], cov[0, 1:])
 
 
 def test_joint_batches_beyond_sixteen_points(gp):
