@@ -407,6 +407,7 @@ def run(args):
             fam_step[fam][1] += cnt
         g.timing(False)
     fused_ms, fused_launches = fam_step["posterior"]
+    extra["top_indices"] = [int(i) for i in np.asarray(idx).ravel()[:TOPK]]  # the last step's top-k (global row numbers)
     extra["ms_per_step_median"] = float(np.median(step_ms))
     extra["ms_per_step_mean"] = float(np.mean(step_ms))
     extra["device_ms_per_step"] = {fam: v[0] / args.steps for fam, v in fam_step.items() if v[1]}

@@ -205,6 +205,38 @@ def test_bench_starts_its_own_ranks_and_reports_one_json_line():
     assert rec["extra"]["roofline_pending_kernels"]["launches"] == 2
 
 
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """The driver's command for N > 1: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`` (ranks from RANK / LOCAL_RANK / WORLD_SIZE) - here with both ranks on
+    the one device (BENCH_SINGLE_DEVICE=1, gloo).  One JSON line from rank 0: the weak line, and in ``extra.strong_cfg3`` the
+    strong-scaled configs[2] step (a 1e6-row grid split over the ranks) whose merged top indices equal the single-process ones."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["BENCH_SINGLE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--cpu-budget", "0", "--greedy", "0"]  # (default rows: rank 0's grid and training rows are the single-process ones)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["config"]["global_rows"] == 2000000
+    strong = rec["extra"]["strong_cfg3"]
+    assert strong["global_rows"] == 1000000 and strong["rows_per_rank"] == 500000 and strong["scaling"] == "strong" and strong["value"] > 0
+    single = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--greedy", "0",
+                             "--e2e", "0"], cwd=root, env={k: v for k, v in env.items() if k != "BENCH_SINGLE_DEVICE"},
+                            capture_output=True, text=True, timeout=900)
+    assert single.returncode == 0, single.stderr[-2000:]
+    srec = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][-1])
+    assert strong["top_indices"] == srec["extra"]["top_indices"]
+
+
 def test_library_rccl_entry_points_on_a_single_rank_communicator():
     """``bbh_comm_init`` / ``bbh_allgather_topk`` / ``bbh_allgather_argmax`` (include/baybe_hip.h) with world = 1 - the
     GPU box has one device: communicator set-up, device-side payload, ncclAllGather, read-back and merge all run; the
