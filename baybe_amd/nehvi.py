@@ -77,6 +77,8 @@ class HipNEHVI:
         self.prune = bool(prune_baseline)
         self._lib = _lib.load_library()
         self._prepared = False
+        self._streams = None
+        self.concurrent = True  # False: the targets' passes one after the other (per-kernel timing, A/B)
         self._pruned = None
 
     # ---- set-up ----------------------------------------------------------------------------------
@@ -146,15 +148,48 @@ class HipNEHVI:
         self._prepared = True
 
     # ---- scoring ---------------------------------------------------------------------------------
+    def _target_streams(self, device):
+        """One HIP stream per target (created once; the extended models' handles are bound to them), or [] for a single target."""
+        if self._streams is None:
+            import os
+
+            import torch
+
+            self._streams = []
+            if self.m > 1 and os.environ.get("BBH_NEHVI_STREAMS", "1") != "0":
+                self._streams = [torch.cuda.Stream(device=device) for _ in self.outputs]
+                for out, st in zip(self.outputs, self._streams):
+                    with torch.cuda.stream(st):
+                        out.ext.use_current_torch_stream()
+        return self._streams
+
     def score(self, X_dev, alive=None):
         import torch
 
         assert self._prepared, "call prepare() first"
         tmats, vars_ = [], []
-        for out in self.outputs:
-            _, var = out.ext.posterior(X_dev)
-            tmats.append(out.ext.posterior_columns(X_dev, sample_major=True))
-            vars_.append(var)
+        # The targets' passes are independent: each target's extended model enqueues its variance pass and its conditional-mean
+        # columns on a stream of its own, so that the launch tails of one target (13 % of a columns launch at 1e5 candidates) fill
+        # with another target's workgroups; the cell kernel runs on the first target's stream after the others have been joined.
+        # BBH_NEHVI_STREAMS=0: everything on the handles' default stream, one launch after the other (A/B).
+        streams = self._target_streams(X_dev.device)
+        if streams:
+            cur = torch.cuda.current_stream(X_dev.device)
+            for out, st in zip(self.outputs, streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    _, var = out.ext.posterior(X_dev)
+                    tmats.append(out.ext.posterior_columns(X_dev, sample_major=True))
+                vars_.append(var)
+                if not self.concurrent:  # (the handles stay bound to their streams: one target after the other = wait for each)
+                    st.synchronize()
+            for st in streams[1:]:
+                streams[0].wait_stream(st)
+        else:
+            for out in self.outputs:
+                _, var = out.ext.posterior(X_dev)
+                tmats.append(out.ext.posterior_columns(X_dev, sample_major=True))
+                vars_.append(var)
         N = X_dev.shape[0]
         scores = torch.empty(N, dtype=torch.float64, device=X_dev.device)
         tp = (C.c_void_p * self.m)(*[t.data_ptr() for t in tmats])

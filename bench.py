@@ -406,6 +406,34 @@ def run(args):
             fam_step[fam][0] += ms
             fam_step[fam][1] += cnt
         g.timing(False)
+    if nehvi is not None and getattr(nehvi, "concurrent", False) and nehvi.m > 1:
+        # the timed steps ran the targets' passes concurrently on their own streams: HIP-event times of one family then include the
+        # others' work.  The per-part times behind the rooflines come from K more steps with the passes one after the other.
+        nehvi.concurrent = False
+        for g in timed_engines:
+            g.timing(True)
+            for fam in FAMILIES:
+                g.timing_read(reset=True, family=fam)
+        step()
+        for g in timed_engines:
+            for fam in FAMILIES:
+                g.timing_read(reset=True, family=fam)
+        fence()
+        t_ser = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        extra["ms_per_step_targets_in_sequence"] = (time.perf_counter() - t_ser) / args.steps * 1e3
+        fam_step = {fam: [0.0, 0] for fam in FAMILIES}
+        for g in timed_engines:
+            for fam in FAMILIES:
+                ms, cnt = g.timing_read(reset=True, family=fam)
+                fam_step[fam][0] += ms
+                fam_step[fam][1] += cnt
+            g.timing(False)
+        nehvi.concurrent = True
+        extra["device_ms_note"] = ("per-family HIP-event times from steps with the targets' passes in sequence; the timed steps overlap them on "
+                                   "one stream per target")
     fused_ms, fused_launches = fam_step["posterior"]
     extra["top_indices"] = [int(i) for i in np.asarray(idx).ravel()[:TOPK]]  # the last step's top-k (global row numbers)
     extra["ms_per_step_median"] = float(np.median(step_ms))

@@ -75,6 +75,10 @@ def test_scores_match_oracle(m, signs):
     assert int(np.argmax(sg[:60])) == int(np.argmax(so))
     # cells on the device side equal the oracle's per-sample decompositions
     assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)
+    # the targets' passes overlap on one stream per target (round 4); in sequence they give bitwise the same scores
+    assert hv.concurrent and len(hv._streams) == m
+    hv.concurrent = False
+    assert np.array_equal(hv.score(torch.from_numpy(X).cuda()).cpu().numpy(), sg)
 
 
 def test_pruning_and_greedy_match_oracle():
