@@ -19,9 +19,19 @@ if stats:
 trace = glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)
 if trace:
     PRE, WARM, STEPS = 8, 3, 20  # bench.py: extra["pre_warm_steps"], --warmup, --steps of scripts/profile_bench.sh
+    try:  # round 4: bench.py pre-warms by time, the count is in its JSON line (first launch of a run = the factorisation's mean pass)
+        import json as _json
+
+        _line = _json.load(open(os.path.join(out, "bench_line.json")))
+        PRE, WARM, STEPS = int(_line["extra"]["pre_warm_steps"]), int(_line["warmup"]), int(_line["steps"])
+    except Exception:  # noqa: BLE001
+        pass
     rows = [r for r in csv.DictReader(open(trace[0])) if "posterior_kernel" in r["Kernel_Name"]]
     if any("qlognehvi" in r["Kernel_Name"] for r in csv.DictReader(open(trace[0]))):  # cfg5: three variance launches per step
         rows = [r for r in csv.DictReader(open(trace[0])) if "qlognehvi_lin_kernel" in r["Kernel_Name"] or "qlognehvi_kernel" in r["Kernel_Name"]]
+    coop_rows = [r for r in rows if "bbh_coop" in r["Kernel_Name"]]  # (the windowed form's launches in a cooperative run are the
+    if len(coop_rows) >= STEPS:                                          # mean-only passes of the set-up and of the greedy extra)
+        rows = coop_rows
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     timed = dur[PRE + WARM : PRE + WARM + STEPS]
