@@ -79,6 +79,45 @@ def test_closed_engines_hand_their_handle_to_the_next_one():
     assert not any(engine._HANDLE_POOL.values())
 
 
+def test_an_idle_handle_does_not_pin_large_buffers():
+    """a pooled handle kept its grow-only buffers - with ``bbh_qlogei_pending_big`` that was q'(q' + 1) / 2 doubles per
+    candidate for as long as the handle sat in the pool.  ``close()`` trims the handle (``bbh_trim``, 64 MB per buffer): the big
+    workspace goes back to the device, the small model stays, and the next engine on the handle works."""
+    import torch
+
+    from _problems import make_problem
+    from baybe_amd import engine, gp_spec
+
+    engine.drain_handle_pool()
+    N, d, n = 200_000, 4, 30
+    X, Xt, y = make_problem(N, d, n, seed=3)
+    g = engine.HipGP(0)
+    g.set_model(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), Xt, y)
+    g.fit()
+    Xd = torch.from_numpy(X).cuda()
+    P = X[:19]
+    m, v = g.posterior(Xd)
+    cr = g.cross_cov_many(Xd, P)
+    z = engine.sobol_normal_base_samples(32, 20, 1)
+    s = g.qlogei_pending_big(m, v, cr, P, z, g.best_f(1.0))  # workspace: 210 doubles per candidate = 336 MB
+    assert torch.isfinite(s).all()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    handle = g._handle.value
+    g.close()
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_after - free_before > 300 * 2**20, (free_before, free_after)
+    g2 = engine.HipGP(0)  # the pooled handle, trimmed
+    assert g2._handle.value == handle
+    g2.set_model(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), Xt, y)
+    g2.fit()
+    m2, _ = g2.posterior(Xd[:1000])
+    assert np.allclose(m2.cpu().numpy(), m[:1000].cpu().numpy(), rtol=1e-6)  # (two fits of the same data)
+    g2.close()
+    engine.drain_handle_pool()
+
+
 @pytest.mark.parametrize("how", ["deepcopy", "pickle"])
 def test_a_fitted_recommender_and_its_copy_recommend_the_same(how):
     import torch
