@@ -247,7 +247,7 @@ extern "C" int bbh_last_posterior_form(bbh_handle* h) { return h ? h->last_form 
 
 extern "C" int bbh_timing_enable(bbh_handle* h, int enable) {
   if (!h) return -1;
-  h->timing = enable != 0;
+  h->timing = enable < 0 ? 0 : enable;  // 1: all families; 2 * mask: the families whose bit is set (events between kernels cost ~5 us each)
   return 0;
 }
 

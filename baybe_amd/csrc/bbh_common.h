@@ -290,7 +290,7 @@ struct bbh_handle {
   bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
   bool select_on = true;          // env BBH_SELECT=0: top-k / argmax by k rounds of workgroup argmax (A/B)
   // timing
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 every kernel family, otherwise 2 x (bit mask of the families that record events)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double timed_ms[BBH_TIMED_FAMILIES] = {};
   int64_t timed_launches[BBH_TIMED_FAMILIES] = {};
@@ -307,7 +307,7 @@ struct bbh_timed_scope {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int family;
   bbh_timed_scope(bbh_handle* h_, int family_, bool wanted = true) : h(h_), family(family_) {
-    if (h->timing && wanted) {
+    if ((h->timing == 1 || ((h->timing >> 1) >> family_ & 1)) && wanted) {
       hipEventCreate(&e0);
       hipEventCreate(&e1);
       hipEventRecord(e0, h->stream);

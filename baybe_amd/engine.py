@@ -742,8 +742,13 @@ class HipGP:
         return {0: "windowed", 1: "cooperative", 2: "materialised", 3: "cooperative-2sweep", 4: "cooperative-generic",
                 5: "register-resident"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
 
-    def timing(self, enable: bool):
-        self._check(self._lib.bbh_timing_enable(self._h, 1 if enable else 0), "bbh_timing_enable")
+    def timing(self, enable, families=None):
+        """HIP-event timing of the kernel families on / off; ``families`` (names as for ``timing_read``) restricts the events to those
+        families - an event between two back-to-back kernels costs the stream ~5 us."""
+        code = 0
+        if enable:
+            code = 1 if not families else 2 * sum(1 << _lib.TIMED_FAMILIES[f] for f in families)
+        self._check(self._lib.bbh_timing_enable(self._h, code), "bbh_timing_enable")
 
     def timing_read(self, reset: bool = True, family: str = "posterior"):
         """(total ms, launches) of one kernel family since the last reset: ``"posterior"`` (variance passes of the fused

@@ -332,7 +332,9 @@ int bbh_allgather_argmax(bbh_handle* h, const double* scores_dev, int64_t N, int
 
 /* ---- instrumentation --------------------------------------------------------------- */
 /* Duration (ms) and launch count of the fused posterior kernel accumulated since the
- * last reset, measured with HIP events on the handle's stream when enabled. */
+ * last reset, measured with HIP events on the handle's stream when enabled.
+ * enable: 0 = off, 1 = every kernel family, 2 * m = only the families whose bit is set in m (1 << BBH_TIMED_POSTERIOR ...): an event
+ * between two back-to-back kernels costs the stream ~5 us, so a timed region brackets only the kernel it reports. */
 int bbh_timing_enable(bbh_handle* h, int enable);
 int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launches, int reset);
 /* The same per kernel family: BBH_TIMED_POSTERIOR = variance passes of the fused posterior kernel (what

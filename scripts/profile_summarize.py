@@ -39,7 +39,8 @@ if trace:
         w = csv.writer(f)
         w.writerow(["launch", "region", "duration_ms"])
         for i, t in enumerate(dur):
-            region = "pre-warm" if i < PRE else "warm-up" if i < PRE + WARM else "timed" if i < PRE + WARM + STEPS else "greedy extra"
+            region = ("pre-warm" if i < PRE else "warm-up" if i < PRE + WARM else "timed" if i < PRE + WARM + STEPS else
+                      "instrumented (every family's events)" if i < PRE + WARM + 2 * STEPS + 1 else "extras (greedy batch, end to end)")
             w.writerow([i, region, f"{t:.4f}"])
         if timed:
             w.writerow(["timed-region average", len(timed), f"{sum(timed) / len(timed):.4f}"])
