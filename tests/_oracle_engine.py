@@ -75,7 +75,7 @@ class OracleEngine(HipGP):
     def use_current_torch_stream(self):
         pass
 
-    def timing(self, enable):
+    def timing(self, enable, families=None):
         pass
 
     def set_slice_rows(self, rows):

@@ -197,3 +197,39 @@ def test_slice_row_hint_makes_shard_scores_bit_identical():
     g.set_slice_rows(0)
     assert np.array_equal(np.concatenate(parts), full)
     g.close()
+
+
+def test_timing_can_be_restricted_to_kernel_families():
+    """``bbh_timing_enable(h, 2 * mask)``: HIP events only around the named families (an event between two back-to-back kernels costs
+    the stream ~5 us, so bench.py's timed region brackets the dominant kernel only); 1 = every family, 0 = none."""
+    import torch
+
+    from _problems import make_problem
+    from baybe_amd import engine, gp_spec
+
+    X, Xt, y = make_problem(20000, 5, 40, seed=2)
+    g = engine.HipGP(0)
+    g.set_model(gp_spec.GPSpec.baybe_default(5, np.zeros(5), np.ones(5)), Xt, y)
+    g.fit()
+    Xd = torch.from_numpy(X).cuda()
+    z = engine.sobol_normal_base_samples(128, 1, 1)[:, 0]
+
+    def one_step():
+        m, v = g.posterior(Xd)
+        g.qlogei_topk(m, v, z, g.best_f(1.0), 1.0, 4)
+
+    fams = ("posterior", "q1", "select")
+    for want, on in ((("posterior",), {"posterior"}), (("q1", "select"), {"q1", "select"}), (None, set(fams))):
+        g.timing(True, want)
+        for f in fams:
+            g.timing_read(reset=True, family=f)
+        one_step()
+        one_step()
+        got = {f: g.timing_read(reset=True, family=f) for f in fams}
+        for f in fams:
+            assert (got[f][1] > 0) == (f in on), (want, got)
+            assert (got[f][0] > 0.0) == (f in on)
+    g.timing(False)
+    one_step()
+    assert all(g.timing_read(reset=True, family=f)[1] == 0 for f in fams)
+    g.close()
