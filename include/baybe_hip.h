@@ -342,6 +342,9 @@ int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launch
  * BBH_TIMED_PENDING = the joint q'-batch acquisition kernels (bbh_qlogei_pending, bbh_mc_acq_pending). */
 /* Form of the fused posterior kernel the last variance pass of this handle ran as: 0 = windowed (one wave per 16
  * candidates, bbh_fused_posterior_kernel), 1 = cooperative (one workgroup per 16 candidates, bbh_coop_posterior_kernel),
+ * 2 = materialised K* (verification path; models outside the fused forms), 3 = two-sweep cooperative (512 < n <= 1024,
+ * bbh_coop2_posterior_kernel), 4 = cooperative with the generic kernel-value production (composite, RQ, piecewise, Linear,
+ * Polynomial, Periodic: bbh_coopg_posterior_kernel), 5 = register- / LDS-resident (n <= 128, bbh_small_posterior_kernel),
  * -1 = none yet. */
 int bbh_last_posterior_form(bbh_handle* h);
 enum bbh_timed_family {
