@@ -37,4 +37,6 @@ def reference_baybe():
             sys.path.insert(0, str(_STUBS))
     if str(REFERENCE_ROOT) not in sys.path:
         sys.path.insert(0, str(REFERENCE_ROOT))
+    # the reference tree is read-only for this repository: importing it must not drop __pycache__ directories into it
+    sys.dont_write_bytecode = True
     return importlib.import_module("baybe")
