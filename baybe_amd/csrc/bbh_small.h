@@ -209,8 +209,12 @@ __host__ inline size_t small_lds_bytes(int kd, int NB) {
 
 // Persistent launch: exactly as many workgroups as the device holds at once (a queued workgroup would start when the others are
 // done and double the launch time).  The occupancy query's answer can be one workgroup per CU too high when a kernel uses more
-// than 80 SGPRs (MI355X_MICROARCH.md, "Residency"): one is taken off above 2 per CU - an empty slot costs a few per cent, a
-// queued workgroup a whole round.
+// than 80 SGPRs: 256-thread workgroups are admitted up to min(API, 8, floor(800 / (ceil(sgpr / 16) 16 + 16))) per CU
+// (MI355X_MICROARCH.md, "Residency").  Every instantiation here reports 104 - 106 SGPRs (hipcc -S, .sgpr_count), i.e. an SGPR bound
+// of 6 workgroups per CU, and the register budgets (small_waves) ask for at most 4: the API's answer is the residency.  Round 4
+// first took one off above 2 per CU "to be safe" - which ran the n <= 64 variants at two waves per SIMD instead of three.  (Dynamic
+// tile tickets from a device-wide atomic counter, which would make the question moot, cost 13 ns per draw - device-scope atomics are
+// executed at the memory side across the 8 XCDs: 0.8 ms per 1e6 candidates whatever n is; dropped.)
 template <int KD, int KVF, int NB>
 static void small_go(int64_t tiles, int num_cu, hipStream_t s, const SmallArgs& a) {
   static int per_cu = 0;
@@ -220,7 +224,7 @@ static void small_go(int64_t tiles, int num_cu, hipStream_t s, const SmallArgs& 
     constexpr int NT = small_threads(NB);
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)bbh_small_posterior_kernel<KD, KVF, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bbh_small_posterior_kernel<KD, KVF, NB>, NT, lds) != hipSuccess || n < 1) n = 1;
-    per_cu = n > 2 ? n - 1 : n;
+    per_cu = n > 5 ? n - 1 : n;  // (beyond the SGPR bound's reach the API may over-report by one)
   }
   constexpr int NW = small_threads(NB) / 64;
   int64_t blocks = (tiles + NW - 1) / NW;
