@@ -40,6 +40,7 @@ class ModelDesc(C.Structure):
         ("combine", C.c_int32),
         ("factor_kind", C.c_int32 * 4),
         ("factor_scaled", C.c_int32 * 4),
+        ("factor_group", C.c_int32 * 4),
     ]
 
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
 #define BBH_MAX_FACTORS 4
 struct bbh_kern_spec {
   int F;                        // factors; 1 = the plain single-kernel model
-  int combine;                  // 0 product, 1 sum
+  int combine;                  // 0 product, 1 sum, 2 sum of products (grp)
+  int grp[BBH_MAX_FACTORS];     // term of the sum each factor multiplies into: k = sum_g prod_{f in g} u_f  (product: all 0; sum: f)
   int kind[BBH_MAX_FACTORS];    // enum bbh_kernel_kind
   int ls_off[BBH_MAX_FACTORS];  // theta offset of the factor's dn lengthscales
   int fos_off;                  // theta offset of the F per-factor outputscales (-1: F == 1)
@@ -133,17 +134,42 @@ __device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double a
 // theta layout: [noise, mean, outputscale, ls[dn], B[T*T], (hadamard: noise_t[T], mean_t[T])]
 // hoff = offset of noise_t (mean_t follows at hoff + T), -1 = the scalar slots are in use
 
+// k = sum over the terms g of prod_{f in g} u[f] (ProductKernel: one term; AdditiveKernel: one factor per term; a sum whose members
+// are products or single kernels: kernels/composite.py:60-91 nested).  u[f] = os_f k_f(x, x').
+template <class GRP>
+__host__ __device__ __forceinline__ double bbh_combine(int F, const GRP& grp, const double* u) {
+  double term[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
+  bool used[BBH_MAX_FACTORS] = {false, false, false, false};
+#pragma unroll
+  for (int f = 0; f < BBH_MAX_FACTORS; f++)
+    if (f < F) {
+      term[grp[f]] *= u[f];
+      used[grp[f]] = true;
+    }
+  double acc = 0.0;
+#pragma unroll
+  for (int g = 0; g < BBH_MAX_FACTORS; g++)
+    if (used[g]) acc += term[g];
+  return acc;
+}
+// d k / d u_f = prod of the other factors of f's term
+template <class GRP>
+__host__ __device__ __forceinline__ double bbh_combine_weight(int F, const GRP& grp, const double* u, int f) {
+  double w = 1.0;
+#pragma unroll
+  for (int g = 0; g < BBH_MAX_FACTORS; g++)
+    if (g < F && g != f && grp[g] == grp[f]) w *= u[g];
+  return w;
+}
 __device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta,
                                             const double (&r2)[BBH_MAX_FACTORS]) {
   if (ks.F <= 1) return bbh_kbase(ks.kind[0], r2[0], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off] : 1.0);
-  double acc = ks.combine ? 0.0 : 1.0;
+  double u[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
   for (int f = 0; f < BBH_MAX_FACTORS; f++)
-    if (f < ks.F) {
-      const double u = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0);
-      acc = ks.combine ? acc + u : acc * u;
-    }
-  return acc;
+    if (f < ks.F)
+      u[f] = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0);
+  return bbh_combine(ks.F, ks.grp, u);
 }
 
 struct bbh_handle {

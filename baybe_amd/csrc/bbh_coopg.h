@@ -36,6 +36,7 @@ struct CoopGArgs {
   CoopArgs c;
   int F, combine, has_tbl, jb;
   int kind[BBH_MAX_FACTORS];
+  int grp[BBH_MAX_FACTORS];       // term of the sum each factor multiplies into (bbh_combine)
   double fos[BBH_MAX_FACTORS];    // per-factor scales (1 for a single kernel)
   double alpha[BBH_MAX_FACTORS];  // RQ alpha / polynomial offset per factor
   const double* trainfrag_f;      // [F][nb + 1][KD][64]
@@ -49,9 +50,7 @@ struct CoopGArgs {
 template <int KD, int F>
 __device__ __forceinline__ void coopg_produce(const CoopGArgs& g, const WaveCtx& c, const double (&cf)[F][KD], int tb,
                                               double (&out)[4]) {
-  double acc[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) acc[r] = g.combine ? 0.0 : 1.0;
+  double uv[4][BBH_MAX_FACTORS];  // [value][factor] os_f k_f
   bool pad[4] = {false, false, false, false};
 #pragma unroll
   for (int f = 0; f < F; f++) {
@@ -92,13 +91,12 @@ __device__ __forceinline__ void coopg_produce(const CoopGArgs& g, const WaveCtx&
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       if (f == 0) pad[r] = (da[r] + db[r]) > 1e7;  // padding rows carry |a|^2 = 1e8: exactly 0 for every kernel kind
-      const double u = g.fos[f] * kv[r];
-      acc[r] = g.combine ? acc[r] + u : acc[r] * u;
+      uv[r][f] = g.fos[f] * kv[r];
     }
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    double v = pad[r] ? 0.0 : acc[r];
+    double v = pad[r] ? 0.0 : (F > 1 ? bbh_combine(F, g.grp, uv[r]) : uv[r][0]);
     if (g.has_tbl) v *= c.tbl[c.tc * c.T + c.taskext[16 * tb + 4 * r + c.q]];
     out[r] = v;
   }
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopG
   const double* xr = a.X + row * a.ldx;
   for (int s = threadIdx.x; s < 16 * a.nb; s += 256) s_alpha[s] = a.meanB[(int64_t)s * 16];
   double cf[F][KD];
-  double kself = g.combine ? 0.0 : 1.0;  // k(x, x) of candidate cnd without table / outputscale (dot kinds: not a constant)
+  double kself_u[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};  // os_f k_f(x, x) of candidate cnd (dot kinds: not a constant)
 #pragma unroll
   for (int f = 0; f < F; f++) {
     double nbsum = 0.0;
@@ -145,8 +143,9 @@ __global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopG
       if (ops[k] == 4) cf[f][k] = nbsum;
     const int kindf = g.kind[f];
     const double ks = BBH_KIND_IS_DOT(kindf) ? ((kindf == BBH_KERNEL_LINEAR) ? nbsum : bbh_powi(nbsum + g.alpha[f], kindf - BBH_KERNEL_POLY1 + 1)) : 1.0;
-    kself = g.combine ? kself + g.fos[f] * ks : kself * (g.fos[f] * ks);
+    kself_u[f] = g.fos[f] * ks;
   }
+  const double kself = F > 1 ? bbh_combine(F, g.grp, kself_u) : kself_u[0];  // without table / outer outputscale
   int tc = 0;
   if (g.has_tbl && a.task_col >= 0) {
     tc = (int)xr[a.task_col];

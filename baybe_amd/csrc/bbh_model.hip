@@ -193,12 +193,10 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   double al[BBH_MAX_FACTORS];
   for (int f = 0; f < ks.F; f++) al[f] = ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0;
   for (int f = 0; f < ks.F; f++) kf[f] = bbh_kbase(ks.kind[f], r2[f], ks.jb, al[f]);
-  for (int f = 0; f < ks.F; f++) {
-    double w = 1.0;
-    if (ks.F > 1 && !ks.combine)
-      for (int g = 0; g < ks.F; g++)
-        if (g != f) w *= theta[ks.fos_off + g] * kf[g];
-    wf[f] = w;  // without the factor's own outputscale
+  {
+    double uf[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
+    for (int f = 0; f < ks.F; f++) uf[f] = (ks.F > 1 ? theta[ks.fos_off + f] : 1.0) * kf[f];
+    for (int f = 0; f < ks.F; f++) wf[f] = ks.F > 1 ? bbh_combine_weight(ks.F, ks.grp, uf, f) : 1.0;  // without the factor's own outputscale
   }
   const double kb = bbh_kcomp(ks, theta, r2);
   double* prow = partial + ((int64_t)(a * gridDim.y + blockIdx.y) * 4 + wave) * nslots;
@@ -331,6 +329,10 @@ bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h) {
   bbh_kern_spec ks{};
   ks.F = h->F;
   ks.combine = h->desc.combine;
+  for (int f = 0; f < BBH_MAX_FACTORS; f++) {
+    const int g = h->desc.combine == 0 ? 0 : h->desc.combine == 1 ? f : h->desc.factor_group[f];
+    ks.grp[f] = (g < 0 || g >= BBH_MAX_FACTORS) ? 0 : g;
+  }
   ks.use_os = h->desc.use_outputscale;
   ks.jb = h->dn / 2 + 1;
   const int base = 3 + h->dn + (h->T > 1 ? h->T * h->T : 0) + (h->hadamard ? 2 * h->T : 0);
@@ -423,11 +425,12 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     return -1;
   }
   if (desc->n_factors > 1) {
-    bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1) &&
+    bool ok = desc->n_factors <= BBH_MAX_FACTORS && (desc->combine == 0 || desc->combine == 1 || desc->combine == 2) &&
               desc->factor_kind[0] == desc->kernel_kind;
+    for (int f = 0; ok && desc->combine == 2 && f < desc->n_factors; f++) ok = desc->factor_group[f] >= 0 && desc->factor_group[f] < BBH_MAX_FACTORS;
     for (int f = 0; ok && f < desc->n_factors; f++) ok = desc->factor_kind[f] >= 0 && desc->factor_kind[f] <= BBH_KERNEL_PERIODIC;
     if (!ok) {
-      h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1, factor_kind[0] == kernel_kind)";
+      h->err = "bbh_set_model: invalid composite kernel (2..4 factors, combine 0 | 1 | 2 with factor_group in 0..3, factor_kind[0] == kernel_kind)";
       return -1;
     }
   }
@@ -444,6 +447,9 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
              desc->criterion, desc->kernel_kind, desc->task_col, desc->n_tasks, desc->use_outputscale, desc->hadamard, desc->n_factors, desc->combine,
              desc->factor_kind[0], desc->factor_kind[1], desc->factor_kind[2], desc->factor_kind[3], desc->factor_scaled[0],
              desc->factor_scaled[1], desc->factor_scaled[2], desc->factor_scaled[3]);
+    if (desc->combine == 2)
+      snprintf(sig + strlen(sig), sizeof(sig) - strlen(sig), ":g%d%d%d%d", desc->factor_group[0], desc->factor_group[1], desc->factor_group[2],
+               desc->factor_group[3]);
     if (h->have_model && h->model_sig == sig) {
       bbh_reset_model_state(h);
     } else {

@@ -598,15 +598,15 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
     g.combine = ks.combine;
     g.has_tbl = has_tbl ? 1 : 0;
     g.jb = ks.jb;
-    g.prior_k0 = (ks.F > 1 && ks.combine) ? 0.0 : 1.0;
     g.has_dot = 0;
     for (int f = 0; f < BBH_MAX_FACTORS; f++) {
       g.kind[f] = ks.kind[f < ks.F ? f : 0];
+      g.grp[f] = ks.grp[f];
       g.fos[f] = (ks.F > 1 && f < ks.F) ? th[ks.fos_off + f] : 1.0;
       g.alpha[f] = (ks.alpha_off >= 0 && f < ks.F) ? th[ks.alpha_off + f] : 1.0;
-      if (ks.F > 1 && f < ks.F) g.prior_k0 = ks.combine ? g.prior_k0 + g.fos[f] : g.prior_k0 * g.fos[f];
       if (f < ks.F && BBH_KIND_IS_DOT(ks.kind[f])) g.has_dot = 1;
     }
+    g.prior_k0 = ks.F > 1 ? bbh_combine(ks.F, ks.grp, g.fos) : 1.0;  // (stationary factors: k_f(x, x) = 1)
     const int kdg = bbh_coopg_kd(h);
     g.trainfrag_f = h->d_trainfrag_f;
     g.tf_stride = (h->nb + 1) * (int64_t)kdg * 64;
@@ -839,9 +839,9 @@ double bbh_prior_base(const bbh_handle* h) {
   double v = h->desc.use_outputscale ? th[2] : 1.0;
   if (h->F > 1) {
     const bbh_kern_spec ks = bbh_kern_spec_of(h);
-    double acc = ks.combine ? 0.0 : 1.0;
-    for (int f = 0; f < ks.F; f++) acc = ks.combine ? acc + th[ks.fos_off + f] : acc * th[ks.fos_off + f];
-    v *= acc;
+    double u[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
+    for (int f = 0; f < ks.F; f++) u[f] = th[ks.fos_off + f];  // (stationary factors: k_f(x, x) = 1)
+    v *= bbh_combine(ks.F, ks.grp, u);
   }
   return v;
 }
@@ -1075,13 +1075,13 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
     for (int64_t k = 0; k < np; k++) m += hK[i * np + k] * hal[k];
     h->pend_mean[i] = h->ybar + h->ysd * ((h->hadamard ? th[bbh_hadamard_offset(h) + T + pt[i]] : th[1]) + m);
     for (int64_t j = 0; j < p; j++) {
-      double kc = ks.combine && ks.F > 1 ? 0.0 : 1.0;
+      double uf[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
       for (int f = 0; f < ks.F; f++) {
         double r2 = 0.0;
         for (int c = 0; c < dn; c++) r2 += bbh_metric_term_f(ks, th, f, c, dn, pn[i * dn + c], pn[j * dn + c], 1.0 / th[ks.ls_off[f] + c]);
-        const double u = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb, ks.alpha_off >= 0 ? th[ks.alpha_off + f] : 1.0);
-        kc = (ks.combine && ks.F > 1) ? kc + u : kc * u;
+        uf[f] = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb, ks.alpha_off >= 0 ? th[ks.alpha_off + f] : 1.0);
       }
+      const double kc = ks.F > 1 ? bbh_combine(ks.F, ks.grp, uf) : uf[0];
       double kpp = os * kc;
       if (T > 1) kpp *= th[3 + dn + pt[i] * T + pt[j]];
       double dot = 0.0;

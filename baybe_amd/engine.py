@@ -356,10 +356,11 @@ class HipGP:
         factors = getattr(spec, "factors", None)
         if factors:  # composite kernel: ProductKernel / AdditiveKernel of stationary factors
             desc.n_factors = len(factors)
-            desc.combine = {"product": 0, "sum": 1}[spec.combine]
+            desc.combine = {"product": 0, "sum": 1, "grouped": 2}[spec.combine]
             for k, f in enumerate(factors):
                 desc.factor_kind[k] = _lib.KERNEL_KINDS[f.kernel]
                 desc.factor_scaled[k] = 1 if f.scaled else 0
+                desc.factor_group[k] = int(getattr(f, "group", 0))
         lo = np.ascontiguousarray(spec.lo, dtype=np.float64)
         hi = np.ascontiguousarray(spec.hi, dtype=np.float64)
         if lo.shape[0] != spec.d or hi.shape[0] != spec.d:

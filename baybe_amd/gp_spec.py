@@ -100,6 +100,7 @@ class KernelFactor:
     alpha_init: float | None = None
     period_prior: tuple | None = None  # periodic kernels: prior / initial value of the period lengths
     period_init: float | None = None
+    group: int = 0  # combine == "grouped": the term of the sum this factor multiplies into (k = sum_g prod_{f in g} os_f k_f)
 
 
 # Lengthscale of a numerical column a kernel does NOT act on (``BasicKernel.parameter_names``, kernels/base.py:198-240: gpytorch
@@ -137,7 +138,7 @@ class GPSpec:
     task_prior: tuple | None = None  # ("beta", a, b) on the lower-triangle task correlations (BOTORCH preset)
     # composite kernels: 2..4 factors combined as a product or a sum; factors[0] IS (kernel, ls_*) above
     factors: "list[KernelFactor] | None" = None
-    combine: str = "product"  # "product" (ProductKernel) | "sum" (AdditiveKernel)
+    combine: str = "product"  # "product" (ProductKernel) | "sum" (AdditiveKernel) | "grouped" (a sum of products: KernelFactor.group)
     active: "np.ndarray | None" = None  # bool [dn]: columns the (first) kernel acts on (``parameter_names``); None = all
     alpha_prior: tuple | None = None  # polynomial kernel: prior / initial value of the offset (KernelFactor.alpha_*)
     alpha_init: float | None = None
@@ -196,8 +197,10 @@ class GPSpec:
         factors = list(factors)
         if not 2 <= len(factors) <= 4:
             raise ValueError("composite kernels have 2..4 factors on the HIP path")
-        if combine not in ("product", "sum"):
+        if combine not in ("product", "sum", "grouped"):
             raise ValueError(combine)
+        if combine == "grouped" and not all(0 <= int(f.group) < 4 for f in factors):
+            raise ValueError("factor groups are 0..3")
         f0 = factors[0]
         self.kernel, self.ls_constraint, self.ls_prior, self.ls_init = f0.kernel, f0.ls_constraint, f0.ls_prior, f0.ls_init
         self.ls_lower = f0.ls_lower if f0.ls_constraint == "box" else self.ls_lower

@@ -278,11 +278,37 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
             return out
 
         members = tuple(flatten(kernel))
+        # A sum whose members are products (or single kernels) - e.g. the reference's (Matern * Matern) + (Matern + Matern),
+        # tests/test_iterations.py:294-296 - is k = sum_g prod_{f in g} os_f k_f: the factors of a product member share a term.
+        # (A product with a sum inside would have to be multiplied out, which duplicates parameters: a different model.)
+        groups = list(range(len(members)))
+        if name == "AdditiveKernel" and any(type(m).__name__ == "ProductKernel" for m in members):
+            expanded, groups = [], []
+            for gi, m in enumerate(members):
+                if type(m).__name__ == "ProductKernel":
+                    def flat_prod(k):
+                        out = []
+                        for b in k.base_kernels:
+                            out.extend(flat_prod(b) if type(b).__name__ == "ProductKernel" else [b])
+                        return out
+
+                    inner = flat_prod(m)
+                    expanded.extend(inner)
+                    groups.extend([gi] * len(inner))
+                else:
+                    expanded.append(m)
+                    groups.append(gi)
+            members = tuple(expanded)
+            if len(set(groups)) > 4:
+                raise IncompatibilityError("A sum of more than 4 terms is not evaluated on the HIP path.")
+            remap = {g: i for i, g in enumerate(dict.fromkeys(groups))}
+            groups = [remap[g] for g in groups]
+            name = "GroupedKernel"
         if not 2 <= len(members) <= 4:
-            raise IncompatibilityError(f"'{name}' with {len(members)} base kernels (nested ones of the same type counted): the HIP path "
+            raise IncompatibilityError(f"'{type(kernel).__name__}' with {len(members)} base kernels (nested ones counted): the HIP path "
                                        f"evaluates 2 to 4 factors.")
         factors = []
-        for member in members:
+        for member, group in zip(members, groups):
             mname, scaled, os_prior, os_init = type(member).__name__, False, None, None
             if mname == "ScaleKernel":
                 if not getattr(member, "outputscale_trainable", True):
@@ -299,8 +325,9 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
                 )
             (c, lower, ls_prior, ls_init), (a_prior, a_init) = _ls_fields(member, kind)
             factors.append(KernelFactor(kind, c, lower, ls_prior, ls_init, scaled, os_prior, os_init,
-                                        _active_mask(spec, member, searchspace), a_prior, a_init, *_period_fields(member)))
-        return spec.set_factors(factors, "product" if name == "ProductKernel" else "sum")
+                                        _active_mask(spec, member, searchspace), a_prior, a_init, *_period_fields(member),
+                                        group=group if name == "GroupedKernel" else 0))
+        return spec.set_factors(factors, {"ProductKernel": "product", "AdditiveKernel": "sum", "GroupedKernel": "grouped"}[name])
     kind = _basic_kind(kernel)
     if kind is None:
         raise IncompatibilityError(

@@ -107,6 +107,10 @@ typedef struct bbh_model_desc {
   int32_t combine;
   int32_t factor_kind[4];
   int32_t factor_scaled[4];
+  /* combine 2 = a sum whose members are products or single kernels - e.g. (Matern * Matern) + (Matern + Matern), the nested entry of the
+   * reference's kernel matrix (tests/test_iterations.py:294-296): factor f multiplies into term factor_group[f] in 0..3,
+   * k = sum_g prod_{f in g} os_f k_f.  Ignored for combine 0 (one term) and 1 (one factor per term). */
+  int32_t factor_group[4];
 } bbh_model_desc;
 
 /*

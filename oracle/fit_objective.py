@@ -231,12 +231,21 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
 
     members = getattr(spec, "members", None)
     if members:
-        K = None
+        scaled = []
         for m, term in enumerate(members):
             Km = gram(term.kernel, m)
-            if term.outputscale is not None:
-                Km = Km * nat[f"outputscale.{m}"]
-            K = Km if K is None else (K * Km if spec.composition == "product" else K + Km)
+            scaled.append(Km * nat[f"outputscale.{m}"] if term.outputscale is not None else Km)
+        if spec.composition == "nested":  # AdditiveKernel([ProductKernel([...]), base kernel, ...]): sum of the summands' products
+            summands = {}
+            for m, Km in enumerate(scaled):
+                t = spec.member_terms[m]
+                summands[t] = Km if t not in summands else summands[t] * Km
+            scaled, composition = list(summands.values()), "sum"
+        else:
+            composition = spec.composition
+        K = scaled[0]
+        for Km in scaled[1:]:
+            K = K * Km if composition == "product" else K + Km
     else:
         K = gram(spec.kernel, None)
     if spec.use_outputscale:

@@ -129,7 +129,8 @@ class GPSpec:
     index_kernel_scaling: str = "none"  # "target": botorch PositiveIndexKernel default, covariance / its [0, 0] entry
     correlation_prior: tuple | None = None  # ("beta", 2.5, 1.5): BetaPrior on the lower-triangle task correlations
     members: "list[KernelTerm] | None" = None  # base kernels of a ProductKernel / AdditiveKernel (replaces `kernel`)
-    composition: str = "product"  # "product" | "sum"
+    composition: str = "product"  # "product" | "sum" | "nested": an AdditiveKernel whose members are ProductKernels or base kernels
+    member_terms: "list[int] | None" = None  # "nested": the summand each member is a factor of (baybe/kernels/composite.py:60-91 nested)
     active_dims: "np.ndarray | None" = None  # single kernel on a parameter subset (see KernelTerm.active_dims)
     offset: "Hyper | None" = None  # single polynomial kernel: its offset (see KernelTerm.offset)
     period: "Hyper | None" = None  # single periodic kernel: its period lengths (see KernelTerm.period)
@@ -423,10 +424,33 @@ def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> 
     if not spec.members:
         c = spec.dims_of(None)
         return base_kernel_from_r2(spec.kernel, _metric(spec.kernel, A[:, c], B[:, c], p.lengthscale, _period_of(p, 0)), len(c), _alpha_of(p, 0))
-    grams = member_grams(spec, p, A, B)
-    out = grams[0].copy()
-    for Km in grams[1:]:
-        out = out * Km if spec.composition == "product" else out + Km
+    return compose_members(spec, member_grams(spec, p, A, B))
+
+
+def compose_members(spec: GPSpec, grams: list):
+    """``reduce(mul, ...)`` of a ProductKernel, ``reduce(add, ...)`` of an AdditiveKernel (composite.py:75,91), or - an AdditiveKernel with
+    ProductKernel members - the sum over its members of the products of theirs."""
+    if spec.composition == "product":
+        out = grams[0]
+        for Km in grams[1:]:
+            out = out * Km
+        return out + 0.0
+    if spec.composition == "sum":
+        return sum(grams[1:], grams[0] + 0.0)
+    summands: dict = {}
+    for m, Km in enumerate(grams):
+        t = spec.member_terms[m]
+        summands[t] = Km if t not in summands else summands[t] * Km
+    return sum(summands.values())
+
+
+def siblings_product(spec: GPSpec, grams: list, m: int):
+    """d(composite) / d(member m's Gram matrix): the product of the other members of m's summand (1 for a plain sum)."""
+    out = 1.0
+    for k, Kk in enumerate(grams):
+        same = spec.composition == "product" or (spec.composition == "nested" and spec.member_terms[k] == spec.member_terms[m])
+        if k != m and same:
+            out = out * Kk
     return out
 
 
@@ -453,12 +477,11 @@ def prior_var(spec: GPSpec, p: GPParams, Xn: np.ndarray) -> np.ndarray:
     v = np.full(Xn.shape[0], p.outputscale if spec.use_outputscale else 1.0)
     Xs = Xn[:, spec.num_idx]
     if spec.members:  # k_m(x, x) = 1 for every stationary member
-        diag = None
+        diags = []
         for m, t in enumerate(spec.members):
             c = spec.dims_of(m)
-            km = p.member_scale[m] * base_kernel_from_r2(t.kernel, _self_metric(t.kernel, Xs[:, c], p.member_ls[m]), len(c), _alpha_of(p, m))
-            diag = km if diag is None else (diag * km if spec.composition == "product" else diag + km)
-        v = v * diag
+            diags.append(p.member_scale[m] * base_kernel_from_r2(t.kernel, _self_metric(t.kernel, Xs[:, c], p.member_ls[m]), len(c), _alpha_of(p, m)))
+        v = v * compose_members(spec, diags)
     elif spec.kernel in DOT_KERNELS:
         c = spec.dims_of(None)
         v = v * base_kernel_from_r2(spec.kernel, _self_metric(spec.kernel, Xs[:, c], p.lengthscale), len(c), _alpha_of(p, 0))
@@ -574,11 +597,7 @@ def _composite_gradients(spec, p, Xn, Xs, G, Kf, value, g_mean_rows, trow) -> Da
     grams = member_grams(spec, p, Xs, Xs)
     g_ls, g_sc, g_al = [], np.zeros(len(spec.members)), np.zeros(len(spec.members))
     for m, t in enumerate(spec.members):
-        others = np.ones((n, n))
-        if spec.composition == "product":
-            for k, Kk in enumerate(grams):
-                if k != m:
-                    others = others * Kk
+        others = np.ones((n, n)) * siblings_product(spec, grams, m)
         r2 = _scaled_sqdist(Xs, Xs, p.member_ls[m])
         front = G * os * Bsel * others * p.member_scale[m] * base_kernel_gfac_from_r2(t.kernel, r2, spec.dn, _alpha_of(p, m))
         gl = np.empty(spec.dn)

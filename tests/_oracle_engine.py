@@ -126,6 +126,27 @@ class OracleEngine(HipGP):
     def fit(self, p0=None, maxiter: int = 15000, max_attempts: int = 5):
         """The product's own fit driver; only the vectorised host objective (``FastObjective``, which feeds theta vectors to the
         device call directly) is switched off so that every evaluation passes through ``data_term`` above."""
+        spec = self.spec
+        if spec.factors or spec.hadamard or spec.has_rq or spec.has_periodic or spec.has_dot_kind:
+            # composite / non-stationary models: the product's raw layout, bounds, initial values and L-BFGS-B driver around the oracle's
+            # autograd objective (its raw vector = the product's free slots; pinned slots - subsets, polynomial weights - do not move)
+            bounds = gp_spec.raw_bounds(spec)
+            free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+
+            def fun(raw):
+                try:
+                    f, g = go.fit_objective(self._ospec, raw[free], self._Xn, self._ystd)
+                except (RuntimeError, ValueError):
+                    return float("inf"), np.zeros_like(raw)
+                full = np.zeros_like(raw)
+                full[free] = g
+                return float(f), full
+
+            res = engine_mod.lbfgsb_minimize(fun, gp_spec.pack_raw(spec, p0 or gp_spec.initial_params(spec)), bounds, maxiter)
+            params = gp_spec.unpack_raw(spec, res.x)
+            self.factorize(params)
+            self.calls.append(("fit", int(res.nfev)))
+            return engine_mod.FitInfo(params, float(res.fun), int(res.nit), int(res.nfev), int(res.status), str(res.message))
         applies = gp_spec.FastObjective.applies
         engine_mod.FastObjective.applies = staticmethod(lambda spec: False)
         try:

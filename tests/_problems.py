@@ -63,7 +63,8 @@ def oracle_spec(spec):
                                None if spec.active_mask(k) is None else np.nonzero(spec.active_mask(k))[0],
                                go.Hyper(0.0, True, f.alpha_prior, f.alpha_init), go.Hyper(0.0, True, f.period_prior, f.period_init))
                  for k, f in enumerate(spec.factors)] if spec.factors else None,
-        composition=spec.combine,
+        composition={"grouped": "nested"}.get(spec.combine, spec.combine),
+        member_terms=[int(f.group) for f in spec.factors] if (spec.factors and spec.combine == "grouped") else None,
         active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0],
         offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init), period=go.Hyper(0.0, True, spec.period_prior, spec.period_init))
 

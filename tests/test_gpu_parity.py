@@ -545,11 +545,14 @@ def _composite_kernels():
                                                   MaternKernel(0.5)]), GammaPrior(2, 0.15)),
         "product4": ProductKernel([RBFKernel(), MaternKernel(1.5), MaternKernel(2.5), ScaleKernel(MaternKernel(0.5))]),
         "piecewise_x_rbf": ProductKernel([PiecewisePolynomialKernel(2, None, 3.0), ScaleKernel(RBFKernel())]),
+        # the nested entry of the reference's kernel matrix (tests/test_iterations.py:294-296): (Matern * Matern) + (Matern + Matern)
+        "sum_of_products": AdditiveKernel([ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), MaternKernel(1.5)]),
+                                           AdditiveKernel([ScaleKernel(MaternKernel(2.5), GammaPrior(2, 0.5)), RBFKernel()])]),
     }
 
 
 @pytest.mark.parametrize("name,tl", [("product", False), ("scaled_sum", False), ("product4", False), ("product", True),
-                                     ("piecewise_x_rbf", False)])
+                                     ("piecewise_x_rbf", False), ("sum_of_products", False), ("sum_of_products", True)])
 def test_composite_kernels_data_term_posterior_and_greedy(gp, name, tl):
     """User ``ProductKernel`` / ``AdditiveKernel`` (baybe/kernels/composite.py:60-91) of 2..4 stationary factors, each with
     its own ARD lengthscales and optionally its own ScaleKernel (``bbh_model_desc.n_factors``): Gram matrix and gradient

@@ -196,13 +196,19 @@ def test_composite_kernel_parameterisation_against_the_autograd_oracle():
     X, Xt, y = make_problem(100, d, n, seed=2)
     for kern in (ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(RBFKernel(), GammaPrior(2, 0.5))]),
                  ScaleKernel(AdditiveKernel([ScaleKernel(MaternKernel(1.5)), ScaleKernel(RBFKernel(LogNormalPrior(0, 1))),
-                                             MaternKernel(0.5)]), GammaPrior(2, 0.15))):
+                                             MaternKernel(0.5)]), GammaPrior(2, 0.15)),
+                 # the nested entry of the reference's kernel matrix (tests/test_iterations.py:294-296): (M * M) + (M + M)
+                 AdditiveKernel([ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), MaternKernel(1.5)]),
+                                 AdditiveKernel([ScaleKernel(MaternKernel(2.5), GammaPrior(2, 0.5)), MaternKernel(0.5)])])):
         spec = apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), kern)
+        if type(kern).__name__ == "AdditiveKernel":
+            assert spec.combine == "grouped" and [f.group for f in spec.factors] == [0, 0, 1, 2]
         ospec = _ospec(spec)
         F = spec.n_factors
         raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
         assert np.allclose(go.pack_raw(ospec, go.initial_params(ospec)), raw) and gp_spec.raw_bounds(spec) == go.raw_bounds(ospec)
         raw = raw + 0.2 * rng.standard_normal(raw.shape)
+        raw[0] = abs(raw[0]) + 1e-3  # (the noise slot is box-constrained: raw = natural value)
         q = gp_spec.unpack_raw(spec, raw)
         assert np.allclose(gp_spec.pack_raw(spec, q), raw)
         theta = gp_spec.theta_from_params(spec, q)
@@ -250,7 +256,7 @@ def test_composite_kernel_parameterisation_against_the_autograd_oracle():
         f1, g1 = gp_spec.objective_from_data_term(spec, raw, n, dt.value, grad_theta)
         f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
         assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
-    with pytest.raises(IncompatibilityError):  # a sum inside a product is a different model class
+    with pytest.raises(IncompatibilityError):  # a sum inside a product would have to be multiplied out (shared parameters): a different model
         apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
                           ProductKernel([MaternKernel(2.5), AdditiveKernel([RBFKernel(), MaternKernel(1.5)])]))
     with pytest.raises(IncompatibilityError):  # so is a scaled product inside a product (one outputscale over two factors)

@@ -283,3 +283,45 @@ def test_piecewise_polynomial_kernel_is_the_textbook_one_and_positive_definite(q
     bad = np.maximum(0, 1 - r) ** 1 if q == 0 else None
     if bad is not None:
         assert np.linalg.eigvalsh(bad).min() < -1e-6
+
+
+def test_a_sum_with_product_members_against_scikit_learn():
+    """AdditiveKernel([ProductKernel([a, b]), c, d]) - the nested entry of the reference's kernel matrix,
+    ``(Matern * Matern) + (Matern + Matern)`` (tests/test_iterations.py:294-296; kernels/composite.py:60-91) - as the oracle composes it
+    (``composition="nested"``, ``member_terms``) against scikit-learn's own Sum / Product kernel algebra: cross-covariance, log marginal
+    likelihood and its gradient with respect to every lengthscale, the member scale and the noise."""
+    d = 3
+    Xt, X, y = _problem(d=d, seed=5)
+    ystd = go.standardize_targets(y)[0]
+    la, lb, lc, ld = np.array([0.5, 0.8, 0.7]), np.array([0.9, 0.6, 1.1]), np.array([0.4, 0.9, 0.6]), np.array([1.2, 0.7, 0.8])
+    members = [go.KernelTerm("matern52", go.Hyper(), None), go.KernelTerm("rbf", go.Hyper(), None),
+               go.KernelTerm("matern32", go.Hyper(), go.Hyper()), go.KernelTerm("rbf", go.Hyper(), None)]
+    spec = go.GPSpec(d=d, num_idx=np.arange(d), lo=np.zeros(d), hi=np.ones(d), members=members, composition="nested",
+                     member_terms=[0, 0, 1, 2], noise=go.Hyper(1e-4, True, None, 0.05))
+    p = go.GPParams(lengthscale=la, noise=0.03, mean=0.0, member_ls=[la, lb, lc, ld], member_scale=np.array([1.0, 1.0, 0.7, 1.0]))
+    k_sk = Matern(length_scale=la, nu=2.5) * RBF(length_scale=lb) + ConstantKernel(0.7) * Matern(length_scale=lc, nu=1.5) + RBF(length_scale=ld)
+    assert np.allclose(go.cross_cov(spec, p, X, Xt), k_sk(X, Xt), rtol=1e-12, atol=1e-14)
+    assert np.allclose(go.prior_var(spec, p, X), np.diag(k_sk(X)), rtol=1e-12)
+    full = k_sk + WhiteKernel(0.03)
+    gpr = sk.GaussianProcessRegressor(kernel=full, alpha=0.0, optimizer=None).fit(Xt, ystd)
+    lml, grad_log = gpr.log_marginal_likelihood(full.theta, eval_gradient=True)
+    dt = go.data_term(spec, p, Xt, ystd)
+    assert math.isclose(dt.value, lml, rel_tol=1e-10)
+    names = [h.name for h in full.hyperparameters]
+    ref = dict(zip(names, np.split(grad_log, np.cumsum([h.n_elements for h in full.hyperparameters])[:-1])))
+    # scikit-learn differentiates with respect to log(theta): d/dlog(l) = l d/dl
+    want = {"k1__k1__k1__k1__length_scale": dt.g_member_ls[0] * la, "k1__k1__k1__k2__length_scale": dt.g_member_ls[1] * lb,
+            "k1__k1__k2__k1__constant_value": np.array([dt.g_member_scale[2] * 0.7]), "k1__k1__k2__k2__length_scale": dt.g_member_ls[2] * lc,
+            "k1__k2__length_scale": dt.g_member_ls[3] * ld, "k2__noise_level": np.array([dt.g_noise * 0.03])}
+    assert set(ref) == set(want), sorted(ref)
+    for key, val in ref.items():
+        assert np.allclose(val, want[key], rtol=1e-7, atol=1e-10), key
+    # and the torch / autograd objective of the fit sees the same function
+    raw = go.pack_raw(spec, p)
+    f0, g0 = go.fit_objective(spec, raw, Xt, ystd)
+    eps, gnum = 1e-6, np.zeros_like(raw)
+    for i in range(len(raw)):
+        e = np.zeros_like(raw)
+        e[i] = eps
+        gnum[i] = (go.fit_objective(spec, raw + e, Xt, ystd)[0] - go.fit_objective(spec, raw - e, Xt, ystd)[0]) / (2 * eps)
+    assert np.allclose(g0, gnum, rtol=1e-5, atol=1e-8)

@@ -267,6 +267,41 @@ def test_surrogate_subclass_runs_in_the_reference_recommender_loop(ref):
     assert len(camp.measurements) == 10
 
 
+def test_the_reference_composite_kernel_matrix_runs_through_the_plugin_surrogate(ref):
+    """``valid_composite_kernels`` of tests/test_iterations.py:290-298 - sums and products of the reference's own kernel objects incl. the
+    nested ``(Matern * Matern) + (Matern + Matern)`` - given to the plug-in surrogate as ``kernel_or_factory`` and run for two iterations
+    of the real ``Campaign`` (tests/test_iterations.py:402-413, ``test_kernels``); the nested entry becomes a sum of products on the
+    device side (``GPSpec.combine == "grouped"``)."""
+    baybe, S, C, R, Eng = ref
+    from baybe import Campaign
+    from baybe.kernels import MaternKernel, PolynomialKernel, RBFKernel, RQKernel
+    from baybe.targets import NumericalTarget
+
+    kernels = [
+        MaternKernel(1.5) + MaternKernel(2.5),
+        PolynomialKernel(1) + PolynomialKernel(2) + PolynomialKernel(3),
+        RBFKernel() + RQKernel() + PolynomialKernel(1),
+        MaternKernel(1.5) * MaternKernel(2.5),
+        RBFKernel() * RQKernel() * PolynomialKernel(1),
+        PolynomialKernel(1) * PolynomialKernel(2) * PolynomialKernel(3),
+        (MaternKernel(1.5) * MaternKernel(2.5)) + (MaternKernel(1.5) + MaternKernel(2.5)),
+    ]
+    rng = np.random.default_rng(8)
+    space = _space3(5)
+    for kernel in kernels:
+        surrogate = S(kernel_or_factory=kernel)
+        camp = Campaign(space, NumericalTarget("yield").to_objective(), R(surrogate_model=surrogate))
+        camp.add_measurements(_measure(space.discrete.exp_rep.iloc[rng.choice(125, 8, replace=False)], rng))
+        for _ in range(2):
+            rec = camp.recommend(2)
+            assert len(rec) == 2
+            camp.add_measurements(_measure(rec, rng))
+        assert len(camp.measurements) == 12
+    spec = camp.recommender._surrogate_model.engine.spec  # the last one: the nested kernel
+    assert spec.combine == "grouped" and [f.group for f in spec.factors] == [0, 0, 1, 2]
+    assert spec.factor_kinds == ["matern32", "matern52", "matern32", "matern52"]
+
+
 # ---- transfer learning, Pareto, batch constraints ------------------------------------------------------------------------------------
 def test_task_parameter_campaign(ref):
     """``TaskParameter`` (parameters/categorical.py:86-91): INT-coded task column, candidates of the active task only; the model
