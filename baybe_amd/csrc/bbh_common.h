@@ -135,30 +135,48 @@ __device__ __forceinline__ double bbh_gfun(int kind, double r2, int jb, double a
 // hoff = offset of noise_t (mean_t follows at hoff + T), -1 = the scalar slots are in use
 
 // k = sum over the terms g of prod_{f in g} u[f] (ProductKernel: one term; AdditiveKernel: one factor per term; a sum whose members
-// are products or single kernels: kernels/composite.py:60-91 nested).  u[f] = os_f k_f(x, x').
+// are products or single kernels: kernels/composite.py:60-91 nested).  u[f] = os_f k_f(x, x').  Every array index below is a
+// compile-time constant after unrolling: indexing term[grp[f]] with the run-time group would put the local arrays into scratch
+// memory (measured: the two-factor fused kernel 6.7 -> 11.6 ms per 1e6 candidates); the group tests are wave-uniform.
 template <class GRP>
-__host__ __device__ __forceinline__ double bbh_combine(int F, const GRP& grp, const double* u) {
-  double term[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
-  bool used[BBH_MAX_FACTORS] = {false, false, false, false};
+__host__ __device__ __forceinline__ double bbh_combine(int F, int combine, const GRP& grp, const double* u) {
+  if (combine == 0) {
+    double acc = 1.0;
 #pragma unroll
-  for (int f = 0; f < BBH_MAX_FACTORS; f++)
-    if (f < F) {
-      term[grp[f]] *= u[f];
-      used[grp[f]] = true;
-    }
+    for (int f = 0; f < BBH_MAX_FACTORS; f++)
+      if (f < F) acc *= u[f];
+    return acc;
+  }
+  if (combine == 1) {
+    double acc = 0.0;
+#pragma unroll
+    for (int f = 0; f < BBH_MAX_FACTORS; f++)
+      if (f < F) acc += u[f];
+    return acc;
+  }
   double acc = 0.0;
 #pragma unroll
-  for (int g = 0; g < BBH_MAX_FACTORS; g++)
-    if (used[g]) acc += term[g];
+  for (int g = 0; g < BBH_MAX_FACTORS; g++) {
+    double term = 1.0;
+    bool used = false;
+#pragma unroll
+    for (int f = 0; f < BBH_MAX_FACTORS; f++)
+      if (f < F && grp[f] == g) {
+        term *= u[f];
+        used = true;
+      }
+    if (used) acc += term;
+  }
   return acc;
 }
 // d k / d u_f = prod of the other factors of f's term
 template <class GRP>
-__host__ __device__ __forceinline__ double bbh_combine_weight(int F, const GRP& grp, const double* u, int f) {
+__host__ __device__ __forceinline__ double bbh_combine_weight(int F, int combine, const GRP& grp, const double* u, int f) {
+  if (combine == 1) return 1.0;
   double w = 1.0;
 #pragma unroll
   for (int g = 0; g < BBH_MAX_FACTORS; g++)
-    if (g < F && g != f && grp[g] == grp[f]) w *= u[g];
+    if (g < F && g != f && (combine == 0 || grp[g] == grp[f])) w *= u[g];
   return w;
 }
 __device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const double* __restrict__ theta,
@@ -169,7 +187,7 @@ __device__ __forceinline__ double bbh_kcomp(const bbh_kern_spec& ks, const doubl
   for (int f = 0; f < BBH_MAX_FACTORS; f++)
     if (f < ks.F)
       u[f] = theta[ks.fos_off + f] * bbh_kbase(ks.kind[f], r2[f], ks.jb, ks.alpha_off >= 0 ? theta[ks.alpha_off + f] : 1.0);
-  return bbh_combine(ks.F, ks.grp, u);
+  return bbh_combine(ks.F, ks.combine, ks.grp, u);
 }
 
 struct bbh_handle {

@@ -96,7 +96,7 @@ __device__ __forceinline__ void coopg_produce(const CoopGArgs& g, const WaveCtx&
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    double v = pad[r] ? 0.0 : (F > 1 ? bbh_combine(F, g.grp, uv[r]) : uv[r][0]);
+    double v = pad[r] ? 0.0 : (F > 1 ? bbh_combine(F, g.combine, g.grp, uv[r]) : uv[r][0]);
     if (g.has_tbl) v *= c.tbl[c.tc * c.T + c.taskext[16 * tb + 4 * r + c.q]];
     out[r] = v;
   }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void bbh_coopg_posterior_kernel(const CoopG
     const double ks = BBH_KIND_IS_DOT(kindf) ? ((kindf == BBH_KERNEL_LINEAR) ? nbsum : bbh_powi(nbsum + g.alpha[f], kindf - BBH_KERNEL_POLY1 + 1)) : 1.0;
     kself_u[f] = g.fos[f] * ks;
   }
-  const double kself = F > 1 ? bbh_combine(F, g.grp, kself_u) : kself_u[0];  // without table / outer outputscale
+  const double kself = F > 1 ? bbh_combine(F, g.combine, g.grp, kself_u) : kself_u[0];  // without table / outer outputscale
   int tc = 0;
   if (g.has_tbl && a.task_col >= 0) {
     tc = (int)xr[a.task_col];

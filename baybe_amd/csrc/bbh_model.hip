@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bbh_grad_pair_kernel(
   {
     double uf[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
     for (int f = 0; f < ks.F; f++) uf[f] = (ks.F > 1 ? theta[ks.fos_off + f] : 1.0) * kf[f];
-    for (int f = 0; f < ks.F; f++) wf[f] = ks.F > 1 ? bbh_combine_weight(ks.F, ks.grp, uf, f) : 1.0;  // without the factor's own outputscale
+    for (int f = 0; f < ks.F; f++) wf[f] = ks.F > 1 ? bbh_combine_weight(ks.F, ks.combine, ks.grp, uf, f) : 1.0;  // without the factor's own outputscale
   }
   const double kb = bbh_kcomp(ks, theta, r2);
   double* prow = partial + ((int64_t)(a * gridDim.y + blockIdx.y) * 4 + wave) * nslots;

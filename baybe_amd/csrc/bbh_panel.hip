@@ -606,7 +606,7 @@ int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx,
       g.alpha[f] = (ks.alpha_off >= 0 && f < ks.F) ? th[ks.alpha_off + f] : 1.0;
       if (f < ks.F && BBH_KIND_IS_DOT(ks.kind[f])) g.has_dot = 1;
     }
-    g.prior_k0 = ks.F > 1 ? bbh_combine(ks.F, ks.grp, g.fos) : 1.0;  // (stationary factors: k_f(x, x) = 1)
+    g.prior_k0 = ks.F > 1 ? bbh_combine(ks.F, ks.combine, ks.grp, g.fos) : 1.0;  // (stationary factors: k_f(x, x) = 1)
     const int kdg = bbh_coopg_kd(h);
     g.trainfrag_f = h->d_trainfrag_f;
     g.tf_stride = (h->nb + 1) * (int64_t)kdg * 64;
@@ -841,7 +841,7 @@ double bbh_prior_base(const bbh_handle* h) {
     const bbh_kern_spec ks = bbh_kern_spec_of(h);
     double u[BBH_MAX_FACTORS] = {1.0, 1.0, 1.0, 1.0};
     for (int f = 0; f < ks.F; f++) u[f] = th[ks.fos_off + f];  // (stationary factors: k_f(x, x) = 1)
-    v *= bbh_combine(ks.F, ks.grp, u);
+    v *= bbh_combine(ks.F, ks.combine, ks.grp, u);
   }
   return v;
 }
@@ -1081,7 +1081,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
         for (int c = 0; c < dn; c++) r2 += bbh_metric_term_f(ks, th, f, c, dn, pn[i * dn + c], pn[j * dn + c], 1.0 / th[ks.ls_off[f] + c]);
         uf[f] = (ks.F > 1 ? th[ks.fos_off + f] : 1.0) * bbh_kbase(ks.kind[f], r2, ks.jb, ks.alpha_off >= 0 ? th[ks.alpha_off + f] : 1.0);
       }
-      const double kc = ks.F > 1 ? bbh_combine(ks.F, ks.grp, uf) : uf[0];
+      const double kc = ks.F > 1 ? bbh_combine(ks.F, ks.combine, ks.grp, uf) : uf[0];
       double kpp = os * kc;
       if (T > 1) kpp *= th[3 + dn + pt[i] * T + pt[j]];
       double dot = 0.0;

@@ -55,3 +55,5 @@ run("Periodic (scaled)", ScaleKernel(PeriodicKernel(GammaPrior(3, 2), 1.0, Gamma
 run("RQ", RQKernel(GammaPrior(3, 1)), 20)
 run("Matern x RBF (product)", ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(RBFKernel(), GammaPrior(2, 0.5))]), 20)
 run("Matern + Linear (sum)", AdditiveKernel([MaternKernel(2.5, GammaPrior(3, 1)), ScaleKernel(LinearKernel(GammaPrior(3, 2)))]), 20)
+run("(Matern * Matern) + (Matern + RBF)", AdditiveKernel([ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), MaternKernel(1.5)]),
+                                                       AdditiveKernel([ScaleKernel(MaternKernel(2.5), GammaPrior(2, 0.5)), RBFKernel()])]), 20)
