@@ -12,7 +12,8 @@ GPU (weak scaling: the global grid has N * 1e6 rows), d = 20, n_train = 512, Mat
 fixed-theta mode (prior modes of the BAYBE preset), qLogEI, fp64.
 
   python bench.py                       # 1 GPU, the metric's own configuration (BASELINE configs[2], one GPU's shard)
-  python bench.py --config cfg2|cfg4|cfg5   # the other single-GPU BASELINE configurations, each with its own roofline record:
+  python bench.py --config cfg2|cfg4|cfg5   # the other BASELINE configurations, each with its own roofline record (cfg2 / cfg5 also
+                                        #   with --gpus N: row shards like the default):
                                         #   cfg2 = configs[1] 1e5 x 15, n = 256;  cfg4 = configs[3] ICM over 4 tasks, 1e5 x (15 + task),
                                         #   n = 1024;  cfg5 = configs[4] qLogNEHVI, 3 targets, 1e5 x 15, n = 256, S = 512 (one GPU)
   python bench.py --gpus N              # spawns one rank per GPU itself (torch.multiprocessing, 127.0.0.1 rendezvous)
@@ -242,7 +243,7 @@ def run(args):
     else:
         rows_local, total_rows = args.rows, args.rows * world
     cfg = args.config
-    if cfg in ("cfg4", "cfg5") and dist_on:
+    if cfg == "cfg4" and dist_on:
         raise SystemExit(f"--config {cfg} is a single-GPU record (its multi-GPU form shards exactly like the default configuration)")
     extra = {}
     nehvi = None
@@ -341,7 +342,12 @@ def run(args):
             # either way, but a separate launch runs it at full occupancy and leaves the fused kernel's LDS to the kernel-value cache
             if nehvi is not None:  # extended-model variance pass + S conditional means per target, then the cell kernel
                 scores = nehvi.score(Xs)
-                return gp.topk(scores, TOPK)
+                if shard is None:
+                    return gp.topk(scores, TOPK)
+                if use_rccl:  # (BASELINE configs[4] is an 8-GPU configuration: row shards, the same all-gather of per-shard top-k)
+                    return gp.allgather_topk(scores, row_start, TOPK)
+                vals, idx = gp.topk(scores, TOPK)
+                return shard.global_topk(vals, idx, TOPK, device=Xs.device)
             mean, var = gp.posterior(Xs, out=(bufs[0], bufs[1]))
             if shard is None:
                 _, vals, idx = gp.qlogei_topk(mean, var, z, best_f, 1.0, TOPK, scores=bufs[2])

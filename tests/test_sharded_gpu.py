@@ -290,6 +290,28 @@ def test_bench_sharded_path_over_rccl_with_one_rank(collective):
     assert sharded["extra"]["greedy_q3_indices"] == plain["extra"]["greedy_q3_indices"] and sharded["n_gpus"] == 1
 
 
+def test_bench_cfg5_shards_like_the_default_configuration():
+    """BASELINE configs[4] (qLogNEHVI, 3 targets) is an 8-GPU configuration: ``bench.py --config cfg5`` through the sharded code path
+    (one-rank RCCL communicator, ``BENCH_FORCE_COLLECTIVE=1``) - replicated set-up, rank-local scores, one all-gather of the per-shard
+    top-k - must select the rows of the single-process run."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_SINGLE_DEVICE")}
+    cmd = [sys.executable, str(root / "bench.py"), "--config", "cfg5", "--steps", "2", "--warmup", "1", "--cpu-budget", "0"]
+    recs = []
+    for env in (dict(base), dict(base, BENCH_FORCE_COLLECTIVE="1", BBH_COLLECTIVE="rccl", MASTER_PORT=str(_free_port()))):
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        recs.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
+    plain, sharded = recs
+    assert plain["config"]["collective"] == "none" and sharded["config"]["collective"] == "rccl (library)"
+    assert sharded["extra"]["top_indices"] == plain["extra"]["top_indices"] and len(set(plain["extra"]["top_indices"])) == 8
+
+
 def test_bench_two_gpus_over_the_library_communicator():
     """``bench.py --gpus 2`` on two real devices: one rank per GPU, the per-step exchange through the library's own RCCL
     communicator (the default for more than one rank: payload built on the device, one ncclAllGather over xGMI, one
