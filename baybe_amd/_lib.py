@@ -138,9 +138,20 @@ SIGNATURES = {
          C.c_void_p, C.c_void_p],
     ),
     "bbh_pareto_frequency": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
+    "bbh_pareto_frequency_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
+    "bbh_nehvi_samples": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "bbh_cells_build_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p, c_int64_p]),
+    "bbh_cells_read_dev": (C.c_int, [C.c_void_p, c_int64_p, c_double_p, c_double_p]),
+    "bbh_qlognehvi_cells": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_double_p, c_double_p,
+         C.c_int64, C.c_void_p, C.c_void_p],
+    ),
     "bbh_cells_create": (C.c_int, [c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, C.POINTER(C.c_void_p), c_int64_p]),
     "bbh_cells_get": (C.c_int, [C.c_void_p, c_int64_p, c_double_p, c_double_p]),
     "bbh_cells_destroy": (C.c_int, [C.c_void_p]),
+    "bbh_sobol_scramble": (C.c_int, [c_int64_p, c_int64_p, C.c_int64]),
+    "bbh_sobol_draw": (C.c_int, [c_int64_p, c_int64_p, C.c_int64, C.c_int64, c_double_p]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
     "bbh_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int64]),

@@ -554,7 +554,7 @@ static int bbh_ensure_red(bbh_handle* h) {
   return 0;
 }
 
-static int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
+int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
   const size_t bytes = sizeof(double) * count;
   if (bytes > h->z_bytes) {
     if (h->d_z) hipFree(h->d_z);
@@ -1292,6 +1292,70 @@ extern "C" int bbh_qlognehvi_sm(bbh_handle* h, int32_t m, int64_t N, const doubl
                             scores_dev, true);
 }
 
+// launches with every operand on the device: a.zx, a.cell_off, a.cell_lo, a.cell_ll set by the caller, len_dev = side lengths
+static int bbh_qlognehvi_run(bbh_handle* h, NehviArgs& a, const double* len_dev) {
+  const int m = a.m;
+  const int64_t N = a.N, S = a.S;
+  dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  bbh_timed_scope timed(h, BBH_TIMED_NEHVI);
+  const char* env_log = getenv("BBH_NEHVI_LOG");
+  if (!(env_log && env_log[0] == '1')) {  // linear-domain sums (default)
+    const double* len = len_dev;
+    // sample slices: ~16 waves per SIMD (4 SIMDs per CU; 11.3 / 10.4 / 10.0 / 9.8 ms for 6 / 12 / 24 / 48 slices at 1e5 candidates), each slice at least 8 samples
+    const int64_t srows = h->slice_rows > 0 ? h->slice_rows : N;
+    int64_t slices = ((int64_t)16 * 4 * h->num_cu * 64 + srows - 1) / srows;
+    if (const char* e = getenv("BBH_NEHVI_SLICES")) slices = atoi(e);
+    if (slices > S / 8) slices = S / 8;
+    if (slices > 64) slices = 64;
+    if (slices < 1) slices = 1;
+    int rc = bbh_ensure_ws(h, sizeof(double) * (size_t)slices * (size_t)N);
+    if (rc) return rc;
+    dim3 sgrid(grid.x, (unsigned)slices);
+    const char* env_pk = getenv("BBH_NEHVI_PK");
+    if (env_pk && env_pk[0] == '0') {
+      switch (m) {
+        case 1: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<1, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 2: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<2, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 3: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<3, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        default: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<4, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      }
+    } else {
+      switch (m) {
+        case 1: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<1, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 2: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<2, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        case 3: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<3, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+        default: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<4, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
+      }
+    }
+    hipLaunchKernelGGL(bbh_qlognehvi_finish_kernel, grid, block, 0, h->stream, h->d_ws, (int)slices, N, (int)S, a.alive, a.scores);
+    BBH_HIP_TRY(h, hipGetLastError());
+    return 0;
+  }
+  switch (m) {
+    case 1: hipLaunchKernelGGL(bbh_qlognehvi_kernel<1>, grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL(bbh_qlognehvi_kernel<2>, grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL(bbh_qlognehvi_kernel<3>, grid, block, 0, h->stream, a); break;
+    default: hipLaunchKernelGGL(bbh_qlognehvi_kernel<4>, grid, block, 0, h->stream, a); break;
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+static void bbh_nehvi_fill_args(NehviArgs& a, int32_t m, int64_t N, const double* const* tmat_dev, const double* const* var_dev,
+                                const double* sign_host, int64_t S, const uint8_t* alive_dev, double* scores_dev, bool sample_major) {
+  for (int o = 0; o < BBH_MAX_OBJECTIVES; o++) {
+    a.tmat[o] = o < m ? tmat_dev[o] : nullptr;
+    a.var[o] = o < m ? var_dev[o] : nullptr;
+    a.sign[o] = o < m ? sign_host[o] : 1.0;
+  }
+  a.m = m;
+  a.N = N;
+  a.S = (int)S;
+  a.alive = alive_dev;
+  a.scores = scores_dev;
+  a.sample_major = sample_major ? 1 : 0;
+}
+
 static int bbh_qlognehvi_impl(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
                              const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
                              const int64_t* cell_off_host, const double* cell_lo_host, const double* cell_loglen_host,
@@ -1323,64 +1387,37 @@ static int bbh_qlognehvi_impl(bbh_handle* h, int32_t m, int64_t N, const double*
   int rc = bbh_upload_z(h, buf.data(), buf.size());
   if (rc) return rc;
   NehviArgs a;
-  for (int o = 0; o < BBH_MAX_OBJECTIVES; o++) {
-    a.tmat[o] = o < m ? tmat_dev[o] : nullptr;
-    a.var[o] = o < m ? var_dev[o] : nullptr;
-    a.sign[o] = o < m ? sign_host[o] : 1.0;
-  }
-  a.m = m;
-  a.N = N;
-  a.S = (int)S;
+  bbh_nehvi_fill_args(a, m, N, tmat_dev, var_dev, sign_host, S, alive_dev, scores_dev, sample_major);
   a.zx = h->d_z;
   a.cell_lo = h->d_z + S * m;
   a.cell_ll = h->d_z + S * m + ncells * m;
   a.cell_off = (const int64_t*)(h->d_z + nd);
-  a.alive = alive_dev;
-  a.scores = scores_dev;
-  a.sample_major = sample_major ? 1 : 0;
-  dim3 grid((unsigned)((N + 255) / 256)), block(256);
-  bbh_timed_scope timed(h, BBH_TIMED_NEHVI);
-  const char* env_log = getenv("BBH_NEHVI_LOG");
-  if (!(env_log && env_log[0] == '1')) {  // linear-domain sums (default)
-    const double* len = h->d_z + S * m + 2 * ncells * m;
-    // sample slices: ~16 waves per SIMD (4 SIMDs per CU; 11.3 / 10.4 / 10.0 / 9.8 ms for 6 / 12 / 24 / 48 slices at 1e5 candidates), each slice at least 8 samples
-    const int64_t srows = h->slice_rows > 0 ? h->slice_rows : N;
-    int64_t slices = ((int64_t)16 * 4 * h->num_cu * 64 + srows - 1) / srows;
-    if (const char* e = getenv("BBH_NEHVI_SLICES")) slices = atoi(e);
-    if (slices > S / 8) slices = S / 8;
-    if (slices > 64) slices = 64;
-    if (slices < 1) slices = 1;
-    rc = bbh_ensure_ws(h, sizeof(double) * (size_t)slices * (size_t)N);
-    if (rc) return rc;
-    dim3 sgrid(grid.x, (unsigned)slices);
-    const char* env_pk = getenv("BBH_NEHVI_PK");
-    if (env_pk && env_pk[0] == '0') {
-      switch (m) {
-        case 1: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<1, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-        case 2: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<2, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-        case 3: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<3, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-        default: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<4, false>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-      }
-    } else {
-      switch (m) {
-        case 1: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<1, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-        case 2: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<2, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-        case 3: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<3, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-        default: hipLaunchKernelGGL((bbh_qlognehvi_lin_kernel<4, true>), sgrid, block, 0, h->stream, a, len, h->d_ws); break;
-      }
-    }
-    hipLaunchKernelGGL(bbh_qlognehvi_finish_kernel, grid, block, 0, h->stream, h->d_ws, (int)slices, N, (int)S, alive_dev, scores_dev);
-    BBH_HIP_TRY(h, hipGetLastError());
-    return 0;
+  return bbh_qlognehvi_run(h, a, h->d_z + S * m + 2 * ncells * m);
+}
+
+// bbh_qlognehvi_sm against the device-resident cell lists of bbh_cells_build_dev on this handle: only the candidate's base
+// samples zx_host [S, m] travel.
+extern "C" int bbh_qlognehvi_cells(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                                   const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                                   const uint8_t* alive_dev, double* scores_dev) {
+  if (!h) return -1;
+  const bbh_nehvi_state* st = (const bbh_nehvi_state*)h->nehvi_state;
+  if (m < 1 || m > BBH_MAX_OBJECTIVES || N < 0 || S < 1 || !tmat_dev || !var_dev || !sign_host || !zx_host || !scores_dev || !st ||
+      st->S != S || st->m != m) {
+    h->err = "bbh_qlognehvi_cells: bad arguments, or no cell lists for this S and m on the handle (bbh_cells_build_dev)";
+    return -1;
   }
-  switch (m) {
-    case 1: hipLaunchKernelGGL(bbh_qlognehvi_kernel<1>, grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL(bbh_qlognehvi_kernel<2>, grid, block, 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL(bbh_qlognehvi_kernel<3>, grid, block, 0, h->stream, a); break;
-    default: hipLaunchKernelGGL(bbh_qlognehvi_kernel<4>, grid, block, 0, h->stream, a); break;
-  }
-  BBH_HIP_TRY(h, hipGetLastError());
-  return 0;
+  if (N == 0) return 0;
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  int rc = bbh_upload_z(h, zx_host, (size_t)S * m);
+  if (rc) return rc;
+  NehviArgs a;
+  bbh_nehvi_fill_args(a, m, N, tmat_dev, var_dev, sign_host, S, alive_dev, scores_dev, true);
+  a.zx = h->d_z;
+  a.cell_off = st->off();
+  a.cell_lo = st->lo();
+  a.cell_ll = st->ll();
+  return bbh_qlognehvi_run(h, a, st->len());
 }
 
 // ---- Pareto frequency of the baseline points over MC samples (pruning) ---------------------------
@@ -1414,36 +1451,48 @@ __global__ __launch_bounds__(256) void bbh_pareto_freq_kernel(const double* __re
   }
 }
 
-extern "C" int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64_t S, int64_t n, int32_t m,
-                                    const double* ref_host, int64_t* counts_host) {
+static int bbh_pareto_frequency_impl(bbh_handle* h, const double* obj, bool on_device, int64_t S, int64_t n, int32_t m,
+                                     const double* ref_host, int64_t* counts_host) {
   if (!h) return -1;
-  if (!obj_host || !ref_host || !counts_host || S < 1 || n < 1 || n > 8192 / (m > 0 ? m : 1) || m < 1 ||
+  if (!obj || !ref_host || !counts_host || S < 1 || n < 1 || n > 8192 / (m > 0 ? m : 1) || m < 1 ||
       m > BBH_MAX_OBJECTIVES) {
     h->err = "bbh_pareto_frequency: bad arguments (n * m <= 8192, 1 <= m <= 4)";
     return -1;
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
-  const size_t nobj = (size_t)S * n * m;
+  const size_t nobj = on_device ? 0 : (size_t)S * n * m;
   int rc = bbh_ensure_ws(h, sizeof(double) * (nobj + m + n));
   if (rc) return rc;
   double* d_obj = h->d_ws;
   double* d_ref = d_obj + nobj;
   unsigned long long* d_cnt = (unsigned long long*)(d_ref + m);
-  BBH_HIP_TRY(h, hipMemcpyAsync(d_obj, obj_host, sizeof(double) * nobj, hipMemcpyHostToDevice, h->stream));
+  if (!on_device) BBH_HIP_TRY(h, hipMemcpyAsync(d_obj, obj, sizeof(double) * nobj, hipMemcpyHostToDevice, h->stream));
+  const double* src = on_device ? obj : d_obj;
   BBH_HIP_TRY(h, hipMemcpyAsync(d_ref, ref_host, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
   BBH_HIP_TRY(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * n, h->stream));
   const size_t lds = sizeof(double) * n * m;
   dim3 grid((unsigned)S), block(256);
   switch (m) {
-    case 1: hipLaunchKernelGGL(bbh_pareto_freq_kernel<1>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
-    case 2: hipLaunchKernelGGL(bbh_pareto_freq_kernel<2>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
-    case 3: hipLaunchKernelGGL(bbh_pareto_freq_kernel<3>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
-    default: hipLaunchKernelGGL(bbh_pareto_freq_kernel<4>, grid, block, lds, h->stream, d_obj, (int)n, d_ref, d_cnt); break;
+    case 1: hipLaunchKernelGGL(bbh_pareto_freq_kernel<1>, grid, block, lds, h->stream, src, (int)n, d_ref, d_cnt); break;
+    case 2: hipLaunchKernelGGL(bbh_pareto_freq_kernel<2>, grid, block, lds, h->stream, src, (int)n, d_ref, d_cnt); break;
+    case 3: hipLaunchKernelGGL(bbh_pareto_freq_kernel<3>, grid, block, lds, h->stream, src, (int)n, d_ref, d_cnt); break;
+    default: hipLaunchKernelGGL(bbh_pareto_freq_kernel<4>, grid, block, lds, h->stream, src, (int)n, d_ref, d_cnt); break;
   }
   BBH_HIP_TRY(h, hipGetLastError());
   BBH_HIP_TRY(h, hipMemcpyAsync(counts_host, d_cnt, sizeof(int64_t) * n, hipMemcpyDeviceToHost, h->stream));
   BBH_HIP_TRY(h, hipStreamSynchronize(h->stream));
   return 0;
+}
+
+extern "C" int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64_t S, int64_t n, int32_t m,
+                                    const double* ref_host, int64_t* counts_host) {
+  return bbh_pareto_frequency_impl(h, obj_host, false, S, n, m, ref_host, counts_host);
+}
+
+// ... with the objective samples already on the device (bbh_nehvi_samples wrote them): nothing but the counts travels
+extern "C" int bbh_pareto_frequency_dev(bbh_handle* h, const double* obj_dev, int64_t S, int64_t n, int32_t m,
+                                        const double* ref_host, int64_t* counts_host) {
+  return bbh_pareto_frequency_impl(h, obj_dev, true, S, n, m, ref_host, counts_host);
 }
 
 // =================================================================================================

@@ -61,6 +61,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   }
   bbh_comm_destroy(h);
   bbh_select_destroy(h);
+  bbh_nehvi_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
   if (h->fit_stream) {

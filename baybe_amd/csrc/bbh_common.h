@@ -330,6 +330,7 @@ struct bbh_handle {
   int small_nb = 0;               // its training blocks ceil(n / 16) <= 4 once the operands are packed (0: form not available)
   bool small_on = true;           // env BBH_SMALL=0: keep the cooperative form for n <= 64 (A/B)
   int64_t slice_rows = 0;         // bbh_set_slice_rows: row count the sample-slice heuristics use instead of the local N (0: local)
+  void* nehvi_state = nullptr;    // device-resident box decompositions + their scratch (bbh_nehvi.hip), null until bbh_cells_build_dev
   void* select_state = nullptr;   // chunk keys, result block and base-sample tables of the selection kernels (bbh_select.hip)
   bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
   bool select_on = true;          // env BBH_SELECT=0: top-k / argmax by k rounds of workgroup argmax (A/B)
@@ -367,6 +368,25 @@ struct bbh_timed_scope {
 
 inline int64_t bbh_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Device-resident box decompositions of one qLogNEHVI selection step (bbh_nehvi.hip: bbh_cells_build_dev writes them,
+// bbh_qlognehvi_cells in bbh_acq.hip scores against them).
+struct bbh_nehvi_state {
+  int64_t S = 0, total = 0, cap = 0;  // samples, cells in all samples, cell capacity per sample
+  int m = 0;
+  double* d_slots = nullptr;  // [S][cap][2][m] per-sample cells as the decomposition kernel leaves them (lower bound, side length)
+  size_t slot_bytes = 0;
+  double* d_pack = nullptr;   // [off: S + 1 (int64) | lo: S cap m | ll: S cap m | len: S cap m], the first `total` cells of each in use
+  size_t pack_bytes = 0;
+  int* d_cnt = nullptr;       // [S] cells per sample, [S] = overflow flag
+  int64_t cnt_cap = 0;
+  double* d_ref = nullptr;    // [BBH_MAX_OBJECTIVES]
+  int64_t* h_status = nullptr;  // pinned: [0] total cells, [1] samples whose bound list overflowed
+  const int64_t* off() const { return (const int64_t*)d_pack; }
+  const double* lo() const { return d_pack + (S + 1); }
+  const double* ll() const { return lo() + S * cap * m; }
+  const double* len() const { return ll() + S * cap * m; }
+};
+
 // ---- linalg (bbh_linalg.hip) ------------------------------------------------------------
 // C[M,N] = alpha * op(A) op(B) + beta * C, fp64 MFMA, M,N multiples of 64, K multiple of 16.
 // transA: A stored [K,M]; transB: B stored [N,K].  Batched over `batch` with element strides.
@@ -384,7 +404,7 @@ void bbh_matvec_t(hipStream_t s, const double* A, int64_t lda, int64_t rows, int
 
 // ---- model (bbh_model.hip) --------------------------------------------------------------
 int bbh_upload_theta(bbh_handle* h, const double* theta_host);
-void bbh_launch_gram(bbh_handle* h, double jitter);
+void bbh_launch_gram(bbh_handle* h, double jitter, double jitter_latent);  // jitter_latent: rows with noise mask 0
 bool bbh_fit_small_launch(bbh_handle* h, double jitter, const double* theta_dev, double* out_dev, int* info_dev);  // whole objective evaluation of a small model in one workgroup; false: not eligible
 bbh_kern_spec bbh_kern_spec_of(const bbh_handle* h);
 int bbh_hadamard_offset(const bbh_handle* h);
@@ -402,5 +422,7 @@ int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ld
                        double* var_dev);
 
 int bbh_ensure_ws(bbh_handle* h, size_t bytes);
+int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count);  // host doubles -> h->d_z through the handle's pinned staging buffer (bbh_acq.hip)
 void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
+void bbh_nehvi_destroy(bbh_handle* h);   // bbh_nehvi.hip
 void bbh_free_model_public(bbh_handle* h);

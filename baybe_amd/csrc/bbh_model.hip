@@ -42,11 +42,12 @@ int bbh_upload_theta(bbh_handle* h, const double* theta_host) {
   return 0;
 }
 
-// K[a][b] = scale * k(r_ab) + (s2 + jitter) [a==b]; identity on the padding.
+// K[a][b] = scale * k(r_ab) + (s2 + jitter) [a==b]; identity on the padding.  Rows with noise mask 0 (latent values: the baseline
+// rows of an extended qLogNEHVI model) take jitter_latent instead of jitter.
 __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict__ xnT, const int* __restrict__ task,
                                                        const double* __restrict__ nmask,
                                                        const double* __restrict__ theta, int n, int np, int dn,
-                                                       const bbh_kern_spec ks, int T, int hoff, double jitter,
+                                                       const bbh_kern_spec ks, int T, int hoff, double jitter, double jitter_latent,
                                                        double* __restrict__ K) {
   extern __shared__ double s_invls[];  // [F][dn]
   for (int e = threadIdx.x; e < ks.F * dn; e += blockDim.x) s_invls[e] = 1.0 / theta[ks.ls_off[e / dn] + e % dn];
@@ -66,15 +67,15 @@ __global__ __launch_bounds__(256) void bbh_gram_kernel(const double* __restrict_
   double k = bbh_kcomp(ks, theta, r2);
   if (ks.use_os) k *= theta[TH_OS];
   if (T > 1) k *= theta[TH_LS + dn + task[a] * T + task[b]];
-  if (a == b) k += (hoff >= 0 ? theta[hoff + task[a]] : theta[TH_NOISE]) * nmask[a] + jitter;
+  if (a == b) k += (hoff >= 0 ? theta[hoff + task[a]] : theta[TH_NOISE]) * nmask[a] + (nmask[a] != 0.0 ? jitter : jitter_latent);
   K[(int64_t)a * np + b] = k;
 }
 
-void bbh_launch_gram(bbh_handle* h, double jitter) {
+void bbh_launch_gram(bbh_handle* h, double jitter, double jitter_latent) {
   dim3 grid((unsigned)((h->np + 255) / 256), (unsigned)h->np), block(256);
   hipLaunchKernelGGL(bbh_gram_kernel, grid, block, sizeof(double) * h->dn * h->F, h->stream, h->d_xnT, h->d_task, h->d_nmask,
                      h->d_theta, (int)h->n, (int)h->np, h->dn, bbh_kern_spec_of(h), h->T, bbh_hadamard_offset(h), jitter,
-                     h->d_K);
+                     jitter_latent, h->d_K);
 }
 
 __global__ void bbh_resid_kernel(const double* __restrict__ ystd, const double* __restrict__ theta,
@@ -599,10 +600,10 @@ extern "C" int bbh_get_standardization(bbh_handle* h, double* ybar, double* ysd)
 
 // K -> L, X = L^-1, r, alpha.  Returns the Cholesky info flag (0 ok) via *info_out.
 // info_out == nullptr: nothing is read back here (the caller fetches d_info together with its own results)
-static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
+static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out, double jitter_latent = -1.0) {
   hipStream_t s = h->stream;
   const int64_t np = h->np;
-  bbh_launch_gram(h, jitter);
+  bbh_launch_gram(h, jitter, jitter_latent < 0.0 ? jitter : jitter_latent);
   bbh_potrf_trtri(h);
   hipLaunchKernelGGL(bbh_resid_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, h->d_ystd, h->d_theta,
                      h->d_task, h->T, bbh_hadamard_offset(h), (int)h->n, (int)np, h->d_r);
@@ -613,9 +614,10 @@ static int bbh_chol_and_alpha(bbh_handle* h, double jitter, int* info_out) {
   BBH_HIP_TRY(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
   if (info == -7 && h->potrf_tiles) {  // tile-dataflow launch gave up: redo with the per-step path
+    if (getenv("BBH_TILE_TRACE")) fprintf(stderr, "bbh_chol_and_alpha: tile-dataflow launch gave up (np = %lld, spin limit %d)\n", (long long)h->np, h->tile_spin_limit);
     h->potrf_tiles = false;
     if (h->tile_spin_limit >= 1024) bbh_potrf_tiles_mark_unusable(h->device);
-    return bbh_chol_and_alpha(h, jitter, info_out);
+    return bbh_chol_and_alpha(h, jitter, info_out, jitter_latent);
   }
   *info_out = info;
   return 0;
@@ -750,6 +752,7 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
             std::chrono::duration<double, std::micro>(t_end - t_enq).count());
   }
   if (*h->pin_info == -7 && h->potrf_tiles) {  // the tile-dataflow launch gave up (workgroups not co-resident): per-step path
+    if (getenv("BBH_TILE_TRACE")) fprintf(stderr, "bbh_fit_value_grad: tile-dataflow launch gave up (np = %lld, spin limit %d)\n", (long long)h->np, h->tile_spin_limit);
     h->potrf_tiles = false;
     if (h->tile_spin_limit >= 1024) bbh_potrf_tiles_mark_unusable(h->device);  // (not when a test forced the give-up with a tiny poll budget)
     if (h->fit_exec) {
@@ -779,19 +782,31 @@ extern "C" int bbh_factorize(bbh_handle* h, const double* theta_host, double* ji
   if (rc) return rc;
   h->factorized = false;
   // gpytorch psd_safe_cholesky: plain attempt, then jitter 1e-8 * 10^i, i = 0..2
-  double jitter = 0.0;
+  // A model with latent rows (noise mask 0: the baseline rows of an extended qLogNEHVI model) whose factorisation fails INSIDE
+  // the latent block: BoTorch factorises the baseline's joint posterior covariance - the Schur complement of that block, in the
+  // target's original scale - with the same ladder, which is this matrix with the jitter on the latent rows' diagonal only
+  // (1e-8 * 10^i / ysd^2 in standardised units).  A failure inside the noisy block keeps the whole-diagonal ladder.
+  bool latent = false;
+  for (int64_t i = 0; i < h->n && !latent; i++) latent = h->nmask_host[i] == 0.0;
+  double jitter = 0.0, jitter_latent = 0.0;
   int info = 0;
   for (int attempt = 0; attempt < 4; attempt++) {
-    rc = bbh_chol_and_alpha(h, jitter, &info);
+    rc = bbh_chol_and_alpha(h, jitter, &info, jitter_latent);
     if (rc) return rc;
     if (info == 0) break;
-    jitter = 1e-8 * pow(10.0, attempt);
+    const double step = 1e-8 * pow(10.0, attempt);
+    if (latent && info > 0 && h->nmask_host[info - 1 < h->n ? info - 1 : h->n - 1] == 0.0 && jitter == 0.0) {
+      jitter_latent = step / (h->ysd * h->ysd);
+    } else {
+      jitter = step;
+      jitter_latent = step;
+    }
   }
   if (info != 0) {
     h->err = "bbh_factorize: train covariance not positive definite (even with jitter 1e-6)";
     return -4;
   }
-  if (jitter_used) *jitter_used = jitter;
+  if (jitter_used) *jitter_used = jitter > 0.0 ? jitter : jitter_latent;
   h->p = 0;
   h->pend_host.clear();
   h->factorized = true;

@@ -1380,6 +1380,35 @@ __global__ void bbh_prep_columns_kernel(const double* __restrict__ Y, int64_t n,
   out[e] = (i < n && s < S) ? (Y[i * S + s] - ybar) / ysd - (taskmean ? taskmean[task[i]] : c) : 0.0;
 }
 
+// The alpha columns A [np, spad] (device, row-major) become the operand of bbh_posterior_columns: fragments for the fused /
+// cooperative kernels, a plain copy for the models that contract the materialised K*.
+static int bbh_install_columns(bbh_handle* h, const double* A, int64_t S, int64_t spad) {
+  hipStream_t s = h->stream;
+  const int64_t np = h->np;
+  const int64_t nks = np / 4, groups = spad / 128;
+  const int64_t elems = groups * nks * 8 * 64;
+  if (!h->d_colfrag || h->colfrag_elems < elems) {
+    if (h->d_colfrag) hipFree(h->d_colfrag);
+    h->d_colfrag = nullptr;
+    BBH_HIP_TRY(h, hipMalloc((void**)&h->d_colfrag, sizeof(double) * elems));
+    h->colfrag_elems = elems;
+  }
+  hipLaunchKernelGGL(bbh_pack_colfrag_kernel, dim3((unsigned)nks, 8, (unsigned)groups), dim3(64), 0, s, A, spad, nks,
+                     h->d_colfrag);
+  if (bbh_materialised_only(h)) {  // these models contract K* with the plain matrix (bbh_posterior_columns)
+    if (!h->d_colA || h->colA_elems < np * spad) {
+      if (h->d_colA) hipFree(h->d_colA);
+      h->d_colA = nullptr;
+      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_colA, sizeof(double) * np * spad));
+      h->colA_elems = np * spad;
+    }
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_colA, A, sizeof(double) * np * spad, hipMemcpyDeviceToDevice, s));
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  h->ncols = S;
+  return 0;
+}
+
 extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t S) {
   if (!h) return -1;
   if (!h->factorized || !Y_host || S < 1 || S > 8192) {
@@ -1402,28 +1431,85 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
                      h->ybar, h->ysd, h->theta[1], h->hadamard ? h->d_theta + bbh_hadamard_offset(h) + h->T : nullptr, h->d_task, Yc);
   bbh_gemm(s, false, false, np, spad, np, 1.0, h->d_X, np, 0, Yc, spad, 0, 0.0, T1, spad, 0, 1);  // L^-1 Yc
   bbh_gemm(s, true, false, np, spad, np, 1.0, h->d_X, np, 0, T1, spad, 0, 0.0, A, spad, 0, 1);    // L^-T (.)
-  const int64_t nks = np / 4, groups = spad / 128;
-  const int64_t elems = groups * nks * 8 * 64;
-  if (!h->d_colfrag || h->colfrag_elems < elems) {
-    if (h->d_colfrag) hipFree(h->d_colfrag);
-    h->d_colfrag = nullptr;
-    BBH_HIP_TRY(h, hipMalloc((void**)&h->d_colfrag, sizeof(double) * elems));
-    h->colfrag_elems = elems;
+  rc = bbh_install_columns(h, A, S, spad);
+  if (rc) return rc;
+  BBH_HIP_TRY(h, hipStreamSynchronize(s));  // the workspace may be reused by the next call
+  return 0;
+}
+
+// t1[i][s] = t_i for the training rows i < n0 (the same in every column), z[s][i - n0] for the nb baseline rows, 0 on the padding
+__global__ void bbh_nehvi_t1_kernel(const double* __restrict__ t, const double* __restrict__ z, int64_t n0, int64_t nb, int64_t S,
+                                    int64_t np, int64_t spad, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np * spad) return;
+  const int64_t i = e / spad, s = e % spad;
+  double v = 0.0;
+  if (s < S) {
+    if (i < n0) v = t[i];
+    else if (i < n0 + nb) v = z[s * nb + (i - n0)];
   }
-  hipLaunchKernelGGL(bbh_pack_colfrag_kernel, dim3((unsigned)nks, 8, (unsigned)groups), dim3(64), 0, s, A, spad, nks,
-                     h->d_colfrag);
-  if (bbh_materialised_only(h)) {  // these models contract K* with the plain matrix (bbh_posterior_columns)
-    if (!h->d_colA || h->colA_elems < np * spad) {
-      if (h->d_colA) hipFree(h->d_colA);
-      h->d_colA = nullptr;
-      BBH_HIP_TRY(h, hipMalloc((void**)&h->d_colA, sizeof(double) * np * spad));
-      h->colA_elems = np * spad;
-    }
-    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_colA, A, sizeof(double) * np * spad, hipMemcpyDeviceToDevice, s));
+  out[e] = v;
+}
+
+// Fb[s][b][o] = sign (ybar + ysd (c_b + sum_{k <= n0 + b} L[n0 + b][k] t1[k][s])): baseline row b of the generative form y = c + L [t; z]
+__global__ __launch_bounds__(256) void bbh_nehvi_fb_kernel(const double* __restrict__ L, int64_t np, const double* __restrict__ t1, int64_t spad,
+                                                           int64_t n0, int64_t nb, int64_t S, double ybar, double ysd, double c,
+                                                           const double* __restrict__ taskmean, const int* __restrict__ task, double sign,
+                                                           int o, int m, double* __restrict__ Fb) {
+  const int64_t b = blockIdx.x, s = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  if (s >= S) return;
+  const int64_t row = n0 + b;
+  const double* lr = L + row * np;
+  double acc0 = 0.0, acc1 = 0.0;
+  int64_t k = 0;
+  for (; k + 1 <= row; k += 2) {
+    acc0 = fma(lr[k], t1[k * spad + s], acc0);
+    acc1 = fma(lr[k + 1], t1[(k + 1) * spad + s], acc1);
+  }
+  if (k <= row) acc0 = fma(lr[k], t1[k * spad + s], acc0);
+  const double cm = taskmean ? taskmean[task[row]] : c;
+  Fb[(s * nb + b) * m + o] = sign * (ybar + ysd * (cm + (acc0 + acc1)));
+}
+
+// qLogNEHVI, one target of one selection step, on the device.  h holds the target's model EXTENDED by nb baseline rows as
+// noise-free observations (bbh_set_model_ex with a noise mask, rows n - nb .. n - 1; their target values are not read) and is
+// factorised.  The joint draw of the baseline values BoTorch takes through a cached Cholesky root is the generative form of
+// that factor:  y_ext,s = c + L_ext [t; z_s],  t = L^-1 (y - c) of the training rows, z_s the sample's base samples - the first
+// n - nb rows reproduce the measurements, the last nb rows ARE the sample  mu_b + chol(Sigma_b) z_s  of the baseline's joint
+// posterior (L_ext's last block row is [K_bn L^-T, chol(Sigma_b)]).  So nothing has to be solved for:
+//   * Fb_dev[s][b][o] (strides nb * m, m, 1) = sign * y_ext,s[n - nb + b] in the target's original scale - input of the box
+//     decompositions (bbh_cells_build_dev) and of the pruning counts (bbh_pareto_frequency_dev);
+//   * want_columns: the S weight columns  A_s = L_ext^-T [t; z_s]  of the model conditioned on that sample
+//     (bbh_posterior_columns), without the (n + nb) x S host array bbh_set_mean_columns takes.
+// z_host [S, nb].  Asynchronous on the handle's stream.  Reference: baybe/acquisition/_builder.py:301-334 (X_baseline,
+// prune_baseline, cache_root), baybe/acquisition/acqfs.py:477-484.
+extern "C" int bbh_nehvi_samples(bbh_handle* h, const double* z_host, int64_t S, int64_t nb, double sign, int32_t o, int32_t m,
+                                 double* Fb_dev, int32_t want_columns) {
+  if (!h) return -1;
+  if (!h->factorized || !z_host || S < 1 || S > 8192 || nb < 1 || nb >= h->n || o < 0 || o >= m || m > BBH_MAX_OBJECTIVES || !Fb_dev) {
+    h->err = "bbh_nehvi_samples: model not factorised / bad arguments (1 <= S <= 8192, 1 <= nb < n, 0 <= o < m <= 4)";
+    return -1;
+  }
+  BBH_HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int64_t np = h->np, n0 = h->n - nb;
+  const int64_t spad = bbh_round_up(S, 128);
+  int rc = bbh_ensure_ws(h, sizeof(double) * 2 * (size_t)np * spad);
+  if (rc) return rc;
+  rc = bbh_upload_z(h, z_host, (size_t)S * nb);
+  if (rc) return rc;
+  double* T1 = h->d_ws;
+  double* A = T1 + np * spad;
+  hipLaunchKernelGGL(bbh_nehvi_t1_kernel, dim3((unsigned)((np * spad + 255) / 256)), dim3(256), 0, s, h->d_t, h->d_z, n0, nb, S, np, spad, T1);
+  hipLaunchKernelGGL(bbh_nehvi_fb_kernel, dim3((unsigned)nb, (unsigned)((S + 255) / 256)), dim3(256), 0, s, h->d_K, np, T1, spad, n0, nb, S,
+                     h->ybar, h->ysd, h->theta[1], h->hadamard ? h->d_theta + bbh_hadamard_offset(h) + h->T : nullptr, h->d_task, sign,
+                     (int)o, (int)m, Fb_dev);
+  if (want_columns) {
+    bbh_gemm(s, true, false, np, spad, np, 1.0, h->d_X, np, 0, T1, spad, 0, 0.0, A, spad, 0, 1);  // L^-T [t; z]
+    rc = bbh_install_columns(h, A, S, spad);
+    if (rc) return rc;
   }
   BBH_HIP_TRY(h, hipGetLastError());
-  BBH_HIP_TRY(h, hipStreamSynchronize(s));  // the workspace may be reused by the next call
-  h->ncols = S;
   return 0;
 }
 

@@ -11,15 +11,30 @@ of the sampled values F_b,s:
 so the per-candidate work is exactly the fused posterior kernel on an *extended model*
 (``bbh_set_model_ex`` with a noise mask): one variance pass, and the S conditional means as a
 contraction of the same cross-covariance with S target columns (``bbh_posterior_columns``).
-Host set-up per selection step (O(n_b^3 + S n_b^2), as in BoTorch): joint posterior of the baseline
-(device), its Cholesky factor and the sampled values, baseline pruning, and the per-sample box
-decomposition.  The per-candidate scoring over cells runs in ``bbh_qlognehvi``.
+Set-up per selection step, on the device (round 5; it was 5 ms of host work per step plus 50 ms of
+pruning per call): the extended model's own Cholesky factor IS the sampler -
+
+    y_ext,s = c + L_ext [t; z_s],   t = L^-1 (y - c) on the training rows,
+
+reproduces the measurements in its first n rows and draws the baseline's joint posterior sample
+mu_b + chol(Sigma_b) z_s in its last n_b rows (L_ext's last block row is [K_bn L^-T, chol(Sigma_b)]),
+and the weight columns of the model conditioned on that sample are L_ext^-T [t; z_s].  So per target:
+``bbh_set_model_ex`` + ``bbh_factorize`` of the extended model, then ``bbh_nehvi_samples`` (sampled
+baseline values into a device array, weight columns installed) - no baseline posterior call, no host
+Cholesky, no (n + n_b) x S host array; the three targets run from three host threads on three
+streams.  ``bbh_cells_build_dev`` decomposes every sample's non-dominated region on the device (one
+wavefront per sample), ``bbh_qlognehvi_cells`` scores against the device-resident cell lists, and
+the pruning counts come from ``bbh_pareto_frequency_dev`` on samples drawn the same way.  The base
+samples themselves (torch's scrambled Sobol engine, as BoTorch) stay on the host; the next step's
+draw is prepared while the device scores the current one.
 """
 
 from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
 import numpy as np
@@ -80,6 +95,13 @@ class HipNEHVI:
         self._streams = None
         self.concurrent = True  # False: the targets' passes one after the other (per-kernel timing, A/B)
         self._pruned = None
+        # BBH_NEHVI_HOST=1: the round-4 host set-up (baseline posterior -> host Cholesky -> host samples -> host box
+        # decompositions -> (n + nb) x S host array per target), kept as the cross-check of the device set-up
+        self.device_setup = os.environ.get("BBH_NEHVI_HOST", "0") != "1"
+        self._pool = ThreadPoolExecutor(max_workers=self.m) if self.m > 1 else None
+        self._z_next = None  # (key, future): base samples of the next selection step, drawn while the device scores
+        self._cells_on_device = False
+        self.last_setup_ms = {}
 
     # ---- set-up ----------------------------------------------------------------------------------
     def _baseline_posteriors(self, Xb):
@@ -90,47 +112,113 @@ class HipNEHVI:
             Ls.append(_chol_with_jitter(cov))
         return mus, Ls
 
+    def _draw(self, S: int, nb: int, seed: int) -> np.ndarray:
+        return sobol_normal_base_samples(S, (nb + 1) * self.m, seed).reshape(S, nb + 1, self.m)
+
+    def _base_samples(self, S: int, nb: int, seed: int) -> np.ndarray:
+        """[S, nb + 1, m] base samples of a step with nb baseline points (the candidate's are the last row); taken from the
+        draw prepared during the previous scoring pass when it matches."""
+        key = (S, nb, seed)
+        nxt, self._z_next = self._z_next, None
+        if nxt is not None and nxt[0] == key:
+            return nxt[1].result()
+        return self._draw(S, nb, seed)
+
+    def prefetch_base_samples(self, nb: int, seed: int):
+        """Draw the base samples of the NEXT selection step on a host thread (the number of baseline points after the pick
+        is known before the pick is): the engine's scrambling and the normal transform overlap the device's scoring pass."""
+        if self._pool is None:
+            return
+        key = (self.S, nb, seed)
+        self._z_next = (key, self._pool.submit(self._draw, self.S, nb, seed))
+
+    def _extend(self, o: int, Xb: np.ndarray, z_o: np.ndarray, S: int, Fb_dev, want_columns: bool):
+        """Target o: extended model (baseline rows as noise-free observations), its factorisation, and the samples /
+        weight columns drawn through the factor itself (``bbh_nehvi_samples``).  Runs on a host thread per target."""
+        out = self.outputs[o]
+        eng = out.engine
+        Xt, yt = eng._X_train, eng._y_train
+        nb = len(Xb)
+        X_ext = np.vstack([Xt, Xb])
+        y_ext = np.concatenate([yt, np.full(nb, eng.ybar)])  # (the baseline rows' values are not read)
+        mask = np.concatenate([np.ones(len(yt), np.uint8), np.zeros(nb, np.uint8)])
+        out.ext.set_model(eng.spec, X_ext, y_ext, noise_mask=mask, standardization=(eng.ybar, eng.ysd))
+        out.ext.factorize(eng.params)
+        z_o = np.ascontiguousarray(z_o, dtype=np.float64)
+        out.ext._check(
+            self._lib.bbh_nehvi_samples(out.ext._h, _dp(z_o), S, nb, float(self.signs[o]), o, self.m, Fb_dev.data_ptr(),
+                                        1 if want_columns else 0),
+            "bbh_nehvi_samples",
+        )
+        if want_columns:
+            out.ext._ncols = S
+
+    def _for_each_target(self, fn):
+        if self._pool is None:
+            return [fn(0)]
+        return [f.result() for f in [self._pool.submit(fn, o) for o in range(self.m)]]
+
+    def _baseline_samples_dev(self, Xb: np.ndarray, z: np.ndarray, want_columns: bool):
+        """Oriented baseline objective samples [S, nb, m] as a device tensor (all targets)."""
+        import torch
+
+        S, nb = z.shape[0], len(Xb)
+        eng0 = self.outputs[0].engine
+        Fb_dev = torch.empty((S, nb, self.m), dtype=torch.float64, device=eng0._dev())
+        torch.cuda.synchronize(eng0.device)  # (Fb_dev's allocation vs the targets' own streams)
+        self._for_each_target(lambda o: self._extend(o, Xb, z[:, :nb, o], S, Fb_dev, want_columns))
+        torch.cuda.synchronize(eng0.device)  # the targets write Fb_dev on their own streams
+        return Fb_dev
+
     def prune_points(self, Xb: np.ndarray, seed: int) -> np.ndarray:
         """Keep baseline points that are Pareto-optimal and above the reference point in at least one
         of 2048 joint posterior samples (``prune_inferior_points_multi_objective``)."""
+        import time
+
         nb = len(Xb)
+        t0 = time.perf_counter()
         z = sobol_normal_base_samples(PRUNE_SAMPLES, nb * self.m, seed).reshape(PRUNE_SAMPLES, nb, self.m)
-        zc = np.ascontiguousarray(z.transpose(2, 0, 1))  # [m, S, nb]: contiguous operands for the BLAS products
-        mus, Ls = self._baseline_posteriors(Xb)
-        obj = np.empty((PRUNE_SAMPLES, nb, self.m))
-        for o in range(self.m):
-            obj[:, :, o] = (mus[o][None, :] + zc[o] @ Ls[o].T) * self.signs[o]
+        self.last_prune_ms = {"base_samples": 1e3 * (time.perf_counter() - t0)}
+        t0 = time.perf_counter()
         counts = np.zeros(nb, dtype=np.int64)
-        obj = np.ascontiguousarray(obj)
         ref = np.ascontiguousarray(self.ref, dtype=np.float64)
         eng = self.outputs[0].engine
-        eng._check(
-            self._lib.bbh_pareto_frequency(eng._h, _dp(obj), PRUNE_SAMPLES, nb, self.m, _dp(ref),
-                                           counts.ctypes.data_as(_lib.c_int64_p)),
-            "bbh_pareto_frequency",
-        )
+        if self.device_setup:
+            obj_dev = self._baseline_samples_dev(Xb, z, want_columns=False)
+            self.last_prune_ms["extend"] = 1e3 * (time.perf_counter() - t0)
+            h = self.outputs[0].ext
+            h._check(
+                self._lib.bbh_pareto_frequency_dev(h._h, obj_dev.data_ptr(), PRUNE_SAMPLES, nb, self.m, _dp(ref),
+                                                   counts.ctypes.data_as(_lib.c_int64_p)),
+                "bbh_pareto_frequency_dev",
+            )
+        else:
+            zc = np.ascontiguousarray(z.transpose(2, 0, 1))  # [m, S, nb]: contiguous operands for the BLAS products
+            mus, Ls = self._baseline_posteriors(Xb)
+            obj = np.empty((PRUNE_SAMPLES, nb, self.m))
+            for o in range(self.m):
+                obj[:, :, o] = (mus[o][None, :] + zc[o] @ Ls[o].T) * self.signs[o]
+            obj = np.ascontiguousarray(obj)
+            eng._check(
+                self._lib.bbh_pareto_frequency(eng._h, _dp(obj), PRUNE_SAMPLES, nb, self.m, _dp(ref),
+                                               counts.ctypes.data_as(_lib.c_int64_p)),
+                "bbh_pareto_frequency",
+            )
+        self.last_prune_ms["total_after_base_samples"] = 1e3 * (time.perf_counter() - t0)
         idx = np.nonzero(counts > 0)[0]
         return Xb[idx] if len(idx) else Xb[:0]
 
-    def prepare(self, seed: int, extra_baseline: np.ndarray | None = None, prune_seed: int | None = None):
-        """Sample the baseline, decompose, and condition the per-output models (one selection step)."""
-        if self._pruned is None:  # pruning happens once, when the acquisition function is built
-            Xb0 = self.X_baseline
-            if self.prune and len(Xb0):
-                Xb0 = self.prune_points(Xb0, draw_sampler_seed() if prune_seed is None else prune_seed)
-            self._pruned = Xb0
-        Xb = self._pruned
-        if extra_baseline is not None and len(extra_baseline):
-            Xb = np.vstack([Xb, np.atleast_2d(extra_baseline)])  # cache_pending: picks join the baseline
+    def _prepare_host(self, Xb: np.ndarray, z: np.ndarray):
+        """The round-4 set-up: samples and box decompositions on the host, full (n + nb) x S target columns per target."""
         nb = len(Xb)
-        z = sobol_normal_base_samples(self.S, (nb + 1) * self.m, seed).reshape(self.S, nb + 1, self.m)
-        self.zx = np.ascontiguousarray(z[:, nb, :])  # [S, m] base samples of the candidate
         Fb = np.empty((self.S, nb, self.m))
+        mus = None
         if nb:
             mus, Ls = self._baseline_posteriors(Xb)
             for o in range(self.m):
                 Fb[:, :, o] = mus[o][None, :] + z[:, :nb, o] @ Ls[o].T
         self.cell_off, self.cell_lo, self.cell_ll = pack_cells_native(Fb * self.signs[None, None, :], self.ref)
+        self._cells_on_device = False
         for o, out in enumerate(self.outputs):
             eng = out.engine
             Xt, yt = eng._X_train, eng._y_train
@@ -144,8 +232,61 @@ class HipNEHVI:
             if nb:
                 Y[len(yt):, :] = Fb[:, :, o].T
             out.ext.set_mean_columns(Y)
+
+    def prepare(self, seed: int, extra_baseline: np.ndarray | None = None, prune_seed: int | None = None):
+        """Sample the baseline, decompose, and condition the per-output models (one selection step)."""
+        import time
+
+        t0 = time.perf_counter()
+        tm = {}
+        if self._pruned is None:  # pruning happens once, when the acquisition function is built
+            Xb0 = self.X_baseline
+            if self.prune and len(Xb0):
+                Xb0 = self.prune_points(Xb0, draw_sampler_seed() if prune_seed is None else prune_seed)
+            self._pruned = Xb0
+            tm["prune"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        Xb = self._pruned
+        if extra_baseline is not None and len(extra_baseline):
+            Xb = np.vstack([Xb, np.atleast_2d(extra_baseline)])  # cache_pending: picks join the baseline
+        nb = len(Xb)
+        z = self._base_samples(self.S, nb, seed)
+        self.zx = np.ascontiguousarray(z[:, nb, :])  # [S, m] base samples of the candidate
+        tm["base_samples"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        if self.device_setup and nb:
+            Fb_dev = self._baseline_samples_dev(Xb, z, want_columns=True)
+            tm["extend"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            h = self.outputs[0].ext
+            total, over = C.c_int64(), C.c_int64()
+            ref = np.ascontiguousarray(self.ref, dtype=np.float64)
+            h._check(self._lib.bbh_cells_build_dev(h._h, Fb_dev.data_ptr(), self.S, nb, self.m, _dp(ref), C.byref(total), C.byref(over)),
+                     "bbh_cells_build_dev")
+            self._cells_on_device = over.value == 0
+            self.n_cells = int(total.value)
+            if not self._cells_on_device:  # a sample's bound list exceeded the kernel's capacity (or nb > 512): host form
+                self.cell_off, self.cell_lo, self.cell_ll = pack_cells_native(Fb_dev.cpu().numpy(), self.ref)
+                self.n_cells = int(self.cell_off[-1])
+            tm["cells"] = time.perf_counter() - t1
+        else:
+            self._prepare_host(Xb, z)
+            self.n_cells = int(self.cell_off[-1])
+            tm["host_setup"] = time.perf_counter() - t1
         self.X_b_current = Xb
         self._prepared = True
+        tm["total"] = time.perf_counter() - t0
+        self.last_setup_ms = {k: 1e3 * v for k, v in tm.items()}
+
+    def cells(self):
+        """(cell_off [S + 1], cell_lo [K, m], cell_loglen [K, m]) of the current step as host arrays."""
+        if not self._cells_on_device:
+            return self.cell_off, self.cell_lo, self.cell_ll
+        h = self.outputs[0].ext
+        off = np.zeros(self.S + 1, dtype=np.int64)
+        lo, ll = np.zeros((self.n_cells, self.m)), np.zeros((self.n_cells, self.m))
+        h._check(self._lib.bbh_cells_read_dev(h._h, off.ctypes.data_as(_lib.c_int64_p), _dp(lo), _dp(ll)), "bbh_cells_read_dev")
+        return off, lo, ll
 
     # ---- scoring ---------------------------------------------------------------------------------
     def _target_streams(self, device):
@@ -163,7 +304,7 @@ class HipNEHVI:
                         out.ext.use_current_torch_stream()
         return self._streams
 
-    def score(self, X_dev, alive=None):
+    def score(self, X_dev, alive=None, sync: bool = True):
         import torch
 
         assert self._prepared, "call prepare() first"
@@ -197,14 +338,21 @@ class HipNEHVI:
         h = self.outputs[0].ext
         sg = np.ascontiguousarray(self.signs)
         zx = np.ascontiguousarray(self.zx)
-        off = np.ascontiguousarray(self.cell_off, dtype=np.int64)
-        rc = self._lib.bbh_qlognehvi_sm(
-            h._h, self.m, N, tp, vp, _dp(sg), _dp(zx), self.S, off.ctypes.data_as(_lib.c_int64_p),
-            _dp(self.cell_lo) if len(self.cell_lo) else None, _dp(self.cell_ll) if len(self.cell_ll) else None,
-            alive.data_ptr() if alive is not None else None, scores.data_ptr(),
-        )
+        if self._cells_on_device:
+            rc = self._lib.bbh_qlognehvi_cells(h._h, self.m, N, tp, vp, _dp(sg), _dp(zx), self.S,
+                                               alive.data_ptr() if alive is not None else None, scores.data_ptr())
+        else:
+            off = np.ascontiguousarray(self.cell_off, dtype=np.int64)
+            rc = self._lib.bbh_qlognehvi_sm(
+                h._h, self.m, N, tp, vp, _dp(sg), _dp(zx), self.S, off.ctypes.data_as(_lib.c_int64_p),
+                _dp(self.cell_lo) if len(self.cell_lo) else None, _dp(self.cell_ll) if len(self.cell_ll) else None,
+                alive.data_ptr() if alive is not None else None, scores.data_ptr(),
+            )
         h._check(rc, "bbh_qlognehvi")
-        torch.cuda.synchronize(X_dev.device)  # tmats / vars_ must outlive the kernel
+        if sync:
+            torch.cuda.synchronize(X_dev.device)  # tmats / vars_ must outlive the kernel
+        else:
+            self._keep = (tmats, vars_)  # (the caller synchronises; the operands live until the next pass)
         return scores
 
     def greedy(self, X_dev, q: int, seed: int | None = None, prune_seed: int | None = None,
@@ -224,10 +372,13 @@ class HipNEHVI:
         if X_pending is not None and len(X_pending):
             picks.append(np.atleast_2d(np.asarray(X_pending, dtype=np.float64)))
         indices, values = [], []
-        for _ in range(q):
+        for step in range(q):
             self.prepare(seed, np.vstack(picks) if picks else None, prune_seed)
-            scores = self.score(X_dev, alive)
+            scores = self.score(X_dev, alive, sync=False)
+            if step + 1 < q:  # the next step's base samples: drawn on a host thread while the device scores this one
+                self.prefetch_base_samples(len(self.X_b_current) + 1, seed)
             val, idx = self.outputs[0].ext.argmax(scores) if X_dev.shape[0] else (-math.inf, -1)
+            torch.cuda.synchronize(X_dev.device)
             if shard is not None:
                 val, gidx, row = shard.global_argmax(val, idx, X_dev)
                 if shard.owns(gidx):

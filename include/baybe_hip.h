@@ -283,6 +283,35 @@ int bbh_qlognehvi_sm(bbh_handle* h, int32_t m, int64_t N, const double* const* t
 int bbh_pareto_frequency(bbh_handle* h, const double* obj_host, int64_t S, int64_t n, int32_t m,
                          const double* ref_host, int64_t* counts_host);
 
+/* bbh_pareto_frequency with the objective samples already on the device (obj_dev [S, n, m], as bbh_nehvi_samples writes them). */
+int bbh_pareto_frequency_dev(bbh_handle* h, const double* obj_dev, int64_t S, int64_t n, int32_t m,
+                             const double* ref_host, int64_t* counts_host);
+
+/* qLogNEHVI set-up of one target on the device (replaces: baseline joint posterior -> host Cholesky -> host samples -> an
+ * (n + nb) x S host array for bbh_set_mean_columns).  h holds the target's model extended by nb baseline rows as noise-free
+ * observations (bbh_set_model_ex with a noise mask: the last nb rows; their target values are not read) and is factorised.
+ * BoTorch's joint draw of the baseline values through the cached Cholesky root (qLogNoisyExpectedHypervolumeImprovement with
+ * cache_root, built at baybe/acquisition/_builder.py:319-324) is the generative form of that factor,
+ * y_ext,s = c + L_ext [t; z_s] with t = L^-1 (y - c) on the training rows and z_s = z_host[s, :] the sample's base samples:
+ * Fb_dev[(s * nb + b) * m + o] = sign * (baseline row b of y_ext,s, original target scale); with want_columns != 0 the S weight
+ * columns L_ext^-T [t; z_s] of the model conditioned on each sample are installed for bbh_posterior_columns(_sm).
+ * Asynchronous on the handle's stream. */
+int bbh_nehvi_samples(bbh_handle* h, const double* z_host, int64_t S, int64_t nb, double sign, int32_t o, int32_t m,
+                      double* Fb_dev, int32_t want_columns);
+
+/* Box decompositions on the device: one wavefront per MC sample over Fb_dev [S, nb, m] (oriented objective samples, as
+ * bbh_nehvi_samples writes them) - the algorithm and visiting order of bbh_cells_create, the cell lists stay on the handle
+ * for bbh_qlognehvi_cells.  *total_out = cells over all samples; *overflow_out = samples whose list of local upper bounds
+ * exceeded the kernel's capacity (then, or for nb > 512, the caller takes the host form).  bbh_cells_read_dev copies the
+ * lists out in the layout of bbh_cells_get (tests, statistics). */
+int bbh_cells_build_dev(bbh_handle* h, const double* Fb_dev, int64_t S, int64_t nb, int32_t m, const double* ref_host,
+                        int64_t* total_out, int64_t* overflow_out);
+int bbh_cells_read_dev(bbh_handle* h, int64_t* off_host, double* lo_host, double* loglen_host);
+/* bbh_qlognehvi_sm against the handle's device-resident cell lists (bbh_cells_build_dev with the same S and m). */
+int bbh_qlognehvi_cells(bbh_handle* h, int32_t m, int64_t N, const double* const* tmat_dev,
+                        const double* const* var_dev, const double* sign_host, const double* zx_host, int64_t S,
+                        const uint8_t* alive_dev, double* scores_dev);
+
 /* Box decomposition of the non-dominated region, one per MC sample (host code, no device work; BoTorch's
  * FastNondominatedPartitioning inside qLogNoisyExpectedHypervolumeImprovement, built at
  * baybe/acquisition/_builder.py:319-324).  obj_host [S, n, m] oriented baseline objective samples, ref_host [m].
@@ -293,6 +322,13 @@ int bbh_cells_create(const double* obj_host, int64_t S, int64_t n, int32_t m, co
                      void** cells_out, int64_t* total_out);
 int bbh_cells_get(void* cells, int64_t* off_host, double* lo_host, double* loglen_host);
 int bbh_cells_destroy(void* cells);
+
+/* Scrambled Sobol points bitwise as torch.quasirandom.SobolEngine(dimension, scramble=True, seed) draws them (host code, integer
+ * arithmetic; the engine botorch's SobolQMCNormalSampler uses).  state [dim, 30]: the engine's unscrambled direction numbers,
+ * scrambled in place with the engine's random lower-triangular bit matrices ltm [dim, 30, 30] (0 / 1 entries as drawn, before
+ * tril);  bbh_sobol_draw: out [n, dim] = the first n points for the scrambled state and the integer shift [dim]. */
+int bbh_sobol_scramble(int64_t* state, const int64_t* ltm, int64_t dim);
+int bbh_sobol_draw(const int64_t* state, const int64_t* shift, int64_t n, int64_t dim, double* out);
 
 /* ---- selection --------------------------------------------------------------------- */
 /* First-index argmax of scores_dev [N] (NaN never wins) -> host. */

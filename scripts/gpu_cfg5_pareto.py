@@ -31,6 +31,6 @@ for S in (128, 512):
     t0 = time.time(); hv.prepare(1234, prune_seed=99); t1 = time.time()
     sc = hv.score(Xd); torch.cuda.synchronize(); t2 = time.time()
     sc = hv.score(Xd); torch.cuda.synchronize(); t3 = time.time()
-    ncell = hv.cell_off[-1] / S
+    ncell = hv.n_cells / S
     print(f"[cfg5] S={S}: pruned baseline {len(hv._pruned)}/{n}, avg cells/sample {ncell:.1f}; prepare {t1 - t0:.2f} s; score {1e3 * (t3 - t2):.1f} ms ({N / (t3 - t2):.3e} cand/s); best {float(sc.max()):.4f} at {int(sc.argmax())}")
 t0 = time.time(); r = hv.greedy(Xd, 2, seed=1234, prune_seed=99); print(f"[cfg5] greedy q=2 (S=512): {time.time() - t0:.2f} s -> {r.indices}")

@@ -334,7 +334,7 @@ def test_cfg5_qlognehvi_scores_at_full_size(cfg5, S):
     keep = no.prune_baseline(models, signs, Xt, ref, pseed)
     assert np.array_equal(hv._pruned, Xt[keep]) and 0 < len(keep) < len(Xt)
     orc = no.NEHVIOracle(models, signs, Xt[keep], ref, no.sobol_normal_base_samples_nd(S, len(keep) + 1, m, seed))
-    assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)  # same box decompositions, sample by sample
+    assert hv.n_cells == sum(len(c[0]) for c in orc.cells)  # same box decompositions, sample by sample
     top = np.argsort(-sg, kind="stable")[:12]
     # 500 random rows, the head of the device's ranking, and grid rows that ARE baseline points (singular joint covariance: the
     # candidate's conditional variance is rounding noise around zero, and the sign of that noise decides whether the 1 x 1 jitter

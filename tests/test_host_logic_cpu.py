@@ -743,3 +743,20 @@ def test_lean_lbfgsb_driver_is_scipys():
     # the first evaluation fails (NaN value, zero gradient): the same outcome from both - the engine's retry logic looks at the value
     res = same(lambda: (lambda x: (float("nan"), np.zeros_like(x))), np.ones(3), [(None, None)] * 3, 100)
     assert np.isnan(res.fun)
+
+
+def test_fast_sobol_points_are_the_engines_bitwise():
+    """``engine._sobol_uniform_fast`` (torch's generator for the scrambling bits + the library's host code for the scrambling and
+    the Gray-code walk) against ``torch.quasirandom.SobolEngine`` itself: every point bitwise, including the engine's
+    single-precision first point; and the base samples built on it are unchanged by the switch."""
+    import torch
+
+    from baybe_amd import engine
+
+    assert engine._fast_sobol_usable()
+    for S, q, seed in ((1, 1, 0), (2, 3, 1), (64, 16, 1234), (513, 96, 999999), (100, 1111, 42)):
+        assert torch.equal(engine._sobol_uniform_fast(S, q, seed), engine._sobol_uniform_engine(S, q, seed)), (S, q, seed)
+    z = engine.sobol_normal_base_samples(128, 12, 77)
+    u = engine._sobol_uniform_engine(128, 12, 77)
+    v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
+    assert np.array_equal(z, (torch.erfinv(2 * v - 1) * np.sqrt(2.0)).numpy())

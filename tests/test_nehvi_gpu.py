@@ -74,7 +74,7 @@ def test_scores_match_oracle(m, signs):
     assert (sg[:60][dup] < so[~dup].max() - 5).all() and (so[dup] < so[~dup].max() - 5).all()
     assert int(np.argmax(sg[:60])) == int(np.argmax(so))
     # cells on the device side equal the oracle's per-sample decompositions
-    assert hv.cell_off[-1] == sum(len(c[0]) for c in orc.cells)
+    assert hv.n_cells == sum(len(c[0]) for c in orc.cells)
     # the targets' passes overlap on one stream per target (round 4); in sequence they give bitwise the same scores
     assert hv.concurrent and len(hv._streams) == m
     hv.concurrent = False
@@ -134,3 +134,81 @@ def test_pareto_recommendation_through_the_plugin_surface():
     assert list(stats.columns) == ["t1_mean", "t1_std", "t2_mean", "t2_std"]
     acq = rec.acquisition_values(exp.iloc[:50], space, obj, meas)
     assert isinstance(acq, pd.Series) and np.isfinite(acq.to_numpy()).all()
+
+
+@pytest.mark.parametrize("m,nb,S", [(1, 5, 16), (2, 12, 64), (3, 31, 128), (3, 130, 64), (4, 24, 64), (3, 1, 8)])
+def test_device_box_decompositions_equal_the_host_form(m, nb, S):
+    """``bbh_cells_build_dev`` (one wavefront per sample, bound lists in LDS) against ``bbh_cells_create`` (host C++) on the same
+    samples: the same cells in the same order - offsets and lower corners bitwise, log side lengths to rounding (the device takes
+    log(len), the host log(min(up, 1e10) - lo): the same expression).  Ties, duplicated points, points below the reference point
+    and dominated points are in the samples."""
+    import ctypes as C
+
+    import torch
+
+    from baybe_amd import _lib, engine
+    from baybe_amd.box_decomposition import pack_cells_native
+
+    rng = np.random.default_rng(100 * m + nb)
+    Y = rng.standard_normal((S, nb, m))
+    Y[:, : nb // 3] = np.round(Y[:, : nb // 3], 1)  # ties in single coordinates
+    if nb >= 4:
+        Y[:, 1] = Y[:, 0]  # an exact duplicate
+        Y[::3, 2] = -5.0  # a point below the reference point in every sample of a third
+    ref = np.full(m, -0.8)
+    g = engine.HipGP(0)
+    lib = _lib.load_library()
+    Yd = torch.from_numpy(Y).cuda()
+    total, over = C.c_int64(), C.c_int64()
+    g._check(lib.bbh_cells_build_dev(g._h, Yd.data_ptr(), S, nb, m, ref.ctypes.data_as(_lib.c_double_p), C.byref(total), C.byref(over)),
+             "bbh_cells_build_dev")
+    off_h, lo_h, ll_h = pack_cells_native(Y, ref)
+    if over.value:  # (only four objectives can exceed the bound capacity; then the product takes the host form)
+        assert m == 4
+        return
+    assert total.value == off_h[-1]
+    off = np.zeros(S + 1, dtype=np.int64)
+    lo, ll = np.zeros((total.value, m)), np.zeros((total.value, m))
+    g._check(lib.bbh_cells_read_dev(g._h, off.ctypes.data_as(_lib.c_int64_p), lo.ctypes.data_as(_lib.c_double_p),
+                                    ll.ctypes.data_as(_lib.c_double_p)), "bbh_cells_read_dev")
+    assert np.array_equal(off, off_h)
+    assert np.array_equal(lo, lo_h)
+    assert np.allclose(ll, ll_h, rtol=0, atol=1e-14)
+    g.close()
+
+
+@pytest.mark.parametrize("n,seed,atol_cells,atol_scores", [(24, 0, 1e-10, 1e-9), (30, 7, None, 1e-3)])
+def test_device_setup_equals_the_host_setup(n, seed, atol_cells, atol_scores):
+    """The device set-up of a selection step (samples through the extended factor, weight columns L^-T [t; z], device box
+    decompositions) against the round-4 host set-up (baseline posterior -> host Cholesky -> host samples / decompositions ->
+    full target columns): the same pruned baseline, the same cells, the same scores.  The second case has three duplicated
+    training rows: the baseline's joint covariance is singular there, both set-ups go up the psd_safe_cholesky ladder (the
+    device one with the jitter on the latent rows of the extended factorisation, which is the ladder on the Schur complement
+    BoTorch factorises); the two samples of a duplicated point then differ by ~sqrt(jitter) z, which of them is the larger one - and
+    with it the ORDER of the cells - depends on rounding, so that case compares pruning, cell counts and scores only."""
+    import torch
+
+    from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+
+    m = 3
+    X, Xt, Y, signs, engines, models = _setup(m, n=n, N=400, seed=seed)
+    assert (len(np.unique(Xt, axis=0)) < len(Xt)) == (n == 30)
+    ref = compute_ref_point(Y)
+    Xd = torch.from_numpy(X).cuda()
+    out = {}
+    for mode in ("device", "host"):
+        hv = HipNEHVI(engines, signs, Xt, ref, n_mc_samples=64, prune_baseline=True)
+        hv.device_setup = mode == "device"
+        hv.prepare(21, prune_seed=22)
+        assert hv._cells_on_device == (mode == "device")
+        out[mode] = (hv._pruned.copy(), hv.cells(), hv.score(Xd).cpu().numpy())
+    assert np.array_equal(out["device"][0], out["host"][0])  # the same pruned baseline
+    (off_d, lo_d, ll_d), (off_h, lo_h, ll_h) = out["device"][1], out["host"][1]
+    assert np.array_equal(off_d, off_h)
+    if atol_cells is not None:
+        assert np.allclose(lo_d, lo_h, rtol=0, atol=atol_cells), np.abs(lo_d - lo_h).max()
+        assert np.allclose(ll_d, ll_h, rtol=0, atol=100 * atol_cells)
+    sd, sh = out["device"][2], out["host"][2]
+    dup = np.array([(np.abs(Xt - x).sum(1) < 1e-12).any() for x in X])
+    assert np.allclose(sd[~dup], sh[~dup], rtol=0, atol=atol_scores), np.abs(sd - sh)[~dup].max()
+    assert int(np.argmax(sd)) == int(np.argmax(sh))
