@@ -30,6 +30,8 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_PENDING_LDS")) h->pending_lds_form = (e[0] != '0');
   if (const char* e = getenv("BBH_FIT_GRAPH")) h->fit_graph_mode = (e[0] != '0');
   if (const char* e = getenv("BBH_FIT_SMALL")) h->fit_small = (e[0] != '0');
+  if (const char* e = getenv("BBH_FIT_FLOW")) h->fit_flow = atoi(e);
+  if (const char* e = getenv("BBH_FLOW_SPIN")) h->flow_spin_limit = atoi(e);
   if (const char* e = getenv("BBH_POTRF_TILES")) h->potrf_tiles = (e[0] != '0');
   if (const char* e = getenv("BBH_TILE_SPIN")) h->tile_spin_limit = atoi(e);
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
@@ -62,6 +64,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   bbh_comm_destroy(h);
   bbh_select_destroy(h);
   bbh_nehvi_destroy(h);
+  bbh_flow_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);
   if (h->fit_stream) {

@@ -330,6 +330,11 @@ struct bbh_handle {
   int small_nb = 0;               // its training blocks ceil(n / 16) <= 4 once the operands are packed (0: form not available)
   bool small_on = true;           // env BBH_SMALL=0: keep the cooperative form for n <= 64 (A/B)
   int64_t slice_rows = 0;         // bbh_set_slice_rows: row count the sample-slice heuristics use instead of the local N (0: local)
+  void* flow_state = nullptr;     // roles, flags and scratch of the one-launch fit evaluation (bbh_fitflow.hip)
+  int flow_spin_limit = 1 << 17;  // env BBH_FLOW_SPIN: polls before a waiting role of the dataflow fit evaluation gives up
+  bool skip_x_memset = false;     // bbh_potrf_trtri: leave the upper tiles of L^-1 alone (the caller reads lower tiles only)
+  bool flow_in_flight = false;    // the evaluation on the stream is the one-launch form (its flag needs the sentinel check)
+  int fit_flow = 1;               // env BBH_FIT_FLOW: 0 fit evaluations for 64 < np <= 1024 launch by launch, 1 (default) Gram + factorisation launches, then ONE dataflow launch for K^-1, alpha, value and gradient, 2 the whole evaluation as one dataflow launch
   void* nehvi_state = nullptr;    // device-resident box decompositions + their scratch (bbh_nehvi.hip), null until bbh_cells_build_dev
   void* select_state = nullptr;   // chunk keys, result block and base-sample tables of the selection kernels (bbh_select.hip)
   bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
@@ -425,4 +430,8 @@ int bbh_ensure_ws(bbh_handle* h, size_t bytes);
 int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count);  // host doubles -> h->d_z through the handle's pinned staging buffer (bbh_acq.hip)
 void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
 void bbh_nehvi_destroy(bbh_handle* h);   // bbh_nehvi.hip
+void bbh_flow_destroy(bbh_handle* h);    // bbh_fitflow.hip
+bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only);  // 64 < np <= 1024: the whole evaluation as one dataflow launch, or (tail_only) everything after the factorisation; false: not eligible
+bool bbh_fit_flow_eligible(bbh_handle* h);
+void bbh_fit_flow_reset(bbh_handle* h);  // after a launch that gave up: clean state, the handle stops using the form
 void bbh_free_model_public(bbh_handle* h);

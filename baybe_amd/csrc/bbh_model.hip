@@ -638,11 +638,45 @@ static int bbh_fit_enqueue(bbh_handle* h) {
       return 0;
     (void)hipGetLastError();
   }
+  {  // 64 < np <= 1024: the whole evaluation as one dataflow launch (bbh_fitflow.hip), the same zero-copy staging
+    void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
+    if (h->fit_flow == 2 && h->np > 64 && h->np <= 1024 && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
+        hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess && hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
+      *h->pin_info = -99;  // (sentinel: the kernel's last role writes the flag; a launch that gave up never does)
+      if (bbh_fit_flow_launch(h, (const double*)th_dev, (double*)out_dev, (int*)info_dev, false)) {
+        h->flow_in_flight = true;
+        return 0;
+      }
+    }
+    (void)hipGetLastError();
+  }
   BBH_HIP_TRY(h, hipMemcpyAsync(h->d_theta, h->pin_theta, sizeof(double) * tl, hipMemcpyHostToDevice, s));
   // One host synchronisation per evaluation: the Cholesky flag is fetched with the results at the end (after a failed
   // factorisation the remaining kernels run on NaNs, harmlessly, and the outcome is discarded).
-  int rc = bbh_chol_and_alpha(h, 0.0, nullptr);
-  if (rc) return rc;
+  {  // default for 64 < np <= 1024: Gram + tile-dataflow factorisation as launches, then everything after the factor - K^-1, alpha,
+     // (LOO: q, Q), value, gradient pairs, their sums - as ONE dataflow launch writing the results into the pinned buffers
+     // (7-10 kernels, a memset and two copies before)
+    void *out_dev = nullptr, *info_dev = nullptr;
+    // (the leave-one-out criterion above np = 512 keeps the launch path: its Q = M diag(u) M tiles walk 16 k-steps each after the
+    //  16 of M - measured 0.90 vs 0.87 ms per evaluation at n = 1024 with four tasks)
+    const bool flow_pays = !(h->desc.criterion == BBH_CRITERION_LOO && h->np > 512);
+    if (h->fit_flow == 1 && flow_pays && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess &&
+        hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
+      bbh_launch_gram(h, 0.0, 0.0);
+      h->skip_x_memset = true;  // (the tail reads the lower tiles of L^-1 only)
+      bbh_potrf_trtri(h);
+      h->skip_x_memset = false;
+      *h->pin_info = -99;
+      if (bbh_fit_flow_launch(h, h->d_theta, (double*)out_dev, (int*)info_dev, true)) {
+        h->flow_in_flight = true;
+        return 0;
+      }
+      (void)hipGetLastError();  // (resources: the handle has stopped using the form; this evaluation starts over on the launch path)
+    }
+    int rc0 = bbh_chol_and_alpha(h, 0.0, nullptr);
+    if (rc0) return rc0;
+  }
+  int rc = 0;
   // M = X^T X.  One 64 x 64 output tile per workgroup means np / 64 squared workgroups walking all of K: 35 us at np = 512
   // on a quarter of the CUs.  Up to np = 1024 the product is split four ways along K (batched launch into four partial
   // matrices) and summed in a fixed order.
@@ -750,6 +784,15 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
     fprintf(stderr, "bbh_fit_value_grad (%s): enqueue %.1f us, wait %.1f us\n", h->fit_exec ? "graph" : "launches",
             std::chrono::duration<double, std::micro>(t_enq - t_begin).count(),
             std::chrono::duration<double, std::micro>(t_end - t_enq).count());
+  }
+  if (h->flow_in_flight) {
+    h->flow_in_flight = false;
+    if (*h->pin_info == -99) {  // the dataflow launch never reported: one of its waits ran out of polls - launch path from now on
+      // (a reported -7 is the tile-dataflow FACTORISATION in front of it giving up: handled below, the dataflow tail stays in use)
+      if (getenv("BBH_TILE_TRACE")) fprintf(stderr, "bbh_fit_value_grad: one-launch evaluation gave up (np = %lld, flag %d)\n", (long long)h->np, *h->pin_info);
+      bbh_fit_flow_reset(h);
+      return bbh_fit_value_grad(h, theta_host, value_host, grad_host);
+    }
   }
   if (*h->pin_info == -7 && h->potrf_tiles) {  // the tile-dataflow launch gave up (workgroups not co-resident): per-step path
     if (getenv("BBH_TILE_TRACE")) fprintf(stderr, "bbh_fit_value_grad: tile-dataflow launch gave up (np = %lld, spin limit %d)\n", (long long)h->np, h->tile_spin_limit);

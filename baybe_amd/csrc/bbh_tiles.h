@@ -1,0 +1,305 @@
+// 64 x 64 tile toolkit of the fit's dataflow kernels (bbh_linalg.hip: bbh_potrf_tiles_kernel, bbh_fitflow.hip: bbh_fit_flow_kernel):
+// 16 x 16-blocked MFMA products on LDS tiles, the factor-and-invert of a diagonal tile, tile loads / stores, and the
+// publish / wait protocol on epoch-stamped flags.  256 threads per workgroup, LDS tiles [64][PD_LD].
+#pragma once
+#include <type_traits>
+
+#include "bbh_common.h"
+
+// ---- the same 64x64 diagonal block, blocked 16 x 16 on the fp64 MFMA ------------------------------------
+// The register form above is one wave walking 64 dependent pivots and then 64 substitution steps: 46 us per block, 8
+// blocks in sequence at n = 512 = 47 % of a fit evaluation (profiles/r02_fit_kernel_stats.csv).  Here the block is a
+// 4 x 4 grid of 16 x 16 sub-blocks in LDS: per block column J the diagonal sub-block is factorised and inverted in the
+// registers of 16 lanes (16 pivots), the sub-diagonal panel is one MFMA chain per sub-block against that inverse, the
+// trailing sub-blocks take rank-16 updates on the MFMA, and L^-1 is assembled block column by block column from the
+// diagonal inverses - 4 short dependent stages instead of 128 long ones.
+//   fragment layouts (bbh_common.h): A (16x4) lane l <- A[l & 15][4 ks + (l >> 4)],  B (4x16) lane l <- B[4 ks + (l >> 4)][l & 15],
+//   C lane l, reg r <-> C[(l >> 4) + 4 r][l & 15]
+#define PD_LD 66  // LDS row pitch (doubles)
+__device__ __forceinline__ d4 pd_mul_nt(const double (*a)[PD_LD], int ar, int ac, const double (*b)[PD_LD], int br, int bc, int l) {
+  // C = A[ar.., ac..] (16x16) * B[br.., bc..]^T (16x16):  C[m][n] = sum_k A[m][k] B[n][k]
+  d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+    c = mfma_f64(a[ar + (l & 15)][ac + 4 * ks + (l >> 4)], b[br + (l & 15)][bc + 4 * ks + (l >> 4)], c);
+  return c;
+}
+__device__ __forceinline__ d4 pd_mul_nn(const double (*a)[PD_LD], int ar, int ac, const double (*b)[PD_LD], int br, int bc, int l, d4 c) {
+  // C += A[ar.., ac..] (16x16) * B[br.., bc..] (16x16):  C[m][n] += sum_k A[m][k] B[k][n]
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+    c = mfma_f64(a[ar + (l & 15)][ac + 4 * ks + (l >> 4)], b[br + 4 * ks + (l >> 4)][bc + (l & 15)], c);
+  return c;
+}
+
+// Row broadcasts for the 16 x 16 diagonal sub-blocks: the 16 lanes of a DPP row hold the 16 rows of the sub-block, and
+// gfx90a+ has `row_newbcast:n` (lane n of every row to all its lanes) on the 64-bit v_mov and v_fmac.  One instruction
+// instead of two v_readlane_b32 + an SGPR operand: the readlane form of this code was 796 readlanes and 272 hazard nops in
+// 2 500 instructions and spilled SGPRs into VGPR lanes.  The `s_nop 1` in front of every DPP instruction covers the "VALU
+// write -> DPP read" hazard (2 wait states) whatever the compiler places before the statement.
+#ifndef BBH_DIAG_DPP
+#define BBH_DIAG_DPP 1
+#endif
+template <int LANE>
+__device__ __forceinline__ double pd_bcast(double v) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+  return r;
+}
+// acc += bcast_LANE(src) * (-mul).  GUARD: src may have been written by the instruction just before (first member of an
+// update series: the scaled pivot column); the others read a register that has been at rest for many instructions.
+template <int LANE, bool GUARD>
+__device__ __forceinline__ void pd_fmac_bcast_neg(double& acc, double src, double mul) {
+  if constexpr (GUARD)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(src), "v"(mul), "n"(LANE));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(src), "v"(mul), "n"(LANE));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void pd_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pd_static_for<I + 1, N>(f);
+  }
+}
+
+// Factor and invert the 64 x 64 SPD block held in LDS array a (in place: lower factor L, strict upper zeroed) into x =
+// L^-1 (lower); s is scratch.  256 threads, all LDS arrays [64][PD_LD]; x must be zero on entry.  row0: global index of
+// the block's first row (failure reports row0 + pivot + 1 through *info).
+// nbk < 4 (one-workgroup fit evaluation of a model with n <= 16 nbk rows): the sub-blocks from nbk on are identity in a AND in x on
+// entry and are left alone.
+__device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[PD_LD], double (*s)[PD_LD], int64_t row0, int* info,
+                                                int* early_flag = nullptr, int epoch = 0, int nbk = 4) {
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  for (int jb = 0; jb < nbk; jb++) {
+    // (tile-dataflow caller: stores issued before this call have landed by now - publish them without a stall)
+    if (jb == 1 && early_flag) {
+      __threadfence();
+      __syncthreads();  // every thread's stores are fenced before the flag goes up
+      if (t == 0) __hip_atomic_store(early_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int o = 16 * jb;
+    if (w == 0) {  // diagonal sub-block: lane i < 16 holds row i; pivots travel by v_readlane
+      double row[16];
+      const int i = l & 15;
+#pragma unroll
+      for (int k = 0; k < 16; k++) row[k] = a[o + i][o + k];
+      int bad = 0;
+      double rd[16];
+      double xc[16];
+#if BBH_DIAG_DPP
+      pd_static_for<0, 16>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const double djj = pd_bcast<j>(row[j]);
+        bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
+        double rs = __builtin_amdgcn_rsq(djj);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rd[j] = rs;  // the same in every lane: 1 / l_jj
+        row[j] = (i == j) ? djj * rs : row[j] * rs;
+        pd_static_for<j + 1, 16>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          pd_fmac_bcast_neg<k, k == j + 1>(row[k], row[j], row[j]);  // row[k] -= l_kj * row[j]   (meaningful for i >= k)
+        });
+      });
+      if (l == 0 && bad) atomicCAS(info, 0, (int)(row0 + o + bad));
+      if (l < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
+      }
+      // inverse of the 16 x 16 factor: lane c < 16 owns column c (forward substitution, l_rk = lane r of row[k])
+      pd_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        double acc = (r == i) ? 1.0 : 0.0;
+        pd_static_for<0, r>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          pd_fmac_bcast_neg<r, false>(acc, row[k], xc[k]);
+        });
+        xc[r] = (r >= i) ? acc * rd[r] : 0.0;
+      });
+#else
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const double djj = bbh_readlane_f64(row[j], j);
+        bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
+        double rs = __builtin_amdgcn_rsq(djj);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+        rd[j] = rs;  // wave-uniform 1 / l_jj
+        row[j] = (i == j) ? djj * rs : row[j] * rs;
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) {
+          const double lkj = bbh_readlane_f64(row[j], k);
+          row[k] = fma(-row[j], lkj, row[k]);  // meaningful for i >= k
+        }
+      }
+      if (l == 0 && bad) atomicCAS(info, 0, (int)(row0 + o + bad));
+      if (l < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
+      }
+      // inverse of the 16 x 16 factor: lane c < 16 owns column c (forward substitution, L rows by readlane)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; k++) acc = fma(-bbh_readlane_f64(row[k], r), xc[k], acc);  // l_rk = row r, entry k
+        xc[r] = (r >= i) ? acc * rd[r] : 0.0;
+      }
+#endif
+      if (l < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[o + r][o + i] = xc[r];
+      }
+    }
+    __syncthreads();
+    // panel: L_IJ = A_IJ T_J^T for the sub-blocks below the diagonal one, one wave each, in place (a wave's LDS
+    // operations complete in order: its operand reads precede its writes)
+    for (int ib = jb + 1 + w; ib < nbk; ib += 4) {
+      const d4 c = pd_mul_nt(a, 16 * ib, o, x, o, o, l);
+#pragma unroll
+      for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][o + (l & 15)] = c[r];
+    }
+    __syncthreads();
+    // trailing update: A_IK -= L_IJ L_KJ^T for jb < K <= I (at most 6 sub-blocks, dealt to the waves)
+    int cnt = 0;
+    for (int ib = jb + 1; ib < nbk; ib++)
+      for (int kb = jb + 1; kb <= ib; kb++, cnt++) {
+        if ((cnt & 3) != w) continue;
+        const d4 c = pd_mul_nt(a, 16 * ib, o, a, 16 * kb, o, l);
+#pragma unroll
+        for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][16 * kb + (l & 15)] -= c[r];
+      }
+    __syncthreads();
+  }
+  // zero the strict upper triangle of L
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    if (j > i) a[i][j] = 0.0;
+  }
+  __syncthreads();
+  // L^-1 by block columns: X_IJ = -T_I (sum_{K=J}^{I-1} L_IK X_KJ), wave J owns block column J (rows I = J+1..3 in turn)
+  {
+    const int jb = w, oj = 16 * jb;
+    for (int ib = jb + 1; ib < nbk; ib++) {
+      d4 c = {0.0, 0.0, 0.0, 0.0};
+      for (int kb = jb; kb < ib; kb++) c = pd_mul_nn(a, 16 * ib, 16 * kb, x, 16 * kb, oj, l, c);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[16 * ib + (l >> 4) + 4 * r][oj + (l & 15)] = c[r];
+      // (wave-private region of s and x: block column jb; LDS operations of one wave complete in order)
+      d4 e = {0.0, 0.0, 0.0, 0.0};
+      e = pd_mul_nn(x, 16 * ib, 16 * ib, s, 16 * ib, oj, l, e);  // T_I is the diagonal sub-block of x
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[16 * ib + (l >> 4) + 4 * r][oj + (l & 15)] = -e[r];
+    }
+  }
+  __syncthreads();
+}
+
+// =====================================================================================================================
+// The whole factorisation L = chol(A), X = L^-1 of an np x np matrix (np <= 1024) in ONE launch: tile dataflow.
+// One workgroup per 64 x 64 tile, all resident at once (<= 256 workgroups, one per CU: 135 KB of LDS each):
+//   L-tile (I, K), K <= I-2: a = A_IK;  for J < K: a -= L_IJ L_KJ^T as soon as both are published;  then wait for D_K,
+//                           L_IK = a D_K^T, publish.
+//   row head I:             the tiles (I, I-1) and (I, I) together: the same updates for both, then L_{I,I-1} = a_left
+//                           D_{I-1}^T, a_diag -= L_{I,I-1} L_{I,I-1}^T, factor + invert (pd_factor_block), publish D_I.
+//   X-tile (I, J), I > J:   acc = sum_{K = J}^{I-1} L_IK X_KJ as the operands appear (X_JJ = D_J), then X_IJ = -D_I acc.
+// "Published" = tile written, __threadfence(), flag[tile] = epoch (release); consumers poll the flag (acquire) with a
+// bounded number of polls - if the workgroups are ever not co-resident (another kernel holding CUs) the launch gives up
+// (*info = -7) instead of hanging and the caller falls back to the launch-per-step path.  The dependency chain is
+// nbk x (factor + one 64^3 panel product + one 64^3 update) inside one kernel instead of 8 x 3 dependent launches.
+// =====================================================================================================================
+__device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info, int spin_limit) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1, it = 0;
+    // Polls are RELAXED loads at device scope: an acquire load per poll invalidates the XCD's L2 every time, and with every
+    // waiting workgroup of a launch polling (130 of them in the one-launch fit evaluation) those invalidations slowed the
+    // critical path's own tile loads and write-backs - hand-offs took up to 19 us instead of 2 (profiles/r05_flow_trace_*).
+    // The acquire side is the fence every thread executes after the flag has flipped.
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      if (++it > spin_limit || ((it & 15) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == -7)) {
+        __hip_atomic_store(info, -7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      if (it < 64)
+        __builtin_amdgcn_s_sleep(1);
+      else
+        __builtin_amdgcn_s_sleep(4);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  __threadfence();  // acquire side for every thread's tile loads
+  __syncthreads();  // (s_ok is reused by the next wait)
+  return ok;
+}
+__device__ __forceinline__ void pd_publish(int* flag, int epoch) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (release: the fence above)
+}
+// (16-byte accesses: tile rows start 16-byte aligned in global memory - ld is a multiple of 64 - and in LDS, pitch 528 B)
+typedef double pd_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pd_load_tile(double (*dst)[PD_LD], const double* src, int64_t ld) {
+#pragma unroll
+  for (int e = threadIdx.x; e < 2048; e += 256)
+    *(pd_d2*)&dst[e >> 5][2 * (e & 31)] = *(const pd_d2*)(src + (int64_t)(e >> 5) * ld + 2 * (e & 31));
+}
+__device__ __forceinline__ void pd_store_tile(double* dst, int64_t ld, const double (*src)[PD_LD], double scale) {
+#pragma unroll
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    pd_d2 v = *(const pd_d2*)&src[e >> 5][2 * (e & 31)];
+    v *= scale;
+    *(pd_d2*)(dst + (int64_t)(e >> 5) * ld + 2 * (e & 31)) = v;
+  }
+}
+// c (+)= sign * a b^T (NT) or a b (NN), 64 x 64 x 64, the 16 output sub-blocks dealt to the four waves.  SKIP names
+// structural zeros / don't-cares at 16 x 16 sub-block granularity:
+//   PD_B_LOWER (NT): b is lower triangular, b[n][k] = 0 for k > n      -> k-blocks kb <= nb only
+//   PD_A_LOWER (NN): a is lower triangular, a[m][k] = 0 for k > m      -> k-blocks kb <= mb only
+//   PD_OUT_LOWER:    only the lower sub-blocks of c (mb >= nb) are read afterwards (symmetric update of a diagonal tile)
+enum { PD_FULL = 0, PD_B_LOWER = 1, PD_A_LOWER = 2, PD_OUT_LOWER = 3 };
+template <bool NT, bool ACCUM, int SKIP>
+__device__ __forceinline__ void pd_gemm64(double (*c)[PD_LD], const double (*a)[PD_LD], const double (*b)[PD_LD], double sign) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // sub-blocks are dealt so that every wave gets the same number of k-blocks: lower-only output - the ten lower sub-blocks
+  // in turn; triangular b - one sub-block of every block column; triangular a - one of every block row
+  constexpr int NSB = SKIP == PD_OUT_LOWER ? 10 : 16;
+  for (int sb = w; sb < NSB; sb += 4) {
+    int mb, nb;
+    if (SKIP == PD_OUT_LOWER) {
+      nb = sb < 4 ? 0 : sb < 7 ? 1 : sb < 9 ? 2 : 3;
+      mb = sb - (nb == 0 ? 0 : nb == 1 ? 3 : nb == 2 ? 5 : 6);
+    } else if (SKIP == PD_A_LOWER) {
+      mb = sb >> 2, nb = sb & 3;
+    } else {
+      mb = sb & 3, nb = sb >> 2;
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+      if (SKIP == PD_B_LOWER && kb > nb) continue;
+      if (SKIP == PD_A_LOWER && kb > mb) continue;
+      if (NT) {
+        const d4 p = pd_mul_nt(a, 16 * mb, 16 * kb, b, 16 * nb, 16 * kb, l);
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] += p[r];
+      } else {
+        acc = pd_mul_nn(a, 16 * mb, 16 * kb, b, 16 * kb, 16 * nb, l, acc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      double* out = &c[16 * mb + (l >> 4) + 4 * r][16 * nb + (l & 15)];
+      *out = ACCUM ? *out + sign * acc[r] : sign * acc[r];
+    }
+  }
+}
+

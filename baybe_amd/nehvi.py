@@ -57,6 +57,20 @@ def compute_ref_point(array, maximize=None, factor: float = 0.1) -> np.ndarray:
     return (lo - factor * (hi - lo)) * mx
 
 
+def _unique_rows(X: np.ndarray):
+    """(rows of X without repeats in first-occurrence order, their indices, index of every row's representative).
+    Repeated baseline points (replicate measurements) carry one latent value: BoTorch's joint draw gives the copies the same
+    sample up to sqrt(jitter), and an extended model with two noise-free rows at one location is singular - the copies keep
+    their base-sample columns (the Sobol dimension counts them) but only the first enters the model and the decompositions."""
+    if len(X) == 0:
+        return X, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    _, first, inverse = np.unique(X, axis=0, return_index=True, return_inverse=True)
+    order = np.sort(first)
+    rank = np.empty(len(first), dtype=np.int64)
+    rank[np.argsort(first)] = np.arange(len(first))
+    return X[order], order, rank[np.asarray(inverse).reshape(-1)]
+
+
 def _chol_with_jitter(A: np.ndarray) -> np.ndarray:
     """psd_safe_cholesky: plain attempt, then jitter 1e-8 * 10^i."""
     jit = 0.0
@@ -175,9 +189,13 @@ class HipNEHVI:
         of 2048 joint posterior samples (``prune_inferior_points_multi_objective``)."""
         import time
 
+        Xb_all = Xb
+        Xb, first, rep = _unique_rows(Xb_all)
         nb = len(Xb)
         t0 = time.perf_counter()
-        z = sobol_normal_base_samples(PRUNE_SAMPLES, nb * self.m, seed).reshape(PRUNE_SAMPLES, nb, self.m)
+        z = sobol_normal_base_samples(PRUNE_SAMPLES, len(Xb_all) * self.m, seed).reshape(PRUNE_SAMPLES, len(Xb_all), self.m)
+        if nb < len(Xb_all):
+            z = np.ascontiguousarray(z[:, first, :])
         self.last_prune_ms = {"base_samples": 1e3 * (time.perf_counter() - t0)}
         t0 = time.perf_counter()
         counts = np.zeros(nb, dtype=np.int64)
@@ -205,8 +223,8 @@ class HipNEHVI:
                 "bbh_pareto_frequency",
             )
         self.last_prune_ms["total_after_base_samples"] = 1e3 * (time.perf_counter() - t0)
-        idx = np.nonzero(counts > 0)[0]
-        return Xb[idx] if len(idx) else Xb[:0]
+        idx = np.nonzero(counts[rep] > 0)[0]  # (a repeated point shares the verdict of its representative)
+        return Xb_all[idx] if len(idx) else Xb_all[:0]
 
     def _prepare_host(self, Xb: np.ndarray, z: np.ndarray):
         """The round-4 set-up: samples and box decompositions on the host, full (n + nb) x S target columns per target."""
@@ -249,9 +267,13 @@ class HipNEHVI:
         Xb = self._pruned
         if extra_baseline is not None and len(extra_baseline):
             Xb = np.vstack([Xb, np.atleast_2d(extra_baseline)])  # cache_pending: picks join the baseline
+        Xb_all = Xb
+        z = self._base_samples(self.S, len(Xb_all), seed)
+        self.zx = np.ascontiguousarray(z[:, len(Xb_all), :])  # [S, m] base samples of the candidate
+        Xb, first, _ = _unique_rows(Xb_all)
         nb = len(Xb)
-        z = self._base_samples(self.S, nb, seed)
-        self.zx = np.ascontiguousarray(z[:, nb, :])  # [S, m] base samples of the candidate
+        if nb < len(Xb_all):  # repeated baseline points: one latent value each (their base-sample columns stay counted)
+            z = np.ascontiguousarray(z[:, np.concatenate([first, [len(Xb_all)]]), :])
         tm["base_samples"] = time.perf_counter() - t1
         t1 = time.perf_counter()
         if self.device_setup and nb:
@@ -273,7 +295,7 @@ class HipNEHVI:
             self._prepare_host(Xb, z)
             self.n_cells = int(self.cell_off[-1])
             tm["host_setup"] = time.perf_counter() - t1
-        self.X_b_current = Xb
+        self.X_b_current = Xb_all
         self._prepared = True
         tm["total"] = time.perf_counter() - t0
         self.last_setup_ms = {k: 1e3 * v for k, v in tm.items()}

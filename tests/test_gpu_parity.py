@@ -1070,3 +1070,101 @@ def test_joint_batches_beyond_sixteen_points(gp):
         gp.greedy_qlogei(X, 5, S=64, seed=1, X_pending=X[:62])  # 62 + 4 picks > 63 pending points
     with pytest.raises(ValueError):
         gp.greedy_qlogei(X, 18, S=64, seed=1, kind="qEI")  # the other MC functions stop at 16 points
+
+
+def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
+    """64 < np <= 1024, one kernel, <= 4 tasks: ``bbh_fit_flow_kernel`` does everything after the factorisation - K^-1, alpha, value,
+    every gradient slot - as one dataflow launch that writes into the pinned result buffers (``BBH_FIT_FLOW=1``, the default), or
+    the whole objective evaluation incl. Gram tiles, factor and inverse (``BBH_FIT_FLOW=2``); ``BBH_FIT_FLOW=0``: launch by launch.  Value 1e-11 / gradient 1e-8 between the two at several points for MLL models of n = 70 ... 1024 (incl. sizes that are
+    not multiples of 64, the alpha slot of RQ, Matern-1/2, a pinned subset), ICM models with the leave-one-out criterion (the
+    configs[3] model) and with the marginal likelihood; a failed factorisation; whole fits end at the same objective value;
+    models the form does not take (two factors) are unaffected."""
+    import time
+
+    from _problems import make_tl_problem
+    from baybe_amd import engine, gp_spec
+    from baybe_amd.kernels import GammaPrior, MaternKernel, ProductKernel, RBFKernel, RQKernel, ScaleKernel, apply_kernel_spec
+
+    class Space:
+        comp_rep_columns = tuple(f"x{j}" for j in range(20))
+
+    rng = np.random.default_rng(11)
+    cases = [("preset", None, 6, 70, 1), ("preset", None, 20, 512, 1), ("preset", None, 15, 300, 1), ("preset", None, 20, 1024, 1),
+             ("rbf", ScaleKernel(RBFKernel(GammaPrior(3, 1)), GammaPrior(2, 0.5)), 8, 130, 1), ("rq", RQKernel(GammaPrior(3, 1)), 4, 200, 1),
+             ("m12", MaternKernel(0.5, GammaPrior(3, 1)), 3, 100, 1),
+             ("subset", ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1), parameter_names=["x0", "x2", "x3"])), 5, 150, 1),
+             ("icm-loo", None, 15, 256, 4), ("icm-loo", None, 15, 1024, 4), ("icm-mll", None, 6, 200, 3)]
+    for tag, kern, d, n, T in cases:
+        if T == 1:
+            X, Xt, y = make_problem(4096, d, n, seed=100 + n)
+            spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+        else:
+            X, Xt, y = make_tl_problem(500, d, n // T, T, seed=n)
+            spec = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=T)
+            if tag == "icm-mll":
+                spec.criterion = "mll"
+        if kern is not None:
+            apply_kernel_spec(spec, kern, Space())
+        bounds = gp_spec.raw_bounds(spec)
+        free = np.array([not (b[0] is not None and b[0] == b[1]) for b in bounds])
+        raw0 = gp_spec.pack_raw(spec, gp_spec.initial_params(spec))
+        points = []
+        for _ in range(3):
+            raw = np.where(free, raw0 + 0.3 * rng.standard_normal(raw0.shape), raw0)
+            raw[0] = abs(raw[0]) + 0.01
+            points.append(gp_spec.unpack_raw(spec, raw))
+        out = {}
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("BBH_FIT_FLOW", mode)
+            g = engine.HipGP(0)
+            g.set_model(spec, Xt, y)
+            evals = [g.data_term(p) for p in points]
+            evals += [g.data_term(points[0])]  # (a repeated point: the epoch-stamped flags and cumulative counters carry over)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g.data_term(points[1])
+            per_eval = (time.perf_counter() - t0) / 20 * 1e3
+            fi = g.fit() if n <= 512 and T == 1 else None
+            out[mode] = (evals, fi, per_eval)
+            g.close()
+        for mode in ("1", "2"):
+            for (v0, g0), (v1, g1) in zip(out["0"][0], out[mode][0]):
+                assert v0 is not None and v1 is not None
+                assert math.isclose(v0, v1, rel_tol=1e-11, abs_tol=1e-11), (tag, n, mode, v0, v1)
+                assert np.allclose(g0, g1, rtol=1e-8, atol=1e-10 * np.abs(g0).max()), (tag, n, mode, g0, g1)
+            assert out[mode][0][0][0] == out[mode][0][3][0] and np.array_equal(out[mode][0][0][1], out[mode][0][3][1])  # reproducible
+        if out["0"][1] is not None:
+            f0, f1 = out["0"][1], out["1"][1]
+            assert abs(f0.fun - f1.fun) <= 2e-6 * max(1.0, abs(f0.fun)), (tag, f0.fun, f1.fun)
+        print(f"   {tag} d={d} n={n} T={T}: evaluation launch by launch {out['0'][2]:.3f} ms, factorisation + one dataflow launch {out['1'][2]:.3f} ms, "
+              f"one launch {out['2'][2]:.3f} ms")
+    # a poll budget of zero: the waiting roles give up at once, the launch never reports, the handle falls back to the launch path
+    for mode in ("1", "2"):
+        monkeypatch.setenv("BBH_FIT_FLOW", mode)
+        monkeypatch.setenv("BBH_FLOW_SPIN", "0")
+        X, Xt, y = make_problem(4096, 6, 200, seed=8)
+        spec = gp_spec.GPSpec.baybe_default(6, np.zeros(6), np.ones(6))
+        g = engine.HipGP(0)
+        g.set_model(spec, Xt, y)
+        p0 = gp_spec.initial_params(spec)
+        va, ga_ = g.data_term(p0)
+        monkeypatch.setenv("BBH_FIT_FLOW", "0")
+        monkeypatch.delenv("BBH_FLOW_SPIN")
+        g0 = engine.HipGP(0)
+        g0.set_model(spec, Xt, y)
+        vb, gb_ = g0.data_term(p0)
+        assert va == vb and np.array_equal(ga_, gb_)  # (after the give-up it IS the launch path)
+        g.close()
+        g0.close()
+    monkeypatch.delenv("BBH_FLOW_SPIN", raising=False)
+    # not positive definite (a negative noise variance: the first pivots fail): the flag comes back through the same channel
+    for mode in ("1", "2"):
+        monkeypatch.setenv("BBH_FIT_FLOW", mode)
+        X, Xt, y = make_problem(600, 3, 100, seed=5)
+        spec = gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
+        g = engine.HipGP(0)
+        g.set_model(spec, Xt, y)
+        assert g.data_term(gp_spec.GPParams(np.full(3, 1.0), -2.0, 0.0)) == (None, None)
+        v, gr = g.data_term(gp_spec.GPParams(np.full(3, 1.0), 0.1, 0.0))  # ... and the next evaluation is clean
+        assert v is not None and np.isfinite(v) and np.isfinite(gr).all()
+        g.close()

@@ -177,15 +177,14 @@ def test_device_box_decompositions_equal_the_host_form(m, nb, S):
     g.close()
 
 
-@pytest.mark.parametrize("n,seed,atol_cells,atol_scores", [(24, 0, 1e-10, 1e-9), (30, 7, None, 1e-3)])
+@pytest.mark.parametrize("n,seed,atol_cells,atol_scores", [(24, 0, 1e-10, 1e-9), (30, 7, 1e-9, 1e-8)])
 def test_device_setup_equals_the_host_setup(n, seed, atol_cells, atol_scores):
     """The device set-up of a selection step (samples through the extended factor, weight columns L^-T [t; z], device box
     decompositions) against the round-4 host set-up (baseline posterior -> host Cholesky -> host samples / decompositions ->
     full target columns): the same pruned baseline, the same cells, the same scores.  The second case has three duplicated
-    training rows: the baseline's joint covariance is singular there, both set-ups go up the psd_safe_cholesky ladder (the
-    device one with the jitter on the latent rows of the extended factorisation, which is the ladder on the Schur complement
-    BoTorch factorises); the two samples of a duplicated point then differ by ~sqrt(jitter) z, which of them is the larger one - and
-    with it the ORDER of the cells - depends on rounding, so that case compares pruning, cell counts and scores only."""
+    training rows (replicate measurements): the baseline's joint covariance is singular there and an extended model with two
+    noise-free rows at one location has a rounding-noise pivot (the first device form returned scores off by O(1) there) - a
+    repeated point enters the model and the decompositions once, its copies keep their base-sample columns (``_unique_rows``)."""
     import torch
 
     from baybe_amd.nehvi import HipNEHVI, compute_ref_point
