@@ -53,14 +53,14 @@ struct FlowArgs {
   double* q;      // [np] LOO
   double* apart;  // [16*16][2][64] alpha partials of the M-tiles
   double* gpart;  // [nG][nsl] gradient partial rows of the G-tiles
-  double* misc;   // [0] value sum, [1] mean-gradient sum (MLL), [2 + I] log-determinant partial of row head I, [32 + I] LOO sum of q over block I
+  double* misc;   // [2 + I] log-determinant partial of row head I, [32 + I] LOO sum of q over block I, [64 + I] value share of block I, [80 + I] mean-gradient share (MLL)
   int* flagsL;    // [16][16]
   int* flagsX;
   int* flagsM;
   int* flagsQ;
-  int* flagsV;    // [0] VEC, [1 + I] QV(I)
-  int* counters;  // [0] tickets, [1] finished M-tiles, [2] finished G-tiles   (cumulative over launches)
-  int ticket_base, doneM_base, doneG_base;
+  int* flagsV;    // [I] VEC(I), [16 + I] QV(I)
+  int* counters;  // [0] tickets, [1] finished M-tiles, [2] finished G-roles, [3] abort word (tail form), [4] finished VEC roles   (cumulative over launches)
+  int ticket_base, doneM_base, doneG_base, doneV_base;
   const int* roles;  // [nroles] type | I << 4 | J << 9 | row quarter << 14 | partial-row index << 16
   int nroles, nM, nG;
   int epoch, spin;
@@ -276,11 +276,11 @@ __device__ __forceinline__ bool ff_wait_count(const int* counter, int target, co
       }
       __builtin_amdgcn_s_sleep(4);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok2 = ok;
   }
   __syncthreads();
   const bool ok = s_ok2 != 0;
-  __threadfence();
   __syncthreads();
   return ok;
 }
@@ -329,10 +329,8 @@ __device__ __forceinline__ bool ff_role_rowhead(const FlowArgs& fa, FlowShared& 
     pd_gemm64<true, true, PD_OUT_LOWER>(a, c, c, -1.0);
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < 4096; e += 256) b[e >> 6][e & 63] = 0.0;
-  __syncthreads();
   if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 4] = wall_clock64();
-  pd_factor_block(a, b, al, (int64_t)I * 64, fa.info, I > 0 ? &fa.flagsL[I * FF_STRIDE + (I - 1)] : nullptr, fa.epoch);
+  pd_factor_block4(a, b, al, (int64_t)I * 64, fa.info, I > 0 ? &fa.flagsL[I * FF_STRIDE + (I - 1)] : nullptr, fa.epoch);
   if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 5] = wall_clock64();
   pd_store_tile(fa.D + (int64_t)I * 4096, 64, b, 1.0);
   pd_publish(&fa.flagsL[I * FF_STRIDE + I], fa.epoch);  // D_I first: the next row head waits for it
@@ -462,35 +460,37 @@ __device__ __forceinline__ bool ff_role_mtile(const FlowArgs& fa, FlowShared& sh
     }
   }
   pd_publish(&fa.flagsM[I * FF_STRIDE + J], fa.epoch);
-  if (t == 0) atomicAdd(&fa.counters[1], 1);
+  if (t == 0) atomicAdd(&fa.counters[1], 1);  // (thread 0's release fence in pd_publish precedes it)
   return true;
 }
 
-// alpha = M r from the tiles' partials (fixed order); MLL: the data-fit sum and the mean gradient; LOO: d, u, w
-__device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh) {
+// alpha_I = (M r)_I for block row I from the tiles' partials (fixed order; four threads per entry); MLL: the block's share of the
+// data-fit sum (with the log-determinant term after a separate factorisation) and of the mean gradient; LOO: d, u, w of the block.
+// One role per block row: a single role for all rows was 7-17 us between the last M-tile and the first gradient role.
+__device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh, int I) {
   if (!ff_wait_count(&fa.counters[1], fa.doneM_base + fa.nM, fa)) return false;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, i = t >> 2, part = t & 3, g = I * 64 + i;
+  double al = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int B2 = part + 4 * k;
+    if (B2 < fa.nbk) al += (B2 <= I) ? fa.apart[(int64_t)(I * FF_STRIDE + B2) * 128 + i] : fa.apart[(int64_t)(B2 * FF_STRIDE + I) * 128 + 64 + i];
+  }
+  al += __shfl_xor(al, 1, 64);
+  al += __shfl_xor(al, 2, 64);
   double v = 0.0, gm = 0.0;
-  for (int g = t; g < fa.np; g += 256) {
-    const int I = g >> 6, i = g & 63;
-    double pv[16];  // the nbk partials of this entry, requested together, added in block order
-#pragma unroll
-    for (int B2 = 0; B2 < 16; B2++)
-      pv[B2] = B2 >= fa.nbk ? 0.0 : (B2 <= I ? fa.apart[(int64_t)(I * FF_STRIDE + B2) * 128 + i] : fa.apart[(int64_t)(B2 * FF_STRIDE + I) * 128 + 64 + i]);
-    double al = 0.0;
-#pragma unroll
-    for (int B2 = 0; B2 < 16; B2++) al += pv[B2];
+  if (part == 0) {
     fa.alpha[g] = al;
     if (g < fa.n) {
       if (fa.criterion == BBH_CRITERION_MLL) {
-        v += -0.5 * (fa.ystd[g] - sh.th[1]) * al;
+        v = -0.5 * (fa.ystd[g] - sh.th[1]) * al;
         if (fa.tail_only) v -= log(fa.A[(int64_t)g * fa.np + g]);  // (the row heads of the one-launch form leave these sums in misc[2 + I])
-        gm += al;
+        gm = al;
       } else {
         const double d = fa.M[(int64_t)g * fa.np + g];
         fa.u[g] = 0.5 / d + 0.5 * al * al / (d * d);
         fa.w[g] = al / d;
-        v += 0.5 * log(d) - 0.5 * al * al / d;
+        v = 0.5 * log(d) - 0.5 * al * al / d;
       }
     } else if (fa.criterion != BBH_CRITERION_MLL) {
       fa.u[g] = 0.0;
@@ -505,17 +505,18 @@ __device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh) 
   }
   __syncthreads();
   if (t == 0) {
-    fa.misc[0] = (sh.red[0][0] + sh.red[1][0]) + (sh.red[2][0] + sh.red[3][0]);
-    fa.misc[1] = (sh.red[0][1] + sh.red[1][1]) + (sh.red[2][1] + sh.red[3][1]);
+    fa.misc[64 + I] = (sh.red[0][0] + sh.red[1][0]) + (sh.red[2][0] + sh.red[3][0]);
+    fa.misc[80 + I] = (sh.red[0][1] + sh.red[1][1]) + (sh.red[2][1] + sh.red[3][1]);
+    if (fa.tail_only) fa.misc[2 + I] = 0.0;
   }
-  if (fa.tail_only && t < 16) fa.misc[2 + t] = 0.0;
-  pd_publish(&fa.flagsV[0], fa.epoch);
+  pd_publish(&fa.flagsV[I], fa.epoch);
+  if (t == 0) atomicAdd(&fa.counters[4], 1);
   return true;
 }
 
 // LOO: q_I = (M w)_I and its sum (the mean gradient)
 __device__ __forceinline__ bool ff_role_qvec(const FlowArgs& fa, FlowShared& sh, int I) {
-  if (!ff_wait(&fa.flagsV[0], fa)) return false;
+  if (!ff_wait_count(&fa.counters[4], fa.doneV_base + fa.nbk, fa)) return false;
   const int t = threadIdx.x, row = t >> 2, part = t & 3;
   const double* mr = fa.M + (int64_t)(I * 64 + row) * fa.np;
   double acc = 0.0;
@@ -532,13 +533,13 @@ __device__ __forceinline__ bool ff_role_qvec(const FlowArgs& fa, FlowShared& sh,
     const double s = ff_wave_sum(sh.vr[t]);
     if (t == 0) fa.misc[32 + I] = s;
   }
-  pd_publish(&fa.flagsV[1 + I], fa.epoch);
+  pd_publish(&fa.flagsV[16 + I], fa.epoch);
   return true;
 }
 
 // LOO: Q_IJ = sum_K M_IK diag(u_K) M_KJ, I >= J (accumulators in registers, operands prefetched through registers)
 __device__ __forceinline__ bool ff_role_qtile(const FlowArgs& fa, tile_t t0, tile_t t1, int I, int J) {
-  if (!ff_wait(&fa.flagsV[0], fa)) return false;
+  if (!ff_wait_count(&fa.counters[4], fa.doneV_base + fa.nbk, fa)) return false;
   d4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -607,8 +608,9 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     }
   }
   ff_stage_meta(sh, fa, I, J);
-  if (!ff_wait(&fa.flagsV[0], fa)) return false;
-  if (loo && (!ff_wait(&fa.flagsQ[I * FF_STRIDE + J], fa) || !ff_wait(&fa.flagsV[1 + I], fa) || !ff_wait(&fa.flagsV[1 + J], fa))) return false;
+  if (!ff_wait(&fa.flagsV[I], fa) || (I != J && !ff_wait(&fa.flagsV[J], fa))) return false;
+  if (loo && (!ff_wait(&fa.flagsQ[I * FF_STRIDE + J], fa) || !ff_wait(&fa.flagsV[16 + I], fa) || !ff_wait(&fa.flagsV[16 + J], fa))) return false;
+  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 1] = wall_clock64();
   {
     const double* src = (loo ? fa.Q : fa.M) + (int64_t)(I * 64 + 16 * qd) * fa.np + J * 64;
     for (int e = t; e < 512; e += 256) *(pd_d2*)&t0[e >> 5][2 * (e & 31)] = *(const pd_d2*)(src + (int64_t)(e >> 5) * fa.np + 2 * (e & 31));
@@ -621,6 +623,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     sh.vc2[t - 64] = loo ? fa.q[J * 64 + (t - 64)] : 0.0;
   }
   __syncthreads();
+  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 4] = wall_clock64();
   const bool dot = BBH_KIND_IS_DOT(kind);
   const double os = fa.ks.use_os ? sh.th[2] : 1.0;
   const double kalpha = fa.ks.alpha_off >= 0 ? sh.th[fa.ks.alpha_off] : 1.0;
@@ -680,6 +683,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
       }
     }
   }
+  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 5] = wall_clock64();
   // a slot's partials of one matrix row: DPP row sum (lane 15 of the row holds it) -> tab[slot][row]
   auto put = [&](int slot, double v) {
     v = ff_row16_sum(v);
@@ -706,6 +710,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     put(3 + cc, (acc0 + acc1) * sh.invls[cc]);
   }
   __syncthreads();
+  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 6] = wall_clock64();
   double* row = fa.gpart + (int64_t)gidx * fa.tl;
   if (t < fa.tl) {
     double acc = 0.0;
@@ -714,15 +719,17 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     row[t] = acc;
   }
   // ---- last role: the sums over all roles' rows, in role order (eight row groups per slot, combined in group order) ----
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const int old = atomicAdd(&fa.counters[2], 1);
     sh.last = (old == fa.doneG_base + fa.nG - 1) ? 1 : 0;
+    if (sh.last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 7] = wall_clock64();
   if (!sh.last) return true;
-  __threadfence();
   {
     const int grp = t >> 5, sl = t & 31;  // 8 groups x 32 slots per sweep
     for (int s0 = 0; s0 < fa.tl; s0 += 32) {
@@ -742,14 +749,15 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
           if (loo)
             for (int B2 = 0; B2 < fa.nbk; B2++) tot += fa.misc[32 + B2];
           else
-            tot = fa.misc[1];
+            for (int B2 = 0; B2 < fa.nbk; B2++) tot += fa.misc[80 + B2];
         }
         fa.out[1 + slot] = tot;
       }
     }
   }
   if (t == 0) {
-    double v = fa.misc[0];
+    double v = 0.0;
+    for (int B2 = 0; B2 < fa.nbk; B2++) v += fa.misc[64 + B2];
     if (!loo)
       for (int B2 = 0; B2 < fa.nbk; B2++) v -= fa.misc[2 + B2];
     fa.out[0] = v - 0.5 * (double)fa.n * 1.8378770664093453;  // log(2 pi)
@@ -795,7 +803,7 @@ __device__ __forceinline__ void ff_kernel_body(const FlowArgs& fa) {
       case FF_L: ok = TAIL ? false : ff_role_ltile(fa, sh, a, b, c, I, J); break;
       case FF_XT: ok = TAIL ? false : ff_role_xtile(fa, a, b, c, I, J); break;
       case FF_MT: ok = ff_role_mtile(fa, sh, a, b, I, J); break;
-      case FF_VEC: ok = ff_role_vec(fa, sh); break;
+      case FF_VEC: ok = ff_role_vec(fa, sh, I); break;
       case FF_QV: ok = ff_role_qvec(fa, sh, I); break;
       case FF_QT: ok = ff_role_qtile(fa, a, b, I, J); break;
       default: ok = ff_role_gtile(fa, sh, a, b, I, J, qd, gidx); break;
@@ -819,7 +827,7 @@ struct bbh_flow_state {
   double* d_gpart = nullptr;  // [nG][tl]
   double* d_misc = nullptr;   // [64]
   long long* d_dbg = nullptr; // BBH_FLOW_TRACE=1
-  int epoch = 0, ticket_base = 0, doneM_base = 0, doneG_base = 0;
+  int epoch = 0, ticket_base = 0, doneM_base = 0, doneG_base = 0, doneV_base = 0;
   bool failed = false, tail_only = false;
 };
 
@@ -878,7 +886,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     for (int I = nbk - 1; I >= 0; I--)  // (the tiles of the last block rows have the fewest terms and can finish first)
       for (int J = 0; J <= I; J++) add(FF_MT, I, J);
     st->nM = nbk * (nbk + 1) / 2;
-    add(FF_VEC, 0, 0);
+    for (int I = 0; I < nbk; I++) add(FF_VEC, I, 0);
     if (loo) {
       for (int I = 0; I < nbk; I++) add(FF_QV, I, 0);
       for (int I = 0; I < nbk; I++)
@@ -896,11 +904,11 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) == hipSuccess && per_cu >= 1 &&
               hipMalloc((void**)&st->d_roles, sizeof(int) * roles.size()) == hipSuccess &&
               hipMemcpy(st->d_roles, roles.data(), sizeof(int) * roles.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc((void**)&st->d_flags, sizeof(int) * (4 * 256 + 32 + 4)) == hipSuccess &&
-              hipMemset(st->d_flags, 0, sizeof(int) * (4 * 256 + 32 + 4)) == hipSuccess &&
+              hipMalloc((void**)&st->d_flags, sizeof(int) * (4 * 256 + 32 + 8)) == hipSuccess &&
+              hipMemset(st->d_flags, 0, sizeof(int) * (4 * 256 + 32 + 8)) == hipSuccess &&
               hipMalloc((void**)&st->d_apart, sizeof(double) * 256 * 128) == hipSuccess &&
               hipMalloc((void**)&st->d_gpart, sizeof(double) * (size_t)st->nG * 64) == hipSuccess /* (nG counts the quarter roles) */ &&
-              hipMalloc((void**)&st->d_misc, sizeof(double) * 64) == hipSuccess &&
+              hipMalloc((void**)&st->d_misc, sizeof(double) * 128) == hipSuccess &&
               // (tail mode: the factorisation already on the stream owns the flag - clearing it here would erase its verdict)
               (tail_only || hipMemset(h->d_info, 0, sizeof(int)) == hipSuccess);
     if (!ok) {
@@ -912,11 +920,11 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     st->grid = st->nroles < slots ? st->nroles : slots;
   }
   if (st->ticket_base > (1 << 30)) {  // cumulative counters: start over long before they wrap
-    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemset(st->d_flags + 4 * 256 + 32, 0, sizeof(int) * 4) != hipSuccess) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemset(st->d_flags + 4 * 256 + 32, 0, sizeof(int) * 8) != hipSuccess) {
       st->failed = true;
       return false;
     }
-    st->ticket_base = st->doneM_base = st->doneG_base = 0;
+    st->ticket_base = st->doneM_base = st->doneG_base = st->doneV_base = 0;
   }
   FlowArgs fa{};
   fa.xnT = h->d_xnT;
@@ -953,6 +961,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   fa.ticket_base = st->ticket_base;
   fa.doneM_base = st->doneM_base;
   fa.doneG_base = st->doneG_base;
+  fa.doneV_base = st->doneV_base;
   fa.roles = st->d_roles;
   fa.nroles = st->nroles;
   fa.nM = st->nM;
@@ -979,6 +988,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   st->ticket_base += st->nroles + st->grid;
   st->doneM_base += st->nM;
   st->doneG_base += st->nG;
+  st->doneV_base += nbk;
   return true;
 }
 
@@ -987,9 +997,9 @@ void bbh_fit_flow_reset(bbh_handle* h) {
   bbh_flow_state* st = (bbh_flow_state*)h->flow_state;
   if (!st) return;
   hipStreamSynchronize(h->stream);
-  if (st->d_flags) hipMemset(st->d_flags, 0, sizeof(int) * (4 * 256 + 32 + 4));
+  if (st->d_flags) hipMemset(st->d_flags, 0, sizeof(int) * (4 * 256 + 32 + 8));
   hipMemset(h->d_info, 0, sizeof(int));
-  st->ticket_base = st->doneM_base = st->doneG_base = 0;
+  st->ticket_base = st->doneM_base = st->doneG_base = st->doneV_base = 0;
   st->failed = true;
   h->fit_flow = false;
 }

