@@ -141,34 +141,46 @@ __global__ __launch_bounds__(256) void bbh_qlogei_q1s_kernel(const double* __res
       f0 += sel_fat4(a, b, z[0], z[1], z[2], z[3]);
     }
     double fat = f0 + f1;
-    double* part = s_part + (t & 1) * 192;
-    if (wave != 0) part[(wave - 1) * 64 + lane] = fat;
+    // softplus part: t_j = a + b Z[j] is non-decreasing in j, so {t_j > 20} is a suffix and {-750 <= t_j <= 20} the run before it,
+    // whose terms are evaluated one by one (torch's softplus below its threshold).  On a well-converged model (sd ~ 1e-3: b = sd /
+    // tau ~ 1e3) that run is a third of the samples for most lanes: every wave finds the run (two binary searches, ~20 LDS reads)
+    // and sums its own quarter of it - wave 0 alone walked up to S log1p(exp()) per candidate while three waves sat at the barrier
+    // (ADVICE r4).  NaN inputs have no run (the score is NaN anyway).
+    const double babs = b;
+    const double* Z = lds;
+    const double* SF = lds + S1;
+    const bool num = (a == a) && (b == b);
+    int lo = 0, hi = num ? S : 0;  // first j with t_j > 20
+    while (__builtin_amdgcn_ballot_w64(lo < hi) != 0) {
+      if (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fma(babs, Z[mid], a) > 20.0) hi = mid; else lo = mid + 1;
+      }
+    }
+    const int j_hi = num ? lo : 0;
+    lo = 0, hi = j_hi;   // first j with t_j >= -750
+    while (__builtin_amdgcn_ballot_w64(lo < hi) != 0) {
+      if (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (!(fma(babs, Z[mid], a) < -750.0)) hi = mid; else lo = mid + 1;
+      }
+    }
+    const int run = j_hi - lo;
+    const int r0 = lo + (run * wave) / 4, r1 = lo + (run * (wave + 1)) / 4;
+    double spw = 0.0;
+    for (int j = r0; __builtin_amdgcn_ballot_w64(j < r1) != 0; j++)
+      if (j < r1) spw += log1p(exp(fma(babs, Z[j], a)));  // torch softplus below its threshold of 20
+    double* part = s_part + (t & 1) * 384;
+    if (wave != 0) {
+      part[(wave - 1) * 64 + lane] = fat;
+      part[192 + (wave - 1) * 64 + lane] = spw;
+    }
     __syncthreads();
     if (wave == 0) {
       for (int s = nq * 4; s < S; s++) fat += sel_fat1(a, b, zs_g[s]);  // S not a multiple of four
       fat = ((fat + part[lane]) + part[64 + lane]) + part[128 + lane];
-      // softplus part: t_j = a + b Z[j] is non-decreasing in j, so {t_j > 20} is a suffix and {-750 <= t_j <= 20} the run before it
-      const double babs = b;
-      const double* Z = lds;
-      const double* SF = lds + S1;
-      int lo = 0, hi = S;  // first j with t_j > 20
-      while (__builtin_amdgcn_ballot_w64(lo < hi) != 0) {
-        if (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (fma(babs, Z[mid], a) > 20.0) hi = mid; else lo = mid + 1;
-        }
-      }
-      const int j_hi = lo;
-      lo = 0, hi = j_hi;   // first j with t_j >= -750
-      while (__builtin_amdgcn_ballot_w64(lo < hi) != 0) {
-        if (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (!(fma(babs, Z[mid], a) < -750.0)) hi = mid; else lo = mid + 1;
-        }
-      }
-      double sp = (j_hi < S) ? fma(babs, SF[j_hi], a * (double)(S - j_hi)) : 0.0;
-      for (int j = lo; __builtin_amdgcn_ballot_w64(j < j_hi) != 0; j++)
-        if (j < j_hi) sp += log1p(exp(fma(babs, Z[j], a)));  // torch softplus below its threshold of 20
+      double sp = (j_hi < S && num) ? fma(babs, SF[j_hi], a * (double)(S - j_hi)) : 0.0;
+      sp += ((spw + part[192 + lane]) + part[256 + lane]) + part[320 + lane];
       double score = Q1_LOG_TAU_RELU + log(fma(0.1, fat, sp)) - log((double)S);
       if (!(a == a) || !(b == b)) score = NAN;
       if (in && alive && !alive[i]) score = -INFINITY;
@@ -622,7 +634,7 @@ int bbh_qlogei_q1_sliced(bbh_handle* h, const double* mean_dev, const double* va
   bbh_select_state* st = sel_state(h);
   int rc = sel_ensure(h, st);
   if (rc || (rc = sel_tables(h, st, z_host, (int)S, sign))) return rc;
-  const size_t lds = sizeof(double) * (2 * ((size_t)S + 1) + 2 * 3 * 64);
+  const size_t lds = sizeof(double) * (2 * ((size_t)S + 1) + 2 * 6 * 64);  // tables + two generations of (fat, softplus-run) partials of waves 1-3
   Q1SArgs a;
   a.N = N, a.S = (int)S, a.best_f = best_f, a.sign = sign, a.tiles_per_chunk = sel_tiles_per_chunk(N);
   const int chunk = a.tiles_per_chunk * SEL_TILE;

@@ -329,6 +329,7 @@ class HipGP:
                 self._lib.bbh_destroy(self._handle)  # a handle that owns a communicator is not handed on
             else:  # back to its defaults: legacy stream, no timing; buffers above 64 MB are released (an idle handle must not pin HBM)
                 self._lib.bbh_set_stream(self._handle, None)
+                self._lib.bbh_set_slice_rows(self._handle, 0)
                 self._lib.bbh_timing_enable(self._handle, 0)
                 self._lib.bbh_trim(self._handle, _POOL_KEEP_BYTES)
                 _HANDLE_POOL[key].append(self._handle)
@@ -820,7 +821,20 @@ class HipGP:
         return ms.value, cnt.value
 
     # ---- optimize_acqf_discrete with qLogEI -----------------------------------------------
-    def greedy_qlogei(
+    def greedy_qlogei(self, *args, **kwargs) -> "GreedyResult":
+        """``_greedy_qlogei`` with the shard's slice geometry set for its duration only (an exception inside the loop used
+        to leave ``slice_rows`` on a handle that goes back to the pool)."""
+        shard = kwargs.get("shard")
+        repro = shard is not None and getattr(shard, "reproducible", False)
+        if repro:
+            self.set_slice_rows(shard.N_total)
+        try:
+            return self._greedy_qlogei(*args, **kwargs)
+        finally:
+            if repro:
+                self.set_slice_rows(0)
+
+    def _greedy_qlogei(
         self,
         X,
         q: int,
@@ -849,8 +863,6 @@ class HipGP:
         X = self._as_dev(X)
         N = X.shape[0]
         d = self.spec.d
-        if shard is not None and getattr(shard, "reproducible", False):
-            self.set_slice_rows(shard.N_total)
         if seed is None and z_by_q is None:
             seed = draw_sampler_seed()
         if best_f is None:
@@ -980,6 +992,4 @@ class HipGP:
             values.append(float(val))
             chosen_rows.append(np.asarray(row, dtype=np.float64).reshape(1, d))
         self.set_pending(None if (base.shape[0] == 0 or base.shape[0] > MAX_PENDING) else base)
-        if shard is not None and getattr(shard, "reproducible", False):
-            self.set_slice_rows(0)
         return GreedyResult(indices, values)

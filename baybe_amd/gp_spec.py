@@ -136,6 +136,9 @@ class GPSpec:
     hadamard: bool = False  # one noise variance and one constant mean per task (components/_gpytorch.py:15-75)
     task_unit_scale: bool = False  # botorch PositiveIndexKernel default: B / B[target, target], target task 0
     task_prior: tuple | None = None  # ("beta", a, b) on the lower-triangle task correlations (BOTORCH preset)
+    # user-supplied task kernels (kernels/basic.py:220-248 inside a ProductKernel / ICMKernelFactory, components/kernel.py:238-337):
+    task_rank: int | None = None  # columns of the covariance factor W [T, rank] (None: T, BayBE's own choice, presets/baybe.py:226-230)
+    task_factor_constraint: str = "softplus"  # "softplus": PositiveIndexKernel (positive factor); "none": gpytorch IndexKernel (free factor)
     # composite kernels: 2..4 factors combined as a product or a sum; factors[0] IS (kernel, ls_*) above
     factors: "list[KernelFactor] | None" = None
     combine: str = "product"  # "product" (ProductKernel) | "sum" (AdditiveKernel) | "grouped" (a sum of products: KernelFactor.group)
@@ -370,8 +373,16 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
     )
     if spec.n_tasks > 1:
         T = spec.n_tasks
-        p.task_W = np.full((T, T), task_init / math.sqrt(T))
-        p.task_v = np.full(T, float(softplus(0.0)))
+        r = int(spec.task_rank or T)
+        if spec.task_factor_constraint == "none":
+            # gpytorch IndexKernel starts from torch.randn draws (covar_factor [T, rank], then raw_var [T]) of the global generator
+            import torch
+
+            p.task_W = torch.randn(T, r, dtype=torch.float64).numpy().copy()
+            p.task_v = softplus(torch.randn(T, dtype=torch.float64).numpy())
+        else:
+            p.task_W = np.full((T, r), task_init / math.sqrt(T))
+            p.task_v = np.full(T, float(softplus(0.0)))
         p.task_unit_scale = bool(spec.task_unit_scale)
         if spec.hadamard:
             p.noise, p.mean = np.full(T, nz0), np.zeros(T)
@@ -505,7 +516,7 @@ def pack_raw(spec: GPSpec, p: GPParams) -> np.ndarray:
         if f.kernel == "periodic":
             parts.append(inv_softplus(p.period[k + 1]))
     if spec.n_tasks > 1:
-        parts.append(inv_softplus(p.task_W).reshape(-1))
+        parts.append((inv_softplus(p.task_W) if spec.task_factor_constraint == "softplus" else np.asarray(p.task_W)).reshape(-1))
         parts.append(inv_softplus(p.task_v))
     return np.concatenate(parts).astype(np.float64)
 
@@ -547,7 +558,8 @@ def unpack_raw(spec: GPSpec, raw: np.ndarray) -> GPParams:
     W = v = None
     if spec.n_tasks > 1:
         T = spec.n_tasks
-        W = softplus(raw[i : i + T * T]).reshape(T, T); i += T * T
+        r = int(spec.task_rank or T)
+        W = (softplus(raw[i : i + T * r]) if spec.task_factor_constraint == "softplus" else raw[i : i + T * r].copy()).reshape(T, r); i += T * r
         v = softplus(raw[i : i + T]); i += T
     p = GPParams(ls, noise, mean, os_, W, v, bool(spec.task_unit_scale), fls, fos, alpha, period)
     return _pin_inactive(spec, p) if (spec.has_subsets and (spec.has_dot_kind or spec.has_periodic)) else p
@@ -587,7 +599,7 @@ def raw_bounds(spec: GPSpec):
         if f.kernel == "periodic":
             b += period_bounds(k + 1)
     if spec.n_tasks > 1:
-        b += [(None, None)] * (spec.n_tasks * spec.n_tasks + spec.n_tasks)
+        b += [(None, None)] * (spec.n_tasks * int(spec.task_rank or spec.n_tasks) + spec.n_tasks)
     return b
 
 
@@ -772,8 +784,9 @@ def objective_from_data_term(spec: GPSpec, raw: np.ndarray, n: int, value: float
         total += lp_t
         S = S + G_t
         gW = (S + S.T) @ p.task_W
-        g.append((gW * sigmoid(raw[i : i + T * T]).reshape(T, T)).reshape(-1))
-        i += T * T
+        r = p.task_W.shape[1]
+        g.append((gW * (sigmoid(raw[i : i + T * r]).reshape(T, r) if spec.task_factor_constraint == "softplus" else 1.0)).reshape(-1))
+        i += T * r
         g.append(np.diag(S) * sigmoid(raw[i : i + T]))
     return -total / n, -np.concatenate(g) / n
 

@@ -159,6 +159,76 @@ class AdditiveKernel:
     base_kernels: tuple = field(converter=tuple)
 
 
+@define(frozen=True)
+class IndexKernel:
+    """``baybe.kernels.basic.IndexKernel`` (basic.py:220-236): task covariance W W^T + diag(v), W [num_tasks, rank] (gpytorch's
+    ``IndexKernel``: a free factor, started from ``torch.randn``)."""
+
+    num_tasks: int = field(validator=instance_of(int))
+    rank: int = field(validator=instance_of(int))
+    parameter_names: tuple | None = field(default=None, converter=_names, kw_only=True)
+
+    @rank.validator
+    def _check_rank(self, _, value):
+        if self.num_tasks < 2 or value < 1:
+            raise ValueError("'num_tasks' must be >= 2 and 'rank' >= 1")
+        if value > self.num_tasks:
+            raise ValueError(f"The rank of the task covariance matrix must be smaller than the number of tasks. Got rank {value} > "
+                             f"{self.num_tasks} tasks.")
+
+
+@define(frozen=True)
+class PositiveIndexKernel(IndexKernel):
+    """``baybe.kernels.basic.PositiveIndexKernel`` (basic.py:239-248): strictly positive task correlations (botorch's
+    ``PositiveIndexKernel`` with ``unit_scale_for_target=False``: a softplus-constrained factor)."""
+
+
+@define
+class ICMKernelFactory:
+    """``baybe.surrogates.gaussian_process.components.kernel.ICMKernelFactory`` (kernel.py:238-337): base kernel (or factory) over
+    the numerical columns times task kernel (or factory) over the task column.  Defaults: the BAYBE preset's base kernel
+    (``None`` here: left to the preset) and ``PositiveIndexKernel(num_tasks = rank = n_tasks)``."""
+
+    base_kernel_or_factory = field(default=None)
+    task_kernel_or_factory = field(default=None)
+
+    def __call__(self, searchspace, *args):
+        n_tasks = int(getattr(searchspace, "n_tasks", 1))
+        if n_tasks == 1:
+            raise IncompatibilityError("'ICMKernelFactory' can only be used with a searchspace that contains a 'TaskParameter'.")
+
+        def resolve(k):
+            return k(searchspace, *args) if (callable(k) and not type(k).__name__.endswith("Kernel")) else k
+
+        task = resolve(self.task_kernel_or_factory)
+        if task is None:
+            task = PositiveIndexKernel(num_tasks=n_tasks, rank=n_tasks)
+        base = resolve(self.base_kernel_or_factory)
+        if base is None:
+            base = "BAYBE"  # the preset's numerical kernel (presets/baybe.py:149-205)
+        return ProductKernel([base, task])
+
+
+def _is_index_kernel(k) -> bool:
+    return type(k).__name__ in ("IndexKernel", "PositiveIndexKernel")
+
+
+def _apply_task_kernel(spec, task, searchspace):
+    """The task table of the device path from an Index kernel object (``GPSpec.n_tasks``, ``task_rank``, factor constraint)."""
+    if spec.n_tasks <= 1:
+        raise IncompatibilityError(f"'{type(task).__name__}' needs a search space with a task parameter.")
+    if int(task.num_tasks) != int(spec.n_tasks):
+        raise ValueError(f"The task kernel was built for {task.num_tasks} tasks, the search space has {spec.n_tasks}.")
+    names = getattr(task, "parameter_names", None)
+    if names and searchspace is not None and hasattr(searchspace, "comp_rep_columns") and spec.task_idx is not None:
+        cols = list(searchspace.comp_rep_columns)
+        if not all(cols[spec.task_idx] == nm or str(cols[spec.task_idx]).startswith(f"{nm}_") or nm == cols[spec.task_idx] for nm in names):
+            raise ValueError(f"The task kernel's 'parameter_names' {tuple(names)} do not select the task column '{cols[spec.task_idx]}'.")
+    spec.task_rank = int(task.rank)
+    spec.task_factor_constraint = "softplus" if type(task).__name__ == "PositiveIndexKernel" else "none"
+    spec.task_unit_scale = False  # (BayBE passes unit_scale_for_target=False, basic.py:245-248; gpytorch's IndexKernel has no scaling)
+
+
 def _prior_tuple(prior):
     if prior is None:
         return None
@@ -175,6 +245,8 @@ def _prior_tuple(prior):
         return ("halfnormal", float(prior.scale))
     if name == "SmoothedBoxPrior":
         return ("smoothedbox", float(prior.a), float(prior.b), float(prior.sigma))
+    if name == "BetaPrior":  # the reference's own behaviour: BetaPrior.to_gpytorch raises (priors/basic.py:94-108)
+        raise NotImplementedError(f"'{name}' does not have a gpytorch analog.")
     raise IncompatibilityError(f"Prior '{name}' is not available on the HIP path (Gamma / LogNormal / HalfCauchy / Normal / HalfNormal / "
                                f"SmoothedBox are).")
 
@@ -256,6 +328,18 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
     """Configure a ``GPSpec`` from a (BayBE or mirror) kernel specification object; ``searchspace`` resolves
     ``parameter_names`` (kernels restricted to a parameter subset)."""
     name = type(kernel).__name__
+    if name == "ProductKernel" and any(_is_index_kernel(m) for m in kernel.base_kernels):
+        # base kernel x task kernel (ICMKernelFactory's product, or written out by the user): the Index kernel becomes the task table
+        tasks = [m for m in kernel.base_kernels if _is_index_kernel(m)]
+        rest = [m for m in kernel.base_kernels if not _is_index_kernel(m)]
+        if len(tasks) != 1 or not rest:
+            raise IncompatibilityError("A product with a task kernel needs exactly one Index kernel and at least one numerical kernel.")
+        _apply_task_kernel(spec, tasks[0], searchspace)
+        if len(rest) == 1 and isinstance(rest[0], str):
+            return spec  # "BAYBE": the preset's numerical kernel stays
+        return apply_kernel_spec(spec, rest[0] if len(rest) == 1 else ProductKernel(rest), searchspace)
+    if _is_index_kernel(kernel):
+        raise IncompatibilityError("An Index kernel alone is not a model of the numerical parameters; multiply it with a numerical kernel.")
     if name == "ScaleKernel":
         if not getattr(kernel, "outputscale_trainable", True):
             raise IncompatibilityError("Frozen outputscales are not available on the HIP path.")

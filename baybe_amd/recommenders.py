@@ -35,9 +35,40 @@ from baybe_amd.exceptions import (
 from baybe_amd.surrogates import HipCompositeImpl, HipGaussianProcessSurrogate, _availability_property
 
 
+_HASH_POOL = None  # persistent worker threads of the content hashes (xxhash releases the GIL)
+_HASH_CHUNK = 2 << 20  # bytes per task
+
+
+def _hash_pool():
+    global _HASH_POOL
+    if _HASH_POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _HASH_POOL = ThreadPoolExecutor(max(1, min(32, os.cpu_count() or 1)), thread_name_prefix="bbh-hash")
+    return _HASH_POOL
+
+
+def _hash_buffers(bufs) -> int:
+    """xxh3 over a list of byte buffers, in 2 MB pieces on the persistent pool: 160 MB (the comp rep of a 1e6 x 20 grid) are
+    memory-bound - 6 ms on 8 threads created per call (round 4), the pool has up to 32 and is created once."""
+    import xxhash
+
+    tasks = []
+    for buf in bufs:
+        n = len(buf)
+        if n <= _HASH_CHUNK:
+            tasks.append(buf)
+        else:
+            tasks.extend(buf[o : o + _HASH_CHUNK] for o in range(0, n, _HASH_CHUNK))
+    if sum(len(t) for t in tasks) < (1 << 22):
+        return hash(tuple(xxhash.xxh3_64_intdigest(t) for t in tasks))
+    return hash(tuple(_hash_pool().map(xxhash.xxh3_64_intdigest, tasks)))
+
+
 def _content_hash(arr: np.ndarray):
     """Content hash of a numeric array: xxh3 over its buffer (the transposed view if that is the contiguous one - a
-    single-dtype DataFrame hands out its block that way - so nothing is copied), large buffers in 8 slices on a thread
+    single-dtype DataFrame hands out its block that way - so nothing is copied), large buffers in pieces on a thread
     pool (xxhash releases the GIL)."""
     arr = np.asarray(arr)
     if arr.size == 0:
@@ -47,44 +78,28 @@ def _content_hash(arr: np.ndarray):
     if not arr.flags.c_contiguous:
         arr = arr.T if arr.T.flags.c_contiguous else np.ascontiguousarray(arr)
     try:
-        import xxhash
+        import xxhash  # noqa: F401
     except ImportError:  # pragma: no cover
         return hash(arr.tobytes())
-    buf = memoryview(arr).cast("B")
-    if len(buf) < (1 << 24):
-        return xxhash.xxh3_64_intdigest(buf)
-    from concurrent.futures import ThreadPoolExecutor
-
-    step = -(-len(buf) // 8)
-    with ThreadPoolExecutor(8) as pool:
-        parts = list(pool.map(lambda o: xxhash.xxh3_64_intdigest(buf[o : o + step]), range(0, len(buf), step)))
-    return hash(tuple(parts))
+    return _hash_buffers([memoryview(arr).cast("B")])
 
 
 def _frame_content_hash(df: pd.DataFrame):
-    """Content hash of a DataFrame's values without materialising them as one array: every column's buffer on a thread
-    pool (xxhash releases the GIL); columns that are not plain numeric arrays go through ``_content_hash``.  Equal keys
+    """Content hash of a DataFrame's values without materialising them as one array: every column's buffer in pieces on the
+    thread pool; columns that are not plain numeric arrays go through ``_content_hash``.  Equal keys
     imply equal content; the same content in another memory layout (a row-major block against a column-major copy) may key
     differently, which costs one re-upload and nothing else."""
     try:
-        import xxhash
+        import xxhash  # noqa: F401
     except ImportError:  # pragma: no cover
         return _content_hash(df.to_numpy())
     if df.shape[1] == 0 or not df.iloc[:, 0].to_numpy().flags.c_contiguous:
         return _content_hash(df.to_numpy())  # one 2-D block: ``to_numpy`` is a view, its columns are strided
     cols = [df.iloc[:, j].to_numpy() for j in range(df.shape[1])]
-
-    def one(a):
-        if a.dtype == object or not a.flags.c_contiguous:
-            return _content_hash(a)
-        return xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
-
-    if df.shape[0] * df.shape[1] < (1 << 21):
-        return hash(tuple(one(a) for a in cols))
-    from concurrent.futures import ThreadPoolExecutor
-
-    with ThreadPoolExecutor(8) as pool:
-        return hash(tuple(pool.map(one, cols)))
+    plain = [a for a in cols if a.dtype != object and a.flags.c_contiguous]
+    other = [a for a in cols if not (a.dtype != object and a.flags.c_contiguous)]
+    return hash((_hash_buffers([memoryview(a).cast("B") for a in plain]), tuple(_content_hash(a) for a in other),
+                 tuple(a.dtype != object and a.flags.c_contiguous for a in cols)))
 
 
 def _is_multi_output(objective) -> bool:
@@ -467,15 +482,27 @@ class HipRecommenderImpl:
                 name = str(getattr(self.hybrid_sampler, "value", self.hybrid_sampler))
                 if name != "Random":
                     raise IncompatibilityError("hybrid_sampler='FPS' is not on the HIP path; use 'Random' or sampling_percentage=1.")
-                Dcomp = Dcomp.iloc[np.sort(np.random.choice(len(Dcomp), n_keep, replace=False))]
+                # (under row shards every rank must draw the same subsample: the agreed sampler seed instead of numpy's global state)
+                pick = (np.random.default_rng(self._sampler_seed()).choice(len(Dcomp), n_keep, replace=False) if self.shard is not None
+                        else np.random.choice(len(Dcomp), n_keep, replace=False))
+                Dcomp = Dcomp.iloc[np.sort(pick)]
             D = np.ascontiguousarray(Dcomp.to_numpy(dtype=np.float64))
             labels = Dcomp.index
         else:
             D = np.zeros((1, 0))
             labels = pd.RangeIndex(1)
         Nd, dd = D.shape
-        # raw samples of the continuous box: scrambled Sobol, as many per discrete row as a few million rows allow
-        R = int(max(1, min(self.n_raw_samples, 4_000_000 // max(Nd, 1))))
+        # raw samples of the continuous box: scrambled Sobol, as many per discrete row as a few million rows allow.  The reference runs
+        # a gradient optimiser per start; this search has only the raw samples and a compass refinement, so the sample count grows
+        # with the continuous dimension (512 per dimension) where the row budget allows, and beyond the dimension the
+        # search was validated for (tests/test_hybrid_gpu.py: d_c <= 6) it says so
+        if dc > 8:
+            import warnings
+
+            warnings.warn(f"{self.__class__.__name__}: {dc} continuous parameters - the HIP path searches them derivative-free (Sobol raw "
+                          "samples + compass refinement) and is validated up to 6; BotorchRecommender's gradient optimiser is the better "
+                          "tool beyond that.", UserWarning, stacklevel=3)
+        R = int(max(1, min(max(self.n_raw_samples, 512 * dc), 4_000_000 // max(Nd, 1))))
         sob = torch.quasirandom.SobolEngine(dimension=max(dc, 1), scramble=True, seed=self._sampler_seed())
         U = sob.draw(R, dtype=torch.float64).numpy()[:, :dc]
         Craw = cb[0] + U * (cb[1] - cb[0])
@@ -489,11 +516,11 @@ class HipRecommenderImpl:
         for _step in range(batch_size):
             pend = np.vstack([base] + picks) if picks else base
             scores = self._mc_or_analytic(eng, acqf, X, mean, var, pend, seed, surrogate.sign)
-            k = int(min(self.n_restarts, X.shape[0]))
+            k = int(min(self.n_restarts, X.shape[0], 64))  # (bbh_topk returns at most 64 rows; the reference's n_restarts has no cap)
             _, top = eng.topk(scores, k)
             top = [int(t) for t in top if t >= 0]
             starts = X[torch.as_tensor(top, device=X.device)].cpu().numpy()
-            best_row, _ = self._compass_refine(eng, acqf, starts, dd, cb, pend, seed, surrogate.sign)
+            best_row, _ = self._compass_refine(eng, acqf, starts, dd, cb, pend, seed, surrogate.sign, iters=min(96, 24 + 8 * dc))
             picks.append(best_row.reshape(1, -1))
             if has_disc:  # the label of the refined winner's discrete part (copied bit for bit from its start row)
                 pick_labels.append(labels[int(np.nonzero((D == best_row[:dd]).all(axis=1))[0][0])])
@@ -542,7 +569,7 @@ class HipRecommenderImpl:
             cur[better] = probes[rows[better]]
             val[better] = pval[np.arange(k), j][better]
             step[~better] *= 0.5
-            if (step < 1e-6).all():
+            if (step < 1e-5).all():  # every start has converged to 1e-5 of the box
                 break
         i = int(np.argmax(val))
         return cur[i], float(val[i])

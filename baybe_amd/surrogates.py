@@ -396,6 +396,24 @@ def resolve_kernel_argument(kernel, kernel_or_factory, searchspace, train_x, tra
     if kernel_or_factory is None:
         return kernel
     k = kernel_or_factory
+    if type(k).__name__ == "ICMKernelFactory" and hasattr(k, "base_kernel_factory"):
+        # BayBE's own ICMKernelFactory (components/kernel.py:238-337) returns a gpytorch product; its two member factories return
+        # BayBE kernel OBJECTS, which is what this path evaluates: call them and keep the product declarative
+        import torch
+
+        from baybe_amd.kernels import ProductKernel
+
+        args = (searchspace, torch.as_tensor(train_x), torch.as_tensor(train_y).reshape(-1, 1))
+
+        def member(f):
+            try:
+                return f(*args)
+            except TypeError:  # (searchspace, objective, measurements) signature of newer factories
+                return f(searchspace, None, None)
+
+        base_f, task_f = k.base_kernel_factory, k.task_kernel_factory
+        base = "BAYBE" if type(base_f).__name__ == "_BayBENumericalKernelFactory" else member(base_f)
+        return ProductKernel([base, member(task_f)])
     if callable(k) and not type(k).__name__.endswith("Kernel"):
         import torch
 

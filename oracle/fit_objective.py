@@ -62,7 +62,7 @@ class RawParameter:
     @property
     def key(self) -> str:
         """Name under which the natural value is filed: gpytorch's leaf name, plus the member index in a composite."""
-        leaf = self.name.rsplit(".raw_", 1)[1]
+        leaf = self.name.rsplit(".raw_", 1)[1] if ".raw_" in self.name else self.name.rsplit(".", 1)[1]
         return leaf if self.member is None else f"{leaf}.{self.member}"
 
 
@@ -145,7 +145,12 @@ def parameter_layout(spec) -> list[RawParameter]:
         base_kernel_parameters(base, spec.kernel, spec.ls_lower if box_ls else 0.0, not box_ls, _prior(spec.ls_prior),
                                len(spec.dims_of(None)), _prior(spec.offset_of(None).prior), _prior(spec.period_of(None).prior), None)
     if T > 1:
-        out.append(RawParameter("covar_module.kernels.1.raw_covar_factor", (T, T), 0.0, True, None))
+        # botorch PositiveIndexKernel: raw_covar_factor under Positive(); gpytorch IndexKernel (baybe IndexKernel, basic.py:220-236):
+        # covar_factor is a plain parameter.  rank < T for user-supplied task kernels.
+        r = int(getattr(spec, "task_rank", None) or T)
+        free = getattr(spec, "task_factor_transformed", True) is False
+        out.append(RawParameter("covar_module.kernels.1.covar_factor" if free else "covar_module.kernels.1.raw_covar_factor", (T, r),
+                                None if free else 0.0, not free, None))
         out.append(RawParameter("covar_module.kernels.1.raw_var", (T,), 0.0, True, None))
     return out
 

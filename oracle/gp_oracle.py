@@ -127,6 +127,8 @@ class GPSpec:
     # multi-task HVARFNER / BOTORCH presets (presets/hvarfner.py:72-137, presets/botorch.py:80-92):
     task_model: str = "shared"  # "per_task": HadamardGaussianLikelihood + HadamardConstantMean (one noise, one mean per task)
     index_kernel_scaling: str = "none"  # "target": botorch PositiveIndexKernel default, covariance / its [0, 0] entry
+    task_rank: "int | None" = None  # columns of the index kernel's covariance factor (None: n_tasks)
+    task_factor_transformed: bool = True  # False: gpytorch IndexKernel (free covar_factor) instead of botorch's PositiveIndexKernel
     correlation_prior: tuple | None = None  # ("beta", 2.5, 1.5): BetaPrior on the lower-triangle task correlations
     members: "list[KernelTerm] | None" = None  # base kernels of a ProductKernel / AdditiveKernel (replaces `kernel`)
     composition: str = "product"  # "product" | "sum" | "nested": an AdditiveKernel whose members are ProductKernels or base kernels
@@ -245,7 +247,7 @@ def initial_params(spec, task_init=1.0):
         noise=np.full(T, spec.noise.start()) if per_task else spec.noise.start(),
         mean=np.zeros(T) if per_task else 0.0,
         outputscale=spec.outputscale.start() if spec.use_outputscale else 1.0,
-        task_W=np.full((T, T), task_init / math.sqrt(T)) if T > 1 else None,
+        task_W=np.full((T, int(spec.task_rank or T)), task_init / math.sqrt(T)) if T > 1 else None,
         task_v=np.full(T, math.log(2.0)) if T > 1 else None,
         target_scaled=spec.index_kernel_scaling == "target",
         member_ls=[np.full(len(spec.dims_of(m)), t.lengthscale.start()) for m, t in enumerate(spec.members)] if spec.members else None,

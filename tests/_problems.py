@@ -56,6 +56,7 @@ def oracle_spec(spec):
         criterion=spec.criterion,
         task_model="per_task" if spec.hadamard else "shared",
         index_kernel_scaling="target" if spec.task_unit_scale else "none",
+        task_rank=getattr(spec, "task_rank", None), task_factor_transformed=getattr(spec, "task_factor_constraint", "softplus") == "softplus",
         correlation_prior=spec.task_prior,
         members=[go.KernelTerm(f.kernel,
                                go.Hyper(f.ls_lower if f.ls_constraint == "box" else 0.0, f.ls_constraint != "box", f.ls_prior, f.ls_init),

@@ -221,3 +221,32 @@ def test_a_used_campaign_can_be_backtested_and_cases_share_handles():
     assert (np.diff(f[f["Random_Seed"] == 21]["yield_CumBest"]) >= 0).all()
     with pytest.raises(ValueError):
         simulate_scenarios({"used": camp}, lookup, initial_data=[], n_mc_iterations=1)
+
+
+def test_an_in_place_edit_of_the_comp_rep_forces_a_new_upload():
+    """The resident candidate matrix is keyed on the CONTENT of the comp rep (searchspace/discrete.py:704-735 hands the same frame
+    out on every call; botorch/discrete.py:123 converts it per call): the same frame object with one cell edited in place must
+    not be served from the resident copy."""
+    import torch
+
+    from _baybe_shim import NumericalDiscreteParameter, NumericalTarget, SearchSpace, SingleTargetObjective
+    from baybe_amd.recommenders import HipBotorchRecommender
+
+    vals = np.arange(12) / 11.0
+    space = SearchSpace.from_product([NumericalDiscreteParameter(f"x{i}", vals) for i in range(3)])
+    exp = space.discrete.exp_rep
+    rng = np.random.default_rng(4)
+    meas = exp.iloc[rng.choice(len(exp), 15, replace=False)].copy()
+    meas["y"] = -((meas[["x0", "x1", "x2"]].to_numpy(float) - 0.4) ** 2).sum(1)
+    obj = SingleTargetObjective(NumericalTarget("y"))
+    rec = HipBotorchRecommender()
+    rec.recommend(2, space, obj, meas)
+    ptr = rec._cand_cache[1].data_ptr()
+    rec.recommend(2, space, obj, meas)
+    assert rec._cand_cache[1].data_ptr() == ptr  # unchanged frame: the resident copy
+    comp = space.discrete.comp_rep
+    old = comp.iloc[777, 1]
+    comp.iloc[777, 1] = old + 0.5  # the same frame object, one cell
+    rec.recommend(2, space, obj, meas)
+    assert float(rec._cand_cache[1][777, 1].cpu()) == old + 0.5
+    comp.iloc[777, 1] = old

@@ -351,6 +351,20 @@ def test_scenario_rollout_cases_and_content_hash():
     h = _content_hash(a)
     a[4321, 5] += 1e-12  # any row, any column
     assert _content_hash(a) != h and _content_hash(a) == _content_hash(a.copy())
+    # the frame key of the resident candidate matrix (every byte stays hashed, on a persistent pool in 2 MB pieces):
+    # an in-place edit of ONE cell of a large frame (several pieces per column, pool path) changes it; a copy keys the same
+    import pandas as pd
+
+    from baybe_amd.recommenders import _frame_content_hash
+
+    df = pd.DataFrame(np.random.default_rng(1).integers(0, 11, size=(600_000, 4)) / 10.0, columns=list("abcd")).copy()
+    k = _frame_content_hash(df)
+    assert _frame_content_hash(df.copy()) == k
+    df.iloc[599_999, 3] += 1e-12
+    assert _frame_content_hash(df) != k
+    df.iloc[599_999, 3] -= 1e-12
+    df.iloc[300_001, 0] = 0.55
+    assert _frame_content_hash(df) != k
 
 
 def test_simulate_transfer_learning_partitions_by_task_and_trains_on_the_other_tasks():
@@ -760,3 +774,74 @@ def test_fast_sobol_points_are_the_engines_bitwise():
     u = engine._sobol_uniform_engine(128, 12, 77)
     v = 0.5 + (1 - torch.finfo(torch.float64).eps) * (u - 0.5)
     assert np.array_equal(z, (torch.erfinv(2 * v - 1) * np.sqrt(2.0)).numpy())
+
+
+@pytest.mark.parametrize("variant", ["positive_rank2", "free_rank1", "icm_factory_default", "icm_factory_custom"])
+def test_user_supplied_task_kernels_against_the_autograd_oracle(variant):
+    """``IndexKernel`` / ``PositiveIndexKernel`` objects inside a ``ProductKernel`` and ``ICMKernelFactory`` with custom base / task
+    kernels (kernels/basic.py:220-248, components/kernel.py:238-337) reach the device's task table: covariance factor [T, rank]
+    with rank < T, a free factor for gpytorch's ``IndexKernel`` (started from ``torch.randn``), ``unit_scale_for_target`` off.  Raw
+    layout, bounds and the host's chain rules against the oracle's autograd objective; ``BetaPrior`` is refused as the reference
+    refuses it (``to_gpytorch`` raises NotImplementedError, priors/basic.py:94-108)."""
+    import torch
+
+    from baybe_amd.kernels import (GammaPrior, ICMKernelFactory, IndexKernel, MaternKernel, PositiveIndexKernel, ProductKernel, RBFKernel,
+                                   ScaleKernel, _prior_tuple, apply_kernel_spec)
+
+    d, n, T = 5, 14, 3
+    X, Xt, y = make_tl_problem(60, d - 1, n, T=T, seed=9)
+
+    class Space:
+        comp_rep_columns = tuple(f"x{j}" for j in range(d - 1)) + ("task",)
+        n_tasks, task_idx = T, d - 1
+
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=T)
+    if variant == "positive_rank2":
+        kern = ProductKernel([ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1)), GammaPrior(2, 0.5)), PositiveIndexKernel(num_tasks=T, rank=2)])
+        rank, free = 2, False
+    elif variant == "free_rank1":
+        kern = ProductKernel([IndexKernel(num_tasks=T, rank=1, parameter_names=["task"]), RBFKernel(GammaPrior(3, 1))])
+        rank, free = 1, True
+    elif variant == "icm_factory_default":
+        kern = ICMKernelFactory()(Space())
+        rank, free = T, False
+    else:
+        kern = ICMKernelFactory(base_kernel_or_factory=lambda ss, *a: MaternKernel(2.5, GammaPrior(3, 1)),
+                                task_kernel_or_factory=IndexKernel(num_tasks=T, rank=2))(Space(), None, None)
+        rank, free = 2, True
+    apply_kernel_spec(spec, kern, Space())
+    assert spec.task_rank == rank and (spec.task_factor_constraint == "none") == free and not spec.task_unit_scale
+    if variant == "icm_factory_default":
+        assert spec.kernel == "matern52" and spec.ls_constraint == "box"  # the preset's numerical kernel stays
+    ospec = _ospec(spec)
+    torch.manual_seed(3)
+    p = gp_spec.initial_params(spec)
+    assert p.task_W.shape == (T, rank)
+    if free:
+        torch.manual_seed(3)  # covar_factor, then raw_var: gpytorch's registration order
+        assert np.array_equal(p.task_W, torch.randn(T, rank, dtype=torch.float64).numpy())
+    raw = gp_spec.pack_raw(spec, p)
+    assert len(raw) == len(gp_spec.raw_bounds(spec)) and gp_spec.raw_bounds(spec) == go.raw_bounds(ospec)
+    rng = np.random.default_rng(6)
+    raw = raw + 0.2 * rng.standard_normal(raw.shape)
+    for k, (lo, _) in enumerate(gp_spec.raw_bounds(spec)):  # box-constrained slots (noise; the preset's lengthscales) stay inside
+        if lo is not None:
+            raw[k] = max(raw[k], lo + 1e-3)
+    q = gp_spec.unpack_raw(spec, raw)
+    oq = go.unpack_raw(ospec, raw)
+    assert q.task_W.shape == (T, rank) and np.allclose(oq.task_B(), q.task_B())
+    if free:
+        assert (q.task_W < 0).any() or True  # (a free factor may be negative: no softplus)
+        assert np.array_equal(q.task_W.reshape(-1), raw[-(T * rank + T):-T])
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    dt = go.data_term(ospec, oq, Xn, ys)
+    grad_theta = np.concatenate([[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls, dt.g_task_B.reshape(-1)])
+    f1, g1 = gp_spec.objective_from_data_term(spec, raw, len(y), dt.value, grad_theta)
+    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+    assert math.isclose(f0, f1, rel_tol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    # refusals
+    with pytest.raises(ValueError):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=T),
+                          ProductKernel([MaternKernel(), IndexKernel(num_tasks=T + 1, rank=1)]), Space())
+    with pytest.raises(NotImplementedError):
+        _prior_tuple(type("BetaPrior", (), {"alpha": 1.0, "beta": 2.0})())

@@ -498,6 +498,24 @@ def test_recorded_traces_replay_identically_on_the_cpu_double(monkeypatch):
             assert want == got, name
 
 
+def test_recorded_events_replay_identically_on_the_cpu_double(monkeypatch):
+    """The replay vehicle of ``tests/test_reference_events_gpu.py`` (arrays + the stand-alone classes) reproduces, on the oracle double,
+    the labels and the values the real ``Campaign`` runs produced - subsets, > 16 joint points, pre-transformed objective, read-backs,
+    user kernel, Pareto read-back."""
+    import _oracle_engine
+    from _replay import load_events, make_recommender, replay_events
+
+    _oracle_engine.install(monkeypatch)
+    meta, data = load_events()
+    assert set(meta) == {"desirability", "subsets", "pending17", "readbacks", "task", "composite", "pareto"}
+    for name, sc in meta.items():
+        for kind, want, got in replay_events(make_recommender(sc), sc["events"], data):
+            if kind == "recommend":
+                assert want == got, name
+            else:
+                assert np.allclose(got, want, rtol=1e-12, atol=1e-13), (name, kind)
+
+
 def test_recorded_traces_are_current(ref, tmp_path):
     """``make_reference_traces.py`` re-run here writes the same calls and labels as the committed fixture."""
     import importlib.util
@@ -514,6 +532,26 @@ def test_recorded_traces_are_current(ref, tmp_path):
     for k in data.files:
         if k.endswith(("_out", "_mask", "_comp", "_meas_x")):
             assert np.array_equal(new[k], data[k]), k
+
+
+def test_recorded_events_are_current(ref, tmp_path):
+    """``make_reference_events.py`` re-run here writes the same events, labels and values as the committed fixture."""
+    import importlib.util
+    import sys
+
+    from _replay import EVENTS, load_events
+
+    sys.path.insert(0, str(EVENTS.parent))
+    spec = importlib.util.spec_from_file_location("make_reference_events", EVENTS.parent / "make_reference_events.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(tmp_path / "e.npz")
+    meta, data = load_events()
+    new = np.load(tmp_path / "e.npz")
+    assert bytes(new["meta"]) == bytes(data["meta"])
+    for k in data.files:
+        if k.endswith(("_out", "_mask", "_comp", "_meas_x", "_meas_y", "_cand", "_sub_masks")):
+            assert np.allclose(new[k], data[k], rtol=1e-12, atol=1e-13), k
 
 
 # ---- the stand-ins used where the reference tree is absent are pinned to the reference here -----------------------------------------------

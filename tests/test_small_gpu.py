@@ -93,6 +93,56 @@ def test_small_form_with_the_scale_and_task_table(variant):
     g.close()
 
 
+@pytest.mark.parametrize("variant", ["positive_rank2", "free_rank1"])
+def test_user_supplied_task_kernels_on_the_device(variant):
+    """``ProductKernel([numerical kernel, (Positive)IndexKernel(num_tasks, rank < T)])`` (kernels/basic.py:220-248; what
+    ``ICMKernelFactory`` with a custom task kernel returns, components/kernel.py:238-337): data term and its gradient through the
+    host's chain rules against the oracle's autograd objective, the posterior against the oracle's, the whole device fit against
+    the oracle's objective at the fit's end point."""
+    import torch
+
+    from baybe_amd import engine, gp_spec
+    from baybe_amd.kernels import GammaPrior, IndexKernel, MaternKernel, PositiveIndexKernel, ProductKernel, RBFKernel, ScaleKernel, apply_kernel_spec
+    from oracle import gp_oracle as go
+
+    d, T = 5, 3
+    X, Xt, y = make_tl_problem(20_000, d, 22, T=T, seed=16)
+    X[:, d] = np.random.default_rng(0).integers(0, T, len(X))
+
+    class Space:
+        comp_rep_columns = tuple(f"x{j}" for j in range(d)) + ("task",)
+        n_tasks, task_idx = T, d
+
+    spec = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=T)
+    if variant == "positive_rank2":
+        kern = ProductKernel([ScaleKernel(MaternKernel(2.5, GammaPrior(3, 1)), GammaPrior(2, 0.5)), PositiveIndexKernel(num_tasks=T, rank=2)])
+    else:
+        kern = ProductKernel([RBFKernel(GammaPrior(3, 1)), IndexKernel(num_tasks=T, rank=1)])
+    apply_kernel_spec(spec, kern, Space())
+    ospec = oracle_spec(spec)
+    torch.manual_seed(5)
+    p = gp_spec.initial_params(spec)
+    raw = gp_spec.pack_raw(spec, p) + 0.15 * np.random.default_rng(3).standard_normal(len(gp_spec.pack_raw(spec, p)))
+    raw[0] = abs(raw[0]) + 2e-4
+    p = gp_spec.unpack_raw(spec, raw)
+    g = engine.HipGP(0)
+    g.set_model(spec, Xt, y)
+    val, gth = g.data_term(p)
+    f1, g1 = gp_spec.objective_from_data_term(spec, raw, len(y), val, gth, params=p)
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+    assert math.isclose(f0, f1, rel_tol=1e-10) and np.allclose(g0, g1, rtol=1e-7, atol=1e-9 * np.abs(g0).max())
+    g.factorize(p)
+    m, v = g.posterior(X)
+    mo, vo = go.GPModel(ospec, oracle_params(spec, p), Xt, y).posterior(X)
+    assert np.allclose(_np(m), mo, rtol=MEAN_RTOL, atol=1e-12) and np.allclose(_np(v), vo, rtol=VAR_RTOL, atol=1e-14)
+    torch.manual_seed(5)
+    fi = g.fit()
+    f_at, _ = go.fit_objective(ospec, go.pack_raw(ospec, oracle_params(spec, fi.params)), Xn, ys)
+    assert math.isclose(f_at, fi.fun, rel_tol=1e-8, abs_tol=1e-10) and fi.fun < f0
+    g.close()
+
+
 def test_greedy_batch_on_a_small_model_equals_the_oracle():
     """The first pass of every selection step runs on the register-resident form, the cross-covariance passes of the later steps on
     the cooperative one: the batch equals the oracle's."""
