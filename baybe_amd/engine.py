@@ -986,7 +986,10 @@ class HipGP:
                     val, idx = float(first_vals[0]), int(first_top[0])
                 else:
                     val, idx = self.argmax(scores) if N > 0 else (-math.inf, -1)
-                row = X[idx, :d].cpu().numpy()
+                if idx in spec_pos and spec_rows is not None:  # the winner is one of the speculative heads: its row is on the host already
+                    row = spec_rows[spec_pos[idx] - b0]
+                else:
+                    row = X[idx, :d].cpu().numpy()
                 alive[idx] = 0
             indices.append(int(idx))
             values.append(float(val))

@@ -7,7 +7,7 @@ import numpy as np, torch
 from bench import synth_problem
 from baybe_amd import engine, gp_spec
 
-N, d, n = 1_000_000, 20, 512
+N, d, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000), 20, 512
 X, Xt, y = synth_problem(N, d, n, 0)
 g = engine.HipGP(0)
 g.set_model(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), Xt, y)
@@ -23,10 +23,14 @@ def wrap(name):
         torch.cuda.synchronize(); acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
         return r
     setattr(g, name, inner)
-for _ in range(2): g.greedy_qlogei(Xd, 5, seed=1234, best_f=best_f)
+for _ in range(20): g.greedy_qlogei(Xd, 5, seed=1234, best_f=best_f)
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); g.greedy_qlogei(Xd, 5, seed=1234, best_f=best_f); torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+print(f"N={N}: greedy q=5 median {np.median(ts):.3f} ms (min {min(ts):.3f})")
 torch.cuda.synchronize(); t0 = time.perf_counter(); g.greedy_qlogei(Xd, 5, seed=1234, best_f=best_f); torch.cuda.synchronize()
 print(f"plain wall {1e3 * (time.perf_counter() - t0):.2f} ms")
-for name in ("posterior", "mc_acq", "set_pending", "cross_cov", "topk", "argmax"):
+for name in ("posterior", "mc_acq", "set_pending", "cross_cov", "topk", "argmax", "qlogei_topk", "qlogei_pending_big"):
     wrap(name)
 orig = engine.sobol_normal_base_samples
 def sob(*a, **k):
