@@ -152,6 +152,7 @@ SIGNATURES = {
     "bbh_cells_destroy": (C.c_int, [C.c_void_p]),
     "bbh_sobol_scramble": (C.c_int, [c_int64_p, c_int64_p, C.c_int64]),
     "bbh_sobol_draw": (C.c_int, [c_int64_p, c_int64_p, C.c_int64, C.c_int64, c_double_p]),
+    "bbh_content_key": (C.c_uint64, [C.POINTER(C.c_void_p), c_int64_p, C.c_int32, C.c_int32]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),
     "bbh_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int64]),

@@ -35,35 +35,23 @@ from baybe_amd.exceptions import (
 from baybe_amd.surrogates import HipCompositeImpl, HipGaussianProcessSurrogate, _availability_property
 
 
-_HASH_POOL = None  # persistent worker threads of the content hashes (xxhash releases the GIL)
-_HASH_CHUNK = 2 << 20  # bytes per task
-
-
-def _hash_pool():
-    global _HASH_POOL
-    if _HASH_POOL is None:
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-
-        _HASH_POOL = ThreadPoolExecutor(max(1, min(32, os.cpu_count() or 1)), thread_name_prefix="bbh-hash")
-    return _HASH_POOL
-
-
 def _hash_buffers(bufs) -> int:
-    """xxh3 over a list of byte buffers, in 2 MB pieces on the persistent pool: 160 MB (the comp rep of a 1e6 x 20 grid) are
-    memory-bound - 6 ms on 8 threads created per call (round 4), the pool has up to 32 and is created once."""
-    import xxhash
+    """64-bit content key of a list of byte buffers: the library's host-side multiply-fold hash over 4 MB pieces on native threads
+    (``bbh_content_key``).  python-xxhash keeps the GIL, so the "8 threads" of round 4 hashed the 160 MB comp rep of a 1e6 x 20 grid
+    at one core's rate - 5 ms of every ``recommend()``; natively it is memory-bound."""
+    import ctypes as C
+    import os
 
-    tasks = []
-    for buf in bufs:
-        n = len(buf)
-        if n <= _HASH_CHUNK:
-            tasks.append(buf)
-        else:
-            tasks.extend(buf[o : o + _HASH_CHUNK] for o in range(0, n, _HASH_CHUNK))
-    if sum(len(t) for t in tasks) < (1 << 22):
-        return hash(tuple(xxhash.xxh3_64_intdigest(t) for t in tasks))
-    return hash(tuple(_hash_pool().map(xxhash.xxh3_64_intdigest, tasks)))
+    from baybe_amd import _lib
+
+    lib = _lib.load_library()
+    n = len(bufs)
+    arrs = [np.frombuffer(b, dtype=np.uint8) for b in bufs]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    lens = (C.c_int64 * n)(*[a.size for a in arrs])
+    total = sum(a.size for a in arrs)
+    threads = 1 if total < (1 << 22) else max(1, min(32, os.cpu_count() or 1))
+    return int(lib.bbh_content_key(ptrs, lens, n, threads))
 
 
 def _content_hash(arr: np.ndarray):
@@ -77,10 +65,6 @@ def _content_hash(arr: np.ndarray):
         return hash((arr.shape, tuple(arr.ravel().tolist())))
     if not arr.flags.c_contiguous:
         arr = arr.T if arr.T.flags.c_contiguous else np.ascontiguousarray(arr)
-    try:
-        import xxhash  # noqa: F401
-    except ImportError:  # pragma: no cover
-        return hash(arr.tobytes())
     return _hash_buffers([memoryview(arr).cast("B")])
 
 
@@ -89,10 +73,6 @@ def _frame_content_hash(df: pd.DataFrame):
     thread pool; columns that are not plain numeric arrays go through ``_content_hash``.  Equal keys
     imply equal content; the same content in another memory layout (a row-major block against a column-major copy) may key
     differently, which costs one re-upload and nothing else."""
-    try:
-        import xxhash  # noqa: F401
-    except ImportError:  # pragma: no cover
-        return _content_hash(df.to_numpy())
     if df.shape[1] == 0 or not df.iloc[:, 0].to_numpy().flags.c_contiguous:
         return _content_hash(df.to_numpy())  # one 2-D block: ``to_numpy`` is a view, its columns are strided
     cols = [df.iloc[:, j].to_numpy() for j in range(df.shape[1])]

@@ -330,6 +330,11 @@ int bbh_cells_destroy(void* cells);
 int bbh_sobol_scramble(int64_t* state, const int64_t* ltm, int64_t dim);
 int bbh_sobol_draw(const int64_t* state, const int64_t* shift, int64_t n, int64_t dim, double* out);
 
+/* 64-bit content key of host buffers (host code, std::threads): multiply-fold hash over 4 MB pieces, the pieces' digests folded in
+ * order.  Keys the device-resident copy of the discrete subspace's computational representation on its content
+ * (baybe/searchspace/discrete.py:704-735 hands the frame out on every call; botorch/discrete.py:123 converts it per call). */
+uint64_t bbh_content_key(const void* const* bufs, const int64_t* lens, int32_t nbuf, int32_t threads);
+
 /* ---- selection --------------------------------------------------------------------- */
 /* First-index argmax of scores_dev [N] (NaN never wins) -> host. */
 int bbh_argmax(bbh_handle* h, const double* scores_dev, int64_t N, double* best_val_host,

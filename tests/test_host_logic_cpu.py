@@ -352,7 +352,7 @@ def test_scenario_rollout_cases_and_content_hash():
     a[4321, 5] += 1e-12  # any row, any column
     assert _content_hash(a) != h and _content_hash(a) == _content_hash(a.copy())
     # the frame key of the resident candidate matrix (every byte stays hashed, on a persistent pool in 2 MB pieces):
-    # an in-place edit of ONE cell of a large frame (several pieces per column, pool path) changes it; a copy keys the same
+    # an in-place edit of ONE cell of a large frame (pool path) changes it; a copy keys the same
     import pandas as pd
 
     from baybe_amd.recommenders import _frame_content_hash
