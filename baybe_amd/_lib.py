@@ -46,7 +46,7 @@ class ModelDesc(C.Structure):
 
 KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3,
                 "piecewise0": 4, "piecewise1": 5, "piecewise2": 6, "piecewise3": 7, "rq": 8,
-                "linear": 9, "poly1": 10, "poly2": 11, "poly3": 12, "poly4": 13, "periodic": 14}  # enum bbh_kernel_kind
+                "linear": 9, "poly1": 10, "poly2": 11, "poly3": 12, "poly4": 13, "periodic": 14, "rff": 15}  # enum bbh_kernel_kind
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15  # pending points per cross-covariance pass / in the handle's pending state (BBH_MAX_PENDING)
 MAX_PENDING_BIG = 63  # joint q'-batches through bbh_qlogei_pending_big: q' = 1 + pending <= 64 (qLogEI)
@@ -63,6 +63,7 @@ SIGNATURES = {
     "bbh_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bbh_version": (C.c_int, []),
     "bbh_selftest": (C.c_int, [C.c_void_p]),
+    "bbh_set_rff_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
     "bbh_set_model": (
         C.c_int,
         [C.c_void_p, C.POINTER(ModelDesc), C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p],

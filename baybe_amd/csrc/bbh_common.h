@@ -335,6 +335,9 @@ struct bbh_handle {
   bool skip_x_memset = false;     // bbh_potrf_trtri: leave the upper tiles of L^-1 alone (the caller reads lower tiles only)
   bool flow_in_flight = false;    // the evaluation on the stream is the one-launch form (its flag needs the sentinel check)
   int fit_flow = 1;               // env BBH_FIT_FLOW: 0 fit evaluations for 64 < np <= 1024 launch by launch, 1 (default) Gram + factorisation launches, then ONE dataflow launch for K^-1, alpha, value and gradient, 2 the whole evaluation as one dataflow launch
+  void* rff_state = nullptr;      // feature-space model of the RFF kernel (bbh_rff.hip), null for every other kernel
+  std::vector<double> rff_w_host; // bbh_set_rff_weights: the frequencies [dn, D] the next bbh_set_model with BBH_KERNEL_RFF takes
+  int rff_w_dn = 0, rff_w_D = 0;
   void* nehvi_state = nullptr;    // device-resident box decompositions + their scratch (bbh_nehvi.hip), null until bbh_cells_build_dev
   void* select_state = nullptr;   // chunk keys, result block and base-sample tables of the selection kernels (bbh_select.hip)
   bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
@@ -435,3 +438,12 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
 bool bbh_fit_flow_eligible(bbh_handle* h);
 void bbh_fit_flow_reset(bbh_handle* h);  // after a launch that gave up: clean state, the handle stops using the form
 void bbh_free_model_public(bbh_handle* h);
+// ---- RFF kernel: the model in feature space (bbh_rff.hip) ----
+inline bool bbh_is_rff(const bbh_handle* h) { return h->desc.kernel_kind == BBH_KERNEL_RFF; }
+int bbh_rff_setup(bbh_handle* h);          // after the generic part of bbh_set_model_ex
+int bbh_rff_fit_enqueue(bbh_handle* h);    // one evaluation of the fit objective on h->stream
+int bbh_rff_factorize(bbh_handle* h);      // theta in h->d_theta -> posterior operands
+int bbh_rff_posterior_launch(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev, double* cross_dev);
+int bbh_rff_pending_set(bbh_handle* h, const double* Xpend_host, int64_t p, double* mean_p_host, double* cov_pp_host);
+int bbh_rff_posterior_joint(bbh_handle* h, const double* Xq_host, int64_t q, double* mean_host, double* cov_host);
+void bbh_rff_destroy(bbh_handle* h);

@@ -376,6 +376,7 @@ static void bbh_free_model(bbh_handle* h) {
                   h->d_rfrag, h->d_meanB,   h->d_sclofs,    h->d_numcol, h->d_tasktbl, h->d_taskext, h->d_beta, h->d_pass_off, h->d_pass_w, h->d_nmask, h->d_colfrag, h->d_pendT, h->d_colA, h->d_Mpart, h->d_trainfrag_f, h->d_sclofs_f};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  bbh_rff_destroy(h);
   h->d_xnT = h->d_ystd = h->d_theta = h->d_K = h->d_X = h->d_M = h->d_Q = h->d_Q2 = h->d_D = h->d_tmp = nullptr;
   h->d_r = h->d_t = h->d_alpha = h->d_u = h->d_w = h->d_q = h->d_partial = h->d_out = nullptr;
   h->d_trainfrag = h->d_rfrag = h->d_meanB = h->d_sclofs = h->d_tasktbl = h->d_beta = nullptr;
@@ -419,7 +420,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     h->err = "bbh_set_model: bad arguments";
     return -1;
   }
-  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_PERIODIC || desc->d < 1 || desc->n_tasks < 1 ||
+  if (desc->kernel_kind < 0 || desc->kernel_kind > BBH_KERNEL_RFF || desc->d < 1 || desc->n_tasks < 1 ||
       (desc->n_tasks > 1 && (desc->task_col < 0 || desc->task_col >= desc->d)) ||
       (desc->criterion != BBH_CRITERION_MLL && desc->criterion != BBH_CRITERION_LOO)) {
     h->err = "bbh_set_model: invalid model description";
@@ -448,6 +449,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
              desc->criterion, desc->kernel_kind, desc->task_col, desc->n_tasks, desc->use_outputscale, desc->hadamard, desc->n_factors, desc->combine,
              desc->factor_kind[0], desc->factor_kind[1], desc->factor_kind[2], desc->factor_kind[3], desc->factor_scaled[0],
              desc->factor_scaled[1], desc->factor_scaled[2], desc->factor_scaled[3]);
+    if (desc->kernel_kind == BBH_KERNEL_RFF) snprintf(sig + strlen(sig), sizeof(sig) - strlen(sig), ":rff%d", h->rff_w_D);
     if (desc->combine == 2)
       snprintf(sig + strlen(sig), sizeof(sig) - strlen(sig), ":g%d%d%d%d", desc->factor_group[0], desc->factor_group[1], desc->factor_group[2],
                desc->factor_group[3]);
@@ -586,8 +588,14 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   h->xraw_host.assign(X_train_host, X_train_host + n * d);
   h->p = 0;
   h->pend_host.clear();
-  h->have_model = true;
   h->factorized = false;
+  if (desc->kernel_kind == BBH_KERNEL_RFF) {
+    int rc = bbh_rff_setup(h);
+    if (rc) return rc;
+  } else {
+    bbh_rff_destroy(h);
+  }
+  h->have_model = true;
   return 0;
 }
 
@@ -629,6 +637,7 @@ static int bbh_fit_enqueue(bbh_handle* h) {
   hipStream_t s = h->stream;
   const int64_t np = h->np, n = h->n;
   const int64_t tl = bbh_theta_len_of(h);
+  if (bbh_is_rff(h)) return bbh_rff_fit_enqueue(h);  // the RFF kernel's model lives in feature space (bbh_rff.hip)
   {  // small models: the whole evaluation in one workgroup (bbh_linalg.hip), reading theta from and writing the results to the
      // pinned staging buffers themselves - one launch, no copies
     void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
@@ -821,6 +830,15 @@ extern "C" int bbh_factorize(bbh_handle* h, const double* theta_host, double* ji
   int rc = bbh_upload_theta(h, theta_host);
   if (rc) return rc;
   h->factorized = false;
+  if (bbh_is_rff(h)) {
+    rc = bbh_rff_factorize(h);
+    if (rc) return rc;
+    if (jitter_used) *jitter_used = 0.0;
+    h->p = 0;
+    h->pend_host.clear();
+    h->factorized = true;
+    return 0;
+  }
   // gpytorch psd_safe_cholesky: plain attempt, then jitter 1e-8 * 10^i, i = 0..2
   // A model with latent rows (noise mask 0: the baseline rows of an extended qLogNEHVI model) whose factorisation fails INSIDE
   // the latent block: BoTorch factorises the baseline's joint posterior covariance - the Schur complement of that block, in the

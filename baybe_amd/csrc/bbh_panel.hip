@@ -472,6 +472,7 @@ int bbh_pack_operands(bbh_handle* h) {
 int bbh_launch_fused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                      double* cross_dev, bool with_var) {
   if (N <= 0) return 0;
+  if (bbh_is_rff(h)) return bbh_rff_posterior_launch(h, X_dev, N, ldx, mean_dev, with_var ? var_dev : nullptr, cross_dev);
   // composite / RQ / piecewise kernels: the cooperative form with the generic production for variance passes without pending
   // columns (bbh_coopg.h), otherwise the materialised-K* path (fused qLogEI: applied by the caller)
   const bool coopg = h->coopg_ready && with_var && h->p == 0 && !cross_dev && !h->fuse_qz && h->use_mean_valu;
@@ -906,6 +907,7 @@ __global__ __launch_bounds__(256) void bbh_ext_epilogue_kernel(const double* __r
 int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
                            double* cross_dev) {
   if (N <= 0) return 0;
+  if (bbh_is_rff(h)) return bbh_rff_posterior_launch(h, X_dev, N, ldx, mean_dev, var_dev, cross_dev);
   const int64_t np = h->np, ldk = np + 16;
   const int64_t chunk = N < 16384 ? bbh_round_up(N, 64) : 16384;  // (small candidate sets: a small workspace)
   const size_t need = sizeof(double) * ((size_t)chunk * ldk + (size_t)chunk * np + 2 * h->dn + (size_t)chunk);
@@ -948,6 +950,7 @@ int bbh_launch_unfused_ext(bbh_handle* h, const double* X_dev, int64_t N, int64_
 }
 
 int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev) {
+  if (bbh_is_rff(h)) return bbh_rff_posterior_launch(h, X_dev, N, ldx, mean_dev, var_dev, nullptr);  // (one form only: feature space)
   const int64_t np = h->np;
   const int64_t chunk = 16384;
   const size_t need = sizeof(double) * (2 * (size_t)chunk * np + 2 * h->dn + (size_t)chunk);
@@ -990,6 +993,7 @@ extern "C" int bbh_pending_set(bbh_handle* h, const double* Xpend_host, int64_t 
     return -1;
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  if (bbh_is_rff(h)) return bbh_rff_pending_set(h, Xpend_host, p, mean_p_host, cov_pp_host);
   hipStream_t s = h->stream;
   const int64_t np = h->np, nb = h->nb;
   const int d = h->desc.d, dn = h->dn, T = h->T;
@@ -1415,6 +1419,10 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
     h->err = "bbh_set_mean_columns: model not factorised / bad arguments (1 <= S <= 8192)";
     return -1;
   }
+  if (bbh_is_rff(h)) {
+    h->err = "bbh_set_mean_columns: conditional-mean columns (qLogNEHVI) are not available with the RFF kernel";
+    return -1;
+  }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const int64_t np = h->np, n = h->n;
@@ -1488,6 +1496,10 @@ extern "C" int bbh_nehvi_samples(bbh_handle* h, const double* z_host, int64_t S,
   if (!h) return -1;
   if (!h->factorized || !z_host || S < 1 || S > 8192 || nb < 1 || nb >= h->n || o < 0 || o >= m || m > BBH_MAX_OBJECTIVES || !Fb_dev) {
     h->err = "bbh_nehvi_samples: model not factorised / bad arguments (1 <= S <= 8192, 1 <= nb < n, 0 <= o < m <= 4)";
+    return -1;
+  }
+  if (bbh_is_rff(h)) {
+    h->err = "bbh_nehvi_samples: not available with the RFF kernel";
     return -1;
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
@@ -1612,6 +1624,10 @@ static int bbh_posterior_columns_impl(bbh_handle* h, const double* X_dev, int64_
     return -1;
   }
   if (N == 0) return 0;
+  if (bbh_is_rff(h)) {
+    h->err = "bbh_posterior_columns: not available with the RFF kernel";
+    return -1;
+  }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   bbh_timed_scope timed(h, BBH_TIMED_COLUMNS);
   if (bbh_materialised_only(h)) return bbh_columns_unfused(h, X_dev, N, ldx, tmat_dev, sample_major);
@@ -1711,6 +1727,7 @@ extern "C" int bbh_posterior_joint(bbh_handle* h, const double* Xq_host, int64_t
     return -1;
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  if (bbh_is_rff(h)) return bbh_rff_posterior_joint(h, Xq_host, q, mean_host, cov_host);
   hipStream_t s = h->stream;
   const int64_t np = h->np, d = h->desc.d, dn = h->dn;
   const int64_t qpad = bbh_round_up(q, 64);

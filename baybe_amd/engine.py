@@ -426,6 +426,8 @@ class HipGP:
         hi = np.ascontiguousarray(spec.hi, dtype=np.float64)
         if lo.shape[0] != spec.d or hi.shape[0] != spec.d:
             raise ValueError("spec.lo / spec.hi must have one entry per comp-rep column")
+        if spec.kernel == "rff":
+            spec = self._with_rff_weights(spec)
         mask_p = None
         if noise_mask is not None:
             mask = np.ascontiguousarray(noise_mask, dtype=np.uint8)
@@ -444,6 +446,30 @@ class HipGP:
         self._y_train = y
         self._model_args = (None if noise_mask is None else np.array(noise_mask, dtype=np.uint8),
                             None if not standardization else (float(standardization[0]), float(standardization[1])))
+
+    def _with_rff_weights(self, spec: GPSpec) -> GPSpec:
+        """The frequencies of an RFF kernel go to the handle before the model: drawn here when the spec carries none - gpytorch's
+        ``RFFKernel._init_weights`` draws ``torch.randn(d, D)`` (global generator, the lengthscale's dtype) at the first forward of a
+        fit, over the kernel's active columns -, and kept on a copy of the spec so that copies / re-created handles use the same ones."""
+        import copy
+
+        if spec.factors or spec.n_tasks > 1 or spec.task_idx is not None or spec.criterion != "mll":
+            raise ValueError("the RFF kernel is available as the single kernel of a single-task model fitted by its marginal likelihood")
+        D = int(spec.rff_num_samples or 0)
+        if not 1 <= D <= 64:
+            raise ValueError("rff_num_samples must be in 1..64")
+        mask = spec.active_mask(0)
+        d_act = spec.dn if mask is None else int(mask.sum())
+        if spec.rff_weights is None:
+            spec = copy.copy(spec)
+            spec.rff_weights = self._torch().randn(d_act, D, dtype=self._torch().float64).numpy().copy()
+        W = np.asarray(spec.rff_weights, dtype=np.float64)
+        if W.shape != (d_act, D):
+            raise ValueError(f"rff_weights must be [{d_act}, {D}] (active numerical columns x num_samples)")
+        full = np.zeros((spec.dn, D))  # (columns the kernel does not act on: zero frequencies - their pinned lengthscale is immaterial)
+        full[np.arange(spec.dn) if mask is None else np.flatnonzero(mask)] = W
+        self._check(self._lib.bbh_set_rff_weights(self._h, _dp(np.ascontiguousarray(full)), spec.dn, D), "bbh_set_rff_weights")
+        return spec
 
     def data_term(self, params: GPParams):
         """Device data term (MLL or LOO) and its gradient in theta layout; (None, None) if the
@@ -802,7 +828,7 @@ class HipGP:
     def posterior_kernel_form(self) -> str:
         """Which form of the fused posterior kernel the last variance pass ran as."""
         return {0: "windowed", 1: "cooperative", 2: "materialised", 3: "cooperative-2sweep", 4: "cooperative-generic",
-                5: "register-resident"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
+                5: "register-resident", 6: "feature-space"}.get(self._lib.bbh_last_posterior_form(self._h), "none")
 
     def timing(self, enable, families=None):
         """HIP-event timing of the kernel families on / off; ``families`` (names as for ``timing_read``) restricts the events to those

@@ -147,6 +147,11 @@ class GPSpec:
     alpha_init: float | None = None
     period_prior: tuple | None = None  # periodic kernel: prior / initial value of the period lengths (KernelFactor.period_*)
     period_init: float | None = None
+    # kernel "rff" (gpytorch RFFKernel, baybe/kernels/basic.py:183-199): k = z(x) . z(x') / D, z = [cos(x (W / l)), sin(x (W / l))]; ARD
+    # lengthscales as for "rbf".  ``rff_weights`` [active columns, D] = the frequencies W; None: the engine draws them from torch's global
+    # RNG when the model is set up (``torch.randn(d, D)``: RFFKernel._init_weights at the first forward of a fit) and stores them here.
+    rff_num_samples: int | None = None
+    rff_weights: "np.ndarray | None" = None
 
     def period_spec(self, k: int = 0):
         if k == 0 or not self.factors:

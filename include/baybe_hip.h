@@ -79,7 +79,11 @@ enum bbh_kernel_kind {
   /* gpytorch PeriodicKernel (baybe/kernels/basic.py:73-112): exp(-2 sum_j sin^2(pi (x_j - x'_j) / p_j) / l_j) with one lengthscale
    * l_j (lengthscale slots; note: not squared) and one period p_j per column.  theta: a block of F * dn periods at the very end
    * (after the alpha slots), present when any factor is periodic; slots of the other factors are ignored.  Materialised-K* path. */
-  BBH_KERNEL_PERIODIC = 14
+  BBH_KERNEL_PERIODIC = 14,
+  /* gpytorch.kernels.RFFKernel (baybe/kernels/basic.py:183-199): k(x, x') = z(x) . z(x') / D with z = [cos(x (W / l)), sin(x (W / l))], D =
+   * num_samples frequencies W [dn, D] drawn once per model (bbh_set_rff_weights BEFORE bbh_set_model); the model is held in feature space:
+   * fit and posterior cost O(n D^2 + D^3) and O(D^2) per candidate.  One task, single kernel, MLL, D <= 64; theta as for RBF. */
+  BBH_KERNEL_RFF = 15
 };
 
 enum bbh_criterion {
@@ -144,6 +148,9 @@ int bbh_version(void);
 int bbh_selftest(bbh_handle* h);
 
 /* ---- model ------------------------------------------------------------------------- */
+/* The random frequencies of a BBH_KERNEL_RFF model: W_host [dn, D] (numerical columns in comp-rep order x num_samples), as gpytorch's
+ * RFFKernel._init_weights draws them (torch.randn(d, D)); kept on the handle for the next bbh_set_model / bbh_set_model_ex. */
+int bbh_set_rff_weights(bbh_handle* h, const double* W_host, int32_t dn, int32_t D);
 /* X_train_host [n,d] raw comp-rep rows; y_train_host [n] raw targets;
  * lo_host/hi_host [d] scaling bounds of every column (task column ignored).
  * Normalises the numerical columns, standardises y (Bessel std, <1e-8 -> 1). */
@@ -390,7 +397,7 @@ int bbh_timing_read(bbh_handle* h, double* fused_ms_total, int64_t* fused_launch
  * 2 = materialised K* (verification path; models outside the fused forms), 3 = two-sweep cooperative (512 < n <= 1024,
  * bbh_coop2_posterior_kernel), 4 = cooperative with the generic kernel-value production (composite, RQ, piecewise, Linear,
  * Polynomial, Periodic: bbh_coopg_posterior_kernel), 5 = register- / LDS-resident (n <= 128, bbh_small_posterior_kernel),
- * -1 = none yet. */
+ * 6 = feature space (BBH_KERNEL_RFF: bbh_rff_posterior_kernel), -1 = none yet. */
 int bbh_last_posterior_form(bbh_handle* h);
 enum bbh_timed_family {
   BBH_TIMED_POSTERIOR = 0, BBH_TIMED_CROSS = 1, BBH_TIMED_PENDING = 2,

@@ -136,6 +136,7 @@ class GPSpec:
     active_dims: "np.ndarray | None" = None  # single kernel on a parameter subset (see KernelTerm.active_dims)
     offset: "Hyper | None" = None  # single polynomial kernel: its offset (see KernelTerm.offset)
     period: "Hyper | None" = None  # single periodic kernel: its period lengths (see KernelTerm.period)
+    rff_weights: "np.ndarray | None" = None  # kernel "rff": gpytorch RFFKernel.randn_weights [active columns, num_samples]
 
     def period_of(self, m: int | None = None) -> Hyper:
         h = self.period if (m is None or not self.members) else self.members[m].period
@@ -420,9 +421,20 @@ def member_grams(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> lis
     return out
 
 
+def rff_features(W: np.ndarray, X: np.ndarray, ls: np.ndarray) -> np.ndarray:
+    """gpytorch ``RFFKernel._featurize`` (baybe/kernels/basic.py:183-199 maps to it): ``x.matmul(randn_weights / lengthscale^T)``, then
+    ``cat([cos, sin], -1)``; the kernel is ``z1 z2^T / D`` (RFFKernel.forward)."""
+    P = X @ (W / np.asarray(ls, dtype=np.float64).reshape(-1, 1))
+    return np.concatenate([np.cos(P), np.sin(P)], axis=1)
+
+
 def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> np.ndarray:
     """The kernel over the numerical columns without outer outputscale / task factor: the single stationary kernel, or
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
+    if not spec.members and spec.kernel == "rff":
+        c = spec.dims_of(None)
+        W = np.asarray(spec.rff_weights, dtype=np.float64)
+        return rff_features(W, A[:, c], p.lengthscale) @ rff_features(W, B[:, c], p.lengthscale).T / W.shape[1]
     if not spec.members:
         c = spec.dims_of(None)
         return base_kernel_from_r2(spec.kernel, _metric(spec.kernel, A[:, c], B[:, c], p.lengthscale, _period_of(p, 0)), len(c), _alpha_of(p, 0))
@@ -524,8 +536,8 @@ def data_term(spec: GPSpec, p: GPParams, Xn: np.ndarray, ystd: np.ndarray) -> Da
     if spec.active_dims is not None or any(t.active_dims is not None for t in (spec.members or [])):
         raise NotImplementedError("analytic data-term gradients are not restated for kernels on parameter subsets; "
                                   "use fit_objective (autograd)")
-    if any(k in DOT_KERNELS or k == "periodic" for k in kernel_names(spec)):
-        raise NotImplementedError("analytic data-term gradients are not restated for Linear / Polynomial / Periodic kernels; use fit_objective")
+    if any(k in DOT_KERNELS or k in ("periodic", "rff") for k in kernel_names(spec)):
+        raise NotImplementedError("analytic data-term gradients are not restated for Linear / Polynomial / Periodic / RFF kernels; use fit_objective")
     trow = task_rows(spec, Xn)
     Kf = cross_cov(spec, p, Xn, Xn)
     Ky = Kf + np.diag(p.noise_of(trow))

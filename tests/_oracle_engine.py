@@ -99,6 +99,12 @@ class OracleEngine(HipGP):
             raise ValueError("X_train must be [n, d] and y_train [n]")
         if noise_mask is not None or standardization is not None:
             raise NotImplementedError("the CPU double has no extended (noise-masked) models; see OracleNEHVI")
+        if spec.kernel == "rff" and spec.rff_weights is None:  # (the engine's own rule: torch.randn(d, D) from the global generator)
+            import copy
+
+            spec = copy.copy(spec)
+            mask = spec.active_mask(0)
+            spec.rff_weights = torch.randn(spec.dn if mask is None else int(mask.sum()), int(spec.rff_num_samples), dtype=torch.float64).numpy().copy()
         self.spec, self.n, self.params, self._model = spec, X.shape[0], None, None
         self._ospec = oracle_spec(spec)
         self._X_train, self._y_train, self._model_args = X, y, (None, None)
@@ -115,7 +121,7 @@ class OracleEngine(HipGP):
         if dt is None or not np.isfinite(dt.value):
             return None, None
         spec = self.spec
-        if spec.factors or spec.hadamard or spec.has_rq or spec.has_periodic or spec.has_dot_kind:
+        if spec.factors or spec.hadamard or spec.has_rq or spec.has_periodic or spec.has_dot_kind or spec.kernel == "rff":
             raise NotImplementedError("the CPU double covers single-kernel (+ task kernel) models")
         parts = [[dt.g_noise, dt.g_mean, dt.g_outputscale], dt.g_ls]
         if spec.n_tasks > 1:
@@ -127,7 +133,7 @@ class OracleEngine(HipGP):
         """The product's own fit driver; only the vectorised host objective (``FastObjective``, which feeds theta vectors to the
         device call directly) is switched off so that every evaluation passes through ``data_term`` above."""
         spec = self.spec
-        if spec.factors or spec.hadamard or spec.has_rq or spec.has_periodic or spec.has_dot_kind:
+        if spec.factors or spec.hadamard or spec.has_rq or spec.has_periodic or spec.has_dot_kind or spec.kernel == "rff":
             # composite / non-stationary models: the product's raw layout, bounds, initial values and L-BFGS-B driver around the oracle's
             # autograd objective (its raw vector = the product's free slots; pinned slots - subsets, polynomial weights - do not move)
             bounds = gp_spec.raw_bounds(spec)

@@ -67,7 +67,8 @@ def oracle_spec(spec):
         composition={"grouped": "nested"}.get(spec.combine, spec.combine),
         member_terms=[int(f.group) for f in spec.factors] if (spec.factors and spec.combine == "grouped") else None,
         active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0],
-        offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init), period=go.Hyper(0.0, True, spec.period_prior, spec.period_init))
+        offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init), period=go.Hyper(0.0, True, spec.period_prior, spec.period_init),
+        rff_weights=getattr(spec, "rff_weights", None))
 
 
 def oracle_params(spec, p):

@@ -845,3 +845,85 @@ def test_user_supplied_task_kernels_against_the_autograd_oracle(variant):
                           ProductKernel([MaternKernel(), IndexKernel(num_tasks=T + 1, rank=1)]), Space())
     with pytest.raises(NotImplementedError):
         _prior_tuple(type("BetaPrior", (), {"alpha": 1.0, "beta": 2.0})())
+
+
+# ---- RFF kernel ---------------------------------------------------------------------------------------------------------------------------
+def test_rff_kernel_oracle_and_the_feature_space_identities():
+    """The oracle's RFF kernel (oracle/gp_oracle.py::rff_features: gpytorch ``RFFKernel._featurize`` / ``forward``) against its own
+    autograd form, and the feature-space expressions csrc/bbh_rff.hip evaluates (m x m system, Woodbury) against the oracle's n x n
+    posterior and objective - in numpy, so that the maths the device uses is pinned where no device exists."""
+    import torch
+    from _problems import oracle_params, oracle_spec
+    from baybe_amd import gp_spec
+    from baybe_amd.kernels import GammaPrior, RFFKernel, ScaleKernel, apply_kernel_spec
+    from oracle import fit_objective as fo
+    from oracle import gp_oracle as go
+
+    d, n, D = 4, 40, 7
+    rng = np.random.default_rng(5)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    apply_kernel_spec(spec, ScaleKernel(RFFKernel(D, GammaPrior(3, 1)), GammaPrior(2, 0.5)))
+    assert (spec.kernel, spec.rff_num_samples, spec.use_outputscale, spec.ls_constraint) == ("rff", D, True, "softplus")
+    spec.rff_weights = rng.standard_normal((d, D))
+    ospec = oracle_spec(spec)
+    Xt, Xc = rng.random((n, d)), rng.random((25, d))
+    y = np.sin(3 * Xt[:, 0]) + Xt[:, 1]
+    p = gp_spec.initial_params(spec)
+    p.lengthscale = 0.3 + rng.random(d)
+    p.noise, p.outputscale, p.mean = 0.02, 1.7, 0.1
+    op = oracle_params(spec, p)
+    Xn, ys = go.normalize_inputs(ospec, Xt), go.standardize_targets(y)[0]
+    K = go.cross_cov(ospec, op, Xn, Xn)
+    assert np.allclose(np.diag(K), p.outputscale, rtol=1e-13)  # k(x, x) = (cos^2 + sin^2) summed / D = 1
+    assert np.linalg.matrix_rank(K) == 2 * D
+    nat = {"lengthscale": torch.as_tensor(p.lengthscale), "outputscale": torch.tensor(p.outputscale, dtype=torch.float64)}
+    assert np.allclose(fo.train_covariance(ospec, nat, torch.as_tensor(Xn)).numpy(), K, rtol=1e-13, atol=1e-14)
+    # autograd gradient of the oracle objective against central differences
+    raw = go.pack_raw(ospec, op)
+    f0, g0 = go.fit_objective(ospec, raw, Xn, ys)
+    for i in range(len(raw)):
+        e = np.zeros_like(raw)
+        e[i] = 1e-6
+        fd = (go.fit_objective(ospec, raw + e, Xn, ys)[0] - go.fit_objective(ospec, raw - e, Xn, ys)[0]) / 2e-6
+        assert math.isclose(fd, g0[i], rel_tol=2e-6, abs_tol=1e-7), (i, fd, g0[i])
+    # feature space: B = eps I + Phi^T Phi, a = B^-1 Phi^T r
+    s2, os_, c = p.noise, p.outputscale, p.mean
+    Phi = go.rff_features(spec.rff_weights, Xn, p.lengthscale) / math.sqrt(D)
+    m = 2 * D
+    B = (s2 / os_) * np.eye(m) + Phi.T @ Phi
+    r = ys - c
+    a = np.linalg.solve(B, Phi.T @ r)
+    alpha = (r - Phi @ a) / s2
+    Ky = K + s2 * np.eye(n)
+    assert np.allclose(alpha, np.linalg.solve(Ky, r), rtol=1e-9, atol=1e-12)
+    logdet = (n - m) * math.log(s2) + m * math.log(os_) + np.linalg.slogdet(B)[1]
+    assert math.isclose(logdet, np.linalg.slogdet(Ky)[1], rel_tol=1e-11)
+    trBinv = np.trace(np.linalg.inv(B))
+    assert math.isclose((n - m + (s2 / os_) * trBinv) / s2, np.trace(np.linalg.inv(Ky)), rel_tol=1e-9)
+    model = go.GPModel(ospec, op, Xt, y)
+    mo, vo = model.posterior(Xc)
+    Pc = go.rff_features(spec.rff_weights, go.normalize_inputs(ospec, Xc), p.lengthscale) / math.sqrt(D)
+    ybar, ysd = go.standardize_targets(y)[1:]
+    assert np.allclose(ybar + ysd * (c + Pc @ a), mo, rtol=1e-10, atol=1e-12)
+    var_f = ysd**2 * s2 * np.einsum("ik,kl,il->i", Pc, np.linalg.inv(B), Pc)
+    assert np.allclose(var_f, vo, rtol=1e-7, atol=1e-12)
+    _, cov = model.posterior_joint(Xc[:5])
+    assert np.allclose(ysd**2 * s2 * Pc[:5] @ np.linalg.inv(B) @ Pc[:5].T, cov, rtol=1e-7, atol=1e-12)
+
+
+def test_rff_kernel_specifications_the_device_does_not_take():
+    from baybe_amd import gp_spec
+    from baybe_amd.exceptions import IncompatibilityError
+    from baybe_amd.kernels import AdditiveKernel, MaternKernel, RFFKernel, apply_kernel_spec
+
+    d = 3
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    with pytest.raises(IncompatibilityError, match="64 frequencies"):
+        apply_kernel_spec(spec, RFFKernel(65))
+    with pytest.raises(IncompatibilityError, match="inside a"):
+        apply_kernel_spec(spec, AdditiveKernel([RFFKernel(5), MaternKernel(2.5)]))
+    tl = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=2)
+    with pytest.raises(IncompatibilityError, match="task parameter"):
+        apply_kernel_spec(tl, RFFKernel(5))
+    with pytest.raises((ValueError, TypeError)):
+        RFFKernel(0)

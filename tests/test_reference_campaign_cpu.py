@@ -302,6 +302,34 @@ def test_the_reference_composite_kernel_matrix_runs_through_the_plugin_surrogate
     assert spec.factor_kinds == ["matern32", "matern52", "matern32", "matern52"]
 
 
+def test_the_reference_rff_kernel_runs_through_the_plugin_surrogate(ref):
+    """``RFFKernel(num_samples=5)`` alone and in a ``ScaleKernel`` (tests/test_iterations.py:283-289: ``valid_base_kernels`` /
+    ``valid_scale_kernels``) - the reference's own kernel objects, given to the plug-in surrogate and run through the real ``Campaign``.
+    The frequencies are drawn per fit (``torch.randn(d, D)``, gpytorch ``RFFKernel._init_weights``)."""
+    baybe, S, C, R, Eng = ref
+    from baybe import Campaign
+    from baybe.kernels import RFFKernel, ScaleKernel
+    from baybe.priors import GammaPrior, HalfCauchyPrior
+    from baybe.targets import NumericalTarget
+
+    rng = np.random.default_rng(18)
+    space = _space3(5)
+    seen = []
+    for kernel in (RFFKernel(lengthscale_prior=GammaPrior(3, 1), num_samples=5),
+                   ScaleKernel(base_kernel=RFFKernel(lengthscale_prior=GammaPrior(3, 1), num_samples=5), outputscale_prior=HalfCauchyPrior(scale=1))):
+        camp = Campaign(space, NumericalTarget("yield").to_objective(), R(surrogate_model=S(kernel_or_factory=kernel)))
+        camp.add_measurements(_measure(space.discrete.exp_rep.iloc[rng.choice(125, 8, replace=False)], rng))
+        for _ in range(2):
+            rec = camp.recommend(2)
+            assert len(rec) == 2
+            camp.add_measurements(_measure(rec, rng))
+            spec = camp.recommender._surrogate_model.engine.spec
+            assert spec.kernel == "rff" and spec.rff_num_samples == 5 and spec.rff_weights.shape == (3, 5)
+            seen.append(spec.rff_weights.copy())
+        assert spec.use_outputscale == (type(kernel).__name__ == "ScaleKernel")
+    assert not any(np.array_equal(a, b) for i, a in enumerate(seen) for b in seen[:i])  # a new draw per fit
+
+
 # ---- transfer learning, Pareto, batch constraints ------------------------------------------------------------------------------------
 def test_task_parameter_campaign(ref):
     """``TaskParameter`` (parameters/categorical.py:86-91): INT-coded task column, candidates of the active task only; the model
