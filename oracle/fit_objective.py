@@ -230,7 +230,7 @@ def train_covariance(spec, nat: dict, Xn: torch.Tensor) -> torch.Tensor:
             diff = Xp[:, None, :] - Xp[None, :, :]
             return diff.sin().pow(2.0).div(nat["lengthscale" + sfx].reshape(1, 1, -1)).sum(-1).mul(-2.0).exp()
         if kind == "rff":  # gpytorch RFFKernel: z = cat([cos, sin](x @ (randn_weights / lengthscale^T))), K = z z^T / num_samples
-            W = torch.as_tensor(np.asarray(spec.rff_weights, dtype=np.float64))
+            W = torch.as_tensor(np.array(spec.frequencies, dtype=float))
             P = Xa @ (W / nat["lengthscale" + sfx].reshape(-1, 1))
             Z = torch.cat([P.cos(), P.sin()], dim=-1)
             return Z @ Z.T / W.shape[1]

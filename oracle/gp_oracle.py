@@ -136,7 +136,7 @@ class GPSpec:
     active_dims: "np.ndarray | None" = None  # single kernel on a parameter subset (see KernelTerm.active_dims)
     offset: "Hyper | None" = None  # single polynomial kernel: its offset (see KernelTerm.offset)
     period: "Hyper | None" = None  # single periodic kernel: its period lengths (see KernelTerm.period)
-    rff_weights: "np.ndarray | None" = None  # kernel "rff": gpytorch RFFKernel.randn_weights [active columns, num_samples]
+    frequencies: "np.ndarray | None" = None  # kernel "rff": gpytorch RFFKernel.randn_weights [active columns, num_samples]
 
     def period_of(self, m: int | None = None) -> Hyper:
         h = self.period if (m is None or not self.members) else self.members[m].period
@@ -433,7 +433,7 @@ def stationary_part(spec: GPSpec, p: GPParams, A: np.ndarray, B: np.ndarray) -> 
     the elementwise product / sum of the members' Gram matrices (``reduce(mul | add, ...)``, composite.py:75,91)."""
     if not spec.members and spec.kernel == "rff":
         c = spec.dims_of(None)
-        W = np.asarray(spec.rff_weights, dtype=np.float64)
+        W = np.array(spec.frequencies, dtype=float)
         return rff_features(W, A[:, c], p.lengthscale) @ rff_features(W, B[:, c], p.lengthscale).T / W.shape[1]
     if not spec.members:
         c = spec.dims_of(None)

@@ -68,7 +68,7 @@ def oracle_spec(spec):
         member_terms=[int(f.group) for f in spec.factors] if (spec.factors and spec.combine == "grouped") else None,
         active_dims=None if (spec.factors or spec.active_mask(0) is None) else np.nonzero(spec.active_mask(0))[0],
         offset=go.Hyper(0.0, True, spec.alpha_prior, spec.alpha_init), period=go.Hyper(0.0, True, spec.period_prior, spec.period_init),
-        rff_weights=getattr(spec, "rff_weights", None))
+        frequencies=getattr(spec, "rff_weights", None))
 
 
 def oracle_params(spec, p):
