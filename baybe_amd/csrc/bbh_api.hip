@@ -32,6 +32,7 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_FIT_SMALL")) h->fit_small = (e[0] != '0');
   if (const char* e = getenv("BBH_FIT_FLOW")) h->fit_flow = atoi(e);
   if (const char* e = getenv("BBH_FLOW_SPIN")) h->flow_spin_limit = atoi(e);
+  if (const char* e = getenv("BBH_TILE_GRAM")) h->tile_gram = (e[0] != '0');
   if (const char* e = getenv("BBH_POTRF_TILES")) h->potrf_tiles = (e[0] != '0');
   if (const char* e = getenv("BBH_TILE_SPIN")) h->tile_spin_limit = atoi(e);
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;

@@ -334,6 +334,10 @@ struct bbh_handle {
   int flow_spin_limit = 1 << 17;  // env BBH_FLOW_SPIN: polls before a waiting role of the dataflow fit evaluation gives up
   bool skip_x_memset = false;     // bbh_potrf_trtri: leave the upper tiles of L^-1 alone (the caller reads lower tiles only)
   bool flow_in_flight = false;    // the evaluation on the stream is the one-launch form (its flag needs the sentinel check)
+  long long* d_tiledbg = nullptr; // BBH_TILE_STAMPS=1: clock stamps of the Gram-building tile launch
+  int tiledbg_n = 0;
+  bool info_clean = false;        // the Cholesky flag on the device is known to be 0 (the dataflow tail's last role resets it)
+  bool tile_gram = true;          // env BBH_TILE_GRAM=0: fit evaluations launch bbh_gram_kernel before the factorisation instead of building the tiles inside it (A/B)
   int fit_flow = 1;               // env BBH_FIT_FLOW: 0 fit evaluations for 64 < np <= 1024 launch by launch, 1 (default) Gram + factorisation launches, then ONE dataflow launch for K^-1, alpha, value and gradient, 2 the whole evaluation as one dataflow launch
   void* rff_state = nullptr;      // feature-space model of the RFF kernel (bbh_rff.hip), null for every other kernel
   std::vector<double> rff_w_host; // bbh_set_rff_weights: the frequencies [dn, D] the next bbh_set_model with BBH_KERNEL_RFF takes
@@ -403,6 +407,7 @@ void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int
               int64_t strideB, double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 // In-place blocked Cholesky of the np x np matrix K (lower), with X = L^-1; info!=0 on failure.
 void bbh_potrf_trtri(bbh_handle* h);
+bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const double* theta_host);  // theta_any null: theta_host travels as kernel arguments  // Gram tiles built inside the tile-dataflow launch (fit evaluations); false: not available, nothing enqueued
 void bbh_potrf_tiles_mark_unusable(int device);  // a tile-dataflow launch gave up: per-step launches from now on, process-wide
 void bbh_ensure_side_stream(bbh_handle* h);  // creates the fit's second stream and its events (not during a capture)
 void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,
@@ -434,7 +439,7 @@ int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count);  // host do
 void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
 void bbh_nehvi_destroy(bbh_handle* h);   // bbh_nehvi.hip
 void bbh_flow_destroy(bbh_handle* h);    // bbh_fitflow.hip
-bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only);  // 64 < np <= 1024: the whole evaluation as one dataflow launch, or (tail_only) everything after the factorisation; false: not eligible
+bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host = nullptr);  // 64 < np <= 1024: the whole evaluation as one dataflow launch, or (tail_only) everything after the factorisation; false: not eligible
 bool bbh_fit_flow_eligible(bbh_handle* h);
 void bbh_fit_flow_reset(bbh_handle* h);  // after a launch that gave up: clean state, the handle stops using the form
 void bbh_free_model_public(bbh_handle* h);

@@ -39,7 +39,8 @@ struct FlowArgs {
   const int* task;      // [np]
   const double* nmask;  // [np]
   const double* ystd;   // [np]
-  const double* theta;  // host-mapped [tl]
+  const double* theta;  // [tl] device or host-mapped; null: thv
+  double thv[PD_GRAM_MAXTHV];  // theta as kernel arguments
   int n, np, nbk, dn, T, tl, criterion;
   bbh_kern_spec ks;
   double* A;      // [np][np] L tiles (lower)
@@ -781,7 +782,7 @@ __device__ __forceinline__ void ff_kernel_body(const FlowArgs& fa) {
   tile_t al = (tile_t)(s_ff + 3 * 64 * PD_LD);
   __shared__ FlowShared sh;
   const int t = threadIdx.x;
-  if (t < fa.tl) sh.th[t] = fa.theta[t];
+  if (t < fa.tl) sh.th[t] = fa.theta ? fa.theta[t] : fa.thv[t < PD_GRAM_MAXTHV ? t : 0];
   __syncthreads();
   if (t < fa.dn) sh.invls[t] = 1.0 / sh.th[3 + t];
   __syncthreads();
@@ -859,7 +860,7 @@ bool bbh_fit_flow_eligible(bbh_handle* h) {
 }
 
 // true: the evaluation is on the stream (theta_dev / out_dev / info_dev are the device views of the pinned staging buffers)
-bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only) {
+bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host) {
   const int64_t np = h->np;
   const int nbk = (int)(np / 64);
   const int64_t tl = bbh_theta_len(h);
@@ -932,6 +933,10 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   fa.nmask = h->d_nmask;
   fa.ystd = h->d_ystd;
   fa.theta = theta_dev;
+  if (!theta_dev) {
+    if (!theta_host || tl > PD_GRAM_MAXTHV) return false;
+    for (int64_t k = 0; k < tl; k++) fa.thv[k] = theta_host[k];
+  }
   fa.n = (int)h->n;
   fa.np = (int)np;
   fa.nbk = nbk;

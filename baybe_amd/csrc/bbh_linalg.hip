@@ -229,8 +229,17 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
 __device__ int pd_spin_limit;  // polls before a waiting workgroup gives up (set per launch)
 __device__ __forceinline__ bool pd_wait(const int* flag, int epoch, int* info) { return pd_wait_n(flag, epoch, info, pd_spin_limit); }
 
+// GRAM: the tiles of K + s2 M are produced here from the training inputs (fit evaluations, pd_gram_tile) instead of being read from A.
+template <bool GRAM>
 __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t lda, int nbk, double* D, double* X, int64_t ldx,
-                                                              int* flagsL, int* flagsX, int epoch, int* info) {
+                                                              int* flagsL, int* flagsX, int epoch, int* info, const pd_gram_src gs) {
+  __shared__ pd_gram_lds gl;
+  auto stamp = [&](int k) {
+    if (GRAM && gs.dbg && threadIdx.x == 0) gs.dbg[8 * blockIdx.x + k] = wall_clock64();
+  };
+  stamp(0);
+  if (GRAM) pd_gram_init(gl, gs);
+  stamp(1);
   extern __shared__ __attribute__((aligned(16))) double s_tiles[];
   double(*a)[PD_LD] = (double(*)[PD_LD])s_tiles;
   double(*b)[PD_LD] = (double(*)[PD_LD])(s_tiles + 64 * PD_LD);
@@ -244,8 +253,25 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
     const int I = id;
     double* Aii = A + (int64_t)(I * 64) * lda + I * 64;
     double* Ail = Aii - 64;
-    pd_load_tile(a, Aii, lda);
-    if (I > 0) pd_load_tile(al, Ail, lda);
+    if (GRAM) {
+      pd_gram_stage((double*)b, gs, I);
+      if (I > 0) pd_gram_stage((double*)c, gs, I - 1);
+      pd_gram_meta(gl, gs, I, I);
+      __syncthreads();
+      stamp(2);
+      pd_gram_tile(a, (const double*)b, (const double*)b, I, I, gs, gl);
+      stamp(3);
+      if (I > 0) {
+        __syncthreads();
+        pd_gram_meta(gl, gs, I, I - 1);
+        __syncthreads();
+        pd_gram_tile(al, (const double*)b, (const double*)c, I, I - 1, gs, gl);
+      }
+      stamp(4);
+    } else {
+      pd_load_tile(a, Aii, lda);
+      if (I > 0) pd_load_tile(al, Ail, lda);
+    }
     __syncthreads();
     for (int J = 0; J + 1 < I; J++) {
       if (!pd_wait(&flagsL[I * nbk + J], epoch, info) || !pd_wait(&flagsL[(I - 1) * nbk + J], epoch, info)) return;
@@ -266,9 +292,11 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       pd_gemm64<true, true, PD_OUT_LOWER>(a, c, c, -1.0);
       __syncthreads();
     }
+    stamp(5);
     pd_factor_block4(a, b, al, (int64_t)I * 64, info, I > 0 ? &flagsL[I * nbk + (I - 1)] : nullptr, epoch);
     pd_store_tile(D + (int64_t)I * 4096, 64, b, 1.0);
     pd_publish(&flagsL[I * nbk + I], epoch);  // D_I first: the next row head waits for it
+    stamp(6);
     pd_store_tile(Aii, lda, a, 1.0);
     pd_store_tile(X + (int64_t)(I * 64) * ldx + I * 64, ldx, b, 1.0);
     return;
@@ -279,7 +307,17 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
     while ((I - 1) * I / 2 <= id) I++;   // tiles of the rows 2 .. I-1 number (I-1)(I-2)/2
     const int K = id - (I - 1) * (I - 2) / 2;
     double* Aik = A + (int64_t)(I * 64) * lda + K * 64;
-    pd_load_tile(a, Aik, lda);
+    if (GRAM) {
+      pd_gram_stage((double*)b, gs, I);
+      pd_gram_stage((double*)c, gs, K);
+      pd_gram_meta(gl, gs, I, K);
+      __syncthreads();
+      stamp(2);
+      pd_gram_tile(a, (const double*)b, (const double*)c, I, K, gs, gl);
+      stamp(3);
+    } else {
+      pd_load_tile(a, Aik, lda);
+    }
     __syncthreads();
     for (int J = 0; J < K; J++) {
       if (!pd_wait(&flagsL[I * nbk + J], epoch, info) || !pd_wait(&flagsL[K * nbk + J], epoch, info)) return;
@@ -340,7 +378,11 @@ void bbh_ensure_side_stream(bbh_handle* h) {
 static bool g_tiles_unusable[64];
 void bbh_potrf_tiles_mark_unusable(int device) { g_tiles_unusable[device & 63] = true; }
 
-static bool bbh_potrf_tiles(bbh_handle* h) {
+// gram_theta != nullptr: the kernel builds the tiles of K + s2 M itself (single-kernel models, bbh_fit_flow_eligible) from theta at
+// that (device or host-mapped) address - the fit evaluation's form, which needs no Gram launch before it.
+static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, const double* gram_theta_host = nullptr) {
+  const bool info_clean = (gram_theta || gram_theta_host) && h->info_clean;
+  h->info_clean = false;  // (whatever runs next may leave a failure flag behind; only a finished dataflow tail re-establishes it)
   const int64_t np = h->np;
   const int nbk = (int)(np / 64);
   if (!h->potrf_tiles || nbk > 16 || g_tiles_unusable[h->device & 63]) return false;
@@ -353,8 +395,9 @@ static bool bbh_potrf_tiles(bbh_handle* h) {
   static const size_t lds = sizeof(double) * 4 * 64 * PD_LD;  // 135 KB: one workgroup per CU
   if (!h->tiles_ready) {
     int per_cu = 0;
-    if (hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bbh_potrf_tiles_kernel, 256, lds) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bbh_potrf_tiles_kernel<true>, 256, lds) != hipSuccess ||
         hipMalloc((void**)&h->d_tileflags, sizeof(int) * 2 * 16 * 16) != hipSuccess ||
         hipMemset(h->d_tileflags, 0, sizeof(int) * 2 * 16 * 16) != hipSuccess) {
       (void)hipGetLastError();
@@ -375,10 +418,36 @@ static bool bbh_potrf_tiles(bbh_handle* h) {
   }
   hipStream_t s = h->stream;
   if (!h->skip_x_memset) hipMemsetAsync(h->d_X, 0, sizeof(double) * np * np, s);  // the upper tiles of L^-1 (XᵀX reads the full matrix)
-  hipMemsetAsync(h->d_info, 0, sizeof(int), s);
+  // (fit evaluations through the dataflow tail: its last role leaves the flag at 0 for the next evaluation - no memset between them)
+  if (!info_clean) hipMemsetAsync(h->d_info, 0, sizeof(int), s);
   const int epoch = ++h->tile_epoch;
-  hipLaunchKernelGGL(bbh_potrf_tiles_kernel, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np,
-                     h->d_tileflags, h->d_tileflags + 256, epoch, h->d_info);
+  pd_gram_src gs{};
+  if (gram_theta || gram_theta_host) {
+    const bbh_kern_spec ks = bbh_kern_spec_of(h);
+    gs.xnT = h->d_xnT;
+    gs.task = h->d_task;
+    gs.nmask = h->d_nmask;
+    gs.theta = gram_theta;
+    if (!gram_theta)
+      for (int64_t k = 0; k < bbh_theta_len(h) && k < PD_GRAM_MAXTHV; k++) gs.thv[k] = gram_theta_host[k];
+    gs.n = (int)h->n;
+    gs.np = (int)np;
+    gs.dn = h->dn;
+    gs.T = h->T;
+    gs.tl = (int)bbh_theta_len(h);
+    gs.kind = ks.kind[0];
+    gs.use_os = ks.use_os;
+    gs.jb = ks.jb;
+    gs.alpha_off = ks.alpha_off;
+    if (getenv("BBH_TILE_STAMPS") && !h->d_tiledbg && hipMalloc((void**)&h->d_tiledbg, sizeof(long long) * 8 * 512) != hipSuccess) h->d_tiledbg = nullptr;
+    gs.dbg = h->d_tiledbg;
+    h->tiledbg_n = ntiles;
+    hipLaunchKernelGGL(bbh_potrf_tiles_kernel<true>, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                       h->d_tileflags + 256, epoch, h->d_info, gs);
+  } else {
+    hipLaunchKernelGGL(bbh_potrf_tiles_kernel<false>, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                       h->d_tileflags + 256, epoch, h->d_info, gs);
+  }
   return true;
 }
 
@@ -587,6 +656,25 @@ bool bbh_fit_small_launch(bbh_handle* h, double jitter, const double* theta_dev,
   hipLaunchKernelGGL(bbh_fit_small_kernel, dim3(1), dim3(256), lds, h->stream, h->d_xnT, h->d_ystd, h->d_nmask, theta_dev, (int)h->n,
                      h->dn, bbh_kern_spec_of(h), jitter, (int)bbh_theta_len(h), out_dev, info_dev);
   return true;
+}
+
+// Fit evaluations of the models bbh_fit_flow_eligible admits: Gram tiles + factor + inverse in the one tile-dataflow launch (theta read
+// at theta_any: device or host-mapped).  false: that launch is not available here - nothing was enqueued.
+bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const double* theta_host) {
+  if (!theta_any && (!theta_host || bbh_theta_len(h) > PD_GRAM_MAXTHV)) return false;
+  if (h->dn > PD_GRAM_MAXD || bbh_theta_len(h) > PD_GRAM_MAXTH || h->F > 1 || h->hadamard || h->desc.kernel_kind == BBH_KERNEL_PERIODIC ||
+      h->desc.kernel_kind == BBH_KERNEL_RFF)
+    return false;
+  return bbh_potrf_tiles(h, theta_any, theta_any ? nullptr : theta_host);
+}
+
+// BBH_TILE_STAMPS=1: clock stamps [tiles][8] of the last Gram-building tile launch (0 entry, 1 theta in LDS, 2 inputs staged, 3 / 4 first /
+// second Gram tile done, 5 factorisation starts, 6 D published); returns the number of tiles
+extern "C" int bbh_tiles_trace_read(bbh_handle* h, long long* stamps_host, int cap) {
+  if (!h || !h->d_tiledbg || !stamps_host || cap < h->tiledbg_n) return -1;
+  hipStreamSynchronize(h->stream);
+  hipMemcpy(stamps_host, h->d_tiledbg, sizeof(long long) * 8 * h->tiledbg_n, hipMemcpyDeviceToHost);
+  return h->tiledbg_n;
 }
 
 void bbh_potrf_trtri(bbh_handle* h) {

@@ -589,6 +589,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   h->p = 0;
   h->pend_host.clear();
   h->factorized = false;
+  h->info_clean = false;  // (d_info may be a fresh allocation)
   if (desc->kernel_kind == BBH_KERNEL_RFF) {
     int rc = bbh_rff_setup(h);
     if (rc) return rc;
@@ -655,6 +656,34 @@ static int bbh_fit_enqueue(bbh_handle* h) {
       if (bbh_fit_flow_launch(h, (const double*)th_dev, (double*)out_dev, (int*)info_dev, false)) {
         h->flow_in_flight = true;
         return 0;
+      }
+    }
+    (void)hipGetLastError();
+  }
+  {  // default for 64 < np <= 1024, zero copies: the tile-dataflow factorisation builds its Gram tiles itself, the dataflow tail reads the
+     // factor - theta from, results into the host-mapped staging buffers (two launches)
+    void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
+    if (h->fit_flow == 1 && h->tile_gram && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
+        hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess && hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
+      // (theta through one H2D copy, not read from the host-mapped buffer by every workgroup: ~100 workgroups fetching it over the
+      // host link at the same moment took 30 us - profiles/r05_tile_gram.log)
+      // theta travels as kernel arguments of the two launches (<= 49 doubles): no copy in the stream, and no workgroup reads it from
+      // the host-mapped buffer (BBH_TILE_GRAM_THETA=copy: one H2D copy and device reads, the A/B form)
+      const char* th_env = getenv("BBH_TILE_GRAM_THETA");
+      const bool by_value = !(th_env && th_env[0] == 'c') && tl <= 52;
+      const double* th_src = by_value ? nullptr : h->d_theta;
+      if (!by_value) BBH_HIP_TRY(h, hipMemcpyAsync(h->d_theta, h->pin_theta, sizeof(double) * tl, hipMemcpyHostToDevice, s));
+      h->skip_x_memset = true;
+      const bool tiles = bbh_potrf_trtri_from_inputs(h, th_src, h->pin_theta);
+      h->skip_x_memset = false;
+      (void)th_dev;
+      if (tiles) {
+        *h->pin_info = -99;
+        if (bbh_fit_flow_launch(h, th_src, (double*)out_dev, (int*)info_dev, true, h->pin_theta)) {
+          h->flow_in_flight = true;
+          return 0;
+        }
+        (void)hipGetLastError();  // (the tail is unavailable: the evaluation starts over below, launch by launch)
       }
     }
     (void)hipGetLastError();
@@ -793,6 +822,7 @@ extern "C" int bbh_fit_value_grad(bbh_handle* h, const double* theta_host, doubl
   }
   if (h->flow_in_flight) {
     h->flow_in_flight = false;
+    h->info_clean = *h->pin_info != -99;  // (the tail's last role copied the Cholesky flag out and reset it)
     if (*h->pin_info == -99) {  // the dataflow launch never reported: one of its waits ran out of polls - launch path from now on
       // (a reported -7 is the tile-dataflow FACTORISATION in front of it giving up: handled below, the dataflow tail stays in use)
       if (getenv("BBH_TILE_TRACE")) fprintf(stderr, "bbh_fit_value_grad: one-launch evaluation gave up (np = %lld, flag %d)\n", (long long)h->np, *h->pin_info);

@@ -302,6 +302,8 @@ __global__ __launch_bounds__(256) void bbh_rff_value_kernel(const double* __rest
   if (t < dn) out[1 + RFF_TH_LS + t] = gl[t];
 }
 
+static int rff_posterior_lds_attr(bbh_handle* h, int Dh);  // (defined with the kernel)
+
 // ---- set-up / fit / factorise ------------------------------------------------------------------------------------------------
 int bbh_rff_setup(bbh_handle* h) {
   if (h->T != 1 || h->F != 1 || h->desc.criterion != BBH_CRITERION_MLL || h->desc.task_col >= 0) {
@@ -354,12 +356,9 @@ int bbh_rff_setup(bbh_handle* h) {
   BBH_HIP_TRY(h, hipMemcpy(st->d_W, Wp.data(), sizeof(double) * Wp.size(), hipMemcpyHostToDevice));
   BBH_HIP_TRY(h, hipMemcpy(st->d_lo, lo3.data(), sizeof(double) * lo3.size(), hipMemcpyHostToDevice));
   BBH_HIP_TRY(h, hipMemset(st->d_E, 0, sizeof(double) * mp * 16));
-  static bool attr_set = false;
-  if (!attr_set) {
-    BBH_HIP_TRY(h, hipFuncSetAttribute((const void*)bbh_rff_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 4 * 64 * PD_LD)));
-    attr_set = true;
-  }
-  return 0;
+  // (per device and cheap: set whenever a model is set up, not once per process)
+  BBH_HIP_TRY(h, hipFuncSetAttribute((const void*)bbh_rff_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 4 * 64 * PD_LD)));
+  return rff_posterior_lds_attr(h, st->Dh);
 }
 
 __global__ void bbh_rff_resid_kernel(const double* __restrict__ ystd, const double* __restrict__ theta, int n, int64_t nr, double* __restrict__ r) {
@@ -552,6 +551,13 @@ __global__ __launch_bounds__(DH == 64 ? 256 : 512) __attribute__((amdgpu_waves_p
   }
 }
 
+static int rff_posterior_lds_attr(bbh_handle* h, int Dh) {
+  const void* fn = Dh == 64 ? (const void*)bbh_rff_posterior_kernel<64> : (const void*)bbh_rff_posterior_kernel<32>;
+  BBH_HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(sizeof(double) * ((size_t)rff_qp_elems(Dh / 8) + 2 * Dh * 16 + RFF_MAXDN * (Dh + 3)))));
+  return 0;
+}
+
 static size_t rff_post_lds(int Dh, int dn) { return sizeof(double) * ((size_t)rff_qp_elems(Dh / 8) + (size_t)2 * Dh * 16 + (size_t)dn * Dh + 3 * (size_t)dn); }
 
 int bbh_rff_posterior_launch(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev, double* cross_dev) {
@@ -579,13 +585,7 @@ int bbh_rff_posterior_launch(bbh_handle* h, const double* X_dev, int64_t N, int6
   a.ysd = h->ysd;
   a.cmean = h->theta[RFF_TH_MEAN];
   const size_t lds = rff_post_lds(st->Dh, st->dn);
-  static bool attr_set[2] = {false, false};
   const int which = st->Dh == 64 ? 1 : 0;
-  if (!attr_set[which]) {
-    const void* fn = which ? (const void*)bbh_rff_posterior_kernel<64> : (const void*)bbh_rff_posterior_kernel<32>;
-    BBH_HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)rff_qp_elems(st->Dh / 8) + 2 * st->Dh * 16 + RFF_MAXDN * (st->Dh + 3)))));
-    attr_set[which] = true;
-  }
   const int threads = which ? 256 : 512, cpw = threads / 2;
   const int64_t tiles = (N + cpw - 1) / cpw;
   const unsigned grid = (unsigned)(tiles < h->num_cu ? tiles : h->num_cu);

@@ -351,6 +351,128 @@ __device__ __forceinline__ void pd_factor_block4(double (*a)[PD_LD], double (*x)
   __syncthreads();  // B7
 }
 
+// ---- Gram tiles produced inside the factorisation's workgroups (fit evaluations: no Gram launch, no HBM round trip) --------------
+// bbh_kbase, inlined (a call from a loop with many live registers saves them to scratch around it)
+__device__ __forceinline__ double pd_kbase(int kind, double r2, int jb, double alpha) {
+  if (kind == BBH_KERNEL_LINEAR) return r2;
+  if (BBH_KIND_IS_POLY(kind)) return bbh_powi(r2 + alpha, kind - BBH_KERNEL_POLY1 + 1);
+  if (kind == BBH_KERNEL_RBF) return exp(-0.5 * r2);
+  if (kind == BBH_KERNEL_RQ) return exp(-alpha * log1p(r2 / (2.0 * alpha)));
+  if (kind >= BBH_KERNEL_PIECEWISE0 && kind <= BBH_KERNEL_PIECEWISE3) return bbh_piecewise(kind - BBH_KERNEL_PIECEWISE0, jb, r2, false);
+  const double r = sqrt(r2);
+  if (kind == BBH_KERNEL_MATERN52) return (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2) * exp(-BBH_SQRT5 * r);
+  if (kind == BBH_KERNEL_MATERN32) return (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
+  return exp(-r);
+}
+#define PD_GRAM_MAXD 32
+#define PD_GRAM_MAXTH 64
+#define PD_GRAM_MAXTHV 52  // theta entries that travel as kernel arguments (bbh_fit_flow_eligible: <= 49)
+struct pd_gram_src {     // by value; the single-kernel models bbh_fit_flow_eligible admits (one factor, shared noise / mean, <= 4 tasks)
+  const double* xnT;     // [dn][np] normalised training inputs, transposed
+  const int* task;       // [np]
+  const double* nmask;   // [np]
+  const double* theta;   // [tl] (device or host-mapped); null: thv below
+  double thv[PD_GRAM_MAXTHV];  // theta by value (kernel argument: no copy, no load from host memory)
+  int n, np, dn, T, tl, kind, use_os, jb, alpha_off;
+  long long* dbg;        // BBH_TILE_STAMPS=1: [tiles][8] wall_clock64 stamps (bbh_tiles_trace_read); null otherwise
+};
+struct pd_gram_lds {
+  double th[PD_GRAM_MAXTH];
+  double inv[PD_GRAM_MAXD];
+  double nm[64];
+  int tr[64], tc[64];
+};
+// theta -> LDS, once per workgroup
+__device__ __forceinline__ void pd_gram_init(pd_gram_lds& g, const pd_gram_src& gs) {
+  const int t = threadIdx.x;
+  if (t < gs.tl) g.th[t] = gs.theta ? gs.theta[t] : gs.thv[t < PD_GRAM_MAXTHV ? t : 0];
+  __syncthreads();
+  if (t < gs.dn) g.inv[t] = 1.0 / g.th[3 + t];
+  __syncthreads();
+}
+// rows of block I of the transposed inputs -> flat [dn][64]
+__device__ __forceinline__ void pd_gram_stage(double* dst, const pd_gram_src& gs, int I) {
+  for (int e = threadIdx.x; e < gs.dn * 64; e += 256) dst[e] = gs.xnT[(int64_t)(e >> 6) * gs.np + I * 64 + (e & 63)];
+}
+__device__ __forceinline__ void pd_gram_meta(pd_gram_lds& g, const pd_gram_src& gs, int I, int K) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    g.tr[t] = gs.task[I * 64 + t];
+    g.nm[t] = gs.nmask[I * 64 + t];
+  } else if (t < 128) {
+    g.tc[t - 64] = gs.task[K * 64 + (t - 64)];
+  }
+}
+// Tile (I, K) of K + s2 M: out[a][b] = os B[ta][tb] k(r_ab) + noise nmask_a [a == b]; identity on the padding (the arithmetic of
+// bbh_gram_kernel).  xr / xc: the staged inputs of block I / K.  Thread t owns row t >> 2 and the columns (t & 3) + 4 m; four columns
+// are in flight together (four independent distance sums and kernel-function chains: the loop is latency-bound otherwise).
+// KIND: the kernel kind as a compile-time constant for the common ones (-1: any kind, through pd_kbase).  With the kind a run-time
+// value inside the entry loop the compiler evaluates pd_kbase's whole chain of alternatives - exp, log1p, the piecewise polynomials'
+// power loops - around every entry: 22 us per tile (profiles/r05_tile_gram.log), 1.4 us per entry and wave.
+template <int KIND>
+__device__ __forceinline__ void pd_gram_tile_k(double (*out)[PD_LD], const double* xr, const double* xc, int I, int K, const pd_gram_src& gs,
+                                               const pd_gram_lds& g) {
+  const int kind = KIND >= 0 ? KIND : gs.kind, dn = gs.dn;
+  const double os = gs.use_os ? g.th[2] : 1.0;
+  const double kalpha = gs.alpha_off >= 0 ? g.th[gs.alpha_off] : 1.0;
+  const int i = threadIdx.x >> 2, part = threadIdx.x & 3, ga = I * 64 + i;
+  const bool dot = KIND >= 0 ? false : BBH_KIND_IS_DOT(kind);
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    double r2[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* xcq = xc + part + 16 * q;
+    for (int c = 0; c < dn; c++) {
+      const double xa = xr[c * 64 + i], iv = g.inv[c];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double xb = xcq[c * 64 + 4 * u];
+        if (dot) {
+          r2[u] += (xa * iv) * (xb * iv);
+        } else {
+          const double df = (xa - xb) * iv;
+          r2[u] += df * df;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = part + 16 * q + 4 * u, gb = K * 64 + j;
+      double v;
+      if (ga >= gs.n || gb >= gs.n) {
+        v = (ga == gb) ? 1.0 : 0.0;
+      } else {
+        if (KIND == BBH_KERNEL_MATERN52) {
+          const double r = sqrt(r2[u]);
+          v = (1.0 + BBH_SQRT5 * r + (5.0 / 3.0) * r2[u]) * exp(-BBH_SQRT5 * r);
+        } else if (KIND == BBH_KERNEL_MATERN32) {
+          const double r = sqrt(r2[u]);
+          v = (1.0 + BBH_SQRT3 * r) * exp(-BBH_SQRT3 * r);
+        } else if (KIND == BBH_KERNEL_MATERN12) {
+          v = exp(-sqrt(r2[u]));
+        } else if (KIND == BBH_KERNEL_RBF) {
+          v = exp(-0.5 * r2[u]);
+        } else {
+          v = pd_kbase(kind, r2[u], gs.jb, kalpha);
+        }
+        if (gs.use_os) v *= os;
+        if (gs.T > 1) v *= g.th[3 + dn + g.tr[i] * gs.T + g.tc[j]];
+        if (ga == gb) v += g.th[0] * g.nm[i];
+      }
+      out[i][j] = v;
+    }
+  }
+}
+__device__ __forceinline__ void pd_gram_tile(double (*out)[PD_LD], const double* xr, const double* xc, int I, int K, const pd_gram_src& gs,
+                                             const pd_gram_lds& g) {
+  switch (gs.kind) {
+    case BBH_KERNEL_MATERN52: pd_gram_tile_k<BBH_KERNEL_MATERN52>(out, xr, xc, I, K, gs, g); break;
+    case BBH_KERNEL_MATERN32: pd_gram_tile_k<BBH_KERNEL_MATERN32>(out, xr, xc, I, K, gs, g); break;
+    case BBH_KERNEL_MATERN12: pd_gram_tile_k<BBH_KERNEL_MATERN12>(out, xr, xc, I, K, gs, g); break;
+    case BBH_KERNEL_RBF: pd_gram_tile_k<BBH_KERNEL_RBF>(out, xr, xc, I, K, gs, g); break;
+    default: pd_gram_tile_k<-1>(out, xr, xc, I, K, gs, g); break;
+  }
+}
+
 // =====================================================================================================================
 // The whole factorisation L = chol(A), X = L^-1 of an np x np matrix (np <= 1024) in ONE launch: tile dataflow.
 // One workgroup per 64 x 64 tile, all resident at once (<= 256 workgroups, one per CU: 135 KB of LDS each):

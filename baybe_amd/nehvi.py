@@ -98,6 +98,11 @@ class HipNEHVI:
         if not 1 <= len(engines) <= _lib.MAX_OBJECTIVES:
             raise ValueError(f"1..{_lib.MAX_OBJECTIVES} objectives are supported")
         self.m = len(engines)
+        if any(getattr(e.spec, "kernel", None) == "rff" for e in engines):
+            from baybe_amd.exceptions import IncompatibilityError
+
+            # (the extended models condition on noise-free latent rows, which the RFF kernel's uniform-noise feature-space form does not have)
+            raise IncompatibilityError("qLogNEHVI (ParetoObjective) is not available with an RFFKernel surrogate on the HIP path.")
         self.outputs = [_Output(e, HipGP(device), float(s)) for e, s in zip(engines, signs)]
         self.signs = np.asarray(signs, dtype=np.float64)
         self.X_baseline = np.ascontiguousarray(np.atleast_2d(X_baseline), dtype=np.float64)
