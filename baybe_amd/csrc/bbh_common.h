@@ -336,6 +336,8 @@ struct bbh_handle {
   bool flow_in_flight = false;    // the evaluation on the stream is the one-launch form (its flag needs the sentinel check)
   long long* d_tiledbg = nullptr; // BBH_TILE_STAMPS=1: clock stamps of the Gram-building tile launch
   int tiledbg_n = 0;
+  bool tile_d_sc1 = true;         // env BBH_TILE_ACQ=1: row heads take D_{I-1} through an acquire fence + plain loads instead of sc1 loads (A/B)
+  bool tile_wt = true;            // env BBH_TILE_WT=0: tiles handed between workgroups through plain stores + an agent-scope release fence instead of write-through (sc1) stores (A/B)
   bool info_clean = false;        // the Cholesky flag on the device is known to be 0 (the dataflow tail's last role resets it)
   bool tile_gram = true;          // env BBH_TILE_GRAM=0: fit evaluations launch bbh_gram_kernel before the factorisation instead of building the tiles inside it (A/B)
   int fit_flow = 1;               // env BBH_FIT_FLOW: 0 fit evaluations for 64 < np <= 1024 launch by launch, 1 (default) Gram + factorisation launches, then ONE dataflow launch for K^-1, alpha, value and gradient, 2 the whole evaluation as one dataflow launch

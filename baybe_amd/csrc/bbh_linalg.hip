@@ -227,19 +227,34 @@ __global__ __launch_bounds__(256) void bbh_potrf_diag16_kernel(double* A, int64_
 }
 
 __device__ int pd_spin_limit;  // polls before a waiting workgroup gives up (set per launch)
-__device__ __forceinline__ bool pd_wait(const int* flag, int epoch, int* info) { return pd_wait_n(flag, epoch, info, pd_spin_limit); }
+__device__ __forceinline__ bool pd_wait(const int* flag, int epoch, int* info, bool urgent = false, bool acquire = true, long long* polls_out = nullptr) {
+  return pd_wait_n(flag, epoch, info, pd_spin_limit, urgent, acquire, polls_out);
+}
+#define PD_FLAG_STRIDE 32  // ints between two flags: one 128-byte line each (polls of different flags go to different lines / channels)
 
 // GRAM: the tiles of K + s2 M are produced here from the training inputs (fit evaluations, pd_gram_tile) instead of being read from A.
-template <bool GRAM>
+// WT: tiles other workgroups wait for are stored write-through and published without a release fence (pd_publish_wt).
+template <bool GRAM, bool WT>
 __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t lda, int nbk, double* D, double* X, int64_t ldx,
                                                               int* flagsL, int* flagsX, int epoch, int* info, const pd_gram_src gs) {
+  auto store_pub = [&](double* dst, int64_t ld, const double (*src)[PD_LD]) {
+    if (WT)
+      pd_store_tile_wt(dst, ld, src, 1.0);
+    else
+      pd_store_tile(dst, ld, src, 1.0);
+  };
+  auto publish = [&](int* flag) {
+    if (WT)
+      pd_publish_wt(flag, epoch);
+    else
+      pd_publish(flag, epoch);
+  };
   __shared__ pd_gram_lds gl;
   auto stamp = [&](int k) {
     if (GRAM && gs.dbg && threadIdx.x == 0) gs.dbg[8 * blockIdx.x + k] = wall_clock64();
   };
   stamp(0);
   if (GRAM) pd_gram_init(gl, gs);
-  stamp(1);
   extern __shared__ __attribute__((aligned(16))) double s_tiles[];
   double(*a)[PD_LD] = (double(*)[PD_LD])s_tiles;
   double(*b)[PD_LD] = (double(*)[PD_LD])(s_tiles + 64 * PD_LD);
@@ -258,45 +273,59 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       if (I > 0) pd_gram_stage((double*)c, gs, I - 1);
       pd_gram_meta(gl, gs, I, I);
       __syncthreads();
-      stamp(2);
       pd_gram_tile(a, (const double*)b, (const double*)b, I, I, gs, gl);
-      stamp(3);
       if (I > 0) {
         __syncthreads();
         pd_gram_meta(gl, gs, I, I - 1);
         __syncthreads();
         pd_gram_tile(al, (const double*)b, (const double*)c, I, I - 1, gs, gl);
       }
-      stamp(4);
     } else {
       pd_load_tile(a, Aii, lda);
       if (I > 0) pd_load_tile(al, Ail, lda);
     }
     __syncthreads();
+    stamp(1);
     for (int J = 0; J + 1 < I; J++) {
-      if (!pd_wait(&flagsL[I * nbk + J], epoch, info) || !pd_wait(&flagsL[(I - 1) * nbk + J], epoch, info)) return;
+      // L_{I,J} (an L-tile's product, early) first and the diagonal tile's update with it; then L_{I-1,J} - for J = I - 2 the tile the
+      // previous row head publishes last - and the left neighbour's update.  (Waiting for both before either update put one product
+      // and one tile load behind the later flag: the row heads reached their D wait 3.7 us after D had been published.)
+      if (!pd_wait(&flagsL[(I * nbk + J) * PD_FLAG_STRIDE], epoch, info)) return;
       pd_load_tile(b, A + (int64_t)(I * 64) * lda + J * 64, lda);
-      pd_load_tile(c, A + (int64_t)((I - 1) * 64) * lda + J * 64, lda);
       __syncthreads();
       pd_gemm64<true, true, PD_OUT_LOWER>(a, b, b, -1.0);
+      if (!pd_wait(&flagsL[((I - 1) * nbk + J) * PD_FLAG_STRIDE], epoch, info)) return;
+      pd_load_tile(c, A + (int64_t)((I - 1) * 64) * lda + J * 64, lda);
+      __syncthreads();
       pd_gemm64<true, true, PD_FULL>(al, b, c, -1.0);
       __syncthreads();
     }
     if (I > 0) {
-      if (!pd_wait(&flagsL[(I - 1) * nbk + (I - 1)], epoch, info)) return;
-      pd_load_tile(b, D + (int64_t)(I - 1) * 4096, 64);
+      // (write-through form: D_{I-1} through sc1 loads, no acquire fence on this critical hand-off; BBH_TILE_ACQ=1 keeps the fence)
+      const bool noacq = WT && gs.d_sc1 != 0;
+      if (!pd_wait(&flagsL[((I - 1) * nbk + (I - 1)) * PD_FLAG_STRIDE], epoch, info, true, !noacq, (GRAM && gs.dbg) ? &gs.dbg[8 * blockIdx.x + 1] : nullptr)) return;
+      stamp(2);
+      if (noacq)
+        pd_load_tile_sc1(b, D + (int64_t)(I - 1) * 4096);
+      else
+        pd_load_tile(b, D + (int64_t)(I - 1) * 4096, 64);
       __syncthreads();
+      stamp(3);
       pd_gemm64<true, false, PD_B_LOWER>(c, al, b, 1.0);  // L_{I,I-1} = A_{I,I-1} D_{I-1}^T
       __syncthreads();
-      pd_store_tile(Ail, lda, c, 1.0);        // (published from inside the factorisation, once the stores have landed)
+      stamp(4);
+      store_pub(Ail, lda, c);
       pd_gemm64<true, true, PD_OUT_LOWER>(a, c, c, -1.0);
-      __syncthreads();
+      // L_{I,I-1} is published HERE, before the factorisation (its stores were issued a product ago): the next row head's last update
+      // waits for it, and from inside the factorisation it came 3 us later than it had to
+      publish(&flagsL[(I * nbk + (I - 1)) * PD_FLAG_STRIDE]);  // (contains the barrier the product needs)
     }
     stamp(5);
-    pd_factor_block4(a, b, al, (int64_t)I * 64, info, I > 0 ? &flagsL[I * nbk + (I - 1)] : nullptr, epoch);
-    pd_store_tile(D + (int64_t)I * 4096, 64, b, 1.0);
-    pd_publish(&flagsL[I * nbk + I], epoch);  // D_I first: the next row head waits for it
+    pd_factor_block4(a, b, al, (int64_t)I * 64, info, nullptr, epoch, WT);
     stamp(6);
+    store_pub(D + (int64_t)I * 4096, 64, b);
+    publish(&flagsL[(I * nbk + I) * PD_FLAG_STRIDE]);  // D_I first: the next row head waits for it
+    stamp(7);
     pd_store_tile(Aii, lda, a, 1.0);
     pd_store_tile(X + (int64_t)(I * 64) * ldx + I * 64, ldx, b, 1.0);
     return;
@@ -312,28 +341,26 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       pd_gram_stage((double*)c, gs, K);
       pd_gram_meta(gl, gs, I, K);
       __syncthreads();
-      stamp(2);
       pd_gram_tile(a, (const double*)b, (const double*)c, I, K, gs, gl);
-      stamp(3);
     } else {
       pd_load_tile(a, Aik, lda);
     }
     __syncthreads();
     for (int J = 0; J < K; J++) {
-      if (!pd_wait(&flagsL[I * nbk + J], epoch, info) || !pd_wait(&flagsL[K * nbk + J], epoch, info)) return;
+      if (!pd_wait(&flagsL[(I * nbk + J) * PD_FLAG_STRIDE], epoch, info) || !pd_wait(&flagsL[(K * nbk + J) * PD_FLAG_STRIDE], epoch, info)) return;
       pd_load_tile(b, A + (int64_t)(I * 64) * lda + J * 64, lda);
       pd_load_tile(c, A + (int64_t)(K * 64) * lda + J * 64, lda);
       __syncthreads();
       pd_gemm64<true, true, PD_FULL>(a, b, c, -1.0);
       __syncthreads();
     }
-    if (!pd_wait(&flagsL[K * nbk + K], epoch, info)) return;
+    if (!pd_wait(&flagsL[(K * nbk + K) * PD_FLAG_STRIDE], epoch, info)) return;
     pd_load_tile(b, D + (int64_t)K * 4096, 64);
     __syncthreads();
     pd_gemm64<true, false, PD_B_LOWER>(c, a, b, 1.0);  // L_IK = A_IK D_K^T
     __syncthreads();
-    pd_store_tile(Aik, lda, c, 1.0);
-    pd_publish(&flagsL[I * nbk + K], epoch);
+    store_pub(Aik, lda, c);
+    publish(&flagsL[(I * nbk + K) * PD_FLAG_STRIDE]);
     return;
   }
   id -= nOther;
@@ -344,8 +371,8 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
   for (int e = threadIdx.x; e < 4096; e += 256) a[e >> 6][e & 63] = 0.0;
   __syncthreads();
   for (int K = J; K < I; K++) {
-    if (!pd_wait(&flagsL[I * nbk + K], epoch, info)) return;
-    if (!pd_wait(K == J ? &flagsL[J * nbk + J] : &flagsX[K * nbk + J], epoch, info)) return;
+    if (!pd_wait(&flagsL[(I * nbk + K) * PD_FLAG_STRIDE], epoch, info)) return;
+    if (!pd_wait(K == J ? &flagsL[(J * nbk + J) * PD_FLAG_STRIDE] : &flagsX[(K * nbk + J) * PD_FLAG_STRIDE], epoch, info)) return;
     pd_load_tile(b, A + (int64_t)(I * 64) * lda + K * 64, lda);
     if (K == J)
       pd_load_tile(c, D + (int64_t)J * 4096, 64);
@@ -355,13 +382,13 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
     pd_gemm64<false, true, PD_FULL>(a, b, c, 1.0);  // acc += L_IK X_KJ
     __syncthreads();
   }
-  if (!pd_wait(&flagsL[I * nbk + I], epoch, info)) return;
+  if (!pd_wait(&flagsL[(I * nbk + I) * PD_FLAG_STRIDE], epoch, info)) return;
   pd_load_tile(b, D + (int64_t)I * 4096, 64);
   __syncthreads();
   pd_gemm64<false, false, PD_A_LOWER>(c, b, a, -1.0);  // X_IJ = -D_I acc
   __syncthreads();
-  pd_store_tile(X + (int64_t)(I * 64) * ldx + J * 64, ldx, c, 1.0);
-  pd_publish(&flagsX[I * nbk + J], epoch);
+  store_pub(X + (int64_t)(I * 64) * ldx + J * 64, ldx, c);
+  publish(&flagsX[(I * nbk + J) * PD_FLAG_STRIDE]);
 }
 
 void bbh_ensure_side_stream(bbh_handle* h) {
@@ -395,11 +422,13 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
   static const size_t lds = sizeof(double) * 4 * 64 * PD_LD;  // 135 KB: one workgroup per CU
   if (!h->tiles_ready) {
     int per_cu = 0;
-    if (hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bbh_potrf_tiles_kernel<true>, 256, lds) != hipSuccess ||
-        hipMalloc((void**)&h->d_tileflags, sizeof(int) * 2 * 16 * 16) != hipSuccess ||
-        hipMemset(h->d_tileflags, 0, sizeof(int) * 2 * 16 * 16) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bbh_potrf_tiles_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bbh_potrf_tiles_kernel<true, true>, 256, lds) != hipSuccess ||
+        hipMalloc((void**)&h->d_tileflags, sizeof(int) * 2 * 16 * 16 * PD_FLAG_STRIDE) != hipSuccess ||
+        hipMemset(h->d_tileflags, 0, sizeof(int) * 2 * 16 * 16 * PD_FLAG_STRIDE) != hipSuccess) {
       (void)hipGetLastError();
       h->potrf_tiles = false;
       return false;
@@ -422,6 +451,7 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
   if (!info_clean) hipMemsetAsync(h->d_info, 0, sizeof(int), s);
   const int epoch = ++h->tile_epoch;
   pd_gram_src gs{};
+  gs.d_sc1 = (h->tile_wt && h->tile_d_sc1) ? 1 : 0;
   if (gram_theta || gram_theta_host) {
     const bbh_kern_spec ks = bbh_kern_spec_of(h);
     gs.xnT = h->d_xnT;
@@ -442,11 +472,18 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
     if (getenv("BBH_TILE_STAMPS") && !h->d_tiledbg && hipMalloc((void**)&h->d_tiledbg, sizeof(long long) * 8 * 512) != hipSuccess) h->d_tiledbg = nullptr;
     gs.dbg = h->d_tiledbg;
     h->tiledbg_n = ntiles;
-    hipLaunchKernelGGL(bbh_potrf_tiles_kernel<true>, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
-                       h->d_tileflags + 256, epoch, h->d_info, gs);
+    if (h->tile_wt)
+      hipLaunchKernelGGL((bbh_potrf_tiles_kernel<true, true>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                         h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
+    else
+      hipLaunchKernelGGL((bbh_potrf_tiles_kernel<true, false>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                         h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
+  } else if (h->tile_wt) {
+    hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, true>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                       h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
   } else {
-    hipLaunchKernelGGL(bbh_potrf_tiles_kernel<false>, dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
-                       h->d_tileflags + 256, epoch, h->d_info, gs);
+    hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, false>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                       h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
   }
   return true;
 }
@@ -668,8 +705,8 @@ bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const d
   return bbh_potrf_tiles(h, theta_any, theta_any ? nullptr : theta_host);
 }
 
-// BBH_TILE_STAMPS=1: clock stamps [tiles][8] of the last Gram-building tile launch (0 entry, 1 theta in LDS, 2 inputs staged, 3 / 4 first /
-// second Gram tile done, 5 factorisation starts, 6 D published); returns the number of tiles
+// BBH_TILE_STAMPS=1: clock stamps [tiles][8] of the row heads of the last Gram-building tile launch (0 entry, 1 own tiles ready, 2 D_{I-1}'s flag
+// seen, 3 D_{I-1} in LDS, 4 panel product done, 5 factorisation starts, 6 ends, 7 D_I published); returns the number of tiles
 extern "C" int bbh_tiles_trace_read(bbh_handle* h, long long* stamps_host, int cap) {
   if (!h || !h->d_tiledbg || !stamps_host || cap < h->tiledbg_n) return -1;
   hipStreamSynchronize(h->stream);

@@ -252,8 +252,10 @@ __device__ __forceinline__ void pd_diag16(double (*a)[PD_LD], double (*x)[PD_LD]
   }
 }
 
+// early_flag: a tile stored before the call is published from inside (its stores have landed by then); early_wt: it was stored
+// write-through (pd_store_tile_wt) - drain + flag, no release fence
 __device__ __forceinline__ void pd_factor_block4(double (*a)[PD_LD], double (*x)[PD_LD], double (*s)[PD_LD], int64_t row0, int* info,
-                                                 int* early_flag = nullptr, int epoch = 0) {
+                                                 int* early_flag = nullptr, int epoch = 0, bool early_wt = false) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   auto panel = [&](int ib, int jb) {  // L_ib,jb = A_ib,jb T_jb^T (in place)
     const d4 c = pd_mul_nt(a, 16 * ib, 16 * jb, x, 16 * jb, 16 * jb, l);
@@ -306,10 +308,18 @@ __device__ __forceinline__ void pd_factor_block4(double (*a)[PD_LD], double (*x)
     pprod(1, 0);
   }
   // (tile-dataflow caller: stores issued before this call have landed by now - publish them without a stall)
-  if (early_flag) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (early_flag) {
+    if (early_wt)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
   __syncthreads();  // B2
   if (early_flag && t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!early_wt) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind buffer_wbl2: cdna guide, Guideline 16 pitfall 12)
+    }
     __hip_atomic_store(early_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- stage 1 ----
@@ -374,6 +384,7 @@ struct pd_gram_src {     // by value; the single-kernel models bbh_fit_flow_elig
   const double* theta;   // [tl] (device or host-mapped); null: thv below
   double thv[PD_GRAM_MAXTHV];  // theta by value (kernel argument: no copy, no load from host memory)
   int n, np, dn, T, tl, kind, use_os, jb, alpha_off;
+  int d_sc1;             // row heads read D_{I-1} with sc1 loads and skip the acquire fence (write-through launches; set outside the Gram form too)
   long long* dbg;        // BBH_TILE_STAMPS=1: [tiles][8] wall_clock64 stamps (bbh_tiles_trace_read); null otherwise
 };
 struct pd_gram_lds {
@@ -486,7 +497,10 @@ __device__ __forceinline__ void pd_gram_tile(double (*out)[PD_LD], const double*
 // (*info = -7) instead of hanging and the caller falls back to the launch-per-step path.  The dependency chain is
 // nbk x (factor + one 64^3 panel product + one 64^3 update) inside one kernel instead of 8 x 3 dependent launches.
 // =====================================================================================================================
-__device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info, int spin_limit) {
+// (urgent: unused - backing off the pollers whose flag is not about to flip (0.4 us between polls) was measured: the delays add up along
+// the off-critical chains until they are critical, 484 -> 712 us at n = 1024; profiles/r05_tile_gram.log)
+__device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info, int spin_limit, bool urgent = false, bool acquire = true,
+                                          long long* polls_out = nullptr) {
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
     int ok = 1, it = 0;
@@ -494,21 +508,30 @@ __device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info,
     // waiting workgroup of a launch polling (130 of them in the one-launch fit evaluation) those invalidations slowed the
     // critical path's own tile loads and write-backs - hand-offs took up to 19 us instead of 2 (profiles/r05_flow_trace_*).
     // The acquire side is the fence every thread executes after the flag has flipped.
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+    const bool rmw = (spin_limit & (1 << 30)) != 0;  // (experiment, BBH_TILE_POLL=rmw: polls as device-scope atomics)
+    spin_limit &= ~(1 << 30);
+    while ((rmw ? __hip_atomic_fetch_or(const_cast<int*>(flag), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                : __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != epoch) {
       if (++it > spin_limit || ((it & 15) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == -7)) {
         __hip_atomic_store(info, -7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
       }
-      if (it < 64)
+      if (urgent) {
+        // (the one waiter on the critical path: no sleep between polls)
+      } else if (it < 64) {
         __builtin_amdgcn_s_sleep(1);
-      else
+      } else {
         __builtin_amdgcn_s_sleep(4);
+      }
     }
     // acquire: ONE agent-scope fence per workgroup (buffer_inv of the CU's L1 and the XCD's L2 - caches the four waves share); every
     // thread executing it meant four invalidations per workgroup and wait, and with 144 workgroups released by one flag the loads
     // behind them took 13 us (profiles/r05_flow_tail_trace.log)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (acquire = false: the caller reads the payload with sc1 loads, which do not look at this CU's L1 - valid when the producer stored it
+    // write-through, cdna guide Guideline 16; saves the 1.7 us of buffer_inv on a critical hand-off)
+    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (polls_out) *polls_out = it;
     s_ok = ok;
   }
   __syncthreads();  // (workgroup-scope ordering: the other waves' loads follow the fence)
@@ -522,8 +545,18 @@ __device__ __forceinline__ void pd_publish(int* flag, int epoch) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (restated where the compiler cannot drop it: cdna guide, Guideline 16 pitfall 12)
     __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+// The write-through form (cdna guide, Guideline 16 R1): a payload stored with sc1 stores (pd_store_tile_wt) leaves the XCD's L2 as it is
+// written, so publishing it needs no release fence (buffer_wbl2 writes back every dirty line of the L2: 1.7 us clean, 6.5 us with a
+// fresh 32 KB tile) - every storing wave drains its stores, one lane stores the flag.  Consumers are unchanged (pd_wait_n: relaxed
+// poll, one agent acquire, plain loads).
+__device__ __forceinline__ void pd_publish_wt(int* flag, int epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (16-byte accesses: tile rows start 16-byte aligned in global memory - ld is a multiple of 64 - and in LDS, pitch 528 B)
 typedef double pd_d2 __attribute__((ext_vector_type(2)));
@@ -532,12 +565,32 @@ __device__ __forceinline__ void pd_load_tile(double (*dst)[PD_LD], const double*
   for (int e = threadIdx.x; e < 2048; e += 256)
     *(pd_d2*)&dst[e >> 5][2 * (e & 31)] = *(const pd_d2*)(src + (int64_t)(e >> 5) * ld + 2 * (e & 31));
 }
+// a contiguous 64 x 64 tile (ld = 64) through sc1 loads: past this CU's L1, so no acquire fence is needed for a tile its producer stored
+// write-through.  src must be wave-uniform (buffer descriptor).
+__device__ __forceinline__ void pd_load_tile_sc1(double (*dst)[PD_LD], const double* src) {
+  typedef unsigned int pd_u4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, 64 * 64 * 8, 0x00020000);
+#pragma unroll
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    const pd_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, e * 16, 0, 16);
+    *(pd_d2*)&dst[e >> 5][2 * (e & 31)] = __builtin_bit_cast(pd_d2, w);
+  }
+}
 __device__ __forceinline__ void pd_store_tile(double* dst, int64_t ld, const double (*src)[PD_LD], double scale) {
 #pragma unroll
   for (int e = threadIdx.x; e < 2048; e += 256) {
     pd_d2 v = *(const pd_d2*)&src[e >> 5][2 * (e & 31)];
     v *= scale;
     *(pd_d2*)(dst + (int64_t)(e >> 5) * ld + 2 * (e & 31)) = v;
+  }
+}
+__device__ __forceinline__ void pd_store_tile_wt(double* dst, int64_t ld, const double (*src)[PD_LD], double scale) {
+#pragma unroll
+  for (int e = threadIdx.x; e < 2048; e += 256) {
+    pd_d2 v = *(const pd_d2*)&src[e >> 5][2 * (e & 31)];
+    v *= scale;
+    double* p = dst + (int64_t)(e >> 5) * ld + 2 * (e & 31);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   }
 }
 // c (+)= sign * a b^T (NT) or a b (NN), 64 x 64 x 64, the 16 output sub-blocks dealt to the four waves.  SKIP names

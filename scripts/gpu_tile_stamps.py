@@ -24,7 +24,8 @@ t0 = st[:, 0].min()
 us = lambda v: (v - t0) / 100.0
 nbk = (n + 63) // 64
 print(f"n={n}: {nt} tiles")
-for k in range(min(nt, nbk + 8)):
-    kind = "RH" if k < nbk else "L"
-    print(f"  tile {k:3d} {kind}: entry {us(st[k,0]):6.1f} theta {us(st[k,1]):6.1f} staged {us(st[k,2]):6.1f} gram1 {us(st[k,3]):6.1f} "
-          + (f"gram2 {us(st[k,4]):6.1f} factor {us(st[k,5]):6.1f} published {us(st[k,6]):6.1f}" if k < nbk else ""))
+for k in range(nbk):
+    r = [us(st[k, j]) for j in range(8)]
+    print(f"  row head {k}: entry {r[0]:6.1f} tiles ready {r[1]:6.1f} | D seen {r[2]:6.1f} loaded {r[3]:6.1f} panel {r[4]:6.1f} factor {r[5]:6.1f} .. {r[6]:6.1f} published {r[7]:6.1f}"
+          + (f"   [wait->seen {r[2] - prev:4.1f}, load {r[3] - r[2]:4.1f}, panel {r[4] - r[3]:4.1f}, update {r[5] - r[4]:4.1f}, factor {r[6] - r[5]:4.1f}, publish {r[7] - r[6]:4.1f}; polls {int(st[k, 1])}]" if k else ""))
+    prev = r[7]
