@@ -338,6 +338,8 @@ struct bbh_handle {
   int tiledbg_n = 0;
   bool tile_d_sc1 = true;         // env BBH_TILE_ACQ=1: row heads take D_{I-1} through an acquire fence + plain loads instead of sc1 loads (A/B)
   bool tile_wt = true;            // env BBH_TILE_WT=0: tiles handed between workgroups through plain stores + an agent-scope release fence instead of write-through (sc1) stores (A/B)
+  bool tiles_did_mt = false;      // the last tile-dataflow launch also built the tiles of K^-1 (bbh_potrf_trtri_from_inputs with mt_args)
+  bool tile_mt = true;            // env BBH_TILE_MT=0: K^-1's tiles stay in the dataflow tail (A/B)
   bool info_clean = false;        // the Cholesky flag on the device is known to be 0 (the dataflow tail's last role resets it)
   bool tile_gram = true;          // env BBH_TILE_GRAM=0: fit evaluations launch bbh_gram_kernel before the factorisation instead of building the tiles inside it (A/B)
   int fit_flow = 1;               // env BBH_FIT_FLOW: 0 fit evaluations for 64 < np <= 1024 launch by launch, 1 (default) Gram + factorisation launches, then ONE dataflow launch for K^-1, alpha, value and gradient, 2 the whole evaluation as one dataflow launch
@@ -409,7 +411,7 @@ void bbh_gemm(hipStream_t s, bool transA, bool transB, int64_t M, int64_t N, int
               int64_t strideB, double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 // In-place blocked Cholesky of the np x np matrix K (lower), with X = L^-1; info!=0 on failure.
 void bbh_potrf_trtri(bbh_handle* h);
-bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const double* theta_host);  // theta_any null: theta_host travels as kernel arguments  // Gram tiles built inside the tile-dataflow launch (fit evaluations); false: not available, nothing enqueued
+bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const double* theta_host, const void* mt_args = nullptr);  // mt_args: pd_mt_args (bbh_tiles.h) - K^-1's tiles built by extra workgroups of the same launch; h->tiles_did_mt says whether they were  // theta_any null: theta_host travels as kernel arguments  // Gram tiles built inside the tile-dataflow launch (fit evaluations); false: not available, nothing enqueued
 void bbh_potrf_tiles_mark_unusable(int device);  // a tile-dataflow launch gave up: per-step launches from now on, process-wide
 void bbh_ensure_side_stream(bbh_handle* h);  // creates the fit's second stream and its events (not during a capture)
 void bbh_matvec(hipStream_t s, const double* A, int64_t lda, int64_t rows, int64_t cols,
@@ -441,7 +443,9 @@ int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count);  // host do
 void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
 void bbh_nehvi_destroy(bbh_handle* h);   // bbh_nehvi.hip
 void bbh_flow_destroy(bbh_handle* h);    // bbh_fitflow.hip
-bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host = nullptr);  // 64 < np <= 1024: the whole evaluation as one dataflow launch, or (tail_only) everything after the factorisation; false: not eligible
+bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host = nullptr,
+                         bool split = false, bool skip_mt = false, bool prepare_only = false);  // split: two launches - the factorisation with K^-1's tiles, then everything behind them; skip_mt: tail form without the M-tile roles
+bool bbh_fit_flow_mt_args(bbh_handle* h, void* pd_mt_args_out);  // arguments for K^-1's tiles inside the factorisation launch, matching the next tail launch  // 64 < np <= 1024: the whole evaluation as one dataflow launch, or (tail_only) everything after the factorisation; false: not eligible
 bool bbh_fit_flow_eligible(bbh_handle* h);
 void bbh_fit_flow_reset(bbh_handle* h);  // after a launch that gave up: clean state, the handle stops using the form
 void bbh_free_model_public(bbh_handle* h);

@@ -62,8 +62,9 @@ struct FlowArgs {
   int* flagsV;    // [I] VEC(I), [16 + I] QV(I)
   int* counters;  // [0] tickets, [1] finished M-tiles, [2] finished G-roles, [3] abort word (tail form), [4] finished VEC roles   (cumulative over launches)
   int ticket_base, doneM_base, doneG_base, doneV_base;
-  const int* roles;  // [nroles] type | I << 4 | J << 9 | row quarter << 14 | partial-row index << 16
+  const int* roles;  // [nroles] type | I << 4 | J << 9 | row quarter << 14 | partial-row index << 16   (this launch's part of the table)
   int nroles, nM, nG;
+  int role_lo;       // index of roles[0] in the whole table (trace slots; split form: the second launch starts behind the first one's roles)
   int epoch, spin;
   int tail_only;   // the factor and its inverse are already in A / D / X (bbh_potrf_trtri ran before): roles MT ... GT only, no waits on them
   int* info;       // device: Cholesky flag (0 ok, > 0 failing pivot + 1, -7 a wait gave up)
@@ -196,12 +197,9 @@ __device__ __forceinline__ double ff_row16_sum(double v) {
 }
 
 struct FlowShared {
-  double th[64];
-  double invls[FF_MAXD];
+  pd_gram_lds g;          // theta, inverse lengthscales, the tile's noise mask and task ids (rows / columns)
   double vr[64], vc[64];  // per-row / per-column vectors of the current tile (r, alpha, ...)
   double vr2[64], vc2[64];
-  double nm[64];
-  int tr[64], tc[64];     // task ids of the tile's rows / columns
   double red[4][64 + 8];
   int ticket;
   int last;
@@ -215,10 +213,10 @@ __device__ __forceinline__ void ff_stage_x(double* dst, const FlowArgs& fa, int 
 __device__ __forceinline__ void ff_stage_meta(FlowShared& sh, const FlowArgs& fa, int I, int K) {
   const int t = threadIdx.x;
   if (t < 64) {
-    sh.tr[t] = fa.task[I * 64 + t];
-    sh.nm[t] = fa.nmask[I * 64 + t];
+    sh.g.tr[t] = fa.task[I * 64 + t];
+    sh.g.nm[t] = fa.nmask[I * 64 + t];
   } else if (t < 128) {
-    sh.tc[t - 64] = fa.task[K * 64 + (t - 64)];
+    sh.g.tc[t - 64] = fa.task[K * 64 + (t - 64)];
   }
 }
 
@@ -226,46 +224,34 @@ __device__ __forceinline__ void ff_stage_meta(FlowShared& sh, const FlowArgs& fa
 // Thread t owns row i = t >> 2 and the columns j = (t & 3) + 4 m: the row's inputs sit in registers for all 16 entries, the columns'
 // come from LDS (four distinct addresses per wave), the dimension loop is unrolled so that the LDS reads are in flight together
 // (a run-time loop with three LDS reads per dimension took 30 us per tile: latency-bound).
+// (the tile arithmetic of the tile-dataflow factorisation: pd_gram_tile, four entries in flight per thread, kind as a template constant)
 __device__ __forceinline__ void ff_gram_tile(tile_t out, const double* xr, const double* xc, int I, int K, const FlowArgs& fa,
                                              const FlowShared& sh) {
-  const int kind = fa.ks.kind[0], dn = fa.dn;
-  const double os = fa.ks.use_os ? sh.th[2] : 1.0;
-  const double kalpha = fa.ks.alpha_off >= 0 ? sh.th[fa.ks.alpha_off] : 1.0;
-  const int i = threadIdx.x >> 2, part = threadIdx.x & 3, ga = I * 64 + i;
-  double xa[FF_MAXD];
-#pragma unroll
-  for (int c = 0; c < FF_MAXD; c++) xa[c] = (c < dn) ? xr[c * 64 + i] * sh.invls[c] : 0.0;
-#pragma unroll 1
-  for (int m = 0; m < 16; m++) {
-    const int j = part + 4 * m, gb = K * 64 + j;
-    double v;
-    if (ga >= fa.n || gb >= fa.n) {
-      v = (ga == gb) ? 1.0 : 0.0;
-    } else {
-      double r2 = 0.0;
-#pragma unroll
-      for (int c = 0; c < FF_MAXD; c++)
-        if (c < dn) {
-          const double xb = xc[c * 64 + j] * sh.invls[c];
-          if (BBH_KIND_IS_DOT(kind)) {
-            r2 = fma(xa[c], xb, r2);
-          } else {
-            const double df = xa[c] - xb;
-            r2 = fma(df, df, r2);
-          }
-        }
-      v = ff_kbase(kind, r2, fa.ks.jb, kalpha) * os;
-      if (fa.T > 1) v *= sh.th[3 + dn + sh.tr[i] * fa.T + sh.tc[j]];
-      if (ga == gb) v += sh.th[0] * sh.nm[i];
-    }
-    out[i][j] = v;
-  }
+  pd_gram_src gs;
+  gs.xnT = fa.xnT;
+  gs.task = fa.task;
+  gs.nmask = fa.nmask;
+  gs.theta = nullptr;
+  gs.n = fa.n;
+  gs.np = fa.np;
+  gs.dn = fa.dn;
+  gs.T = fa.T;
+  gs.tl = fa.tl;
+  gs.kind = fa.ks.kind[0];
+  gs.use_os = fa.ks.use_os;
+  gs.jb = fa.ks.jb;
+  gs.alpha_off = fa.ks.alpha_off;
+  gs.d_sc1 = 0;
+  gs.dbg = nullptr;
+  pd_gram_tile(out, xr, xc, I, K, gs, sh.g);
 }
 
-__device__ __forceinline__ bool ff_wait(const int* flag, const FlowArgs& fa) { return pd_wait_n(flag, fa.epoch, fa.abort, fa.spin); }
+__device__ __forceinline__ bool ff_wait(const int* flag, const FlowArgs& fa, bool urgent = false, bool lazy = false) {
+  return pd_wait_n(flag, fa.epoch, fa.abort, fa.spin, urgent, true, nullptr, lazy);
+}
 
 // wait until a cumulative counter reaches target
-__device__ __forceinline__ bool ff_wait_count(const int* counter, int target, const FlowArgs& fa) {
+__device__ __forceinline__ bool ff_wait_count(const int* counter, int target, const FlowArgs& fa, bool lazy = false) {
   __shared__ int s_ok2;
   if (threadIdx.x == 0) {
     int ok = 1, it = 0;
@@ -275,7 +261,10 @@ __device__ __forceinline__ bool ff_wait_count(const int* counter, int target, co
         ok = 0;
         break;
       }
-      __builtin_amdgcn_s_sleep(4);
+      if (lazy)
+        __builtin_amdgcn_s_sleep(32);
+      else
+        __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok2 = ok;
@@ -309,33 +298,35 @@ __device__ __forceinline__ bool ff_role_rowhead(const FlowArgs& fa, FlowShared& 
     ff_gram_tile(al, (const double*)b, (const double*)c, I, I - 1, fa, sh);
   }
   __syncthreads();
-  for (int J = 0; J + 1 < I; J++) {
-    if (!ff_wait(&fa.flagsL[I * FF_STRIDE + J], fa) || !ff_wait(&fa.flagsL[(I - 1) * FF_STRIDE + J], fa)) return false;
+  for (int J = 0; J + 1 < I; J++) {  // (order and the early publication below: as in bbh_potrf_tiles_kernel)
+    if (!ff_wait(&fa.flagsL[I * FF_STRIDE + J], fa)) return false;
     pd_load_tile(b, fa.A + (int64_t)(I * 64) * fa.np + J * 64, fa.np);
-    pd_load_tile(c, fa.A + (int64_t)((I - 1) * 64) * fa.np + J * 64, fa.np);
     __syncthreads();
     pd_gemm64<true, true, PD_OUT_LOWER>(a, b, b, -1.0);
+    if (!ff_wait(&fa.flagsL[(I - 1) * FF_STRIDE + J], fa)) return false;
+    pd_load_tile(c, fa.A + (int64_t)((I - 1) * 64) * fa.np + J * 64, fa.np);
+    __syncthreads();
     pd_gemm64<true, true, PD_FULL>(al, b, c, -1.0);
     __syncthreads();
   }
   if (I > 0) {
-    if (!ff_wait(&fa.flagsL[(I - 1) * FF_STRIDE + (I - 1)], fa)) return false;
-    if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 1] = wall_clock64();
+    if (!ff_wait(&fa.flagsL[(I - 1) * FF_STRIDE + (I - 1)], fa, true)) return false;
+    if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 1] = wall_clock64();
     pd_load_tile(b, fa.D + (int64_t)(I - 1) * 4096, 64);
     __syncthreads();
-    if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 7] = wall_clock64();
+    if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 7] = wall_clock64();
     pd_gemm64<true, false, PD_B_LOWER>(c, al, b, 1.0);  // L_{I,I-1} = A_{I,I-1} D_{I-1}^T
     __syncthreads();
-    pd_store_tile(Ail, fa.np, c, 1.0);  // (published from inside the factorisation, once the stores have landed)
+    pd_store_tile_wt(Ail, fa.np, c, 1.0);
     pd_gemm64<true, true, PD_OUT_LOWER>(a, c, c, -1.0);
-    __syncthreads();
+    pd_publish_wt(&fa.flagsL[I * FF_STRIDE + (I - 1)], fa.epoch);  // (before the factorisation: the next row head's last update waits for it)
   }
-  if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 4] = wall_clock64();
-  pd_factor_block4(a, b, al, (int64_t)I * 64, fa.info, I > 0 ? &fa.flagsL[I * FF_STRIDE + (I - 1)] : nullptr, fa.epoch);
-  if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 5] = wall_clock64();
-  pd_store_tile(fa.D + (int64_t)I * 4096, 64, b, 1.0);
-  pd_publish(&fa.flagsL[I * FF_STRIDE + I], fa.epoch);  // D_I first: the next row head waits for it
-  if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * sh.ticket + 6] = wall_clock64();
+  if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 4] = wall_clock64();
+  pd_factor_block4(a, b, al, (int64_t)I * 64, fa.info, nullptr, fa.epoch);
+  if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 5] = wall_clock64();
+  pd_store_tile_wt(fa.D + (int64_t)I * 4096, 64, b, 1.0);
+  pd_publish_wt(&fa.flagsL[I * FF_STRIDE + I], fa.epoch);  // D_I first: the next row head waits for it
+  if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 6] = wall_clock64();
   if (threadIdx.x < 64) {  // log-determinant partial (the padding's diagonal is 1)
     const double v = ff_wave_sum(log(a[threadIdx.x][threadIdx.x]));
     if (threadIdx.x == 0) fa.misc[2 + I] = v;
@@ -366,8 +357,8 @@ __device__ __forceinline__ bool ff_role_ltile(const FlowArgs& fa, FlowShared& sh
   __syncthreads();
   pd_gemm64<true, false, PD_B_LOWER>(c, a, b, 1.0);  // L_IK = A_IK D_K^T
   __syncthreads();
-  pd_store_tile(Aik, fa.np, c, 1.0);
-  pd_publish(&fa.flagsL[I * FF_STRIDE + K], fa.epoch);
+  pd_store_tile_wt(Aik, fa.np, c, 1.0);
+  pd_publish_wt(&fa.flagsL[I * FF_STRIDE + K], fa.epoch);
   return true;
 }
 
@@ -391,8 +382,8 @@ __device__ __forceinline__ bool ff_role_xtile(const FlowArgs& fa, tile_t a, tile
   __syncthreads();
   pd_gemm64<false, false, PD_A_LOWER>(c, b, a, -1.0);  // X_IJ = -D_I acc
   __syncthreads();
-  pd_store_tile(fa.X + (int64_t)(I * 64) * fa.np + J * 64, fa.np, c, 1.0);
-  pd_publish(&fa.flagsX[I * FF_STRIDE + J], fa.epoch);
+  pd_store_tile_wt(fa.X + (int64_t)(I * 64) * fa.np + J * 64, fa.np, c, 1.0);
+  pd_publish_wt(&fa.flagsX[I * FF_STRIDE + J], fa.epoch);
   return true;
 }
 
@@ -400,66 +391,26 @@ __device__ __forceinline__ bool ff_role_xtile(const FlowArgs& fa, tile_t a, tile
 // the sum in MFMA accumulators, the next k-step's operands on their way into registers while this one's MFMAs run.
 __device__ __forceinline__ bool ff_role_mtile(const FlowArgs& fa, FlowShared& sh, tile_t t0, tile_t t1, int I, int J) {
   const int t = threadIdx.x;
-  if (t < 64) {
-    const int g = I * 64 + t;
-    sh.vr[t] = g < fa.n ? fa.ystd[g] - sh.th[1] : 0.0;
-  } else if (t < 128) {
-    const int g = J * 64 + (t - 64);
-    sh.vc[t - 64] = g < fa.n ? fa.ystd[g] - sh.th[1] : 0.0;
-  }
-  d4 acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
-  pd_d2 rb[8], rc[8];
-  auto fetch = [&](int K) -> bool {
-    if (!fa.tail_only) {
-      if (!ff_wait(K == I ? &fa.flagsL[I * FF_STRIDE + I] : &fa.flagsX[K * FF_STRIDE + I], fa)) return false;
-      if (I != J && !ff_wait(&fa.flagsX[K * FF_STRIDE + J], fa)) return false;  // (K >= I > J)
-    }
-    if (K == I)
-      ff_ld_regs(rb, fa.D + (int64_t)I * 4096, 64);
-    else
-      ff_ld_regs(rb, fa.X + (int64_t)(K * 64) * fa.np + I * 64, fa.np);
-    if (I != J) ff_ld_regs(rc, fa.X + (int64_t)(K * 64) * fa.np + J * 64, fa.np);
-    return true;
+  pd_mt_args ma;
+  ma.nM = 0;
+  ma.M = fa.M;
+  ma.ld = fa.np;
+  ma.apart = fa.apart;
+  ma.ystd = fa.ystd;
+  ma.theta = nullptr;
+  ma.cmean = sh.g.th[1];
+  ma.n = fa.n;
+  ma.loo = fa.criterion == BBH_CRITERION_LOO;
+  ma.flagsM = fa.flagsM;
+  ma.doneM = &fa.counters[1];
+  ma.flow_epoch = fa.epoch;
+  auto wait = [&](int K) -> bool {
+    if (fa.tail_only) return true;
+    // (single-launch form: these roles poll from the first microsecond on - lazily, see pd_wait_n)
+    if (!ff_wait(K == I ? &fa.flagsL[I * FF_STRIDE + I] : &fa.flagsX[K * FF_STRIDE + I], fa, false, true)) return false;
+    return I == J || ff_wait(&fa.flagsX[K * FF_STRIDE + J], fa, false, true);  // (K >= I > J)
   };
-  if (!fetch(I)) return false;
-  for (int K = I; K < fa.nbk; K++) {
-    ff_st_regs(t0, rb);
-    if (I != J) ff_st_regs(t1, rc);
-    __syncthreads();
-    if (K + 1 < fa.nbk && !fetch(K + 1)) return false;
-    ff_mma_tn(acc, t0, I != J ? t1 : t0);
-    __syncthreads();
-  }
-  tile_t a = t0;
-  ff_acc_to_tile(a, acc);
-  __syncthreads();
-  pd_store_tile(fa.M + (int64_t)(I * 64) * fa.np + J * 64, fa.np, a, 1.0);
-  if (fa.criterion == BBH_CRITERION_LOO && I != J) {  // the leave-one-out terms contract whole rows of M: keep both triangles
-    for (int e = t; e < 4096; e += 256) {
-      const int i = e >> 6, j = e & 63;
-      fa.M[(int64_t)(J * 64 + i) * fa.np + I * 64 + j] = a[j][i];
-    }
-  }
-  // alpha partials: row part (M_IJ r_J) and, off the diagonal, column part (M_IJ^T r_I); four threads per entry
-  {
-    const int row = t >> 2, part = t & 3;
-    double s1 = 0.0, s2 = 0.0;
-    for (int j = part; j < 64; j += 4) {
-      s1 = fma(a[row][j], sh.vc[j], s1);
-      s2 = fma(a[j][row], sh.vr[j], s2);
-    }
-    s1 += __shfl_xor(s1, 1, 64);
-    s1 += __shfl_xor(s1, 2, 64);
-    s2 += __shfl_xor(s2, 1, 64);
-    s2 += __shfl_xor(s2, 2, 64);
-    if (part == 0) {
-      double* ap = fa.apart + (int64_t)(I * FF_STRIDE + J) * 128;
-      ap[row] = s1;
-      ap[64 + row] = (I != J) ? s2 : 0.0;
-    }
-  }
+  if (!pd_mtile_core(t0, t1, sh.vr, sh.vc, I, J, fa.nbk, fa.D, fa.X, fa.np, ma, sh.g.th[1], wait)) return false;
   pd_publish(&fa.flagsM[I * FF_STRIDE + J], fa.epoch);
   if (t == 0) atomicAdd(&fa.counters[1], 1);  // (thread 0's release fence in pd_publish precedes it)
   return true;
@@ -469,7 +420,7 @@ __device__ __forceinline__ bool ff_role_mtile(const FlowArgs& fa, FlowShared& sh
 // data-fit sum (with the log-determinant term after a separate factorisation) and of the mean gradient; LOO: d, u, w of the block.
 // One role per block row: a single role for all rows was 7-17 us between the last M-tile and the first gradient role.
 __device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh, int I) {
-  if (!ff_wait_count(&fa.counters[1], fa.doneM_base + fa.nM, fa)) return false;
+  if (!ff_wait_count(&fa.counters[1], fa.doneM_base + fa.nM, fa, !fa.tail_only)) return false;
   const int t = threadIdx.x, i = t >> 2, part = t & 3, g = I * 64 + i;
   double al = 0.0;
 #pragma unroll
@@ -484,7 +435,7 @@ __device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh, 
     fa.alpha[g] = al;
     if (g < fa.n) {
       if (fa.criterion == BBH_CRITERION_MLL) {
-        v = -0.5 * (fa.ystd[g] - sh.th[1]) * al;
+        v = -0.5 * (fa.ystd[g] - sh.g.th[1]) * al;
         if (fa.tail_only) v -= log(fa.A[(int64_t)g * fa.np + g]);  // (the row heads of the one-launch form leave these sums in misc[2 + I])
         gm = al;
       } else {
@@ -517,7 +468,7 @@ __device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh, 
 
 // LOO: q_I = (M w)_I and its sum (the mean gradient)
 __device__ __forceinline__ bool ff_role_qvec(const FlowArgs& fa, FlowShared& sh, int I) {
-  if (!ff_wait_count(&fa.counters[4], fa.doneV_base + fa.nbk, fa)) return false;
+  if (!ff_wait_count(&fa.counters[4], fa.doneV_base + fa.nbk, fa, !fa.tail_only)) return false;
   const int t = threadIdx.x, row = t >> 2, part = t & 3;
   const double* mr = fa.M + (int64_t)(I * 64 + row) * fa.np;
   double acc = 0.0;
@@ -540,7 +491,7 @@ __device__ __forceinline__ bool ff_role_qvec(const FlowArgs& fa, FlowShared& sh,
 
 // LOO: Q_IJ = sum_K M_IK diag(u_K) M_KJ, I >= J (accumulators in registers, operands prefetched through registers)
 __device__ __forceinline__ bool ff_role_qtile(const FlowArgs& fa, tile_t t0, tile_t t1, int I, int J) {
-  if (!ff_wait_count(&fa.counters[4], fa.doneV_base + fa.nbk, fa)) return false;
+  if (!ff_wait_count(&fa.counters[4], fa.doneV_base + fa.nbk, fa, !fa.tail_only)) return false;
   d4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -602,16 +553,17 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     for (int k = 0; k < (FF_MAXD * 64 + 255) / 256; k++) {
       const int e = t + 256 * k;
       if (e < dn * 64) {
-        const double il = sh.invls[e >> 6];
+        const double il = sh.g.inv[e >> 6];
         xr[e] = xv[2 * k] * il;
         xc[e] = xv[2 * k + 1] * il;
       }
     }
   }
   ff_stage_meta(sh, fa, I, J);
-  if (!ff_wait(&fa.flagsV[I], fa) || (I != J && !ff_wait(&fa.flagsV[J], fa))) return false;
-  if (loo && (!ff_wait(&fa.flagsQ[I * FF_STRIDE + J], fa) || !ff_wait(&fa.flagsV[16 + I], fa) || !ff_wait(&fa.flagsV[16 + J], fa))) return false;
-  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 1] = wall_clock64();
+  const bool lz = !fa.tail_only;
+  if (!ff_wait(&fa.flagsV[I], fa, false, lz) || (I != J && !ff_wait(&fa.flagsV[J], fa, false, lz))) return false;
+  if (loo && (!ff_wait(&fa.flagsQ[I * FF_STRIDE + J], fa, false, lz) || !ff_wait(&fa.flagsV[16 + I], fa, false, lz) || !ff_wait(&fa.flagsV[16 + J], fa, false, lz))) return false;
+  if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 1] = wall_clock64();
   {
     const double* src = (loo ? fa.Q : fa.M) + (int64_t)(I * 64 + 16 * qd) * fa.np + J * 64;
     for (int e = t; e < 512; e += 256) *(pd_d2*)&t0[e >> 5][2 * (e & 31)] = *(const pd_d2*)(src + (int64_t)(e >> 5) * fa.np + 2 * (e & 31));
@@ -624,10 +576,10 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     sh.vc2[t - 64] = loo ? fa.q[J * 64 + (t - 64)] : 0.0;
   }
   __syncthreads();
-  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 4] = wall_clock64();
+  if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 4] = wall_clock64();
   const bool dot = BBH_KIND_IS_DOT(kind);
-  const double os = fa.ks.use_os ? sh.th[2] : 1.0;
-  const double kalpha = fa.ks.alpha_off >= 0 ? sh.th[fa.ks.alpha_off] : 1.0;
+  const double os = fa.ks.use_os ? sh.g.th[2] : 1.0;
+  const double kalpha = fa.ks.alpha_off >= 0 ? sh.g.th[fa.ks.alpha_off] : 1.0;
   const double wsym = (I == J) ? 1.0 : 2.0;
   const int il_ = t >> 4, i = 16 * qd + il_, part = t & 15, ga = I * 64 + i;
   double Gg[4];
@@ -660,8 +612,8 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
       const double r2 = r2a + r2b;
       double kb, gf;
       ff_kv_pair(kind, r2, fa.ks.jb, kalpha, kb, gf);
-      const double Bab = (T > 1) ? sh.th[3 + dn + sh.tr[i] * T + sh.tc[j]] : 1.0;
-      if (ga == gb) g_noise += G * sh.nm[i];
+      const double Bab = (T > 1) ? sh.g.th[3 + dn + sh.g.tr[i] * T + sh.g.tc[j]] : 1.0;
+      if (ga == gb) g_noise += G * sh.g.nm[i];
       g_os += wsym * G * kb * Bab;
       Gg[m] = wsym * G * gf * os * Bab;
       if (fa.ks.alpha_off >= 0) {
@@ -675,7 +627,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
       }
       if (T > 1) {
         const double gk = G * kb * os;
-        const int s1 = sh.tr[i] * T + sh.tc[j], s2 = sh.tc[j] * T + sh.tr[i];
+        const int s1 = sh.g.tr[i] * T + sh.g.tc[j], s2 = sh.g.tc[j] * T + sh.g.tr[i];
 #pragma unroll
         for (int q2 = 0; q2 < FF_MAXT * FF_MAXT; q2++) {
           g_B[q2] += (q2 == s1) ? gk : 0.0;
@@ -684,7 +636,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
       }
     }
   }
-  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 5] = wall_clock64();
+  if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 5] = wall_clock64();
   // a slot's partials of one matrix row: DPP row sum (lane 15 of the row holds it) -> tab[slot][row]
   auto put = [&](int slot, double v) {
     v = ff_row16_sum(v);
@@ -708,10 +660,10 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
       acc0 = fma(Gg[m], dot ? xa * xb0 : (xa - xb0) * (xa - xb0), acc0);
       acc1 = fma(Gg[m + 1], dot ? xa * xb1 : (xa - xb1) * (xa - xb1), acc1);
     }
-    put(3 + cc, (acc0 + acc1) * sh.invls[cc]);
+    put(3 + cc, (acc0 + acc1) * sh.g.inv[cc]);
   }
   __syncthreads();
-  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 6] = wall_clock64();
+  if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 6] = wall_clock64();
   double* row = fa.gpart + (int64_t)gidx * fa.tl;
   if (t < fa.tl) {
     double acc = 0.0;
@@ -729,7 +681,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     if (sh.last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  if (fa.dbg && t == 0) fa.dbg[8 * sh.ticket + 7] = wall_clock64();
+  if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 7] = wall_clock64();
   if (!sh.last) return true;
   {
     const int grp = t >> 5, sl = t & 31;  // 8 groups x 32 slots per sweep
@@ -773,8 +725,13 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
 
 // TAIL: only the roles after the factorisation (MT, VEC, QV, QT, GT) - two tile buffers and at most 256 registers, so that two
 // workgroups share a CU; the full form carries the row heads' four buffers and register budget.
-template <bool TAIL>
+// RS (role set): 0 everything; 1 the roles after the factorisation (MT ... GT: the tail of a tile-dataflow factorisation launch); 2 the
+// factorisation and M = X^T X (RH, L, XT, MT); 3 what follows M (VEC, QV, QT, GT).  2 + 3 back to back = the split form: K^-1's tiles are
+// built while the factorisation runs, and the heavy gradient roles - whose registers made the all-in-one kernel's row heads 3 us per
+// step slower (502 VGPRs) - stay out of the first kernel.
+template <int RS>
 __device__ __forceinline__ void ff_kernel_body(const FlowArgs& fa) {
+  constexpr bool FACT = RS == 0 || RS == 2, MTS = RS != 3, POST = RS != 2;
   extern __shared__ __attribute__((aligned(16))) double s_ff[];
   tile_t a = (tile_t)s_ff;
   tile_t b = (tile_t)(s_ff + 64 * PD_LD);
@@ -782,9 +739,9 @@ __device__ __forceinline__ void ff_kernel_body(const FlowArgs& fa) {
   tile_t al = (tile_t)(s_ff + 3 * 64 * PD_LD);
   __shared__ FlowShared sh;
   const int t = threadIdx.x;
-  if (t < fa.tl) sh.th[t] = fa.theta ? fa.theta[t] : fa.thv[t < PD_GRAM_MAXTHV ? t : 0];
+  if (t < fa.tl) sh.g.th[t] = fa.theta ? fa.theta[t] : fa.thv[t < PD_GRAM_MAXTHV ? t : 0];
   __syncthreads();
-  if (t < fa.dn) sh.invls[t] = 1.0 / sh.th[3 + t];
+  if (t < fa.dn) sh.g.inv[t] = 1.0 / sh.g.th[3 + t];
   __syncthreads();
   for (;;) {
     if (t == 0) sh.ticket = atomicAdd(&fa.counters[0], 1) - fa.ticket_base;
@@ -792,31 +749,49 @@ __device__ __forceinline__ void ff_kernel_body(const FlowArgs& fa) {
     const int ticket = sh.ticket;
     if (ticket >= fa.nroles) return;
     if (fa.dbg && t == 0) {
-      fa.dbg[8 * ticket + 0] = wall_clock64();
-      fa.dbg[8 * ticket + 1] = 0;
-      fa.dbg[8 * ticket + 3] = blockIdx.x;
+      fa.dbg[8 * (fa.role_lo + sh.ticket) + 0] = wall_clock64();
+      fa.dbg[8 * (fa.role_lo + sh.ticket) + 1] = 0;
+      fa.dbg[8 * (fa.role_lo + sh.ticket) + 3] = blockIdx.x;
     }
     const int role = fa.roles[ticket];
     const int type = role & 15, I = (role >> 4) & 31, J = (role >> 9) & 31, qd = (role >> 14) & 3, gidx = (role >> 16) & 0xfff;
     bool ok = true;
     switch (type) {
-      case FF_RH: ok = TAIL ? false : ff_role_rowhead(fa, sh, a, b, c, al, I); break;
-      case FF_L: ok = TAIL ? false : ff_role_ltile(fa, sh, a, b, c, I, J); break;
-      case FF_XT: ok = TAIL ? false : ff_role_xtile(fa, a, b, c, I, J); break;
-      case FF_MT: ok = ff_role_mtile(fa, sh, a, b, I, J); break;
-      case FF_VEC: ok = ff_role_vec(fa, sh, I); break;
-      case FF_QV: ok = ff_role_qvec(fa, sh, I); break;
-      case FF_QT: ok = ff_role_qtile(fa, a, b, I, J); break;
-      default: ok = ff_role_gtile(fa, sh, a, b, I, J, qd, gidx); break;
+      case FF_RH:
+        if constexpr (FACT) ok = ff_role_rowhead(fa, sh, a, b, c, al, I); else ok = false;
+        break;
+      case FF_L:
+        if constexpr (FACT) ok = ff_role_ltile(fa, sh, a, b, c, I, J); else ok = false;
+        break;
+      case FF_XT:
+        if constexpr (FACT) ok = ff_role_xtile(fa, a, b, c, I, J); else ok = false;
+        break;
+      case FF_MT:
+        if constexpr (MTS) ok = ff_role_mtile(fa, sh, a, b, I, J); else ok = false;
+        break;
+      case FF_VEC:
+        if constexpr (POST) ok = ff_role_vec(fa, sh, I); else ok = false;
+        break;
+      case FF_QV:
+        if constexpr (POST) ok = ff_role_qvec(fa, sh, I); else ok = false;
+        break;
+      case FF_QT:
+        if constexpr (POST) ok = ff_role_qtile(fa, a, b, I, J); else ok = false;
+        break;
+      default:
+        if constexpr (POST) ok = ff_role_gtile(fa, sh, a, b, I, J, qd, gidx); else ok = false;
+        break;
     }
     if (!ok) return;
-    if (fa.dbg && t == 0) fa.dbg[8 * ticket + 2] = wall_clock64();
+    if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 2] = wall_clock64();
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(256) void bbh_fit_flow_kernel(const FlowArgs fa) { ff_kernel_body<false>(fa); }
-__global__ __launch_bounds__(256, 2) void bbh_fit_tail_kernel(const FlowArgs fa) { ff_kernel_body<true>(fa); }
+__global__ __launch_bounds__(256) void bbh_fit_flow_kernel(const FlowArgs fa) { ff_kernel_body<0>(fa); }
+__global__ __launch_bounds__(256, 2) void bbh_fit_tail_kernel(const FlowArgs fa) { ff_kernel_body<1>(fa); }
+__global__ __launch_bounds__(256) void bbh_fit_factor_kernel(const FlowArgs fa) { ff_kernel_body<2>(fa); }
+__global__ __launch_bounds__(256, 2) void bbh_fit_post_kernel(const FlowArgs fa) { ff_kernel_body<3>(fa); }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 struct bbh_flow_state {
@@ -829,7 +804,8 @@ struct bbh_flow_state {
   double* d_misc = nullptr;   // [64]
   long long* d_dbg = nullptr; // BBH_FLOW_TRACE=1
   int epoch = 0, ticket_base = 0, doneM_base = 0, doneG_base = 0, doneV_base = 0;
-  bool failed = false, tail_only = false;
+  bool failed = false, tail_only = false, split = false;
+  int nA = 0, gridA = 0, gridB = 0;  // split form: roles / workgroups of the first launch (RH, L, XT, MT), workgroups of the second
 };
 
 void bbh_flow_destroy(bbh_handle* h) {
@@ -860,7 +836,12 @@ bool bbh_fit_flow_eligible(bbh_handle* h) {
 }
 
 // true: the evaluation is on the stream (theta_dev / out_dev / info_dev are the device views of the pinned staging buffers)
-bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host) {
+// skip_mt (tail form): K^-1's tiles were built by the factorisation launch (bbh_fit_flow_mt_args) - only the roles behind them run.
+// prepare_only: create the state (roles, flags, counters) for this model and form, launch nothing.
+bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host, bool split,
+                         bool skip_mt, bool prepare_only) {
+  if (tail_only) split = false;
+  if (!tail_only) skip_mt = false;
   const int64_t np = h->np;
   const int nbk = (int)(np / 64);
   const int64_t tl = bbh_theta_len(h);
@@ -869,13 +850,14 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   bbh_flow_state* st = (bbh_flow_state*)h->flow_state;
   if (st && st->failed) return false;
   const bool loo = h->desc.criterion == BBH_CRITERION_LOO;
-  if (!st || st->np != np || st->criterion != h->desc.criterion || st->tail_only != tail_only) {
+  if (!st || st->np != np || st->criterion != h->desc.criterion || st->tail_only != tail_only || st->split != split) {
     if (st) bbh_flow_destroy(h);
     st = new bbh_flow_state();
     h->flow_state = st;
     st->np = (int)np;
     st->criterion = h->desc.criterion;
     st->tail_only = tail_only;
+    st->split = split;
     // roles in dependency order: column K of the factorisation (row head, its X-tiles, the L-tiles below it), then M, VEC, (QV, QT), G
     std::vector<int> roles;
     auto add = [&](int type, int I, int J, int qd = 0, int g = 0) { roles.push_back(type | (I << 4) | (J << 9) | (qd << 14) | (g << 16)); };
@@ -887,6 +869,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     for (int I = nbk - 1; I >= 0; I--)  // (the tiles of the last block rows have the fewest terms and can finish first)
       for (int J = 0; J <= I; J++) add(FF_MT, I, J);
     st->nM = nbk * (nbk + 1) / 2;
+    st->nA = (int)roles.size();  // (split form: the first launch ends here)
     for (int I = 0; I < nbk; I++) add(FF_VEC, I, 0);
     if (loo) {
       for (int I = 0; I < nbk; I++) add(FF_QV, I, 0);
@@ -899,10 +882,13 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
         for (int qd = 0; qd < 4; qd++) add(FF_GT, I, J, qd, g++);  // four roles per tile: 16 rows x 64 columns each
     st->nG = g;
     st->nroles = (int)roles.size();
-    int per_cu = 0;
-    const void* kfn = tail_only ? (const void*)bbh_fit_tail_kernel : (const void*)bbh_fit_flow_kernel;
+    int per_cu = 0, per_cu_b = 0;
+    const void* kfn = tail_only ? (const void*)bbh_fit_tail_kernel : (split ? (const void*)bbh_fit_factor_kernel : (const void*)bbh_fit_flow_kernel);
+    const size_t lds_b = sizeof(double) * 2 * 64 * PD_LD;
     bool ok = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) == hipSuccess && per_cu >= 1 &&
+              (!split || (hipFuncSetAttribute((const void*)bbh_fit_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) == hipSuccess &&
+                          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)bbh_fit_post_kernel, 256, lds_b) == hipSuccess && per_cu_b >= 1)) &&
               hipMalloc((void**)&st->d_roles, sizeof(int) * roles.size()) == hipSuccess &&
               hipMemcpy(st->d_roles, roles.data(), sizeof(int) * roles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&st->d_flags, sizeof(int) * (4 * 256 + 32 + 8)) == hipSuccess &&
@@ -919,7 +905,13 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     }
     const int slots = per_cu * h->num_cu;
     st->grid = st->nroles < slots ? st->nroles : slots;
+    if (split) {
+      const int nB = st->nroles - st->nA, slots_b = per_cu_b * h->num_cu;
+      st->gridA = st->nA < slots ? st->nA : slots;
+      st->gridB = nB < slots_b ? nB : slots_b;
+    }
   }
+  if (prepare_only) return true;
   if (st->ticket_base > (1 << 30)) {  // cumulative counters: start over long before they wrap
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemset(st->d_flags + 4 * 256 + 32, 0, sizeof(int) * 8) != hipSuccess) {
       st->failed = true;
@@ -982,6 +974,53 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     if (!st->d_dbg && hipMalloc((void**)&st->d_dbg, sizeof(long long) * 8 * 1024) != hipSuccess) st->d_dbg = nullptr;
     fa.dbg = st->d_dbg;
   }
+  if (split) {
+    // first launch: the factorisation and K^-1's tiles (tickets 0 .. nA); second: VEC ... GT, its own ticket range and its own abort word
+    FlowArgs fb = fa;
+    fa.nroles = st->nA;
+    hipLaunchKernelGGL(bbh_fit_factor_kernel, dim3((unsigned)st->gridA), dim3(256), lds, h->stream, fa);
+    fb.roles = st->d_roles + st->nA;
+    fb.role_lo = st->nA;
+    fb.nroles = st->nroles - st->nA;
+    fb.ticket_base = st->ticket_base + st->nA + st->gridA;
+    fb.tail_only = 1;
+    fb.abort = st->d_flags + 1024 + 32 + 3;
+    hipLaunchKernelGGL(bbh_fit_post_kernel, dim3((unsigned)st->gridB), dim3(256), sizeof(double) * 2 * 64 * PD_LD, h->stream, fb);
+    if (hipGetLastError() != hipSuccess) {
+      st->failed = true;
+      return false;
+    }
+    st->ticket_base += st->nroles + st->gridA + st->gridB;
+    st->doneM_base += st->nM;
+    st->doneG_base += st->nG;
+    st->doneV_base += nbk;
+    return true;
+  }
+  if (skip_mt) {  // the table starts with the nM M-tile roles: begin behind them (their count was added by the factorisation's workgroups)
+    int per_cu_b = 0;
+    const int nB = st->nroles - st->nA;
+    if (!st->gridB) {
+      if (hipFuncSetAttribute((const void*)bbh_fit_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)bbh_fit_post_kernel, 256, lds) != hipSuccess || per_cu_b < 1) {
+        (void)hipGetLastError();
+        return false;
+      }
+      st->gridB = nB < per_cu_b * h->num_cu ? nB : per_cu_b * h->num_cu;
+    }
+    fa.roles = st->d_roles + st->nA;
+    fa.role_lo = st->nA;
+    fa.nroles = nB;
+    hipLaunchKernelGGL(bbh_fit_post_kernel, dim3((unsigned)st->gridB), dim3(256), lds, h->stream, fa);
+    if (hipGetLastError() != hipSuccess) {
+      st->failed = true;
+      return false;
+    }
+    st->ticket_base += nB + st->gridB;
+    st->doneM_base += st->nM;
+    st->doneG_base += st->nG;
+    st->doneV_base += nbk;
+    return true;
+  }
   if (tail_only)
     hipLaunchKernelGGL(bbh_fit_tail_kernel, dim3((unsigned)st->grid), dim3(256), lds, h->stream, fa);
   else
@@ -1007,6 +1046,28 @@ void bbh_fit_flow_reset(bbh_handle* h) {
   st->ticket_base = st->doneM_base = st->doneG_base = st->doneV_base = 0;
   st->failed = true;
   h->fit_flow = false;
+}
+
+// The M-tile arguments of the NEXT tail launch of this model (state created if need be): what the factorisation launch needs to build
+// K^-1's tiles itself (bbh_potrf_trtri_from_inputs).  out: pd_mt_args.
+bool bbh_fit_flow_mt_args(bbh_handle* h, void* out) {
+  if (!bbh_fit_flow_launch(h, nullptr, nullptr, nullptr, true, nullptr, false, false, true)) return false;
+  bbh_flow_state* st = (bbh_flow_state*)h->flow_state;
+  if (!st || st->failed || !st->tail_only) return false;
+  pd_mt_args* ma = (pd_mt_args*)out;
+  ma->nM = st->nM;
+  ma->M = h->d_M;
+  ma->ld = h->np;
+  ma->apart = st->d_apart;
+  ma->ystd = h->d_ystd;
+  ma->theta = nullptr;
+  ma->cmean = 0.0;  // (the Gram-building launch has theta in LDS)
+  ma->n = (int)h->n;
+  ma->loo = h->desc.criterion == BBH_CRITERION_LOO;
+  ma->flagsM = st->d_flags + 512;
+  ma->doneM = st->d_flags + 1024 + 32 + 1;
+  ma->flow_epoch = st->epoch + 1;
+  return true;
 }
 
 // BBH_FLOW_TRACE=1: the last launch's per-role clock stamps [nroles][4] (start, after the last wait of a row head, end, workgroup) and the role table

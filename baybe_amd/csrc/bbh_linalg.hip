@@ -236,7 +236,8 @@ __device__ __forceinline__ bool pd_wait(const int* flag, int epoch, int* info, b
 // WT: tiles other workgroups wait for are stored write-through and published without a release fence (pd_publish_wt).
 template <bool GRAM, bool WT>
 __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t lda, int nbk, double* D, double* X, int64_t ldx,
-                                                              int* flagsL, int* flagsX, int epoch, int* info, const pd_gram_src gs) {
+                                                              int* flagsL, int* flagsX, int epoch, int* info, const pd_gram_src gs,
+                                                              const pd_mt_args ma) {
   auto store_pub = [&](double* dst, int64_t ld, const double (*src)[PD_LD]) {
     if (WT)
       pd_store_tile_wt(dst, ld, src, 1.0);
@@ -262,6 +263,30 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
   double(*al)[PD_LD] = (double(*)[PD_LD])(s_tiles + 3 * 64 * PD_LD);  // row heads: the tile left of the diagonal one
   const int nOther = (nbk - 1) * (nbk - 2) / 2;
   int id = blockIdx.x;
+  {  // ---- M-tile (I, J) of K^-1 = X^T X: the workgroups behind the factorisation's own (fit evaluations, ma.nM > 0)
+    const int nfact = nbk + nOther + nbk * (nbk - 1) / 2;
+    if (id >= nfact) {
+      const int m = id - nfact;
+      int I = 0;
+      while ((I + 1) * (I + 2) / 2 <= m) I++;
+      const int J = m - I * (I + 1) / 2;
+      double* vr = (double*)c;
+      auto wait = [&](int K) -> bool {  // (lazy polls: these workgroups wait from the first microsecond on)
+        if (!pd_wait_n(K == I ? &flagsL[(I * nbk + I) * PD_FLAG_STRIDE] : &flagsX[(K * nbk + I) * PD_FLAG_STRIDE], epoch, info, pd_spin_limit, false, true,
+                       nullptr, true))
+          return false;
+        return I == J || pd_wait_n(&flagsX[(K * nbk + J) * PD_FLAG_STRIDE], epoch, info, pd_spin_limit, false, true, nullptr, true);
+      };
+      const double cmean = GRAM ? gl.th[1] : (ma.theta ? ma.theta[1] : ma.cmean);
+      if (!pd_mtile_core(a, b, vr, vr + 64, I, J, nbk, D, X, ldx, ma, cmean, wait)) return;
+      __syncthreads();  // (consumers run in the next launch: the kernel boundary publishes the tile; the flag and the count only say "done")
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&ma.flagsM[I * 16 + J], ma.flow_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(ma.doneM, 1);
+      }
+      return;
+    }
+  }
   if (id < nbk) {
     // ---- row head I: the diagonal tile (I, I) AND its left neighbour (I, I-1) in one workgroup, so that the critical
     // chain D_{I-1} -> L_{I,I-1} -> update of (I, I) -> factor -> D_I never leaves LDS in between
@@ -407,7 +432,8 @@ void bbh_potrf_tiles_mark_unusable(int device) { g_tiles_unusable[device & 63] =
 
 // gram_theta != nullptr: the kernel builds the tiles of K + s2 M itself (single-kernel models, bbh_fit_flow_eligible) from theta at
 // that (device or host-mapped) address - the fit evaluation's form, which needs no Gram launch before it.
-static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, const double* gram_theta_host = nullptr) {
+static_assert(sizeof(pd_mt_args) <= 128, "bbh_model.hip hands pd_mt_args over in a 128-byte buffer");
+static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, const double* gram_theta_host = nullptr, const pd_mt_args* mt = nullptr) {
   const bool info_clean = (gram_theta || gram_theta_host) && h->info_clean;
   h->info_clean = false;  // (whatever runs next may leave a failure flag behind; only a finished dataflow tail re-establishes it)
   const int64_t np = h->np;
@@ -437,6 +463,10 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
     h->tiles_ready = true;
   }
   if (ntiles > h->tiles_per_device) return false;  // the dataflow needs every tile resident: not on this device / partition
+  pd_mt_args ma{};
+  if (mt && mt->nM > 0 && ntiles + mt->nM <= h->tiles_per_device) ma = *mt;  // (K^-1's tiles in the same launch only if they are co-resident too)
+  h->tiles_did_mt = ma.nM > 0;
+  const int grid_tiles = ntiles + ma.nM;
   if (h->tile_spin_limit != h->tile_spin_limit_set) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(pd_spin_limit), &h->tile_spin_limit, sizeof(int)) != hipSuccess) {
       (void)hipGetLastError();
@@ -473,17 +503,17 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
     gs.dbg = h->d_tiledbg;
     h->tiledbg_n = ntiles;
     if (h->tile_wt)
-      hipLaunchKernelGGL((bbh_potrf_tiles_kernel<true, true>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
-                         h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
+      hipLaunchKernelGGL((bbh_potrf_tiles_kernel<true, true>), dim3((unsigned)grid_tiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                         h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs, ma);
     else
-      hipLaunchKernelGGL((bbh_potrf_tiles_kernel<true, false>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
-                         h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
+      hipLaunchKernelGGL((bbh_potrf_tiles_kernel<true, false>), dim3((unsigned)grid_tiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                         h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs, ma);
   } else if (h->tile_wt) {
-    hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, true>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
-                       h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
+    hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, true>), dim3((unsigned)grid_tiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                       h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs, ma);
   } else {
-    hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, false>), dim3((unsigned)ntiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
-                       h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs);
+    hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, false>), dim3((unsigned)grid_tiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
+                       h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs, ma);
   }
   return true;
 }
@@ -697,12 +727,12 @@ bool bbh_fit_small_launch(bbh_handle* h, double jitter, const double* theta_dev,
 
 // Fit evaluations of the models bbh_fit_flow_eligible admits: Gram tiles + factor + inverse in the one tile-dataflow launch (theta read
 // at theta_any: device or host-mapped).  false: that launch is not available here - nothing was enqueued.
-bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const double* theta_host) {
+bool bbh_potrf_trtri_from_inputs(bbh_handle* h, const double* theta_any, const double* theta_host, const void* mt_args) {
   if (!theta_any && (!theta_host || bbh_theta_len(h) > PD_GRAM_MAXTHV)) return false;
   if (h->dn > PD_GRAM_MAXD || bbh_theta_len(h) > PD_GRAM_MAXTH || h->F > 1 || h->hadamard || h->desc.kernel_kind == BBH_KERNEL_PERIODIC ||
       h->desc.kernel_kind == BBH_KERNEL_RFF)
     return false;
-  return bbh_potrf_tiles(h, theta_any, theta_any ? nullptr : theta_host);
+  return bbh_potrf_tiles(h, theta_any, theta_any ? nullptr : theta_host, (const pd_mt_args*)mt_args);
 }
 
 // BBH_TILE_STAMPS=1: clock stamps [tiles][8] of the row heads of the last Gram-building tile launch (0 entry, 1 own tiles ready, 2 D_{I-1}'s flag

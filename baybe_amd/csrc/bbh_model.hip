@@ -650,10 +650,11 @@ static int bbh_fit_enqueue(bbh_handle* h) {
   }
   {  // 64 < np <= 1024: the whole evaluation as one dataflow launch (bbh_fitflow.hip), the same zero-copy staging
     void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
-    if (h->fit_flow == 2 && h->np > 64 && h->np <= 1024 && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
+    if ((h->fit_flow == 2 || h->fit_flow == 3) && h->np > 64 && h->np <= 1024 && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
         hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess && hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
       *h->pin_info = -99;  // (sentinel: the kernel's last role writes the flag; a launch that gave up never does)
-      if (bbh_fit_flow_launch(h, (const double*)th_dev, (double*)out_dev, (int*)info_dev, false)) {
+      // (theta as kernel arguments when it fits: ~250 workgroups fetching it from the host-mapped buffer is the slower way)
+      if (bbh_fit_flow_launch(h, tl <= 52 ? nullptr : (const double*)th_dev, (double*)out_dev, (int*)info_dev, false, h->pin_theta, h->fit_flow == 3)) {
         h->flow_in_flight = true;
         return 0;
       }
@@ -673,17 +674,23 @@ static int bbh_fit_enqueue(bbh_handle* h) {
       const bool by_value = !(th_env && th_env[0] == 'c') && tl <= 52;
       const double* th_src = by_value ? nullptr : h->d_theta;
       if (!by_value) BBH_HIP_TRY(h, hipMemcpyAsync(h->d_theta, h->pin_theta, sizeof(double) * tl, hipMemcpyHostToDevice, s));
+      // K^-1's tiles ride in the factorisation launch where its workgroups and theirs are co-resident (n <= 832): they follow the rows of
+      // L^-1 as these appear, and the launch behind it starts at alpha
+      alignas(16) unsigned char mt_buf[128];
+      static_assert(sizeof(mt_buf) >= 96, "pd_mt_args");
+      const bool want_mt = h->tile_mt && bbh_fit_flow_mt_args(h, mt_buf);
       h->skip_x_memset = true;
-      const bool tiles = bbh_potrf_trtri_from_inputs(h, th_src, h->pin_theta);
+      const bool tiles = bbh_potrf_trtri_from_inputs(h, th_src, h->pin_theta, want_mt ? mt_buf : nullptr);
       h->skip_x_memset = false;
       (void)th_dev;
       if (tiles) {
         *h->pin_info = -99;
-        if (bbh_fit_flow_launch(h, th_src, (double*)out_dev, (int*)info_dev, true, h->pin_theta)) {
+        if (bbh_fit_flow_launch(h, th_src, (double*)out_dev, (int*)info_dev, true, h->pin_theta, false, h->tiles_did_mt)) {
           h->flow_in_flight = true;
           return 0;
         }
         (void)hipGetLastError();  // (the tail is unavailable: the evaluation starts over below, launch by launch)
+        if (h->tiles_did_mt) bbh_fit_flow_reset(h);  // (the M-tile count of a tail that never ran must not be credited to a later one)
       }
     }
     (void)hipGetLastError();

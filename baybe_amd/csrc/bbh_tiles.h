@@ -499,8 +499,11 @@ __device__ __forceinline__ void pd_gram_tile(double (*out)[PD_LD], const double*
 // =====================================================================================================================
 // (urgent: unused - backing off the pollers whose flag is not about to flip (0.4 us between polls) was measured: the delays add up along
 // the off-critical chains until they are critical, 484 -> 712 us at n = 1024; profiles/r05_tile_gram.log)
+// lazy: a waiter that starts polling long before its flag can flip (the roles behind the factorisation in the single-launch fit
+// evaluation: ~190 workgroups from the first microsecond on) sleeps ~0.85 us between polls - at full rate they take memory bandwidth
+// from the critical chain; the price is up to one sleep at the moment the flag flips.
 __device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info, int spin_limit, bool urgent = false, bool acquire = true,
-                                          long long* polls_out = nullptr) {
+                                          long long* polls_out = nullptr, bool lazy = false) {
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
     int ok = 1, it = 0;
@@ -519,6 +522,8 @@ __device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info,
       }
       if (urgent) {
         // (the one waiter on the critical path: no sleep between polls)
+      } else if (lazy) {
+        __builtin_amdgcn_s_sleep(32);
       } else if (it < 64) {
         __builtin_amdgcn_s_sleep(1);
       } else {
@@ -636,3 +641,121 @@ __device__ __forceinline__ void pd_gemm64(double (*c)[PD_LD], const double (*a)[
   }
 }
 
+
+// ---- tiles of M = K^-1 = X^T X (X = L^-1, lower block triangular): M_IJ = sum_{K >= I} X_KI^T X_KJ, X_KK = D_K, I >= J ---------------
+// The role of the fit's dataflow tail (bbh_fitflow.hip) and - for matrices small enough that these workgroups are co-resident with the
+// factorisation's - extra workgroups of bbh_potrf_tiles_kernel: K^-1's tiles are then built while the factorisation runs, as the rows
+// of X appear.  Two LDS tiles for the operands, the sum in MFMA accumulators, the next k-step's operands on their way into registers
+// while this one's MFMAs run.
+struct pd_mt_args {
+  int nM;                // M-tile workgroups appended to the factorisation's grid (0: none)
+  double* M;             // [np][ld] lower tiles (LOO: both triangles)
+  int64_t ld;
+  double* apart;         // [(I * 16 + J) * 128] alpha partials: row part M_IJ r_J, column part M_IJ^T r_I
+  const double* ystd;    // [np]
+  const double* theta;   // null: cmean
+  double cmean;          // constant mean (theta[1])
+  int n, loo;
+  int* flagsM;           // [I * 16 + J], stamped with flow_epoch
+  int* doneM;            // cumulative counter of finished M-tiles
+  int flow_epoch;
+};
+__device__ __forceinline__ void pd_mma_tn(d4 (&acc)[4], const double (*a)[PD_LD], const double (*b)[PD_LD]) {  // acc += a^T b
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int sb = w + 4 * q, mb = sb & 3, nb = sb >> 2;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+        acc[q] = mfma_f64(a[16 * kb + 4 * ks + (l >> 4)][16 * mb + (l & 15)], b[16 * kb + 4 * ks + (l >> 4)][16 * nb + (l & 15)], acc[q]);
+  }
+}
+__device__ __forceinline__ void pd_ld_regs(pd_d2 (&r)[8], const double* src, int64_t ld) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int e = threadIdx.x + 256 * k;
+    r[k] = *(const pd_d2*)(src + (int64_t)(e >> 5) * ld + 2 * (e & 31));
+  }
+}
+__device__ __forceinline__ void pd_st_regs(double (*dst)[PD_LD], const pd_d2 (&r)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int e = threadIdx.x + 256 * k;
+    *(pd_d2*)&dst[e >> 5][2 * (e & 31)] = r[k];
+  }
+}
+// WAIT(K) -> bool: the operands of k-step K (D_I for K == I, X_KI and - off the diagonal - X_KJ) are visible.  vr / vc: 64 doubles of LDS
+// each (residuals of block I / J).  On return the tile and its alpha partials are stored (plain stores); the caller publishes.
+template <class WAIT>
+__device__ __forceinline__ bool pd_mtile_core(double (*t0)[PD_LD], double (*t1)[PD_LD], double* vr, double* vc, int I, int J, int nbk, const double* D,
+                                              const double* X, int64_t ldx, const pd_mt_args& ma, double cmean, WAIT&& wait) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    const int g = I * 64 + t;
+    vr[t] = g < ma.n ? ma.ystd[g] - cmean : 0.0;
+  } else if (t < 128) {
+    const int g = J * 64 + (t - 64);
+    vc[t - 64] = g < ma.n ? ma.ystd[g] - cmean : 0.0;
+  }
+  d4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  pd_d2 rb[8], rc[8];
+  auto fetch = [&](int K) -> bool {
+    if (!wait(K)) return false;
+    if (K == I)
+      pd_ld_regs(rb, D + (int64_t)I * 4096, 64);
+    else
+      pd_ld_regs(rb, X + (int64_t)(K * 64) * ldx + I * 64, ldx);
+    if (I != J) pd_ld_regs(rc, X + (int64_t)(K * 64) * ldx + J * 64, ldx);
+    return true;
+  };
+  if (!fetch(I)) return false;
+  for (int K = I; K < nbk; K++) {
+    pd_st_regs(t0, rb);
+    if (I != J) pd_st_regs(t1, rc);
+    __syncthreads();
+    if (K + 1 < nbk && !fetch(K + 1)) return false;
+    pd_mma_tn(acc, t0, I != J ? t1 : t0);
+    __syncthreads();
+  }
+  double(*a)[PD_LD] = t0;
+  {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int sb = w + 4 * q, mb = sb & 3, nb = sb >> 2;
+#pragma unroll
+      for (int r = 0; r < 4; r++) a[16 * mb + (l >> 4) + 4 * r][16 * nb + (l & 15)] = acc[q][r];
+    }
+  }
+  __syncthreads();
+  pd_store_tile(ma.M + (int64_t)(I * 64) * ma.ld + J * 64, ma.ld, a, 1.0);
+  if (ma.loo && I != J) {  // the leave-one-out terms contract whole rows of M: keep both triangles
+    for (int e = t; e < 4096; e += 256) {
+      const int i = e >> 6, j = e & 63;
+      ma.M[(int64_t)(J * 64 + i) * ma.ld + I * 64 + j] = a[j][i];
+    }
+  }
+  // alpha partials: row part (M_IJ r_J) and, off the diagonal, column part (M_IJ^T r_I); four threads per entry
+  {
+    const int row = t >> 2, part = t & 3;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = part; j < 64; j += 4) {
+      s1 = fma(a[row][j], vc[j], s1);
+      s2 = fma(a[j][row], vr[j], s2);
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64);
+    s2 += __shfl_xor(s2, 2, 64);
+    if (part == 0) {
+      double* ap = ma.apart + (int64_t)(I * 16 + J) * 128;
+      ap[row] = s1;
+      ap[64 + row] = (I != J) ? s2 : 0.0;
+    }
+  }
+  return true;
+}

@@ -23,10 +23,11 @@ st, roles = st[:nr], roles[:nr]
 t0 = st[:, 0].min()
 us = lambda v: (v - t0) / 100.0
 names = ["RH", "L", "XT", "MT", "VEC", "QV", "QT", "GT"]
+nbk_ = (n + 63) // 64
 print(f"n={n}: {nr} roles, span {us(st[:, 2].max()):.1f} us")
 for k in range(nr):
-    ty, I, J = roles[k] & 255, (roles[k] >> 8) & 255, (roles[k] >> 16) & 255
-    if ty == 0 or (ty in (1, 2) and I <= 3) or (ty == 3 and (J == 0 or I == J)) or ty == 4 or (ty == 7 and J == 0):
+    ty, I, J = roles[k] & 15, (roles[k] >> 4) & 31, (roles[k] >> 9) & 31
+    if ty == 0 or (ty == 1 and J == I - 2) or (ty == 2 and I == nbk_ - 1) or (ty == 3 and J == 0) or ty == 4:
         extra = (f" D at {us(st[k, 1]):7.1f} loaded {us(st[k, 7]):7.1f} factor {us(st[k, 4]):7.1f} .. {us(st[k, 5]):7.1f} published {us(st[k, 6]):7.1f}"
                  if ty == 0 and st[k, 1] else (f" factor {us(st[k, 4]):7.1f} .. {us(st[k, 5]):7.1f} published {us(st[k, 6]):7.1f}" if ty == 0 else ""))
         print(f"  ticket {k:3d} {names[ty]:>3s}({I},{J}) wg {st[k, 3]:3d}: start {us(st[k, 0]):7.1f}  end {us(st[k, 2]):7.1f}{extra}")

@@ -42,3 +42,9 @@ if m.any():
     print(f"  GT medians: role start -> flag seen {d(1, 0):.1f}; loads {d(4, 1):.1f}; pass 1 {d(5, 4):.1f}; pass 2 + row sums {d(6, 5):.1f}; row write + fence + count {d(7, 6):.1f}; end {d(2, 7):.1f}")
     late = us(st[m, 1])
     print(f"  GT flag seen: min {late.min():.1f} median {np.median(late):.1f} max {late.max():.1f}")
+for k, nm in ((0, "RH"), (2, "XT")):
+    m = ty == k
+    if m.any():
+        for i in sorted(set(I[m])):
+            mm = m & (I == i)
+            print(f"    {nm} row {i}: ends {np.round(np.sort(us(st[mm, 2])), 1).tolist()}")
