@@ -338,7 +338,8 @@ struct bbh_handle {
   int tiledbg_n = 0;
   bool tile_d_sc1 = true;         // env BBH_TILE_ACQ=1: row heads take D_{I-1} through an acquire fence + plain loads instead of sc1 loads (A/B)
   bool tile_wt = true;            // env BBH_TILE_WT=0: tiles handed between workgroups through plain stores + an agent-scope release fence instead of write-through (sc1) stores (A/B)
-  bool tiles_did_mt = false;      // the last tile-dataflow launch also built the tiles of K^-1 (bbh_potrf_trtri_from_inputs with mt_args)
+  int tiles_did_mt = 0;           // tiles of K^-1 the last tile-dataflow launch built itself (bbh_potrf_trtri_from_inputs with mt_args; block row 0 first)
+  bool tile_mt_partial = false;   // env BBH_TILE_MT=partial
   bool tile_mt = true;            // env BBH_TILE_MT=0: K^-1's tiles stay in the dataflow tail (A/B)
   bool info_clean = false;        // the Cholesky flag on the device is known to be 0 (the dataflow tail's last role resets it)
   bool tile_gram = true;          // env BBH_TILE_GRAM=0: fit evaluations launch bbh_gram_kernel before the factorisation instead of building the tiles inside it (A/B)
@@ -444,7 +445,7 @@ void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
 void bbh_nehvi_destroy(bbh_handle* h);   // bbh_nehvi.hip
 void bbh_flow_destroy(bbh_handle* h);    // bbh_fitflow.hip
 bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host = nullptr,
-                         bool split = false, bool skip_mt = false, bool prepare_only = false);  // split: two launches - the factorisation with K^-1's tiles, then everything behind them; skip_mt: tail form without the M-tile roles
+                         bool split = false, int skip_mt = 0, bool prepare_only = false);  // split: two launches - the factorisation with K^-1's tiles, then everything behind them; skip_mt: tail form without the M-tile roles
 bool bbh_fit_flow_mt_args(bbh_handle* h, void* pd_mt_args_out);  // arguments for K^-1's tiles inside the factorisation launch, matching the next tail launch  // 64 < np <= 1024: the whole evaluation as one dataflow launch, or (tail_only) everything after the factorisation; false: not eligible
 bool bbh_fit_flow_eligible(bbh_handle* h);
 void bbh_fit_flow_reset(bbh_handle* h);  // after a launch that gave up: clean state, the handle stops using the form

@@ -836,12 +836,13 @@ bool bbh_fit_flow_eligible(bbh_handle* h) {
 }
 
 // true: the evaluation is on the stream (theta_dev / out_dev / info_dev are the device views of the pinned staging buffers)
-// skip_mt (tail form): K^-1's tiles were built by the factorisation launch (bbh_fit_flow_mt_args) - only the roles behind them run.
+// skip_mt (tail form): the first skip_mt tiles of K^-1 were built by the factorisation launch (bbh_fit_flow_mt_args) - the tail starts
+// at role skip_mt (all of them: only the roles behind the M-tiles run, in the kernel without their code).
 // prepare_only: create the state (roles, flags, counters) for this model and form, launch nothing.
 bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host, bool split,
-                         bool skip_mt, bool prepare_only) {
+                         int skip_mt, bool prepare_only) {
   if (tail_only) split = false;
-  if (!tail_only) skip_mt = false;
+  if (!tail_only) skip_mt = 0;
   const int64_t np = h->np;
   const int nbk = (int)(np / 64);
   const int64_t tl = bbh_theta_len(h);
@@ -866,8 +867,15 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
       for (int I = K + 2; I < nbk; I++) add(FF_L, I, K);
       for (int J = 0; J < K; J++) add(FF_XT, K, J);
     }
-    for (int I = nbk - 1; I >= 0; I--)  // (the tiles of the last block rows have the fewest terms and can finish first)
-      for (int J = 0; J <= I; J++) add(FF_MT, I, J);
+    if (tail_only) {
+      // block row 0 first - the tiles with the most terms -, in the order the factorisation launch numbers the M-tiles it builds itself
+      // (bbh_potrf_tiles_kernel: m = I (I + 1) / 2 + J): when only its first k are built there, the tail starts at role k
+      for (int I = 0; I < nbk; I++)
+        for (int J = 0; J <= I; J++) add(FF_MT, I, J);
+    } else {
+      for (int I = nbk - 1; I >= 0; I--)  // (the tiles of the last block rows have the fewest terms and can finish first)
+        for (int J = 0; J <= I; J++) add(FF_MT, I, J);
+    }
     st->nM = nbk * (nbk + 1) / 2;
     st->nA = (int)roles.size();  // (split form: the first launch ends here)
     for (int I = 0; I < nbk; I++) add(FF_VEC, I, 0);
@@ -996,7 +1004,24 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     st->doneV_base += nbk;
     return true;
   }
-  if (skip_mt) {  // the table starts with the nM M-tile roles: begin behind them (their count was added by the factorisation's workgroups)
+  if (skip_mt > 0 && skip_mt < st->nM) {  // some of K^-1's tiles are done: the tail's table starts behind them
+    const int nB = st->nroles - skip_mt, slots = st->grid;  // (st->grid = min(nroles, slots))
+    const int grid = nB < slots ? nB : slots;
+    fa.roles = st->d_roles + skip_mt;
+    fa.role_lo = skip_mt;
+    fa.nroles = nB;
+    hipLaunchKernelGGL(bbh_fit_tail_kernel, dim3((unsigned)grid), dim3(256), lds, h->stream, fa);
+    if (hipGetLastError() != hipSuccess) {
+      st->failed = true;
+      return false;
+    }
+    st->ticket_base += nB + grid;
+    st->doneM_base += st->nM;
+    st->doneG_base += st->nG;
+    st->doneV_base += nbk;
+    return true;
+  }
+  if (skip_mt >= st->nM) {  // the table starts with the nM M-tile roles: begin behind them (their count was added by the factorisation's workgroups)
     int per_cu_b = 0;
     const int nB = st->nroles - st->nA;
     if (!st->gridB) {
@@ -1051,7 +1076,7 @@ void bbh_fit_flow_reset(bbh_handle* h) {
 // The M-tile arguments of the NEXT tail launch of this model (state created if need be): what the factorisation launch needs to build
 // K^-1's tiles itself (bbh_potrf_trtri_from_inputs).  out: pd_mt_args.
 bool bbh_fit_flow_mt_args(bbh_handle* h, void* out) {
-  if (!bbh_fit_flow_launch(h, nullptr, nullptr, nullptr, true, nullptr, false, false, true)) return false;
+  if (!bbh_fit_flow_launch(h, nullptr, nullptr, nullptr, true, nullptr, false, 0, true)) return false;
   bbh_flow_state* st = (bbh_flow_state*)h->flow_state;
   if (!st || st->failed || !st->tail_only) return false;
   pd_mt_args* ma = (pd_mt_args*)out;

@@ -464,8 +464,13 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
   }
   if (ntiles > h->tiles_per_device) return false;  // the dataflow needs every tile resident: not on this device / partition
   pd_mt_args ma{};
-  if (mt && mt->nM > 0 && ntiles + mt->nM <= h->tiles_per_device) ma = *mt;  // (K^-1's tiles in the same launch only if they are co-resident too)
-  h->tiles_did_mt = ma.nM > 0;
+  if (mt && mt->nM > 0 && ntiles < h->tiles_per_device) {  // K^-1's tiles in the same launch - as many as are co-resident too, block row 0 first
+    ma = *mt;
+    // (a part of them - block row 0 first - is possible and handled by the tail (skip_mt), but measured without gain at n = 1024, where the
+    // tail's gradient roles, not K^-1, are the long pole: BBH_TILE_MT=partial)
+    if (ntiles + ma.nM > h->tiles_per_device) ma.nM = h->tile_mt_partial ? h->tiles_per_device - ntiles : 0;
+  }
+  h->tiles_did_mt = ma.nM;
   const int grid_tiles = ntiles + ma.nM;
   if (h->tile_spin_limit != h->tile_spin_limit_set) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(pd_spin_limit), &h->tile_spin_limit, sizeof(int)) != hipSuccess) {
