@@ -1114,8 +1114,14 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
             raw[0] = abs(raw[0]) + 0.01
             points.append(gp_spec.unpack_raw(spec, raw))
         out = {}
-        for mode in ("0", "1", "2"):
-            monkeypatch.setenv("BBH_FIT_FLOW", mode)
+        # "1": Gram tiles and (n <= 832) K^-1's tiles inside the factorisation launch, theta as kernel arguments, write-through hand-offs;
+        # the suffixed forms switch one of these off each; "3": the split form (factorisation + K^-1 as one ticketed launch, then the rest)
+        variants = {"0": {}, "1": {}, "2": {}, "3": {}, "1-mt0": {"BBH_TILE_MT": "0"}, "1-gram0": {"BBH_TILE_GRAM": "0"},
+                    "1-wt0": {"BBH_TILE_WT": "0"}, "1-copy": {"BBH_TILE_GRAM_THETA": "copy"}}
+        for mode, extra in variants.items():
+            monkeypatch.setenv("BBH_FIT_FLOW", mode[0])
+            for k_, v_ in extra.items():
+                monkeypatch.setenv(k_, v_)
             g = engine.HipGP(0)
             g.set_model(spec, Xt, y)
             evals = [g.data_term(p) for p in points]
@@ -1127,7 +1133,9 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
             fi = g.fit() if n <= 512 and T == 1 else None
             out[mode] = (evals, fi, per_eval)
             g.close()
-        for mode in ("1", "2"):
+            for k_ in extra:
+                monkeypatch.delenv(k_)
+        for mode in [m for m in variants if m != "0"]:
             for (v0, g0), (v1, g1) in zip(out["0"][0], out[mode][0]):
                 assert v0 is not None and v1 is not None
                 assert math.isclose(v0, v1, rel_tol=1e-11, abs_tol=1e-11), (tag, n, mode, v0, v1)
@@ -1139,7 +1147,7 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
         print(f"   {tag} d={d} n={n} T={T}: evaluation launch by launch {out['0'][2]:.3f} ms, factorisation + one dataflow launch {out['1'][2]:.3f} ms, "
               f"one launch {out['2'][2]:.3f} ms")
     # a poll budget of zero: the waiting roles give up at once, the launch never reports, the handle falls back to the launch path
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         monkeypatch.setenv("BBH_FIT_FLOW", mode)
         monkeypatch.setenv("BBH_FLOW_SPIN", "0")
         X, Xt, y = make_problem(4096, 6, 200, seed=8)
@@ -1158,7 +1166,7 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
         g0.close()
     monkeypatch.delenv("BBH_FLOW_SPIN", raising=False)
     # not positive definite (a negative noise variance: the first pivots fail): the flag comes back through the same channel
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         monkeypatch.setenv("BBH_FIT_FLOW", mode)
         X, Xt, y = make_problem(600, 3, 100, seed=5)
         spec = gp_spec.GPSpec.baybe_default(3, np.zeros(3), np.ones(3))
