@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
         return I == J || pd_wait_n(&flagsX[(K * nbk + J) * PD_FLAG_STRIDE], epoch, info, pd_spin_limit, false, true, nullptr, true);
       };
       const double cmean = GRAM ? gl.th[1] : (ma.theta ? ma.theta[1] : ma.cmean);
-      if (!pd_mtile_core(a, b, vr, vr + 64, I, J, nbk, D, X, ldx, ma, cmean, wait)) return;
+      // (a wait that gave up - info = -7, the launch is lost -: still count the tile, so that the launch behind this one runs through
+      // (on garbage) and hands the flag to the host, which then repeats the evaluation on the per-step path)
+      (void)pd_mtile_core(a, b, vr, vr + 64, I, J, nbk, D, X, ldx, ma, cmean, wait);
       __syncthreads();  // (consumers run in the next launch: the kernel boundary publishes the tile; the flag and the count only say "done")
       if (threadIdx.x == 0) {
         __hip_atomic_store(&ma.flagsM[I * 16 + J], ma.flow_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
