@@ -34,14 +34,13 @@ extern "C" int bbh_create(int device_id, bbh_handle** out) {
   if (const char* e = getenv("BBH_FLOW_SPIN")) h->flow_spin_limit = atoi(e);
   if (const char* e = getenv("BBH_TILE_GRAM")) h->tile_gram = (e[0] != '0');
   if (const char* e = getenv("BBH_TILE_WT")) h->tile_wt = (e[0] != '0');
-  if (const char* e = getenv("BBH_TILE_ACQ")) h->tile_d_sc1 = (e[0] == '0');
+  if (const char* e = getenv("BBH_TILE_ACQ")) h->tile_d_sc1 = (e[0] == '0');  // (default: acquire fence)
   if (const char* e = getenv("BBH_TILE_MT")) {
     h->tile_mt = (e[0] != '0');
     h->tile_mt_partial = (e[0] == 'p');
   }
   if (const char* e = getenv("BBH_POTRF_TILES")) h->potrf_tiles = (e[0] != '0');
   if (const char* e = getenv("BBH_TILE_SPIN")) h->tile_spin_limit = atoi(e);
-  if (const char* e = getenv("BBH_TILE_POLL")) h->tile_spin_limit |= (e[0] == 'r') ? (1 << 30) : 0;
   if (const char* e = getenv("BBH_KV_GLOBAL")) h->kv_global_mode = (e[0] != '0') ? 1 : 0;
   if (const char* e = getenv("BBH_KV_LDS")) h->kv_lds_blocks = atoi(e);
   if (const char* e = getenv("BBH_MEAN_VALU")) h->use_mean_valu = (e[0] != '0');

@@ -336,7 +336,7 @@ struct bbh_handle {
   bool flow_in_flight = false;    // the evaluation on the stream is the one-launch form (its flag needs the sentinel check)
   long long* d_tiledbg = nullptr; // BBH_TILE_STAMPS=1: clock stamps of the Gram-building tile launch
   int tiledbg_n = 0;
-  bool tile_d_sc1 = true;         // env BBH_TILE_ACQ=1: row heads take D_{I-1} through an acquire fence + plain loads instead of sc1 loads (A/B)
+  bool tile_d_sc1 = false;        // env BBH_TILE_ACQ=0: row heads take D_{I-1} through sc1 loads without an acquire fence (valid after write-through stores; measured: no gain, so the fence form stays the default)
   bool tile_wt = true;            // env BBH_TILE_WT=0: tiles handed between workgroups through plain stores + an agent-scope release fence instead of write-through (sc1) stores (A/B)
   int tiles_did_mt = 0;           // tiles of K^-1 the last tile-dataflow launch built itself (bbh_potrf_trtri_from_inputs with mt_args; block row 0 first)
   bool tile_mt_partial = false;   // env BBH_TILE_MT=partial

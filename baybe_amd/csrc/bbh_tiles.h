@@ -511,10 +511,8 @@ __device__ __forceinline__ bool pd_wait_n(const int* flag, int epoch, int* info,
     // waiting workgroup of a launch polling (130 of them in the one-launch fit evaluation) those invalidations slowed the
     // critical path's own tile loads and write-backs - hand-offs took up to 19 us instead of 2 (profiles/r05_flow_trace_*).
     // The acquire side is the fence every thread executes after the flag has flipped.
-    const bool rmw = (spin_limit & (1 << 30)) != 0;  // (experiment, BBH_TILE_POLL=rmw: polls as device-scope atomics)
-    spin_limit &= ~(1 << 30);
-    while ((rmw ? __hip_atomic_fetch_or(const_cast<int*>(flag), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                : __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != epoch) {
+    // (polls as device-scope atomic read-modify-writes instead of loads were measured: no difference)
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
       if (++it > spin_limit || ((it & 15) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == -7)) {
         __hip_atomic_store(info, -7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
