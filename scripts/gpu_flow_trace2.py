@@ -20,6 +20,8 @@ lib.bbh_flow_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 st = np.zeros((1024, 8), dtype=np.int64); roles = np.zeros(1024, dtype=np.int32)
 nr = lib.bbh_flow_trace_read(g._h, st.ctypes.data, roles.ctypes.data, 1024)
 st, roles = st[:nr], roles[:nr]
+ran = st[:, 0] > 0  # (roles of the table that another launch ran carry no stamps)
+st, roles = st[ran], roles[ran]
 t0 = st[:, 0].min()
 us = lambda v: (v - t0) / 100.0
 names = ["RH", "L", "XT", "MT", "VEC", "QV", "QT", "GT"]
