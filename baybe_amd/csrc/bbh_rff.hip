@@ -43,7 +43,7 @@ struct bbh_rff_state {
   double* d_T = nullptr;      // [nr][mp] Phi B^-1, then dL/dP in its first Dh columns
   double* d_vec = nullptr;    // b [mp] | t [mp] | a [mp] | scalars [8]: 0 log|B|, 1 tr B^-1 (real features)
   double* d_alpha = nullptr;  // [nr]
-  double* d_gl = nullptr;     // [dn]
+  double* d_gl = nullptr;     // [dn][nr / 64] per-chunk partial sums of the lengthscale gradient
   double* d_Qp = nullptr;     // packed lower block rows of sqrt(s2) L^-T (posterior operand), rff_qp_elems(mp / 16) doubles
   double* d_E = nullptr;      // [mp][16] column 0: a, columns 1..p: s2 B^-1 phi_p of the pending points
   double* d_lo = nullptr;     // [dn] lower scaling bound, [dn] 1 / (hi - lo), then numcol as doubles [dn]
@@ -240,33 +240,31 @@ __global__ void bbh_rff_dp_kernel(const double* __restrict__ Phi, const double* 
   T[a * mp + j] = out;
 }
 
-// gl[i] = -(1 / l_i^2) sum_{a < n, j < D} xn[a][i] W[i][j] dP[a][j]      (one workgroup per numerical column, fixed order)
+// glp[i][c] = sum_{a in chunk c (64 rows), j < D} xn[a][i] W[i][j] dP[a][j]   (one workgroup per numerical column and row chunk; the value
+// kernel adds the chunks in a fixed order: gl[i] = -(sum_c glp[i][c]) / l_i^2).  One workgroup per column over all rows was 42 us.
 __global__ __launch_bounds__(256) void bbh_rff_gls_kernel(const double* __restrict__ xnT, int64_t ldxn, const double* __restrict__ W,
-                                                          const double* __restrict__ dP, const double* __restrict__ theta, int n, int D, int Dh,
-                                                          double* __restrict__ gl) {
+                                                          const double* __restrict__ dP, int n, int D, int Dh, int nchunks,
+                                                          double* __restrict__ glp) {
   __shared__ double sm[4];
-  const int i = blockIdx.x, t = threadIdx.x;
+  const int i = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
   const int mp = 2 * Dh;
   double acc = 0.0;
-  for (int64_t e = t; e < (int64_t)n * Dh; e += 256) {
-    const int64_t a = e / Dh;
-    const int j = (int)(e % Dh);
-    if (j < D) acc = fma(xnT[(int64_t)i * ldxn + a] * W[i * Dh + j], dP[a * mp + j], acc);
+  for (int e = t; e < 64 * Dh; e += 256) {
+    const int64_t a = (int64_t)c * 64 + e / Dh;
+    const int j = e % Dh;
+    if (a < n && j < D) acc = fma(xnT[(int64_t)i * ldxn + a] * W[i * Dh + j], dP[a * mp + j], acc);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((t & 63) == 0) sm[t >> 6] = acc;
   __syncthreads();
-  if (t == 0) {
-    const double l = theta[RFF_TH_LS + i];
-    gl[i] = -(sm[0] + sm[1] + sm[2] + sm[3]) / (l * l);
-  }
+  if (t == 0) glp[i * nchunks + c] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
 // out[0] = value, out[1 + slot] = gradient   (one workgroup)
 __global__ __launch_bounds__(256) void bbh_rff_value_kernel(const double* __restrict__ r, const double* __restrict__ alpha, const double* __restrict__ vec,
-                                                            const double* __restrict__ gl, const double* __restrict__ theta, int use_os, int n,
-                                                            int mp, int D, int dn, double* __restrict__ out) {
+                                                            const double* __restrict__ glp, int nchunks, const double* __restrict__ theta, int use_os,
+                                                            int n, int mp, int D, int dn, double* __restrict__ out) {
   __shared__ double sm[4];
   const int t = threadIdx.x;
   double ra = 0.0, aa = 0.0, sa = 0.0;
@@ -299,7 +297,12 @@ __global__ __launch_bounds__(256) void bbh_rff_value_kernel(const double* __rest
     for (int k = 0; k < mp; k++) a2 = fma(vec[2 * mp + k], vec[2 * mp + k], a2);
     out[1 + RFF_TH_OS] = use_os ? 0.5 * (a2 / (os * os) - (m - eps * trBinv) / os) : 0.0;
   }
-  if (t < dn) out[1 + RFF_TH_LS + t] = gl[t];
+  if (t < dn) {
+    double g = 0.0;
+    for (int c = 0; c < nchunks; c++) g += glp[t * nchunks + c];
+    const double l = theta[RFF_TH_LS + t];
+    out[1 + RFF_TH_LS + t] = -g / (l * l);
+  }
 }
 
 static int rff_posterior_lds_attr(bbh_handle* h, int Dh);  // (defined with the kernel)
@@ -340,7 +343,7 @@ int bbh_rff_setup(bbh_handle* h) {
   RFF_ALLOC(st->d_T, nr * mp);
   RFF_ALLOC(st->d_vec, 3 * mp + 8);
   RFF_ALLOC(st->d_alpha, nr);
-  RFF_ALLOC(st->d_gl, dn);
+  RFF_ALLOC(st->d_gl, (size_t)dn * (size_t)(nr / 64));
   RFF_ALLOC(st->d_Qp, rff_qp_elems(mp / 16));
   RFF_ALLOC(st->d_E, mp * 16);
   RFF_ALLOC(st->d_lo, 3 * dn);
@@ -399,9 +402,11 @@ int bbh_rff_fit_enqueue(bbh_handle* h) {
   bbh_gemm(s, false, false, nr, mp, mp, 1.0, st->d_Phi, mp, 0, st->d_Binv, mp, 0, 0.0, st->d_T, mp, 0, 1);  // Phi B^-1
   hipLaunchKernelGGL(bbh_rff_dp_kernel, dim3((unsigned)((nr * Dh + 255) / 256)), dim3(256), 0, s, st->d_Phi, st->d_vec + 2 * mp, st->d_alpha, (int)n, nr, D,
                      Dh, st->d_T);
-  hipLaunchKernelGGL(bbh_rff_gls_kernel, dim3((unsigned)dn), dim3(256), 0, s, h->d_xnT, h->np, st->d_W, st->d_T, h->d_theta, (int)n, D, Dh, st->d_gl);
-  hipLaunchKernelGGL(bbh_rff_value_kernel, dim3(1), dim3(256), 0, s, r, st->d_alpha, st->d_vec, st->d_gl, h->d_theta, h->desc.use_outputscale, (int)n, mp, D,
-                     dn, h->d_out);
+  const int nchunks = (int)(nr / 64);
+  hipLaunchKernelGGL(bbh_rff_gls_kernel, dim3((unsigned)dn, (unsigned)nchunks), dim3(256), 0, s, h->d_xnT, h->np, st->d_W, st->d_T, (int)n, D, Dh, nchunks,
+                     st->d_gl);
+  hipLaunchKernelGGL(bbh_rff_value_kernel, dim3(1), dim3(256), 0, s, r, st->d_alpha, st->d_vec, st->d_gl, nchunks, h->d_theta, h->desc.use_outputscale, (int)n,
+                     mp, D, dn, h->d_out);
   BBH_HIP_TRY(h, hipMemcpyAsync(h->pin_out, h->d_out, sizeof(double) * (1 + tl), hipMemcpyDeviceToHost, s));
   BBH_HIP_TRY(h, hipMemcpyAsync(h->pin_info, st->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   return 0;
