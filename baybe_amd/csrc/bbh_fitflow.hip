@@ -676,6 +676,9 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
   __syncthreads();
   if (t == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (the wait behind buffer_wbl2 restated where the compiler cannot drop it - it does when the wave's scoreboard is provably empty, as
+    // after the workgroup fence above, and the count could then overtake the write-back of the partial rows: cdna guide, Guideline 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int old = atomicAdd(&fa.counters[2], 1);
     sh.last = (old == fa.doneG_base + fa.nG - 1) ? 1 : 0;
     if (sh.last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
