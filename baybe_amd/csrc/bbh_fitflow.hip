@@ -669,16 +669,14 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc += tab[t * 16 + e];
-    row[t] = acc;
+    // write-through (sc1) store: the row is at the memory side once this wave's stores have drained - no release fence (buffer_wbl2 of
+    // the whole L2) before the arrival count; the last arriver's acquire + plain loads read it (cdna guide, Guideline 16 R1)
+    __hip_atomic_store(&row[t], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- last role: the sums over all roles' rows, in role order (eight row groups per slot, combined in group order) ----
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every storing wave drains)
   __syncthreads();
   if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    // (the wait behind buffer_wbl2 restated where the compiler cannot drop it - it does when the wave's scoreboard is provably empty, as
-    // after the workgroup fence above, and the count could then overtake the write-back of the partial rows: cdna guide, Guideline 16)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int old = atomicAdd(&fa.counters[2], 1);
     sh.last = (old == fa.doneG_base + fa.nG - 1) ? 1 : 0;
     if (sh.last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
