@@ -927,3 +927,16 @@ def test_rff_kernel_specifications_the_device_does_not_take():
         apply_kernel_spec(tl, RFFKernel(5))
     with pytest.raises((ValueError, TypeError)):
         RFFKernel(0)
+
+
+def test_qlognehvi_refuses_rff_surrogates_before_touching_a_device():
+    """The extended models of qLogNEHVI condition on noise-free latent rows, which the RFF kernel's feature-space form does not have: the
+    scorer refuses such surrogates by name, before any device object exists (no HIP library is needed for the refusal)."""
+    from types import SimpleNamespace
+
+    from baybe_amd.exceptions import IncompatibilityError
+    from baybe_amd.nehvi import HipNEHVI
+
+    engines = [SimpleNamespace(spec=SimpleNamespace(kernel="matern52")), SimpleNamespace(spec=SimpleNamespace(kernel="rff"))]
+    with pytest.raises(IncompatibilityError, match="RFFKernel"):
+        HipNEHVI(engines, [1.0, 1.0], np.zeros((3, 2)), np.zeros(2))
