@@ -313,4 +313,4 @@ def main(out_path: Path):
 
 
 if __name__ == "__main__":
-    main(HERE / "reference_events.npz")
+    main(Path(sys.argv[1]) if len(sys.argv) > 1 else HERE / "reference_events.npz")

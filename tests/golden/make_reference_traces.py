@@ -222,4 +222,4 @@ def main(out_path: Path):
 
 
 if __name__ == "__main__":
-    main(HERE / "reference_traces.npz")
+    main(Path(sys.argv[1]) if len(sys.argv) > 1 else HERE / "reference_traces.npz")
