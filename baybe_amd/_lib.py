@@ -141,6 +141,8 @@ SIGNATURES = {
     "bbh_pareto_frequency": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
     "bbh_pareto_frequency_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p]),
     "bbh_nehvi_samples": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "bbh_nehvi_samples_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_int32]),
     "bbh_cells_build_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_int64_p, c_int64_p]),
     "bbh_cells_read_dev": (C.c_int, [C.c_void_p, c_int64_p, c_double_p, c_double_p]),
     "bbh_qlognehvi_cells": (
@@ -153,6 +155,8 @@ SIGNATURES = {
     "bbh_cells_destroy": (C.c_int, [C.c_void_p]),
     "bbh_sobol_scramble": (C.c_int, [c_int64_p, c_int64_p, C.c_int64]),
     "bbh_sobol_draw": (C.c_int, [c_int64_p, c_int64_p, C.c_int64, C.c_int64, c_double_p]),
+    "bbh_sobol_normal": (C.c_int, [c_int64_p, C.c_uint64, C.c_int64, C.c_int64, c_double_p]),
+    "bbh_sobol_normal_dev": (C.c_int, [C.c_void_p, c_int64_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p]),
     "bbh_content_key": (C.c_uint64, [C.POINTER(C.c_void_p), c_int64_p, C.c_int32, C.c_int32]),
     "bbh_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_int64_p]),
     "bbh_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_int64_p]),

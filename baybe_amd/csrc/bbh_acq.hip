@@ -554,6 +554,32 @@ static int bbh_ensure_red(bbh_handle* h) {
   return 0;
 }
 
+// The handle's pinned staging buffer: at least `bytes` large and no longer read by an earlier staged copy.  The caller fills it,
+// enqueues its hipMemcpyAsync calls from it on h->stream and then calls bbh_stage_done.  (A synchronous hipMemcpy from pageable
+// memory is not an alternative: four 4 KB copies of bbh_set_model_ex took 13 - 26 ms in a process holding a 1e5-row search space -
+// profiles/r06_set_model_probe.log.)
+void* bbh_stage_pinned(bbh_handle* h, size_t bytes) {
+  if (!h->z_evt) {
+    if (hipEventCreateWithFlags(&h->z_evt, hipEventDisableTiming) != hipSuccess) return nullptr;
+  } else if (hipEventSynchronize(h->z_evt) != hipSuccess) {  // previous staged copy has been consumed
+    return nullptr;
+  }
+  if (bytes > h->zstage_bytes) {
+    if (h->h_zstage) hipHostFree(h->h_zstage);
+    h->h_zstage = nullptr;
+    h->zstage_bytes = 0;
+    const size_t want = bytes < 4096 ? 4096 : bytes;
+    if (hipHostMalloc((void**)&h->h_zstage, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    h->zstage_bytes = want;
+  }
+  return h->h_zstage;
+}
+
+int bbh_stage_done(bbh_handle* h) {
+  BBH_HIP_TRY(h, hipEventRecord(h->z_evt, h->stream));
+  return 0;
+}
+
 int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
   const size_t bytes = sizeof(double) * count;
   if (bytes > h->z_bytes) {
@@ -565,19 +591,15 @@ int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count) {
   }
   // Staged through a pinned buffer of the handle, so that the call neither waits for the kernels already in
   // the stream (a synchronous copy would: it is ordered behind them) nor depends on the caller's buffer.
-  if (!h->z_evt) BBH_HIP_TRY(h, hipEventCreateWithFlags(&h->z_evt, hipEventDisableTiming));
-  else BBH_HIP_TRY(h, hipEventSynchronize(h->z_evt));  // previous staged copy has been consumed
-  if (bytes > h->zstage_bytes) {
-    if (h->h_zstage) hipHostFree(h->h_zstage);
-    h->h_zstage = nullptr;
-    h->zstage_bytes = 0;
-    BBH_HIP_TRY(h, hipHostMalloc((void**)&h->h_zstage, bytes, hipHostMallocDefault));
-    h->zstage_bytes = bytes;
+  void* stage = bbh_stage_pinned(h, bytes);
+  if (!stage) {
+    h->err = "bbh_upload_z: no pinned staging buffer";
+    (void)hipGetLastError();
+    return -2;
   }
-  memcpy(h->h_zstage, z_host, bytes);
-  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_z, h->h_zstage, bytes, hipMemcpyHostToDevice, h->stream));
-  BBH_HIP_TRY(h, hipEventRecord(h->z_evt, h->stream));
-  return 0;
+  memcpy(stage, z_host, bytes);
+  BBH_HIP_TRY(h, hipMemcpyAsync(h->d_z, stage, bytes, hipMemcpyHostToDevice, h->stream));
+  return bbh_stage_done(h);
 }
 
 int bbh_qlogei_q1_sliced(bbh_handle* h, const double* mean_dev, const double* var_dev, int64_t N, const double* z_host, int64_t S,

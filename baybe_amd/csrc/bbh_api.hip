@@ -71,6 +71,7 @@ extern "C" int bbh_destroy(bbh_handle* h) {
   bbh_comm_destroy(h);
   bbh_select_destroy(h);
   bbh_nehvi_destroy(h);
+  bbh_sobol_destroy(h);
   bbh_flow_destroy(h);
   bbh_free_model_public(h);
   if (h->d_ws) hipFree(h->d_ws);

@@ -349,6 +349,7 @@ struct bbh_handle {
   int rff_w_dn = 0, rff_w_D = 0;
   void* nehvi_state = nullptr;    // device-resident box decompositions + their scratch (bbh_nehvi.hip), null until bbh_cells_build_dev
   void* select_state = nullptr;   // chunk keys, result block and base-sample tables of the selection kernels (bbh_select.hip)
+  void* sobol_state = nullptr;    // staging of the device-side base-sample draw (bbh_sobol.hip), null until bbh_sobol_normal_dev
   bool q1_sliced = true;          // env BBH_Q1_SLICED=0: q' = 1 qLogEI as one thread per candidate (A/B)
   bool select_on = true;          // env BBH_SELECT=0: top-k / argmax by k rounds of workgroup argmax (A/B)
   // timing
@@ -440,9 +441,12 @@ int bbh_launch_unfused(bbh_handle* h, const double* X_dev, int64_t N, int64_t ld
                        double* var_dev);
 
 int bbh_ensure_ws(bbh_handle* h, size_t bytes);
+void* bbh_stage_pinned(bbh_handle* h, size_t bytes);  // the handle's pinned staging buffer, free to be rewritten (bbh_acq.hip); null on failure
+int bbh_stage_done(bbh_handle* h);                   // the copies enqueued from it on h->stream are the last readers
 int bbh_upload_z(bbh_handle* h, const double* z_host, size_t count);  // host doubles -> h->d_z through the handle's pinned staging buffer (bbh_acq.hip)
 void bbh_select_destroy(bbh_handle* h);  // bbh_select.hip
 void bbh_nehvi_destroy(bbh_handle* h);   // bbh_nehvi.hip
+void bbh_sobol_destroy(bbh_handle* h);   // bbh_sobol.hip
 void bbh_flow_destroy(bbh_handle* h);    // bbh_fitflow.hip
 bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev, int* info_dev, bool tail_only, const double* theta_host = nullptr,
                          bool split = false, int skip_mt = 0, bool prepare_only = false);  // split: two launches - the factorisation with K^-1's tiles, then everything behind them; skip_mt: tail form without the M-tile roles

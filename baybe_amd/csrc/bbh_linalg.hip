@@ -7,7 +7,10 @@
 // These replace what linear_operator/LAPACK do under gpytorch's ExactMarginalLogLikelihood
 // (reference call site baybe/surrogates/gaussian_process/core.py:340-341).  All matrices are
 // padded to multiples of 64 with an identity block, so no kernel needs edge handling.
+#include <mutex>
+#include <thread>
 #include <type_traits>
+#include <vector>
 
 #include "bbh_common.h"
 #include "bbh_tiles.h"
@@ -432,6 +435,81 @@ void bbh_ensure_side_stream(bbh_handle* h) {
 static bool g_tiles_unusable[64];
 void bbh_potrf_tiles_mark_unusable(int device) { g_tiles_unusable[device & 63] = true; }
 
+// Residency ledger.  The dataflow needs every tile of a launch resident at once, and its block order is not topological
+// (row heads wait on L-tiles with higher indices).  The per-launch check `ntiles <= tiles_per_device` says nothing about launches of
+// OTHER handles on other streams (the targets of a CompositeSurrogate fitted side by side, the extended models of qLogNEHVI): two
+// half-resident launches would starve each other until the spin limit.  So every launch is entered here with an event recorded
+// behind it; a new launch on another stream waits (host side, polling the events) until the tiles still in flight plus its own
+// fit the device.  A launch on the SAME stream as an entry is ordered behind it and replaces it - the single-handle case never polls.
+namespace {
+struct pd_lease {
+  hipStream_t stream;
+  hipEvent_t evt;
+  int tiles;
+};
+struct pd_ledger {
+  std::mutex mu;
+  std::vector<pd_lease> live;
+  std::vector<hipEvent_t> spare;
+};
+pd_ledger g_tile_ledger[64];
+
+// true: `tiles` more workgroups fit next to what other streams still have in flight (waits up to ~20 ms for that); the caller
+// launches and then calls pd_ledger_commit.  false: give this evaluation to the per-step path.
+bool pd_ledger_reserve(int device, hipStream_t s, int tiles, int cap) {
+  pd_ledger& L = g_tile_ledger[device & 63];
+  for (int spin = 0;; spin++) {
+    {
+      std::lock_guard<std::mutex> lk(L.mu);
+      int in_flight = 0;
+      for (size_t k = 0; k < L.live.size();) {
+        if (L.live[k].stream == s || hipEventQuery(L.live[k].evt) == hipSuccess) {
+          L.spare.push_back(L.live[k].evt);
+          L.live[k] = L.live.back();
+          L.live.pop_back();
+        } else {
+          in_flight += L.live[k].tiles;
+          k++;
+        }
+      }
+      (void)hipGetLastError();  // (hipErrorNotReady of the queries)
+      if (in_flight + tiles <= cap) {
+        // entered BEFORE the launch (without an event yet: counted as in flight by everyone else until committed)
+        L.live.push_back({s, nullptr, tiles});
+        return true;
+      }
+    }
+    if (spin > 20000) return false;
+    std::this_thread::yield();
+  }
+}
+
+void pd_ledger_commit(int device, hipStream_t s) {
+  pd_ledger& L = g_tile_ledger[device & 63];
+  std::lock_guard<std::mutex> lk(L.mu);
+  for (size_t k = 0; k < L.live.size(); k++)
+    if (L.live[k].stream == s && !L.live[k].evt) {
+      hipEvent_t e = nullptr;
+      if (!L.spare.empty()) {
+        e = L.spare.back();
+        L.spare.pop_back();
+      } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        e = nullptr;
+      }
+      if (!e || hipEventRecord(e, s) != hipSuccess) {  // cannot track it: wait for it here instead
+        (void)hipGetLastError();
+        hipStreamSynchronize(s);
+        if (e) L.spare.push_back(e);
+        L.live[k] = L.live.back();
+        L.live.pop_back();
+      } else {
+        L.live[k].evt = e;
+      }
+      return;
+    }
+}
+}  // namespace
+
 // gram_theta != nullptr: the kernel builds the tiles of K + s2 M itself (single-kernel models, bbh_fit_flow_eligible) from theta at
 // that (device or host-mapped) address - the fit evaluation's form, which needs no Gram launch before it.
 static_assert(sizeof(pd_mt_args) <= 128, "bbh_model.hip hands pd_mt_args over in a 128-byte buffer");
@@ -483,6 +561,10 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
     h->tile_spin_limit_set = h->tile_spin_limit;
   }
   hipStream_t s = h->stream;
+  if (!pd_ledger_reserve(h->device, s, grid_tiles, h->tiles_per_device)) {  // other streams' launches hold the device: per-step path this time
+    h->tiles_did_mt = 0;
+    return false;
+  }
   if (!h->skip_x_memset) hipMemsetAsync(h->d_X, 0, sizeof(double) * np * np, s);  // the upper tiles of L^-1 (XᵀX reads the full matrix)
   // (fit evaluations through the dataflow tail: its last role leaves the flag at 0 for the next evaluation - no memset between them)
   if (!info_clean) hipMemsetAsync(h->d_info, 0, sizeof(int), s);
@@ -522,6 +604,7 @@ static bool bbh_potrf_tiles(bbh_handle* h, const double* gram_theta = nullptr, c
     hipLaunchKernelGGL((bbh_potrf_tiles_kernel<false, false>), dim3((unsigned)grid_tiles), dim3(256), lds, s, h->d_K, np, nbk, h->d_D, h->d_X, np, h->d_tileflags,
                        h->d_tileflags + 256 * PD_FLAG_STRIDE, epoch, h->d_info, gs, ma);
   }
+  pd_ledger_commit(h->device, s);
   return true;
 }
 

@@ -359,11 +359,8 @@ static void bbh_reset_model_state(bbh_handle* h) {
   if (h->fit_exec) hipGraphExecDestroy(h->fit_exec);
   h->fit_exec = nullptr;
   h->fit_graph_failed = false;
-  if (h->d_colfrag) hipFree(h->d_colfrag);
-  if (h->d_colA) hipFree(h->d_colA);
-  h->d_colfrag = h->d_colA = nullptr;
-  h->colfrag_elems = 0;
-  h->colA_elems = 0;
+  // (the installed weight columns are INVALIDATED, not freed: the shape signature is unchanged, so the buffers fit the next
+  // bbh_install_columns - hipFree synchronises the device)
   h->ncols = 0;
   h->have_model = false;
   h->factorized = false;
@@ -437,6 +434,12 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     }
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
+  // BBH_SETMODEL_TRACE=1: wall-clock stamps of the stages below on stderr (scripts/gpu_set_model_probe.py)
+  static const bool sm_trace = getenv("BBH_SETMODEL_TRACE") != nullptr;
+  const auto sm_t0 = std::chrono::steady_clock::now();
+  auto sm_stamp = [&](const char* what) {
+    if (sm_trace) fprintf(stderr, "bbh_set_model %-10s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - sm_t0).count());
+  };
   // A campaign re-fits after every batch of measurements: the model description is the same and the padded size np changes only
   // every 64 measurements.  Then every device buffer keeps its size - freeing and re-allocating ~40 of them (hipFree synchronises
   // the device) was 1 ms of a 6.8 ms small-space recommend().  Buffers are kept when the shape signature is unchanged.
@@ -460,6 +463,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
       h->model_sig = sig;
     }
   }
+  sm_stamp("reset");
   h->desc = *desc;
   h->n = n;
   h->np = bbh_round_up(n, BBH_PAD);
@@ -553,6 +557,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     ypad[i] = h->ystd_host[i];
     tpad[i] = h->task_host[i];
   }
+  sm_stamp("host-prep");
 #define BBH_ALLOC(ptr, count) \
   if (!(ptr)) BBH_HIP_TRY(h, hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)))  /* (kept from the previous model of the same shape) */
   BBH_ALLOC(h->d_xnT, h->dn * np);
@@ -580,11 +585,37 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   BBH_ALLOC(h->d_beta, np * BBH_MEANCOLS);
   if (np >= 256 && np <= 1024) BBH_ALLOC(h->d_Mpart, 4 * np * np);
   BBH_ALLOC(h->d_pendT, (int64_t)h->dn * 16);
-  BBH_HIP_TRY(h, hipMemset(h->d_pendT, 0, sizeof(double) * h->dn * 16));
-  BBH_HIP_TRY(h, hipMemcpy(h->d_xnT, xnT.data(), sizeof(double) * xnT.size(), hipMemcpyHostToDevice));
-  BBH_HIP_TRY(h, hipMemcpy(h->d_task, tpad.data(), sizeof(int) * np, hipMemcpyHostToDevice));
-  BBH_HIP_TRY(h, hipMemcpy(h->d_nmask, h->nmask_host.data(), sizeof(double) * np, hipMemcpyHostToDevice));
-  BBH_HIP_TRY(h, hipMemcpy(h->d_ystd, ypad.data(), sizeof(double) * np, hipMemcpyHostToDevice));
+  sm_stamp("alloc");
+  // The model's arrays go up through the handle's pinned staging buffer as stream-ordered copies: everything that reads them is
+  // enqueued on h->stream behind them.  (They were four synchronous copies from pageable memory - 13 - 26 ms of a 1e5-row campaign
+  // step, profiles/r06_set_model_probe.log; VERDICT r5 item 3 measured it as "8 ms of set_model".)
+  {
+    const size_t b_x = sizeof(double) * xnT.size(), b_t = sizeof(int) * (size_t)np, b_m = sizeof(double) * (size_t)np, b_y = sizeof(double) * (size_t)np;
+    const size_t o_x = 0, o_m = o_x + b_x, o_y = o_m + b_m, o_t = o_y + b_y;  // (doubles first: the int block needs no padding behind them)
+    unsigned char* stage = (unsigned char*)bbh_stage_pinned(h, o_t + b_t);
+    if (!stage) {
+      (void)hipGetLastError();
+      h->err = "bbh_set_model: no pinned staging buffer";
+      return -2;
+    }
+    memcpy(stage + o_x, xnT.data(), b_x);
+    memcpy(stage + o_m, h->nmask_host.data(), b_m);
+    memcpy(stage + o_y, ypad.data(), b_y);
+    memcpy(stage + o_t, tpad.data(), b_t);
+    hipStream_t s = h->stream;
+    BBH_HIP_TRY(h, hipMemsetAsync(h->d_pendT, 0, sizeof(double) * h->dn * 16, s));
+    sm_stamp("memset");
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_xnT, stage + o_x, b_x, hipMemcpyHostToDevice, s));
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_nmask, stage + o_m, b_m, hipMemcpyHostToDevice, s));
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_ystd, stage + o_y, b_y, hipMemcpyHostToDevice, s));
+    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_task, stage + o_t, b_t, hipMemcpyHostToDevice, s));
+    int rc_stage = bbh_stage_done(h);
+    if (rc_stage) return rc_stage;
+    // (complete before the call returns, as the synchronous copies were: the handle's stream may be changed before the model is used -
+    // bbh_set_stream, the captured-graph stream of BBH_FIT_GRAPH - and the side streams are not ordered behind h->stream)
+    BBH_HIP_TRY(h, hipStreamSynchronize(s));
+  }
+  sm_stamp("copies");
   h->xraw_host.assign(X_train_host, X_train_host + n * d);
   h->p = 0;
   h->pend_host.clear();

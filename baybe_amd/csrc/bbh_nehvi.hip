@@ -308,6 +308,15 @@ extern "C" int bbh_cells_build_dev(bbh_handle* h, const double* Fb_dev, int64_t 
   if (cap < 8) cap = 8;
   if (cap > NV_MAXBOUNDS) cap = NV_MAXBOUNDS;
   const size_t lds = nv_lds((int)nb, m, cap);
+  // the device's own LDS limit decides (160 KB on gfx950); a sample set that does not fit goes to the host form like an overflow
+  int lds_max = 0;
+  if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess) lds_max = 64 * 1024;
+  const int lds_limit = lds_max - 64;
+  if (lds > (size_t)lds_limit) {
+    *total_out = 0;
+    *overflow_out = S;
+    return 0;
+  }
   const size_t slot_bytes = sizeof(double) * (size_t)S * cap * 2 * m;
   const size_t pack_bytes = sizeof(double) * ((size_t)S + 1 + 3 * (size_t)S * cap * m);
   hipStream_t s = h->stream;
@@ -340,12 +349,13 @@ extern "C" int bbh_cells_build_dev(bbh_handle* h, const double* Fb_dev, int64_t 
   BBH_HIP_TRY(h, hipMemcpyAsync(st->d_ref, ref_host, sizeof(double) * m, hipMemcpyHostToDevice, s));
   BBH_HIP_TRY(h, hipMemsetAsync(st->d_cnt + S, 0, sizeof(int), s));
   dim3 grid((unsigned)S), block(64);
+  // hipFuncSetAttribute is per DEVICE (a process-wide flag left a second GPU of the same process without the raised limit)
 #define NV_LAUNCH(MM)                                                                                                                \
   {                                                                                                                                  \
-    static bool attr_set = false;                                                                                                    \
-    if (!attr_set) {                                                                                                                 \
-      BBH_HIP_TRY(h, hipFuncSetAttribute((const void*)bbh_cells_kernel<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
-      attr_set = true;                                                                                                               \
+    static bool attr_set[64] = {};                                                                                                   \
+    if (!attr_set[h->device & 63]) {                                                                                                 \
+      BBH_HIP_TRY(h, hipFuncSetAttribute((const void*)bbh_cells_kernel<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit)); \
+      attr_set[h->device & 63] = true;                                                                                               \
     }                                                                                                                                \
     hipLaunchKernelGGL(bbh_cells_kernel<MM>, grid, block, lds, s, Fb_dev, (int)nb, st->d_ref, cap, st->d_slots, st->d_cnt, st->d_cnt + S); \
   }

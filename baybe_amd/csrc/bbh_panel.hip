@@ -1446,15 +1446,16 @@ extern "C" int bbh_set_mean_columns(bbh_handle* h, const double* Y_host, int64_t
 }
 
 // t1[i][s] = t_i for the training rows i < n0 (the same in every column), z[s][i - n0] for the nb baseline rows, 0 on the padding
-__global__ void bbh_nehvi_t1_kernel(const double* __restrict__ t, const double* __restrict__ z, int64_t n0, int64_t nb, int64_t S,
-                                    int64_t np, int64_t spad, double* __restrict__ out) {
+// (cols: where baseline row b's base sample sits in a row of z - null: z is [S, nb])
+__global__ void bbh_nehvi_t1_kernel(const double* __restrict__ t, const double* __restrict__ z, int64_t ldz, const int32_t* __restrict__ cols,
+                                    int64_t n0, int64_t nb, int64_t S, int64_t np, int64_t spad, double* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= np * spad) return;
   const int64_t i = e / spad, s = e % spad;
   double v = 0.0;
   if (s < S) {
     if (i < n0) v = t[i];
-    else if (i < n0 + nb) v = z[s * nb + (i - n0)];
+    else if (i < n0 + nb) v = z[s * ldz + (cols ? (int64_t)cols[i - n0] : i - n0)];
   }
   out[e] = v;
 }
@@ -1491,10 +1492,28 @@ __global__ __launch_bounds__(256) void bbh_nehvi_fb_kernel(const double* __restr
 //     (bbh_posterior_columns), without the (n + nb) x S host array bbh_set_mean_columns takes.
 // z_host [S, nb].  Asynchronous on the handle's stream.  Reference: baybe/acquisition/_builder.py:301-334 (X_baseline,
 // prune_baseline, cache_root), baybe/acquisition/acqfs.py:477-484.
+static int bbh_nehvi_samples_impl(bbh_handle* h, const double* z_host, const double* z_dev, int64_t ldz, const int32_t* cols_dev, int64_t S,
+                                  int64_t nb, double sign, int32_t o, int32_t m, double* Fb_dev, int32_t want_columns);
+
 extern "C" int bbh_nehvi_samples(bbh_handle* h, const double* z_host, int64_t S, int64_t nb, double sign, int32_t o, int32_t m,
                                  double* Fb_dev, int32_t want_columns) {
   if (!h) return -1;
-  if (!h->factorized || !z_host || S < 1 || S > 8192 || nb < 1 || nb >= h->n || o < 0 || o >= m || m > BBH_MAX_OBJECTIVES || !Fb_dev) {
+  return bbh_nehvi_samples_impl(h, z_host, nullptr, nb, nullptr, S, nb, sign, o, m, Fb_dev, want_columns);
+}
+
+extern "C" int bbh_nehvi_samples_dev(bbh_handle* h, const double* z_dev, int64_t ld, const int32_t* cols_dev, int64_t S, int64_t nb,
+                                     double sign, int32_t o, int32_t m, double* Fb_dev, int32_t want_columns) {
+  if (!h) return -1;
+  if (!z_dev || !cols_dev || ld < 1) {
+    h->err = "bbh_nehvi_samples_dev: bad arguments";
+    return -1;
+  }
+  return bbh_nehvi_samples_impl(h, nullptr, z_dev, ld, cols_dev, S, nb, sign, o, m, Fb_dev, want_columns);
+}
+
+static int bbh_nehvi_samples_impl(bbh_handle* h, const double* z_host, const double* z_dev, int64_t ldz, const int32_t* cols_dev, int64_t S,
+                                  int64_t nb, double sign, int32_t o, int32_t m, double* Fb_dev, int32_t want_columns) {
+  if (!h->factorized || (!z_host && !z_dev) || S < 1 || S > 8192 || nb < 1 || nb >= h->n || o < 0 || o >= m || m > BBH_MAX_OBJECTIVES || !Fb_dev) {
     h->err = "bbh_nehvi_samples: model not factorised / bad arguments (1 <= S <= 8192, 1 <= nb < n, 0 <= o < m <= 4)";
     return -1;
   }
@@ -1508,11 +1527,14 @@ extern "C" int bbh_nehvi_samples(bbh_handle* h, const double* z_host, int64_t S,
   const int64_t spad = bbh_round_up(S, 128);
   int rc = bbh_ensure_ws(h, sizeof(double) * 2 * (size_t)np * spad);
   if (rc) return rc;
-  rc = bbh_upload_z(h, z_host, (size_t)S * nb);
-  if (rc) return rc;
+  if (z_host) {
+    rc = bbh_upload_z(h, z_host, (size_t)S * nb);
+    if (rc) return rc;
+  }
   double* T1 = h->d_ws;
   double* A = T1 + np * spad;
-  hipLaunchKernelGGL(bbh_nehvi_t1_kernel, dim3((unsigned)((np * spad + 255) / 256)), dim3(256), 0, s, h->d_t, h->d_z, n0, nb, S, np, spad, T1);
+  hipLaunchKernelGGL(bbh_nehvi_t1_kernel, dim3((unsigned)((np * spad + 255) / 256)), dim3(256), 0, s, h->d_t, z_host ? h->d_z : z_dev,
+                     z_host ? nb : ldz, z_host ? (const int32_t*)nullptr : cols_dev, n0, nb, S, np, spad, T1);
   hipLaunchKernelGGL(bbh_nehvi_fb_kernel, dim3((unsigned)nb, (unsigned)((S + 255) / 256)), dim3(256), 0, s, h->d_K, np, T1, spad, n0, nb, S,
                      h->ybar, h->ysd, h->theta[1], h->hadamard ? h->d_theta + bbh_hadamard_offset(h) + h->T : nullptr, h->d_task, sign,
                      (int)o, (int)m, Fb_dev);

@@ -383,8 +383,11 @@ def initial_params(spec: GPSpec, task_init: float = 1.0) -> GPParams:
             # gpytorch IndexKernel starts from torch.randn draws (covar_factor [T, rank], then raw_var [T]) of the global generator
             import torch
 
-            p.task_W = torch.randn(T, r, dtype=torch.float64).numpy().copy()
-            p.task_v = softplus(torch.randn(T, dtype=torch.float64).numpy())
+            # (at torch's DEFAULT dtype, as gpytorch does - float32 until some Prior.to_gpytorch() has switched the default to
+            # float64, baybe/priors/base.py:25 - and cast afterwards: a float32 draw cast to double is not the float64 draw of the
+            # same generator state.  ADVICE r5)
+            p.task_W = torch.randn(T, r).to(torch.float64).numpy().copy()
+            p.task_v = softplus(torch.randn(T).to(torch.float64).numpy())
         else:
             p.task_W = np.full((T, r), task_init / math.sqrt(T))
             p.task_v = np.full(T, float(softplus(0.0)))

@@ -34,6 +34,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
@@ -41,7 +42,7 @@ import numpy as np
 
 from baybe_amd import _lib
 from baybe_amd.box_decomposition import pack_cells_native, pareto_mask
-from baybe_amd.engine import GreedyResult, HipGP, _dp, draw_sampler_seed, sobol_normal_base_samples
+from baybe_amd.engine import GreedyResult, HipGP, _dp, _native_sobol_usable, draw_sampler_seed, sobol_normal_base_samples
 
 PRUNE_SAMPLES = 2048  # prune_inferior_points_multi_objective(num_samples=2048)
 
@@ -117,6 +118,9 @@ class HipNEHVI:
         # BBH_NEHVI_HOST=1: the round-4 host set-up (baseline posterior -> host Cholesky -> host samples -> host box
         # decompositions -> (n + nb) x S host array per target), kept as the cross-check of the device set-up
         self.device_setup = os.environ.get("BBH_NEHVI_HOST", "0") != "1"
+        # BBH_NEHVI_DRAW=host: base samples from the host path (torch's generator and erfinv) - the A/B form of the device draw
+        self.device_draw = os.environ.get("BBH_NEHVI_DRAW", "device") != "host"
+        self._factorize_lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=self.m) if self.m > 1 else None
         self._z_next = None  # (key, future): base samples of the next selection step, drawn while the device scores
         self._cells_on_device = False
@@ -151,9 +155,11 @@ class HipNEHVI:
         key = (self.S, nb, seed)
         self._z_next = (key, self._pool.submit(self._draw, self.S, nb, seed))
 
-    def _extend(self, o: int, Xb: np.ndarray, z_o: np.ndarray, S: int, Fb_dev, want_columns: bool):
+    def _extend(self, o: int, Xb: np.ndarray, z_o, S: int, Fb_dev, want_columns: bool):
         """Target o: extended model (baseline rows as noise-free observations), its factorisation, and the samples /
-        weight columns drawn through the factor itself (``bbh_nehvi_samples``).  Runs on a host thread per target."""
+        weight columns drawn through the factor itself (``bbh_nehvi_samples``).  Runs on a host thread per target.
+        ``z_o``: the target's base samples as a host array [S, nb], or (device draw [S, ld], ld, device int32 offsets [nb]) when the
+        draw was made on the device (``bbh_nehvi_samples_dev``)."""
         out = self.outputs[o]
         eng = out.engine
         Xt, yt = eng._X_train, eng._y_train
@@ -162,13 +168,25 @@ class HipNEHVI:
         y_ext = np.concatenate([yt, np.full(nb, eng.ybar)])  # (the baseline rows' values are not read)
         mask = np.concatenate([np.ones(len(yt), np.uint8), np.zeros(nb, np.uint8)])
         out.ext.set_model(eng.spec, X_ext, y_ext, noise_mask=mask, standardization=(eng.ybar, eng.ysd))
-        out.ext.factorize(eng.params)
-        z_o = np.ascontiguousarray(z_o, dtype=np.float64)
-        out.ext._check(
-            self._lib.bbh_nehvi_samples(out.ext._h, _dp(z_o), S, nb, float(self.signs[o]), o, self.m, Fb_dev.data_ptr(),
-                                        1 if want_columns else 0),
-            "bbh_nehvi_samples",
-        )
+        # The tile-dataflow factorisation needs every tile of a launch co-resident (one 135 KB-LDS workgroup per CU); two or three
+        # targets' launches overlapping can exceed the 256 CUs and starve each other until the spin limit - the
+        # factorisations take turns, the sample and weight-column kernels stay concurrent.
+        with self._factorize_lock:  # (bbh_factorize returns after its stream has drained: it reads the Cholesky flag back)
+            out.ext.factorize(eng.params)
+        if isinstance(z_o, tuple):
+            z_dev, ld, cols_dev = z_o
+            out.ext._check(
+                self._lib.bbh_nehvi_samples_dev(out.ext._h, z_dev.data_ptr(), ld, cols_dev.data_ptr(), S, nb, float(self.signs[o]), o,
+                                                self.m, Fb_dev.data_ptr(), 1 if want_columns else 0),
+                "bbh_nehvi_samples_dev",
+            )
+        else:
+            z_o = np.ascontiguousarray(z_o, dtype=np.float64)
+            out.ext._check(
+                self._lib.bbh_nehvi_samples(out.ext._h, _dp(z_o), S, nb, float(self.signs[o]), o, self.m, Fb_dev.data_ptr(),
+                                            1 if want_columns else 0),
+                "bbh_nehvi_samples",
+            )
         if want_columns:
             out.ext._ncols = S
 
@@ -177,15 +195,25 @@ class HipNEHVI:
             return [fn(0)]
         return [f.result() for f in [self._pool.submit(fn, o) for o in range(self.m)]]
 
-    def _baseline_samples_dev(self, Xb: np.ndarray, z: np.ndarray, want_columns: bool):
-        """Oriented baseline objective samples [S, nb, m] as a device tensor (all targets)."""
+    def _baseline_samples_dev(self, Xb: np.ndarray, z, want_columns: bool, S: int | None = None, first=None):
+        """Oriented baseline objective samples [S, nb, m] as a device tensor (all targets).  ``z``: host base samples [S, >= nb, m],
+        or a device draw [S, n_all * m] over all baseline rows (``first``: which of them the unique rows ``Xb`` are)."""
         import torch
 
-        S, nb = z.shape[0], len(Xb)
+        nb = len(Xb)
         eng0 = self.outputs[0].engine
+        on_device = isinstance(z, torch.Tensor)
+        S = int(z.shape[0]) if S is None else S
         Fb_dev = torch.empty((S, nb, self.m), dtype=torch.float64, device=eng0._dev())
-        torch.cuda.synchronize(eng0.device)  # (Fb_dev's allocation vs the targets' own streams)
-        self._for_each_target(lambda o: self._extend(o, Xb, z[:, :nb, o], S, Fb_dev, want_columns))
+        if on_device:  # offsets of (baseline row b, target o) within a row of the draw: row-of-draw index * m + o
+            base = np.arange(nb, dtype=np.int64) if first is None else np.asarray(first, dtype=np.int64)
+            cols = torch.from_numpy((base[None, :] * self.m + np.arange(self.m)[:, None]).astype(np.int32)).to(eng0._dev())
+            ld = int(z.shape[1])
+            arg = lambda o: (z, ld, cols[o])  # noqa: E731
+        else:
+            arg = lambda o: z[:, :nb, o]  # noqa: E731
+        torch.cuda.synchronize(eng0.device)  # (Fb_dev's allocation, the draw and the offsets vs the targets' own streams)
+        self._for_each_target(lambda o: self._extend(o, Xb, arg(o), S, Fb_dev, want_columns))
         torch.cuda.synchronize(eng0.device)  # the targets write Fb_dev on their own streams
         return Fb_dev
 
@@ -198,16 +226,20 @@ class HipNEHVI:
         Xb, first, rep = _unique_rows(Xb_all)
         nb = len(Xb)
         t0 = time.perf_counter()
-        z = sobol_normal_base_samples(PRUNE_SAMPLES, len(Xb_all) * self.m, seed).reshape(PRUNE_SAMPLES, len(Xb_all), self.m)
-        if nb < len(Xb_all):
-            z = np.ascontiguousarray(z[:, first, :])
+        draw_on_device = self.device_setup and self.device_draw and _native_sobol_usable()
+        if draw_on_device:  # 2048 x (n_b m) values: the transform alone was 19.9 ms on the host
+            z = self.outputs[0].ext.sobol_normal_dev(PRUNE_SAMPLES, len(Xb_all) * self.m, seed)
+        else:
+            z = sobol_normal_base_samples(PRUNE_SAMPLES, len(Xb_all) * self.m, seed).reshape(PRUNE_SAMPLES, len(Xb_all), self.m)
+            if nb < len(Xb_all):
+                z = np.ascontiguousarray(z[:, first, :])
         self.last_prune_ms = {"base_samples": 1e3 * (time.perf_counter() - t0)}
         t0 = time.perf_counter()
         counts = np.zeros(nb, dtype=np.int64)
         ref = np.ascontiguousarray(self.ref, dtype=np.float64)
         eng = self.outputs[0].engine
         if self.device_setup:
-            obj_dev = self._baseline_samples_dev(Xb, z, want_columns=False)
+            obj_dev = self._baseline_samples_dev(Xb, z, want_columns=False, S=PRUNE_SAMPLES, first=first if draw_on_device else None)
             self.last_prune_ms["extend"] = 1e3 * (time.perf_counter() - t0)
             h = self.outputs[0].ext
             h._check(

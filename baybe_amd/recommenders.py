@@ -71,7 +71,7 @@ def _content_hash(arr: np.ndarray):
 def _frame_content_hash(df: pd.DataFrame):
     """Content hash of a DataFrame's values without materialising them as one array: every column's buffer in pieces on the
     thread pool; columns that are not plain numeric arrays go through ``_content_hash``.  Equal keys
-    imply equal content; the same content in another memory layout (a row-major block against a column-major copy) may key
+    mean equal content up to the collision chance of a 64-bit hash (2^-64 per pair of contents); the same content in another memory layout (a row-major block against a column-major copy) may key
     differently, which costs one re-upload and nothing else."""
     if df.shape[1] == 0 or not df.iloc[:, 0].to_numpy().flags.c_contiguous:
         return _content_hash(df.to_numpy())  # one 2-D block: ``to_numpy`` is a view, its columns are strided

@@ -355,8 +355,12 @@ class HipCompositeImpl:
             t = self.template
             self._models = [attrs.evolve(t, target_index=i, fixed_hyperparameters=_per_target(t.fixed_hyperparameters, i))
                             for i in range(m)]
-        for model in self._models:
-            model.fit(searchspace, objective, measurements)
+        # the targets' fits side by side: one host thread and one stream each (the reference fits them in sequence,
+        # surrogates/composite.py:101-134; the results do not depend on the order - every model has its own handle and data)
+        from baybe_amd.engine import fit_side_by_side
+
+        fit_side_by_side([(lambda mod=model: mod.fit(searchspace, objective, measurements)) for model in self._models],
+                         device=getattr(self.template, "device", 0))
         self._objective = objective
 
     @property

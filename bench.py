@@ -72,14 +72,43 @@ def synth_pareto_targets(Xt: np.ndarray):
     return [fo + 0.05 * np.random.default_rng(30 + o).standard_normal(len(Xt)) for o, fo in enumerate(f)]
 
 
-def issue_frac_of(cfg_name, kernel_prefix):
-    """{kernel: issue_frac} from the committed PMC summary of this configuration (profiles/r04_<cfg>_issue.json), or None."""
+def _latest_profile(cfg_name, what):
+    """Newest committed ``profiles/rNN_<cfg>_<what>.json`` (the round number decides), as (path name, parsed content) or (None, None)."""
+    import re
+
+    best = None
+    for fn in (ROOT / "profiles").glob(f"r*_{cfg_name}_{what}.json"):
+        m = re.fullmatch(rf"r(\d+)_{re.escape(cfg_name)}_{what}\.json", fn.name)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), fn)
+    if best is None:
+        return None, None
     try:
-        ij = json.loads((ROOT / "profiles" / f"r04_{cfg_name}_issue.json").read_text())
+        return best[1].name, json.loads(best[1].read_text())
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def issue_frac_of(cfg_name, kernel_prefix):
+    """{kernel: issue_frac} from the newest committed PMC summary of this configuration (profiles/rNN_<cfg>_issue.json), or None."""
+    _, ij = _latest_profile(cfg_name, "issue")
+    try:
         got = {k: round(v["issue_frac"], 4) for k, v in ij["kernels"].items() if k.startswith(kernel_prefix)}
         return got or None
     except Exception:  # noqa: BLE001
         return None
+
+
+def traffic_of_kernel(cfg_name, kernel_prefix):
+    """(bytes per launch, source file) of the dominant kernel from the newest committed PMC traffic record of this configuration
+    (profiles/rNN_<cfg>_traffic.json: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE in separate --pmc passes, scripts/profile_config.sh)."""
+    name, tj = _latest_profile(cfg_name, "traffic")
+    try:
+        cands = [(k, v) for k, v in tj.items() if isinstance(v, dict) and kernel_prefix in k and "hbm_bytes_per_launch" in v]
+        k, v = max(cands, key=lambda kv: kv[1]["hbm_bytes_per_launch"])
+        return v["hbm_bytes_per_launch"], f"profiles/{name}: {k}"
+    except Exception:  # noqa: BLE001
+        return None, None
 
 
 class _BenchSpace:
@@ -99,34 +128,43 @@ class _BenchSpace:
     class _Continuous:
         is_empty = True
 
-    def __init__(self, X):
+    def __init__(self, X, task_idx=None, n_tasks=1):
         import pandas as pd
 
         cols = [f"x{j}" for j in range(X.shape[1])]
         self.discrete, self.continuous, self.parameters = self._Discrete(pd.DataFrame(X, columns=cols)), self._Continuous(), ()
-        self.comp_rep_columns, self.task_idx, self.n_tasks = tuple(cols), None, 1
-        self.scaling_bounds = pd.DataFrame([np.zeros(len(cols)), np.ones(len(cols))], index=["min", "max"], columns=cols)
+        self.comp_rep_columns, self.task_idx, self.n_tasks = tuple(cols), task_idx, n_tasks
+        hi = np.ones(len(cols))
+        if task_idx is not None:
+            hi[task_idx] = float(max(n_tasks - 1, 1))
+        self.scaling_bounds = pd.DataFrame([np.zeros(len(cols)), hi], index=["min", "max"], columns=cols)
 
     def transform(self, df, allow_extra=False):
         return df[list(self.comp_rep_columns)]
 
 
-def time_recommend_e2e(X, Xt, y, d, batch):
+def time_recommend_e2e(X, Xt, ys, d, batch, task=None, acquisition_function=None):
     """``recommend(batch)`` of the plug-in recommender on the bench's own grid and measurements, wall clock in ms: the first call
     (comp rep hashed and uploaded, hyper-parameters fitted), a call with unchanged measurements (resident matrix, cached fit: the
-    hot path plus the pandas boundary) and a call after one more measurement (refit)."""
+    hot path plus the pandas boundary) and a call after one more measurement (refit).  ``ys``: one target column (array) or several
+    (list: ParetoObjective -> replicated surrogate + qLogNEHVI, whose baseline pruning runs in EVERY call because the reference builds
+    a new acquisition function per call, acqfs.py:477-484); ``task`` = (task column, number of tasks) for the transfer-learning form."""
     import pandas as pd
     import torch
     from types import SimpleNamespace
 
     from baybe_amd.recommenders import HipBotorchRecommender
 
-    space = _BenchSpace(X)
+    space = _BenchSpace(X) if task is None else _BenchSpace(X, task[0], task[1])
     cols = list(space.comp_rep_columns)
     meas = pd.DataFrame(Xt, columns=cols)
-    meas["y"] = y
-    objective = SimpleNamespace(targets=(SimpleNamespace(name="y", minimize=False, transformation=None),), is_multi_output=False)
-    rec = HipBotorchRecommender()
+    ys = ys if isinstance(ys, (list, tuple)) else [ys]
+    names = ["y"] if len(ys) == 1 else [f"y{o}" for o in range(len(ys))]
+    for nm, yo in zip(names, ys):
+        meas[nm] = yo
+    objective = SimpleNamespace(targets=tuple(SimpleNamespace(name=nm, minimize=False, transformation=None) for nm in names),
+                                is_multi_output=len(names) > 1)
+    rec = HipBotorchRecommender() if acquisition_function is None else HipBotorchRecommender(acquisition_function=acquisition_function)
     out = {}
 
     def timed(label, m):
@@ -141,10 +179,13 @@ def time_recommend_e2e(X, Xt, y, d, batch):
     timed("first_call_upload_and_fit", meas)
     timed("unchanged_measurements", meas)
     got = timed("unchanged_measurements_again", meas)
-    more = pd.concat([meas, got.assign(y=float(np.mean(y)))], ignore_index=True)
+    more = pd.concat([meas, got.assign(**{nm: float(np.mean(yo)) for nm, yo in zip(names, ys)})], ignore_index=True)
     timed("after_new_measurements_refit", more)
+    got = timed("unchanged_measurements_after_refit", more)
+    more2 = pd.concat([more, got.assign(**{nm: float(np.mean(yo)) for nm, yo in zip(names, ys)})], ignore_index=True)
+    timed("after_new_measurements_refit_again", more2)
     out["batch_size"] = batch
-    out["rows"], out["n_train"] = int(X.shape[0]), int(len(y))
+    out["rows"], out["n_train"], out["targets"] = int(X.shape[0]), int(len(Xt)), len(names)
     return out
 
 
@@ -167,7 +208,10 @@ def parse_args(argv=None):
     ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--n-train", type=int, default=None)
     ap.add_argument("--mc-samples", type=int, default=512)
-    ap.add_argument("--strong", action="store_true", help="fixed global grid of --rows rows, split over the GPUs")
+    ap.add_argument("--strong", action="store_true", help="fixed global grid of --rows rows, split over the GPUs (the default for more "
+                                                          "than one GPU: BASELINE configs[2] is ONE 1e6-row grid row-sharded)")
+    ap.add_argument("--weak", action="store_true", help="--rows rows PER GPU (weak scaling; for more than one GPU the headline is "
+                                                        "otherwise the strong-scaled grid and the weak figure sits in extra)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--fit", nargs="?", type=int, const=1, default=-1,
                     help="time a device hyper-parameter fit outside the timed region (extra.fit_ms); default: on for single-task "
@@ -237,6 +281,10 @@ def run(args):
     from baybe_amd.distributed import RowShard, shard_bounds
 
     d, n, S = args.d, args.n_train, args.mc_samples
+    if world > 1 and not args.weak:
+        # BASELINE configs[2] / configs[4] and north_star's ">= 6 x further at 8 GPUs" are ONE grid row-sharded over the GPUs: for N > 1
+        # the headline is that strong-scaled configuration; the weak-scaled figure goes to extra.weak_<cfg>
+        args.strong = True
     if args.strong:
         a, b = shard_bounds(args.rows, rank, world)
         rows_local, total_rows = b - a, args.rows
@@ -258,9 +306,12 @@ def run(args):
         X = np.random.default_rng(1000 + rank).integers(0, 11, size=(rows_local, d)) / 10.0
         Xt = y = None
     else:
-        X, Xt, y = synth_problem(rows_local, d, n, rank if not args.strong else 0)
-        if args.strong:
-            X = synth_problem(args.rows, d, n, 0)[0][a:b]
+        if args.strong:  # one global grid: every rank derives the same measurements from it and keeps its own rows
+            Xg, Xt, y = synth_problem(args.rows, d, n, 0)
+            X = np.ascontiguousarray(Xg[a:b])
+            del Xg
+        else:
+            X, Xt, y = synth_problem(rows_local, d, n, rank)
     if dist_on and not args.strong and cfg != "cfg4":
         box = [(Xt, y)]
         dist.broadcast_object_list(box, src=0, device=torch.device("cpu") if single_dev else torch.device("cuda", local_rank))
@@ -280,13 +331,10 @@ def run(args):
             g.set_model(spec, Xt, yo)
             engines.append(g)
         if args.fit == 1 or (args.fit < 0 and world == 1):  # the three targets' fits, one host thread and one stream each (CompositeSurrogate)
-            from concurrent.futures import ThreadPoolExecutor
-
-            with ThreadPoolExecutor(len(engines)) as pool:
-                for _ in range(2):
-                    t0 = time.perf_counter()
-                    fis = list(pool.map(lambda g: g.fit(), engines))
-                    extra["fit_ms"] = (time.perf_counter() - t0) * 1e3
+            for _ in range(2):  # (what HipCompositeImpl.fit does: engine.fit_side_by_side - a private stream per fit)
+                t0 = time.perf_counter()
+                fis = engine.fit_side_by_side([g.fit for g in engines], device=local_rank)
+                extra["fit_ms"] = (time.perf_counter() - t0) * 1e3
             extra["fit_nfev"] = [f.nfev for f in fis]
             t0 = time.perf_counter()
             for g in engines:
@@ -303,6 +351,7 @@ def run(args):
         torch.cuda.synchronize()
         extra["nehvi_first_setup_ms"] = (time.perf_counter() - t0) * 1e3  # (also pays the first allocations of the extended models)
         extra["nehvi_prune_ms"] = nehvi.last_setup_ms.get("prune")
+        extra["nehvi_prune_parts_ms"] = {k: round(v, 3) for k, v in getattr(nehvi, "last_prune_ms", {}).items()}
         ts_setup = []
         for _ in range(5):  # the per-selection-step set-up: extended models, baseline samples, box decompositions (device)
             t0 = time.perf_counter()
@@ -521,13 +570,21 @@ def run(args):
             extra[f"greedy_q{args.greedy}_ms"] = (time.perf_counter() - t0) * 1e3
             extra[f"greedy_q{args.greedy}_indices"] = gres.indices
 
-    # ---- extra: the strong-scaled form of BASELINE configs[2] (a 1e6-row grid split over the ranks) next to the weak line ----------
-    if dist_on and cfg == "cfg3" and not args.strong and nehvi is None:
+    # ---- extra: the OTHER scaling mode of the same configuration next to the headline (N > 1 only) ----------------------------------
+    # headline strong (default for N > 1: the configuration's grid split over the ranks) -> extra.weak_cfg3: a full grid per rank;
+    # headline weak (--weak) -> extra.strong_cfg3: BASELINE configs[2]'s 1e6 rows split over the ranks
+    if dist_on and cfg == "cfg3" and nehvi is None and (world > 1 or not args.strong):
+        other_strong = not args.strong
         g_rows = CONFIGS["cfg3"][0]
-        a_s, b_s = shard_bounds(g_rows, rank, world)
-        Xs = torch.from_numpy(np.ascontiguousarray(synth_problem(g_rows, d, n, 0)[0][a_s:b_s])).cuda()
-        keep = (shard.start, shard.stop)
+        if other_strong:
+            a_s, b_s = shard_bounds(g_rows, rank, world)
+            Xs = torch.from_numpy(np.ascontiguousarray(synth_problem(g_rows, d, n, 0)[0][a_s:b_s])).cuda()
+        else:
+            a_s, b_s = rank * g_rows, (rank + 1) * g_rows
+            Xs = torch.from_numpy(np.ascontiguousarray(synth_problem(g_rows, d, n, rank)[0])).cuda()
+        keep = (shard.start, shard.stop, shard.N_total)
         shard.start, shard.stop = a_s, b_s
+        shard.N_total = g_rows if other_strong else g_rows * world
         sstep = make_step(Xs, a_s)
         pre_warm(sstep, 3)
         fence()
@@ -541,10 +598,12 @@ def run(args):
         sdt = time.perf_counter() - t0
         tt = torch.tensor([sdt, float(np.median(ts_ms))], dtype=torch.float64, device="cpu" if single_dev else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        shard.start, shard.stop = keep
-        extra["strong_cfg3"] = {"global_rows": g_rows, "rows_per_rank": b_s - a_s, "ms_per_step": float(tt[1].item()),
-                                "value": g_rows * args.steps / float(tt[0].item()), "unit": "candidates/s", "scaling": "strong",
-                                "top_indices": [int(i) for i in sidx]}
+        shard.start, shard.stop, shard.N_total = keep
+        tot = g_rows if other_strong else g_rows * world
+        extra["strong_cfg3" if other_strong else "weak_cfg3"] = {
+            "global_rows": tot, "rows_per_rank": b_s - a_s, "ms_per_step": float(tt[1].item()),
+            "value": tot * args.steps / float(tt[0].item()), "unit": "candidates/s", "scaling": "strong" if other_strong else "weak",
+            "top_indices": [int(i) for i in sidx]}
         del Xs
 
     # ---- extra: one greedy batch (optimize_acqf_discrete, q = --greedy) on the same shard, timed per kernel family ----
@@ -590,16 +649,23 @@ def run(args):
             }
 
     # ---- extra: end-to-end recommend() through the plug-in surface ("report additionally ... end-to-end recommend()") ----
-    if (args.e2e == 1 or (args.e2e < 0 and world == 1 and cfg in ("cfg3", "cfg2"))) and nehvi is None and not dist_on:
-        extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, y, d, args.greedy if args.greedy > 0 else 5)
+    if (args.e2e == 1 or (args.e2e < 0 and world == 1)) and not dist_on:
+        q_e2e = args.greedy if args.greedy > 0 else 5
+        if nehvi is not None:  # configs[4]: three fits + baseline pruning + the greedy batch, per call
+            from baybe_amd.acquisition import qLogNoisyExpectedHypervolumeImprovement
+
+            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, ys, d, q_e2e,
+                                                           acquisition_function=qLogNoisyExpectedHypervolumeImprovement(n_mc_samples=S))
+        elif cfg == "cfg4":  # configs[3]: the ICM / LOO fit is the call
+            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, y, d + 1, q_e2e, task=(d, 4))
+        else:
+            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, y, d, q_e2e)
 
     # ---- roofline of the dominant kernel, algorithmic flops ----
-    def traffic_of(key):  # PMC-derived L2<->fabric bytes per launch for this exact workload (collected offline, profiles/)
-        try:
-            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-            return tj["workloads"].get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            return None
+    # PMC-derived L2<->fabric bytes per launch of the dominant kernel for this exact workload: this round's record if one is committed
+    # (profiles/rNN_<cfg>_traffic.json, newest round), collected offline by scripts/profile_config.sh
+    prof_cfg = cfg + ("_125k" if (cfg == "cfg3" and rows_local == 125_000) else "")
+    standard_rows = rows_local == (125_000 if prof_cfg.endswith("125k") else CONFIGS[cfg][0]) and d == CONFIGS[cfg][1] and n == CONFIGS[cfg][2]
 
     kernel_names = {"cooperative": "bbh_coop_posterior_kernel", "windowed": "bbh_fused_posterior_kernel",
                     "cooperative-2sweep": "bbh_coop2_posterior_kernel"}
@@ -617,8 +683,9 @@ def run(args):
             "peak_mfma_stream_microbench": 77.8,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": traffic_of(f"{rows_local}x{d}_n{n}" + ("" if cfg in ("cfg3", "cfg2") else f"_{cfg}")),
-            "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/traffic.json); "
+            "traffic": traffic_of_kernel(prof_cfg, kernel_names.get(form, form))[0] if standard_rows else None,
+            "traffic_source": traffic_of_kernel(prof_cfg, kernel_names.get(form, form))[1] if standard_rows else None,
+            "traffic_unit": "L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes); "
                             "algorithmic = %d (read every candidate row once, write mean + variance)" % (rows_local * (8 * d + 16)),
             "kernel": kernel_names.get(form, form),
             "kernel_form": form,
@@ -665,8 +732,9 @@ def run(args):
             "achieved": recs[dom]["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": recs[dom].get("frac"),  # measured in this run, or null: the cell kernel is VALU-issue-bound, its utilisation is ...
             "issue_frac_offline": {"value": (recs[dom].get("issue_frac") or {}).get("bbh_qlognehvi_lin_kernel<3, true>"),
-                                   "source": "profiles/r04_cfg5_issue.json (SQ_INSTS_VALU x static class mix over SIMD cycles, offline PMC passes)"},
-            "traffic": traffic_of(f"{rows_local}x{d}_n{n}_cfg5"),
+                                   "source": f"profiles/{_latest_profile(cfg, 'issue')[0]} (SQ_INSTS_VALU x static class mix over SIMD cycles, offline PMC passes)"},
+            "traffic": traffic_of_kernel(cfg, "bbh_qlognehvi")[0] if standard_rows else None,
+            "traffic_source": traffic_of_kernel(cfg, "bbh_qlognehvi")[1] if standard_rows else None,
             "kernel": {"variance": kernel_names.get(form, form), "columns": "bbh_coop_columns_kernel", "cells": "bbh_qlognehvi_lin_kernel"}[dom],
             "dominant_part": dom, "parts": recs,
             "note": "cells: operation count by the maths of qLogNEHVI (exp / log at 20 flops, a division at 8) against the fp64 roof; "
@@ -698,12 +766,14 @@ def run(args):
         "data": "synthetic",
         "config": {
             "workload": {
-                "cfg3": f"{rows_local} x {d} discrete grid per GPU, n_train={n}, Matern-5/2 ARD, qLogEI S={S}, fixed-theta, top-{TOPK} to host",
+                "cfg3": (f"{total_rows} x {d} discrete grid row-sharded over {world} GPUs ({rows_local} rows on rank 0), " if (args.strong and world > 1)
+                         else f"{rows_local} x {d} discrete grid per GPU, ") + f"n_train={n}, Matern-5/2 ARD, qLogEI S={S}, fixed-theta, top-{TOPK} to host",
                 "cfg2": f"{rows_local} x {d} discrete grid per GPU, n_train={n}, Matern-5/2 ARD, qLogEI S={S}, fixed-theta, top-{TOPK} to host "
                         f"(BASELINE configs[1])",
                 "cfg4": f"{rows_local} x ({d} + task) candidates of the active task, transfer-learning GP (ICM over 4 tasks), n_train={n}, "
                         f"qLogEI S={S}, fixed-theta, top-{TOPK} to host (BASELINE configs[3])",
-                "cfg5": f"{rows_local} x {d} discrete grid, ParetoObjective of 3 targets -> qLogNEHVI, n_train={n}, S={S} MC samples, "
+                "cfg5": (f"{total_rows} x {d} discrete grid row-sharded over {world} GPUs ({rows_local} rows on rank 0)" if (args.strong and world > 1)
+                         else f"{rows_local} x {d} discrete grid") + f", ParetoObjective of 3 targets -> qLogNEHVI, n_train={n}, S={S} MC samples, "
                         f"pruned baseline, top-{TOPK} to host (BASELINE configs[4], one GPU's share); the timed step is the SCORING PASS - a "
                         f"selection step adds {extra.get('nehvi_setup_ms', float('nan')):.2f} ms of set-up: extra.ms_per_selection_step = "
                         f"{extra.get('ms_per_selection_step', float('nan')):.2f} ms",

@@ -305,6 +305,11 @@ int bbh_pareto_frequency_dev(bbh_handle* h, const double* obj_dev, int64_t S, in
  * Asynchronous on the handle's stream. */
 int bbh_nehvi_samples(bbh_handle* h, const double* z_host, int64_t S, int64_t nb, double sign, int32_t o, int32_t m,
                       double* Fb_dev, int32_t want_columns);
+/* The same with the base samples already on the device (bbh_sobol_normal_dev): sample s, baseline row b reads
+ * z_dev[s * ld + cols_dev[b]] (cols_dev [nb] int32: where the row's base sample sits in a draw over all baseline rows and
+ * targets - repeated baseline rows are skipped by the caller). */
+int bbh_nehvi_samples_dev(bbh_handle* h, const double* z_dev, int64_t ld, const int32_t* cols_dev, int64_t S, int64_t nb, double sign,
+                          int32_t o, int32_t m, double* Fb_dev, int32_t want_columns);
 
 /* Box decompositions on the device: one wavefront per MC sample over Fb_dev [S, nb, m] (oriented objective samples, as
  * bbh_nehvi_samples writes them) - the algorithm and visiting order of bbh_cells_create, the cell lists stay on the handle
@@ -336,6 +341,13 @@ int bbh_cells_destroy(void* cells);
  * tril);  bbh_sobol_draw: out [n, dim] = the first n points for the scrambled state and the integer shift [dim]. */
 int bbh_sobol_scramble(int64_t* state, const int64_t* ltm, int64_t dim);
 int bbh_sobol_draw(const int64_t* state, const int64_t* shift, int64_t n, int64_t dim, double* out);
+/* The sampler's complete base-sample draw, sqrt(2) erfinv(2 v - 1) of the engine's points for a seed (SobolQMCNormalSampler, built
+ * through BoTorch's acquisition constructors at baybe/acquisition/_builder.py:195-334): state0 [dim, 30] = the engine's UNSCRAMBLED
+ * direction numbers; the scrambling bits come from an MT19937 restating torch's CPU generator.  bbh_sobol_normal: host code,
+ * out_host [n, dim];  bbh_sobol_normal_dev: generator and scrambling on the host, points and transform on the device into
+ * out_dev [n, dim], asynchronous on the handle's stream. */
+int bbh_sobol_normal(const int64_t* state0, uint64_t seed, int64_t n, int64_t dim, double* out_host);
+int bbh_sobol_normal_dev(bbh_handle* h, const int64_t* state0, uint64_t seed, int64_t n, int64_t dim, double* out_dev);
 
 /* 64-bit content key of host buffers (host code, std::threads): multiply-fold hash over 4 MB pieces, the pieces' digests folded in
  * order.  Keys the device-resident copy of the discrete subspace's computational representation on its content

@@ -959,6 +959,7 @@ class GreedyResult:
     indices: list[int]  # positions into the candidate matrix, in selection order
     values: list[float]  # acquisition value of each greedy step
     first_scores: np.ndarray | None = None  # q=1 scores of all candidates (step 0)
+    runner_up: list | None = None  # per greedy step: (index, value) of the second-best remaining candidate
 
 
 def optimize_acqf_discrete_qlogei(
@@ -989,6 +990,7 @@ def optimize_acqf_discrete_qlogei(
     alive = np.ones(N, dtype=bool)
     chosen: list[int] = []
     values: list[float] = []
+    runner_up: list = []
     first_scores = None
 
     def get_z(qp):
@@ -1017,7 +1019,12 @@ def optimize_acqf_discrete_qlogei(
         chosen.append(best)
         values.append(float(scores[best]))
         alive[best] = False
-    return GreedyResult(chosen, values, first_scores)
+        if N > 1:  # how decisive the step was: the best of the rest (a test may need it to judge a differing pick)
+            held, scores[best] = scores[best], -np.inf
+            second = int(np.argmax(scores))
+            runner_up.append((second, float(scores[second])))
+            scores[best] = held
+    return GreedyResult(chosen, values, first_scores, runner_up)
 
 
 def topk_first_index(scores: np.ndarray, k: int) -> np.ndarray:

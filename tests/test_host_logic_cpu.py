@@ -818,8 +818,18 @@ def test_user_supplied_task_kernels_against_the_autograd_oracle(variant):
     p = gp_spec.initial_params(spec)
     assert p.task_W.shape == (T, rank)
     if free:
-        torch.manual_seed(3)  # covar_factor, then raw_var: gpytorch's registration order
-        assert np.array_equal(p.task_W, torch.randn(T, rank, dtype=torch.float64).numpy())
+        # covar_factor, then raw_var: gpytorch's registration order - drawn at torch's DEFAULT dtype (float32 in a fresh process,
+        # float64 once a BayBE prior has been converted, baybe/priors/base.py:25) and cast to double, as gpytorch's parameters are
+        for default in (torch.float32, torch.float64):
+            was = torch.get_default_dtype()
+            try:
+                torch.set_default_dtype(default)
+                torch.manual_seed(3)
+                pd_ = gp_spec.initial_params(spec)
+                torch.manual_seed(3)
+                assert np.array_equal(pd_.task_W, torch.randn(T, rank).to(torch.float64).numpy())
+            finally:
+                torch.set_default_dtype(was)
     raw = gp_spec.pack_raw(spec, p)
     assert len(raw) == len(gp_spec.raw_bounds(spec)) and gp_spec.raw_bounds(spec) == go.raw_bounds(ospec)
     rng = np.random.default_rng(6)

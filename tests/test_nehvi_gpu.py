@@ -211,3 +211,63 @@ def test_device_setup_equals_the_host_setup(n, seed, atol_cells, atol_scores):
     dup = np.array([(np.abs(Xt - x).sum(1) < 1e-12).any() for x in X])
     assert np.allclose(sd[~dup], sh[~dup], rtol=0, atol=atol_scores), np.abs(sd - sh)[~dup].max()
     assert int(np.argmax(sd)) == int(np.argmax(sh))
+
+
+# ---- round 6: base samples drawn on the device, fits side by side -------------------------------------------------------------------
+@pytest.mark.parametrize("S,q,seed", [(9, 1, 3), (128, 96, 1234), (2048, 768, 4321), (512, 6, 99)])
+def test_device_base_samples_equal_the_host_draw(S, q, seed):
+    """``bbh_sobol_normal_dev`` (generator and scrambling on the host, points and the normal transform one thread per value on the
+    device) against ``sobol_normal_base_samples`` (torch's engine + torch.erfinv): the same values up to the last bits of erfinv."""
+    from baybe_amd import engine
+
+    gp = engine.HipGP(0)
+    got = gp.sobol_normal_dev(S, q, seed).cpu().numpy()
+    want = engine.sobol_normal_base_samples(S, q, seed)
+    assert got.shape == want.shape
+    from conftest import record_deviation
+
+    record_deviation(f"device_base_samples_rel_{S}x{q}", float(np.abs(got / want - 1).max()), 1e-14)
+    assert np.allclose(got, want, rtol=1e-14, atol=0)
+    gp.close()
+
+
+def test_pruning_with_the_device_draw_equals_the_host_draw(monkeypatch):
+    """The 2048-sample pruning draw never exists on the host (``bbh_nehvi_samples_dev`` reads the device draw through per-target
+    offsets, repeated baseline rows skipped): same kept points as with the host draw, with and without repeated measurements."""
+    from baybe_amd.nehvi import HipNEHVI, compute_ref_point
+
+    X, Xt, Y, signs, engines, _ = _setup(3, n=40, seed=3)
+    ref = compute_ref_point(Y * signs[None, :])
+    for Xb in (Xt, np.vstack([Xt, Xt[[3, 7, 7]]])):
+        kept = []
+        for draw in (True, False):
+            hv = HipNEHVI(engines, signs, Xb, ref, n_mc_samples=32, prune_baseline=True)
+            hv.device_draw = draw
+            kept.append(hv.prune_points(Xb, 4321))
+            assert ("base_samples" in hv.last_prune_ms)
+        assert kept[0].shape == kept[1].shape and np.array_equal(kept[0], kept[1])
+        assert 0 < len(kept[0]) <= len(Xb)
+
+
+def test_fits_side_by_side_equal_fits_in_sequence():
+    """``engine.fit_side_by_side`` (what ``HipCompositeImpl.fit`` runs: one host thread and one private stream per target, the
+    tile-dataflow launches entered in the device's residency ledger) ends at the hyper-parameters of the same fits run one after the
+    other - every evaluation is a function of its own handle's data only."""
+    from baybe_amd import engine, gp_spec
+
+    rng = np.random.default_rng(5)
+    d, n = 6, 300  # np = 320: the tile-dataflow factorisation + dataflow tail (64 < np <= 1024)
+    Xt = rng.integers(0, 11, size=(n, d)) / 10.0
+    Y = _targets(Xt, rng)
+    engines = []
+    for o in range(3):
+        g = engine.HipGP(0)
+        g.set_model(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)), Xt, Y[:, o])
+        engines.append(g)
+    seq = [g.fit() for g in engines]
+    par = engine.fit_side_by_side([g.fit for g in engines], device=0)
+    for a, b in zip(seq, par):
+        assert a.nfev == b.nfev and a.fun == b.fun
+        assert np.array_equal(a.params.lengthscale, b.params.lengthscale) and a.params.noise == b.params.noise
+    for g in engines:
+        g.close()

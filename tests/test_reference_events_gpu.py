@@ -8,7 +8,7 @@ recorded ones, the values agree with the recorded ones (the oracle double's) to 
 import numpy as np
 import pytest
 
-from _replay import load_events, make_recommender, replay_events
+from _replay import check_repins, load_events, make_recommender, replay_events
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,7 @@ def test_reference_recorded_events_on_the_device(name):
         else:
             assert np.shape(want) == np.shape(got)
             assert np.allclose(got, want, rtol=VALUE_RTOL, atol=VALUE_ATOL), (name, i, kind, np.abs(np.asarray(got) - want).max())
+    check_repins("events", name, replay_events.repinned, len(results))
     model = rec._surrogate_model
     engines = [m.engine for m in model.models] if hasattr(model, "models") else [model.engine]
     assert all(e._handle is not None for e in engines)  # the values came through the C-ABI

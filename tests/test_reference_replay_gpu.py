@@ -7,7 +7,7 @@ in the campaign).  Expected: the recorded index labels, which are the oracle's (
 import numpy as np
 import pytest
 
-from _replay import load_traces, replay
+from _replay import check_repins, load_traces, replay
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,8 @@ def test_reference_recorded_calls_on_the_device(name):
     assert len(results) == len(META[name]) >= 1
     for i, (want, got) in enumerate(results):
         assert want == got, f"{name} call {i}: device picked {got}, the reference run (oracle double) {want}"
+    # calls compared on the RECORDED hyper-parameters (tests/_replay.py::recommend_on_recorded_fit): counted, recorded, allow-listed
+    check_repins("traces", name, replay.repinned, len(results))
     model = rec._surrogate_model
     engines = [m.engine for m in model.models] if hasattr(model, "models") else [model.engine]
     assert all(e._handle is not None for e in engines)  # the picks came through the C-ABI

@@ -198,8 +198,9 @@ def test_bench_starts_its_own_ranks_and_reports_one_json_line():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "candidates/s"
-    assert rec["config"]["global_rows"] == 300000 and rec["value"] > 0 and rec["dtype"] == "f64"
+    # more than one rank: --rows is the GLOBAL grid, split over the ranks (BASELINE configs[2] is one row-sharded grid)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "strong" and rec["unit"] == "candidates/s"
+    assert rec["config"]["global_rows"] == 150000 and rec["value"] > 0 and rec["dtype"] == "f64"
     assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
     assert len(set(rec["extra"]["greedy_q3_indices"])) == 3
     assert rec["extra"]["roofline_pending_kernels"]["launches"] == 2
@@ -208,8 +209,8 @@ def test_bench_starts_its_own_ranks_and_reports_one_json_line():
 def test_bench_under_torchrun_as_the_driver_launches_it():
     """The driver's command for N > 1: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps K --warmup W`` (ranks from RANK / LOCAL_RANK / WORLD_SIZE) - here with both ranks on
-    the one device (BENCH_SINGLE_DEVICE=1, gloo).  One JSON line from rank 0: the weak line, and in ``extra.strong_cfg3`` the
-    strong-scaled configs[2] step (a 1e6-row grid split over the ranks) whose merged top indices equal the single-process ones."""
+    the one device (BENCH_SINGLE_DEVICE=1, gloo).  One JSON line from rank 0: the strong-scaled configs[2] step (a 1e6-row grid split
+    over the ranks) whose merged top indices equal the single-process ones, and in ``extra.weak_cfg3`` the weak-scaled figure."""
     import json
     import subprocess
     import sys
@@ -226,9 +227,12 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["config"]["global_rows"] == 2000000
-    strong = rec["extra"]["strong_cfg3"]
-    assert strong["global_rows"] == 1000000 and strong["rows_per_rank"] == 500000 and strong["scaling"] == "strong" and strong["value"] > 0
+    # the headline for N > 1 IS BASELINE configs[2]: the 1e6-row grid row-sharded; the weak figure sits in extra
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "strong" and rec["config"]["global_rows"] == 1_000_000
+    assert rec["config"]["workload"].startswith("1000000 x 20 discrete grid row-sharded over 2 GPUs (500000 rows")
+    weak = rec["extra"]["weak_cfg3"]
+    assert weak["global_rows"] == 2000000 and weak["rows_per_rank"] == 1000000 and weak["scaling"] == "weak" and weak["value"] > 0
+    strong = {"top_indices": rec["extra"]["top_indices"]}
     single = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--greedy", "0",
                              "--e2e", "0"], cwd=root, env={k: v for k, v in env.items() if k != "BENCH_SINGLE_DEVICE"},
                             capture_output=True, text=True, timeout=900)
@@ -334,7 +338,7 @@ def test_bench_two_gpus_over_the_library_communicator():
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert rec["n_gpus"] == 2 and rec["config"]["collective"] == "rccl (library)" and rec["config"]["global_rows"] == 400000
-    single = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "1", "--warmup", "1", "--rows", "400000", "--cpu-budget",
+    assert rec["n_gpus"] == 2 and rec["config"]["collective"] == "rccl (library)" and rec["config"]["global_rows"] == 200000
+    single = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "1", "--warmup", "1", "--rows", "200000", "--cpu-budget",
                              "0", "--greedy", "0", "--strong"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert single.returncode == 0 and rec["value"] > 0
