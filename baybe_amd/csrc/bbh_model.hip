@@ -592,7 +592,9 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   {
     const size_t b_x = sizeof(double) * xnT.size(), b_t = sizeof(int) * (size_t)np, b_m = sizeof(double) * (size_t)np, b_y = sizeof(double) * (size_t)np;
     const size_t o_x = 0, o_m = o_x + b_x, o_y = o_m + b_m, o_t = o_y + b_y;  // (doubles first: the int block needs no padding behind them)
+    sm_stamp("packed");
     unsigned char* stage = (unsigned char*)bbh_stage_pinned(h, o_t + b_t);
+    sm_stamp("staged");
     if (!stage) {
       (void)hipGetLastError();
       h->err = "bbh_set_model: no pinned staging buffer";
@@ -613,6 +615,7 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     if (rc_stage) return rc_stage;
     // (complete before the call returns, as the synchronous copies were: the handle's stream may be changed before the model is used -
     // bbh_set_stream, the captured-graph stream of BBH_FIT_GRAPH - and the side streams are not ordered behind h->stream)
+    sm_stamp("enqueued");
     BBH_HIP_TRY(h, hipStreamSynchronize(s));
   }
   sm_stamp("copies");

@@ -143,12 +143,13 @@ class _BenchSpace:
         return df[list(self.comp_rep_columns)]
 
 
-def time_recommend_e2e(X, Xt, ys, d, batch, task=None, acquisition_function=None):
+def time_recommend_e2e(X, Xt, ys, d, batch, task=None, acquisition_function=None, measure=None):
     """``recommend(batch)`` of the plug-in recommender on the bench's own grid and measurements, wall clock in ms: the first call
     (comp rep hashed and uploaded, hyper-parameters fitted), a call with unchanged measurements (resident matrix, cached fit: the
     hot path plus the pandas boundary) and a call after one more measurement (refit).  ``ys``: one target column (array) or several
     (list: ParetoObjective -> replicated surrogate + qLogNEHVI, whose baseline pruning runs in EVERY call because the reference builds
-    a new acquisition function per call, acqfs.py:477-484); ``task`` = (task column, number of tasks) for the transfer-learning form."""
+    a new acquisition function per call, acqfs.py:477-484); ``task`` = (task column, number of tasks) for the transfer-learning form;
+    ``measure(rows) -> [target columns]``: the synthetic experiment that "measures" a recommended batch (default: the targets' means)."""
     import pandas as pd
     import torch
     from types import SimpleNamespace
@@ -176,13 +177,19 @@ def time_recommend_e2e(X, Xt, ys, d, batch, task=None, acquisition_function=None
         out[label] = (time.perf_counter() - t0) * 1e3
         return got
 
+    def measured(got):
+        if measure is None:
+            return got.assign(**{nm: float(np.mean(yo)) for nm, yo in zip(names, ys)})
+        vals = measure(got[cols].to_numpy(dtype=np.float64))
+        return got.assign(**{nm: np.asarray(v, dtype=np.float64) for nm, v in zip(names, vals)})
+
     timed("first_call_upload_and_fit", meas)
     timed("unchanged_measurements", meas)
     got = timed("unchanged_measurements_again", meas)
-    more = pd.concat([meas, got.assign(**{nm: float(np.mean(yo)) for nm, yo in zip(names, ys)})], ignore_index=True)
+    more = pd.concat([meas, measured(got)], ignore_index=True)
     timed("after_new_measurements_refit", more)
     got = timed("unchanged_measurements_after_refit", more)
-    more2 = pd.concat([more, got.assign(**{nm: float(np.mean(yo)) for nm, yo in zip(names, ys)})], ignore_index=True)
+    more2 = pd.concat([more, measured(got)], ignore_index=True)
     timed("after_new_measurements_refit_again", more2)
     out["batch_size"] = batch
     out["rows"], out["n_train"], out["targets"] = int(X.shape[0]), int(len(Xt)), len(names)
@@ -654,12 +661,15 @@ def run(args):
         if nehvi is not None:  # configs[4]: three fits + baseline pruning + the greedy batch, per call
             from baybe_amd.acquisition import qLogNoisyExpectedHypervolumeImprovement
 
-            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, ys, d, q_e2e,
+            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, ys, d, q_e2e, measure=synth_pareto_targets,
                                                            acquisition_function=qLogNoisyExpectedHypervolumeImprovement(n_mc_samples=S))
-        elif cfg == "cfg4":  # configs[3]: the ICM / LOO fit is the call
-            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, y, d + 1, q_e2e, task=(d, 4))
+        elif cfg == "cfg4":  # configs[3]: the ICM / LOO fit is the call (the new rows are measurements of the active task 0)
+            extra["recommend_e2e_ms"] = time_recommend_e2e(
+                X, Xt, y, d + 1, q_e2e, task=(d, 4),
+                measure=lambda R: [-((R[:, :d] - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * R[:, 0])])
         else:
-            extra["recommend_e2e_ms"] = time_recommend_e2e(X, Xt, y, d, q_e2e)
+            extra["recommend_e2e_ms"] = time_recommend_e2e(
+                X, Xt, y, d, q_e2e, measure=lambda R: [-((R - 0.5) ** 2).sum(1) + 0.1 * np.sin(2 * np.pi * R[:, 0])])
 
     # ---- roofline of the dominant kernel, algorithmic flops ----
     # PMC-derived L2<->fabric bytes per launch of the dominant kernel for this exact workload: this round's record if one is committed
