@@ -50,6 +50,7 @@ KERNEL_KINDS = {"matern12": 0, "matern32": 1, "matern52": 2, "rbf": 3,
 CRITERIA = {"mll": 0, "loo": 1}
 MAX_PENDING = 15  # pending points per cross-covariance pass / in the handle's pending state (BBH_MAX_PENDING)
 MAX_PENDING_BIG = 63  # joint q'-batches through bbh_qlogei_pending_big: q' = 1 + pending <= 64 (qLogEI)
+MAX_RFF_SAMPLES = 256  # RFFKernel(num_samples): frequencies of the feature-space model (csrc/bbh_rff.hip: m = 2 D <= 512)
 MAX_OBJECTIVES = 4
 TIMED_FAMILIES = {"posterior": 0, "cross": 1, "pending": 2, "columns": 3, "nehvi": 4, "q1": 5, "select": 6}  # enum bbh_timed_family
 ACQ_KINDS = {"qLogEI": 0, "qEI": 1, "qPI": 2, "qSR": 3, "qUCB": 4, "qPSTD": 5,

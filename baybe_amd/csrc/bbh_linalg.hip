@@ -880,6 +880,28 @@ void bbh_potrf_trtri(bbh_handle* h) {
   }
 }
 
+// The same factorisation + inverse on caller-owned buffers (no handle state, no second stream): A [np, np] SPD -> L in its lower part,
+// X [np, np] (zeroed here) -> L^-1, D [np / 64, 64, 64] the inverses of the diagonal blocks, tmp [64, np].  Used by the feature-space
+// system of the RFF kernel beyond two tiles (bbh_rff.hip).
+void bbh_potrf_trtri_buf(hipStream_t s, double* A, int64_t np, double* D, double* X, double* tmp, int* info) {
+  const int64_t nbk = np / 64;
+  hipMemsetAsync(X, 0, sizeof(double) * np * np, s);
+  for (int64_t J = 0; J < nbk; J++) {
+    hipLaunchKernelGGL(bbh_potrf_diag16_kernel, dim3(1), dim3(256), 0, s, A, np, J, D, X, np, info);
+    if (J > 0) {
+      bbh_gemm(s, false, false, 64, 64 * J, 64 * J, 1.0, A + (J * 64) * np, np, 0, X, np, 0, 0.0, tmp, 64 * J, 0, 1);
+      bbh_gemm(s, false, false, 64, 64 * J, 64, -1.0, D + J * 4096, 64, 0, tmp, 64 * J, 0, 0.0, X + (J * 64) * np, np, 0, 1);
+    }
+    const int64_t rem = nbk - J - 1;
+    if (rem > 0) {
+      double* A21 = A + ((J + 1) * 64) * np + J * 64;
+      double* A22 = A + ((J + 1) * 64) * np + (J + 1) * 64;
+      bbh_gemm(s, false, true, rem * 64, 64, 64, 1.0, A21, np, 0, D + J * 4096, 64, 0, 0.0, A21, np, 0, 1);
+      bbh_gemm(s, false, true, rem * 64, rem * 64, 64, -1.0, A21, np, 0, A21, np, 0, 1.0, A22, np, 0, 1);
+    }
+  }
+}
+
 // ---- matvecs -----------------------------------------------------------------------------
 __global__ void bbh_matvec_kernel(const double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols,
                                   const double* __restrict__ x, double* __restrict__ y) {

@@ -17,7 +17,9 @@
 // Candidates never leave feature space either: one kernel featurises a tile of candidates in registers (the A operand of the fp64
 // MFMA), multiplies by sqrt(s2) L^-T (lower-triangular blocks skipped) for the variance and by [a | s2 B^-1 phi_p] for the mean and
 // the pending points' cross-covariances: 2 m^2 / 2 + 2 m 16 flops per candidate instead of n^2.
-// One task, one kernel, MLL, no latent rows; D <= 64.
+// One task, one kernel, MLL, no latent rows.  D <= 64: everything above in two dedicated kernels (one-workgroup m x m solve, fused
+// featurise-and-multiply posterior).  64 < D <= 256 (m up to 512 - round 6): the m x m system goes through the blocked factorisation
+// (bbh_potrf_trtri_buf), candidates through a chunked form - features of 8192 candidates materialised, two GEMMs, a row-sum kernel.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -29,9 +31,12 @@
 #define RFF_TH_OS 2
 #define RFF_TH_LS 3
 #define RFF_MAXDN 64
+#define RFF_MAXD 256
+
+void bbh_potrf_trtri_buf(hipStream_t s, double* A, int64_t np, double* D, double* X, double* tmp, int* info);  // bbh_linalg.hip
 
 struct bbh_rff_state {
-  int D = 0, Dh = 0, mp = 0;  // frequencies; half of the padded feature count (32 | 64); padded feature count 2 Dh
+  int D = 0, Dh = 0, mp = 0;  // frequencies; half of the padded feature count (32 | 64 | 128 | 256); padded feature count 2 Dh
   int64_t nr = 0;             // n rounded up to 64: rows of Phi
   int dn = 0;
   double* d_W = nullptr;      // [dn][Dh] the frequencies as drawn (zero columns beyond D)
@@ -47,6 +52,8 @@ struct bbh_rff_state {
   double* d_Qp = nullptr;     // packed lower block rows of sqrt(s2) L^-T (posterior operand), rff_qp_elems(mp / 16) doubles
   double* d_E = nullptr;      // [mp][16] column 0: a, columns 1..p: s2 B^-1 phi_p of the pending points
   double* d_lo = nullptr;     // [dn] lower scaling bound, [dn] 1 / (hi - lo), then numcol as doubles [dn]
+  double* d_Dg = nullptr;     // m > 128: [mp / 64][64][64] inverses of the diagonal blocks (bbh_potrf_trtri_buf)
+  double* d_tmp = nullptr;    // m > 128: [64][mp] scratch of the blocked inverse
   int* d_info = nullptr;
   std::vector<double> W_host;  // [dn][D] as handed over
 };
@@ -54,7 +61,7 @@ struct bbh_rff_state {
 void bbh_rff_destroy(bbh_handle* h) {
   auto* st = (bbh_rff_state*)h->rff_state;
   if (!st) return;
-  for (double* p : {st->d_W, st->d_wS, st->d_Phi, st->d_B, st->d_Linv, st->d_Binv, st->d_T, st->d_vec, st->d_alpha, st->d_gl, st->d_Qp, st->d_E, st->d_lo})
+  for (double* p : {st->d_W, st->d_wS, st->d_Phi, st->d_B, st->d_Linv, st->d_Binv, st->d_T, st->d_vec, st->d_alpha, st->d_gl, st->d_Qp, st->d_E, st->d_lo, st->d_Dg, st->d_tmp})
     if (p) hipFree(p);
   if (st->d_info) hipFree(st->d_info);
   delete st;
@@ -63,8 +70,8 @@ void bbh_rff_destroy(bbh_handle* h) {
 
 extern "C" int bbh_set_rff_weights(bbh_handle* h, const double* W_host, int32_t dn, int32_t D) {
   if (!h) return -1;
-  if (!W_host || dn < 1 || dn > RFF_MAXDN || D < 1 || D > 64) {
-    h->err = "bbh_set_rff_weights: weights [dn, D] with 1 <= dn <= 64 numerical columns and 1 <= D <= 64 frequencies";
+  if (!W_host || dn < 1 || dn > RFF_MAXDN || D < 1 || D > RFF_MAXD) {
+    h->err = "bbh_set_rff_weights: weights [dn, D] with 1 <= dn <= 64 numerical columns and 1 <= D <= 256 frequencies";
     return -1;
   }
   h->rff_w_host.assign(W_host, W_host + (size_t)dn * D);
@@ -165,39 +172,32 @@ __global__ __launch_bounds__(256) void bbh_rff_solve_kernel(const double* __rest
   store(T0, 0, 1);
 }
 
-// t = L^-1 b, a = L^-T t, log|B| and tr B^-1 over the real features   (one workgroup; vec = b | t | a | scalars)
+// t = L^-1 b, a = L^-T t, log|B| and tr B^-1 over the real features   (one workgroup; vec = b | t | a | scalars; mp <= 512)
 __global__ __launch_bounds__(256) void bbh_rff_vec_kernel(const double* __restrict__ Linv, int mp, int D, int Dh, double* __restrict__ vec) {
-  __shared__ double sb[128], stv[128], red[4];
+  __shared__ double sb[512], stv[512], s_tr[512], s_ld[512];
   const int t = threadIdx.x;
-  if (t < mp) sb[t] = vec[t];
+  for (int r = t; r < mp; r += 256) sb[r] = vec[r];
   __syncthreads();
-  double tr = 0.0, ld = 0.0;
-  if (t < mp) {
-    double acc = 0.0;
-    const bool real = (t % Dh) < D;
-    for (int k = 0; k <= t; k++) {
-      const double v = Linv[(int64_t)t * mp + k];
+  for (int r = t; r < mp; r += 256) {
+    double acc = 0.0, tr = 0.0;
+    const bool real = (r % Dh) < D;
+    for (int k = 0; k <= r; k++) {
+      const double v = Linv[(int64_t)r * mp + k];
       acc = fma(v, sb[k], acc);
       if (real) tr = fma(v, v, tr);  // (rows of padded features are unit vectors; real rows have zeros in padded columns)
     }
-    if (real) ld = -2.0 * log(Linv[(int64_t)t * mp + t]);
-    stv[t] = acc;
-    vec[mp + t] = acc;
+    stv[r] = acc;
+    vec[mp + r] = acc;
+    s_tr[r] = tr;
+    s_ld[r] = real ? -2.0 * log(Linv[(int64_t)r * mp + r]) : 0.0;
   }
   __syncthreads();
-  if (t < mp) {
+  for (int r = t; r < mp; r += 256) {
     double acc = 0.0;
-    for (int o = t; o < mp; o++) acc = fma(Linv[(int64_t)o * mp + t], stv[o], acc);
-    vec[2 * mp + t] = acc;
+    for (int o = r; o < mp; o++) acc = fma(Linv[(int64_t)o * mp + r], stv[o], acc);
+    vec[2 * mp + r] = acc;
   }
-  // fixed-order sums
-  __shared__ double s_tr[128], s_ld[128];
-  if (t < 128) {
-    s_tr[t] = t < mp ? tr : 0.0;
-    s_ld[t] = t < mp ? ld : 0.0;
-  }
-  __syncthreads();
-  if (t == 0) {
+  if (t == 0) {  // fixed-order sums
     double a = 0.0, b = 0.0;
     for (int k = 0; k < mp; k++) {
       a += s_ld[k];
@@ -206,7 +206,14 @@ __global__ __launch_bounds__(256) void bbh_rff_vec_kernel(const double* __restri
     vec[3 * mp + 0] = a;
     vec[3 * mp + 1] = b;
   }
-  (void)red;
+}
+
+// m > 128: the diagonal of B = Phi^T Phi gets eps on the real features and 1 on the padded ones (what bbh_rff_solve_kernel does while loading)
+__global__ void bbh_rff_diag_kernel(double* __restrict__ B, int mp, int D, int Dh, const double* __restrict__ theta, int use_os) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= mp) return;
+  const double eps = theta[RFF_TH_NOISE] / (use_os ? theta[RFF_TH_OS] : 1.0);
+  B[(int64_t)k * mp + k] = ((k % Dh) < D) ? B[(int64_t)k * mp + k] + eps : 1.0;
 }
 
 // alpha = (r - Phi a) / s2   (one wave per training row)
@@ -326,7 +333,7 @@ int bbh_rff_setup(bbh_handle* h) {
   auto* st = new bbh_rff_state;
   h->rff_state = st;
   st->D = h->rff_w_D;
-  st->Dh = st->D <= 32 ? 32 : 64;
+  st->Dh = st->D <= 32 ? 32 : st->D <= 64 ? 64 : st->D <= 128 ? 128 : 256;
   st->mp = 2 * st->Dh;
   st->nr = bbh_round_up(h->n, 64);
   st->dn = h->dn;
@@ -344,7 +351,11 @@ int bbh_rff_setup(bbh_handle* h) {
   RFF_ALLOC(st->d_vec, 3 * mp + 8);
   RFF_ALLOC(st->d_alpha, nr);
   RFF_ALLOC(st->d_gl, (size_t)dn * (size_t)(nr / 64));
-  RFF_ALLOC(st->d_Qp, rff_qp_elems(mp / 16));
+  RFF_ALLOC(st->d_Qp, Dh <= 64 ? rff_qp_elems(mp / 16) : 16);  // (the fused posterior kernel's operand: D <= 64 only)
+  if (Dh > 64) {
+    RFF_ALLOC(st->d_Dg, (size_t)(mp / 64) * 4096);
+    RFF_ALLOC(st->d_tmp, (size_t)64 * mp);
+  }
   RFF_ALLOC(st->d_E, mp * 16);
   RFF_ALLOC(st->d_lo, 3 * dn);
   RFF_ALLOC(st->d_info, 1);
@@ -361,7 +372,7 @@ int bbh_rff_setup(bbh_handle* h) {
   BBH_HIP_TRY(h, hipMemset(st->d_E, 0, sizeof(double) * mp * 16));
   // (per device and cheap: set whenever a model is set up, not once per process)
   BBH_HIP_TRY(h, hipFuncSetAttribute((const void*)bbh_rff_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 4 * 64 * PD_LD)));
-  return rff_posterior_lds_attr(h, st->Dh);
+  return st->Dh <= 64 ? rff_posterior_lds_attr(h, st->Dh) : 0;
 }
 
 __global__ void bbh_rff_resid_kernel(const double* __restrict__ ystd, const double* __restrict__ theta, int n, int64_t nr, double* __restrict__ r) {
@@ -381,8 +392,13 @@ static void bbh_rff_core(bbh_handle* h, bbh_rff_state* st) {
   bbh_gemm(s, true, false, mp, mp, nr, 1.0, st->d_Phi, mp, 0, st->d_Phi, mp, 0, 0.0, st->d_B, mp, 0, 1);  // Phi^T Phi
   bbh_matvec_t(s, st->d_Phi, mp, n, mp, h->d_r, st->d_vec);                                              // b = Phi^T r
   hipMemsetAsync(st->d_info, 0, sizeof(int), s);
-  hipLaunchKernelGGL(bbh_rff_solve_kernel, dim3(1), dim3(256), sizeof(double) * 4 * 64 * PD_LD, s, st->d_B, mp, D, Dh, h->d_theta,
-                     h->desc.use_outputscale, st->d_Linv, st->d_info);
+  if (mp <= 128) {
+    hipLaunchKernelGGL(bbh_rff_solve_kernel, dim3(1), dim3(256), sizeof(double) * 4 * 64 * PD_LD, s, st->d_B, mp, D, Dh, h->d_theta,
+                       h->desc.use_outputscale, st->d_Linv, st->d_info);
+  } else {  // 4 x 4 or 8 x 8 tiles: the blocked factorisation + inverse on the model's own buffers
+    hipLaunchKernelGGL(bbh_rff_diag_kernel, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s, st->d_B, mp, D, Dh, h->d_theta, h->desc.use_outputscale);
+    bbh_potrf_trtri_buf(s, st->d_B, mp, st->d_Dg, st->d_Linv, st->d_tmp, st->d_info);
+  }
   hipLaunchKernelGGL(bbh_rff_vec_kernel, dim3(1), dim3(256), 0, s, st->d_Linv, mp, D, Dh, st->d_vec);
   bbh_gemm(s, true, false, mp, mp, mp, 1.0, st->d_Linv, mp, 0, st->d_Linv, mp, 0, 0.0, st->d_Binv, mp, 0, 1);  // B^-1 = L^-T L^-1
 }
@@ -422,16 +438,25 @@ __global__ void bbh_rff_pack_kernel(const double* __restrict__ Linv, const doubl
   Qp[rff_qp_off(NB, kb) + (k % 16) * rff_qp_pitch(NB, kb) + (o - 16 * kb)] = sqrt(theta[RFF_TH_NOISE]) * Linv[(int64_t)o * mp + k];
 }
 
+__global__ void bbh_rff_ecol0_kernel(const double* __restrict__ avec, int mp, double* __restrict__ E) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < mp) E[k * 16] = avec[k];
+}
+
 // bbh_factorize for the RFF model: theta (host, already validated) -> every posterior operand
 int bbh_rff_factorize(bbh_handle* h) {
   auto* st = (bbh_rff_state*)h->rff_state;
   hipStream_t s = h->stream;
   bbh_rff_core(h, st);
   const int mp = st->mp;
-  BBH_HIP_TRY(h, hipMemsetAsync(st->d_Qp, 0, sizeof(double) * rff_qp_elems(mp / 16), s));
   BBH_HIP_TRY(h, hipMemsetAsync(st->d_E, 0, sizeof(double) * mp * 16, s));
-  hipLaunchKernelGGL(bbh_rff_pack_kernel, dim3((unsigned)((mp * mp + 255) / 256)), dim3(256), 0, s, st->d_Linv, st->d_vec + 2 * mp, h->d_theta, mp, st->d_Qp,
-                     st->d_E);
+  if (st->Dh <= 64) {
+    BBH_HIP_TRY(h, hipMemsetAsync(st->d_Qp, 0, sizeof(double) * rff_qp_elems(mp / 16), s));
+    hipLaunchKernelGGL(bbh_rff_pack_kernel, dim3((unsigned)((mp * mp + 255) / 256)), dim3(256), 0, s, st->d_Linv, st->d_vec + 2 * mp, h->d_theta, mp, st->d_Qp,
+                       st->d_E);
+  } else {  // (the chunked posterior reads L^-1 itself; only the mean column of E is needed)
+    hipLaunchKernelGGL(bbh_rff_ecol0_kernel, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s, st->d_vec + 2 * mp, mp, st->d_E);
+  }
   int info = 0;
   BBH_HIP_TRY(h, hipMemcpyAsync(&info, st->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   BBH_HIP_TRY(h, hipStreamSynchronize(s));
@@ -565,6 +590,76 @@ static int rff_posterior_lds_attr(bbh_handle* h, int Dh) {
 
 static size_t rff_post_lds(int Dh, int dn) { return sizeof(double) * ((size_t)rff_qp_elems(Dh / 8) + (size_t)2 * Dh * 16 + (size_t)dn * Dh + 3 * (size_t)dn); }
 
+__global__ void bbh_rff_features_raw_kernel(const double* __restrict__ X, int64_t ldx, int64_t q, int64_t qpad, const double* __restrict__ lo3,
+                                            const double* __restrict__ wS, int dn, int D, int Dh, double* __restrict__ Fq);
+
+// ---- candidates, 64 < D <= 256: chunked form ---------------------------------------------------------------------------------------
+// var[i] = scale * sum_k V[i][k]^2   (one wave per row, fixed summation order)
+__global__ __launch_bounds__(256) void bbh_rff_rowsq_kernel(const double* __restrict__ V, int mp, int64_t rows, double scale, double* __restrict__ var) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  double s = 0.0;
+  for (int k = lane; k < mp; k += 64) {
+    const double v = V[row * mp + k];
+    s = fma(v, v, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) var[row] = scale * s;
+}
+
+// mean[i] = ybar + ysd (c + Z[i] . E[:, 0]),  cross[i][c - 1] = ysd^2 Z[i] . E[:, c]  for c = 1 .. p   (one wave per row)
+__global__ __launch_bounds__(256) void bbh_rff_me_kernel(const double* __restrict__ Z, const double* __restrict__ E, int mp, int64_t rows, int p,
+                                                         double ybar, double ysd, double cmean, double* __restrict__ mean, double* __restrict__ cross) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c0 = mean ? 0 : 1, c1 = cross ? p : 0;
+  for (int c = c0; c <= c1; c++) {
+    double s = 0.0;
+    for (int k = lane; k < mp; k += 64) s = fma(Z[row * mp + k], E[k * 16 + c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) {
+      if (c == 0)
+        mean[row] = ybar + ysd * (cmean + s);
+      else
+        cross[row * p + (c - 1)] = ysd * ysd * s;
+    }
+  }
+}
+
+static int bbh_rff_posterior_chunked(bbh_handle* h, bbh_rff_state* st, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev,
+                                     double* cross_dev) {
+  // features of a chunk of candidates in global memory, then two GEMM-shaped products: 2 m^2 flops per candidate either way; what the
+  // fused kernel keeps in registers (64 feature values per lane at D = 64) would be 256 per lane at D = 256
+  hipStream_t s = h->stream;
+  const int mp = st->mp, Dh = st->Dh;
+  const int64_t chunk = 8192;
+  int rc = bbh_ensure_ws(h, sizeof(double) * 2 * (size_t)chunk * mp);
+  if (rc) return rc;
+  double* Z = h->d_ws;
+  double* V = Z + chunk * mp;
+  const double s2 = h->theta[RFF_TH_NOISE];
+  bbh_timed_scope scope(h, cross_dev ? BBH_TIMED_CROSS : BBH_TIMED_POSTERIOR);
+  for (int64_t off = 0; off < N; off += chunk) {
+    const int64_t cn = N - off < chunk ? N - off : chunk, cpad = bbh_round_up(cn, 64);
+    hipLaunchKernelGGL(bbh_rff_features_raw_kernel, dim3((unsigned)((cpad * Dh + 255) / 256)), dim3(256), 0, s, X_dev + off * ldx, ldx, cn, cpad, st->d_lo,
+                       st->d_wS, st->dn, st->D, Dh, Z);
+    if (var_dev) {
+      bbh_gemm(s, false, true, cpad, mp, mp, 1.0, Z, mp, 0, st->d_Linv, mp, 0, 0.0, V, mp, 0, 1);  // V = Z L^-T
+      hipLaunchKernelGGL(bbh_rff_rowsq_kernel, dim3((unsigned)((cn + 3) / 4)), dim3(256), 0, s, V, mp, cn, h->ysd * h->ysd * s2, var_dev + off);
+    }
+    if (mean_dev || cross_dev)
+      hipLaunchKernelGGL(bbh_rff_me_kernel, dim3((unsigned)((cn + 3) / 4)), dim3(256), 0, s, Z, st->d_E, mp, cn, h->p, h->ybar, h->ysd,
+                         h->theta[RFF_TH_MEAN], mean_dev ? mean_dev + off : nullptr, cross_dev ? cross_dev + off * h->p : nullptr);
+  }
+  BBH_HIP_TRY(h, hipGetLastError());
+  h->last_form = 6;
+  return 0;
+}
+
 int bbh_rff_posterior_launch(bbh_handle* h, const double* X_dev, int64_t N, int64_t ldx, double* mean_dev, double* var_dev, double* cross_dev) {
   if (N <= 0) return 0;
   auto* st = (bbh_rff_state*)h->rff_state;
@@ -572,6 +667,7 @@ int bbh_rff_posterior_launch(bbh_handle* h, const double* X_dev, int64_t N, int6
     h->err = "RFF model state missing";
     return -1;
   }
+  if (st->Dh > 64) return bbh_rff_posterior_chunked(h, st, X_dev, N, ldx, mean_dev, var_dev, cross_dev);
   RffArgs a;
   a.X = X_dev;
   a.N = N;

@@ -543,11 +543,17 @@ class HipGP:
         fit, over the kernel's active columns -, and kept on a copy of the spec so that copies / re-created handles use the same ones."""
         import copy
 
+        from baybe_amd.exceptions import IncompatibleSurrogateError  # (BayBE's own class where it is importable)
+
         if spec.factors or spec.n_tasks > 1 or spec.task_idx is not None or spec.criterion != "mll":
-            raise ValueError("the RFF kernel is available as the single kernel of a single-task model fitted by its marginal likelihood")
+            raise IncompatibleSurrogateError("On the HIP path the RFF kernel is the single kernel of a single-task model fitted by its "
+                                             "marginal likelihood (alone or in a ScaleKernel).")
         D = int(spec.rff_num_samples or 0)
-        if not 1 <= D <= 64:
-            raise ValueError("rff_num_samples must be in 1..64")
+        if D < 1:
+            raise ValueError("rff_num_samples must be at least 1")  # (kernels/basic.py:183-200 validates the same)
+        if D > _lib.MAX_RFF_SAMPLES:
+            raise IncompatibleSurrogateError(f"RFFKernel(num_samples={D}): the HIP path holds up to {_lib.MAX_RFF_SAMPLES} frequencies "
+                                             f"(a {2 * _lib.MAX_RFF_SAMPLES} x {2 * _lib.MAX_RFF_SAMPLES} feature-space system).")
         mask = spec.active_mask(0)
         d_act = spec.dn if mask is None else int(mask.sum())
         if spec.rff_weights is None:

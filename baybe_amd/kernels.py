@@ -415,8 +415,10 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
                 mname = type(member).__name__
             kind = _basic_kind(member)
             if kind == "rff":
-                raise IncompatibilityError("An RFFKernel inside a Product / Additive kernel is not evaluated on the HIP path (alone or in a "
-                                           "ScaleKernel it is).")
+                from baybe_amd.exceptions import IncompatibleSurrogateError
+
+                raise IncompatibleSurrogateError("An RFFKernel inside a Product / Additive kernel is not evaluated on the HIP path (alone or in a "
+                                                 "ScaleKernel it is).")
             if kind is None:
                 raise IncompatibilityError(
                     f"Kernel '{mname}' inside a {name} is not evaluated on the HIP path (Matern / RBF / RQ / PiecewisePolynomial / "
@@ -435,10 +437,15 @@ def apply_kernel_spec(spec, kernel, searchspace=None):
         )
     spec.kernel = kind
     if kind == "rff":
-        if int(kernel.num_samples) > 64:
-            raise IncompatibilityError(f"RFFKernel(num_samples={kernel.num_samples}): the HIP path holds up to 64 frequencies.")
+        from baybe_amd._lib import MAX_RFF_SAMPLES
+        from baybe_amd.exceptions import IncompatibleSurrogateError
+
+        if int(kernel.num_samples) > MAX_RFF_SAMPLES:
+            raise IncompatibleSurrogateError(f"RFFKernel(num_samples={kernel.num_samples}): the HIP path holds up to {MAX_RFF_SAMPLES} frequencies.")
         if spec.n_tasks > 1 or spec.task_idx is not None:
-            raise IncompatibilityError("An RFFKernel together with a task parameter is not evaluated on the HIP path.")
+            raise IncompatibleSurrogateError("An RFFKernel together with a task parameter (inside the ICM product) is not evaluated on the "
+                                             "HIP path: its model lives in feature space, which the task covariance would multiply by the "
+                                             "number of tasks.")
         spec.rff_num_samples, spec.rff_weights = int(kernel.num_samples), None
     spec.active = _active_mask(spec, kernel, searchspace)
     (spec.ls_constraint, _, spec.ls_prior, spec.ls_init), (spec.alpha_prior, spec.alpha_init) = _ls_fields(kernel, kind)

@@ -923,17 +923,20 @@ def test_rff_kernel_oracle_and_the_feature_space_identities():
 
 def test_rff_kernel_specifications_the_device_does_not_take():
     from baybe_amd import gp_spec
-    from baybe_amd.exceptions import IncompatibilityError
+    from baybe_amd.exceptions import IncompatibleSurrogateError  # BayBE's own type for "this surrogate cannot do that" (exceptions.py:61)
     from baybe_amd.kernels import AdditiveKernel, MaternKernel, RFFKernel, apply_kernel_spec
 
     d = 3
     spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
-    with pytest.raises(IncompatibilityError, match="64 frequencies"):
-        apply_kernel_spec(spec, RFFKernel(65))
-    with pytest.raises(IncompatibilityError, match="inside a"):
+    apply_kernel_spec(spec, RFFKernel(256))  # (round 6: up to 256 frequencies)
+    assert spec.rff_num_samples == 256
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    with pytest.raises(IncompatibleSurrogateError, match="256 frequencies"):
+        apply_kernel_spec(spec, RFFKernel(257))
+    with pytest.raises(IncompatibleSurrogateError, match="inside a"):
         apply_kernel_spec(spec, AdditiveKernel([RFFKernel(5), MaternKernel(2.5)]))
     tl = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=2)
-    with pytest.raises(IncompatibilityError, match="task parameter"):
+    with pytest.raises(IncompatibleSurrogateError, match="task parameter"):
         apply_kernel_spec(tl, RFFKernel(5))
     with pytest.raises((ValueError, TypeError)):
         RFFKernel(0)

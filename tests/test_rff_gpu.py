@@ -55,12 +55,19 @@ def _model(which, d):
         "d33": RFFKernel(33, GammaPrior(3, 2), 0.7),
         "d64": ScaleKernel(RFFKernel(64, GammaPrior(3, 2), 0.8), GammaPrior(2, 0.5)),
         "d20_subset": ScaleKernel(RFFKernel(20, GammaPrior(3, 2), parameter_names=["x0", "x2", "x3"]), GammaPrior(2, 0.5)),
+        # round 6: beyond two feature tiles - m = 2 D up to 512 through the blocked m x m factorisation and the chunked
+        # candidate form; the reference validates only num_samples >= 1 (kernels/basic.py:183-200)
+        "d65": RFFKernel(65, GammaPrior(3, 2), 0.8),
+        "d100": ScaleKernel(RFFKernel(100, GammaPrior(3, 2), 0.8), GammaPrior(2, 0.5)),
+        "d128": RFFKernel(128, GammaPrior(3, 2), 0.7),
+        "d256": ScaleKernel(RFFKernel(256, GammaPrior(3, 2), 0.8), GammaPrior(2, 0.5)),
     }[which]
     apply_kernel_spec(spec, kern, _Space(d))
     return spec
 
 
-@pytest.mark.parametrize("which,n", [("d5", 50), ("d5_scaled", 7), ("d32", 40), ("d33", 150), ("d64", 30), ("d64", 300), ("d20_subset", 90)])
+@pytest.mark.parametrize("which,n", [("d5", 50), ("d5_scaled", 7), ("d32", 40), ("d33", 150), ("d64", 30), ("d64", 300), ("d20_subset", 90),
+                                     ("d65", 60), ("d100", 40), ("d100", 320), ("d128", 200), ("d256", 90), ("d256", 600)])
 def test_rff_kernel_matches_the_oracle(gp, which, n):
     from _problems import oracle_params, oracle_spec
     from baybe_amd import gp_spec
@@ -168,14 +175,25 @@ def test_rff_engine_survives_copies_and_rejects_what_it_cannot_do(gp):
     # latent rows, LOO, task models
     with pytest.raises(HipError, match="latent"):
         gp.set_model(gp.spec, Xt, y, noise_mask=np.r_[np.ones(len(y) - 1), 0].astype(np.uint8))
+    from baybe_amd.exceptions import IncompatibleSurrogateError
+
     bad = copy.copy(spec)
     bad.criterion = "loo"
-    with pytest.raises(ValueError, match="marginal likelihood"):
+    with pytest.raises(IncompatibleSurrogateError, match="marginal likelihood"):
         HipGP(0).set_model(bad, Xt, y)
     big = copy.copy(spec)
-    big.rff_num_samples = 65
-    with pytest.raises(ValueError, match="1..64"):
+    big.rff_num_samples, big.rff_weights = 257, None
+    with pytest.raises(IncompatibleSurrogateError, match="up to 256"):  # BayBE's own exception type, not ValueError
         HipGP(0).set_model(big, Xt, y)
+    # an RFF kernel next to a task parameter or inside a composite: refused with the same type before any device object exists
+    from baybe_amd.kernels import GammaPrior, MaternKernel, ProductKernel, RFFKernel, apply_kernel_spec
+
+    tl = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=3)
+    with pytest.raises(IncompatibleSurrogateError, match="task parameter"):
+        apply_kernel_spec(tl, RFFKernel(8, GammaPrior(3, 1)), _Space(d + 1))
+    with pytest.raises(IncompatibleSurrogateError, match="Product / Additive"):
+        apply_kernel_spec(gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d)),
+                          ProductKernel([MaternKernel(2.5, GammaPrior(3, 1)), RFFKernel(8, GammaPrior(3, 1))]), _Space(d))
 
 
 def test_rff_kernel_through_the_recommender():
