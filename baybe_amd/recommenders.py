@@ -35,6 +35,9 @@ from baybe_amd.exceptions import (
 from baybe_amd.surrogates import HipCompositeImpl, HipGaussianProcessSurrogate, _availability_property
 
 
+MAX_HYBRID_CONTINUOUS = 4  # continuous parameters of a hybrid / continuous space the derivative-free search is validated for
+
+
 def _hash_buffers(bufs) -> int:
     """64-bit content key of a list of byte buffers: the library's host-side multiply-fold hash over 4 MB pieces on native threads
     (``bbh_content_key``).  python-xxhash keeps the GIL, so the "8 threads" of round 4 hashed the 160 MB comp rep of a 1e6 x 20 grid
@@ -127,6 +130,12 @@ def _check_continuous_part(cont) -> None:
                 f"The continuous subspace carries '{name}'; the HIP path searches box-bounded continuous parameters only. "
                 f"Use BotorchRecommender."
             )
+    dc = len(getattr(getattr(cont, "comp_rep_bounds", None), "columns", ()))
+    if dc > MAX_HYBRID_CONTINUOUS:  # (before anything is fitted)
+        raise IncompatibilityError(
+            f"{dc} continuous parameters: the HIP path searches the continuous box derivative-free (Sobol raw samples + pattern "
+            f"search) and is held to the reference's enumeration (optimize_acqf_mixed) for up to {MAX_HYBRID_CONTINUOUS} of them "
+            f"(tests/test_hybrid_gpu.py); use BotorchRecommender, whose gradient optimiser is the tool beyond that.")
 
 
 class HipRecommenderImpl:
@@ -476,12 +485,6 @@ class HipRecommenderImpl:
         # a gradient optimiser per start; this search has only the raw samples and a compass refinement, so the sample count grows
         # with the continuous dimension (512 per dimension) where the row budget allows, and beyond the dimension the
         # search was validated for (tests/test_hybrid_gpu.py: d_c <= 6) it says so
-        if dc > 8:
-            import warnings
-
-            warnings.warn(f"{self.__class__.__name__}: {dc} continuous parameters - the HIP path searches them derivative-free (Sobol raw "
-                          "samples + compass refinement) and is validated up to 6; BotorchRecommender's gradient optimiser is the better "
-                          "tool beyond that.", UserWarning, stacklevel=3)
         R = int(max(1, min(max(self.n_raw_samples, 512 * dc), 4_000_000 // max(Nd, 1))))
         sob = torch.quasirandom.SobolEngine(dimension=max(dc, 1), scramble=True, seed=self._sampler_seed())
         U = sob.draw(R, dtype=torch.float64).numpy()[:, :dc]
