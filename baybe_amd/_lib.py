@@ -173,6 +173,8 @@ SIGNATURES = {
     "bbh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bbh_timing_read": (C.c_int, [C.c_void_p, c_double_p, c_int64_p, C.c_int]),
     "bbh_timing_read_family": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p, C.c_int]),
+    "bbh_flow_trace_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "bbh_tiles_trace_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
 }
 
 

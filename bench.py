@@ -773,6 +773,12 @@ def run(args):
         "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
+        # the timed step of the single-target configurations (posterior + q' = 1 qLogEI + selection) is fp64 throughout; off the headline
+        # two kernel families evaluate their smoothing factors in packed single precision (A/B against the
+        # fp64 form: max |delta score| 1.7e-9; BBH_NEHVI_PK=0 at run time / -DBBH_PENDING_PK=0 at build time select the fp64 forms)
+        "dtype_note": ("fp64 + packed-fp32 smoothing factors (the fat-min / fat-max factors of the qLogNEHVI cell kernel; posterior, "
+                       "conditional means and the log-sum-exp are fp64)" if cfg == "cfg5" else
+                       "fp64 (timed step); extra.greedy_q*: the joint q' >= 2 qLogEI kernels are fp64 + packed-fp32 smoothing factors"),
         "data": "synthetic",
         "config": {
             "workload": {

@@ -421,6 +421,14 @@ enum bbh_timed_family {
 };
 int bbh_timing_read_family(bbh_handle* h, int32_t family, double* ms_total, int64_t* launches, int reset);
 
+/* Diagnostics of the dataflow fit evaluation (declared because the library exports them; scripts/gpu_flow_trace.py,
+ * scripts/gpu_tile_stamps.py).  With BBH_FLOW_TRACE=1 / BBH_TILE_STAMPS=1 in the environment the last launch leaves device clock
+ * stamps behind: bbh_flow_trace_read copies the per-role stamps [nroles][8] and the role table and returns nroles;
+ * bbh_tiles_trace_read the row heads' stamps [tiles][8] of the tile-dataflow factorisation and returns the tile count.  -1 when no
+ * trace exists or cap is too small.  No reference counterpart (baybe has no native code). */
+int bbh_flow_trace_read(bbh_handle* h, long long* stamps_host, int* roles_host, int cap);
+int bbh_tiles_trace_read(bbh_handle* h, long long* stamps_host, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,13 @@ def probe(tag, g, spec):
 
 which = sys.argv[1:] or ["128", "256", "512", "1024", "icm"]
 for w in which:
-    if w == "icm":
+    if w.startswith("icm") and w != "icm":  # e.g. icm1040: the configs[3] model a few measurements later (beyond the dataflow forms: np > 1024)
+        T, d, n = 4, 15, int(w[3:])
+        X, Xt, y = synth_tl_problem(4096, d, -(-n // T), T)
+        Xt, y = Xt[:n], y[:n]
+        spec = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=T)
+        g = engine.HipGP(0); g.set_model(spec, Xt, y); probe(f"icm n={n} d=15+task LOO", g, spec); g.close()
+    elif w == "icm":
         T, d = 4, 15
         X, Xt, y = synth_tl_problem(4096, d, 1024 // T, T)
         spec = gp_spec.GPSpec.baybe_default(d + 1, np.zeros(d + 1), np.ones(d + 1), task_idx=d, n_tasks=T)
