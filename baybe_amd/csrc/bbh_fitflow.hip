@@ -1,4 +1,4 @@
-// One objective evaluation of the hyper-parameter fit as ONE launch for 64 < np <= 1024: Gram tiles -> Cholesky factor and its
+// One objective evaluation of the hyper-parameter fit as ONE launch for 64 < np <= 2048: Gram tiles -> Cholesky factor and its
 // inverse -> K^-1 -> alpha -> criterion value -> gradient sums, as a dataflow of 64 x 64 tile roles handed to persistent
 // workgroups by ticket.  theta is read from, and (value, gradient, Cholesky flag) are written to, host-mapped pinned memory:
 // one launch and one stream synchronisation per evaluation, no copies, no memsets.
@@ -30,7 +30,15 @@
 
 #define FF_MAXD 32
 #define FF_MAXT 4
-#define FF_STRIDE 16  // flag arrays are [16][16]
+#define FF_STRIDE PD_MT_STRIDE  // flag arrays are [32][32]
+#define FF_MAXBLK 32             // block rows the dataflow forms take (np <= 2048); beyond 16 only the one-launch form exists (bbh_potrf_tiles_kernel
+                                // needs every tile co-resident: 16 block rows on 256 CUs)
+#define FF_FLAGS (FF_STRIDE * FF_STRIDE)
+#define FF_MISC_LOGDET 0                  // misc: four per-block-row tables of FF_STRIDE doubles
+#define FF_MISC_QSUM FF_STRIDE
+#define FF_MISC_VALUE (2 * FF_STRIDE)
+#define FF_MISC_MEANG (3 * FF_STRIDE)
+#define FF_COUNTERS (4 * FF_FLAGS + 2 * FF_STRIDE)  // offset of the counters in the flag block: L | X | M | Q | V [2][stride] | counters [8]
 
 enum { FF_RH = 0, FF_L = 1, FF_XT = 2, FF_MT = 3, FF_VEC = 4, FF_QV = 5, FF_QT = 6, FF_GT = 7 };
 
@@ -52,14 +60,14 @@ struct FlowArgs {
   double* u;      // [np] LOO
   double* w;      // [np] LOO
   double* q;      // [np] LOO
-  double* apart;  // [16*16][2][64] alpha partials of the M-tiles
+  double* apart;  // [32*32][2][64] alpha partials of the M-tiles
   double* gpart;  // [nG][nsl] gradient partial rows of the G-tiles
-  double* misc;   // [2 + I] log-determinant partial of row head I, [32 + I] LOO sum of q over block I, [64 + I] value share of block I, [80 + I] mean-gradient share (MLL)
-  int* flagsL;    // [16][16]
+  double* misc;   // FF_MISC_LOGDET + I: log-determinant partial of row head I, _QSUM: LOO sum of q over block I, _VALUE: value share of block I, _MEANG: mean-gradient share (MLL)
+  int* flagsL;    // [32][32]
   int* flagsX;
   int* flagsM;
   int* flagsQ;
-  int* flagsV;    // [I] VEC(I), [16 + I] QV(I)
+  int* flagsV;    // [I] VEC(I), [FF_STRIDE + I] QV(I)
   int* counters;  // [0] tickets, [1] finished M-tiles, [2] finished G-roles, [3] abort word (tail form), [4] finished VEC roles   (cumulative over launches)
   int ticket_base, doneM_base, doneG_base, doneV_base;
   const int* roles;  // [nroles] type | I << 4 | J << 9 | row quarter << 14 | partial-row index << 16   (this launch's part of the table)
@@ -329,7 +337,7 @@ __device__ __forceinline__ bool ff_role_rowhead(const FlowArgs& fa, FlowShared& 
   if (fa.dbg && threadIdx.x == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 6] = wall_clock64();
   if (threadIdx.x < 64) {  // log-determinant partial (the padding's diagonal is 1)
     const double v = ff_wave_sum(log(a[threadIdx.x][threadIdx.x]));
-    if (threadIdx.x == 0) fa.misc[2 + I] = v;
+    if (threadIdx.x == 0) fa.misc[FF_MISC_LOGDET + I] = v;
   }
   pd_store_tile(Aii, fa.np, a, 1.0);
   (void)nbk;
@@ -423,11 +431,8 @@ __device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh, 
   if (!ff_wait_count(&fa.counters[1], fa.doneM_base + fa.nM, fa, !fa.tail_only)) return false;
   const int t = threadIdx.x, i = t >> 2, part = t & 3, g = I * 64 + i;
   double al = 0.0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int B2 = part + 4 * k;
-    if (B2 < fa.nbk) al += (B2 <= I) ? fa.apart[(int64_t)(I * FF_STRIDE + B2) * 128 + i] : fa.apart[(int64_t)(B2 * FF_STRIDE + I) * 128 + 64 + i];
-  }
+  for (int B2 = part; B2 < fa.nbk; B2 += 4)  // (the order of the sum for nbk <= 16 is what it was with the four unrolled steps)
+    al += (B2 <= I) ? fa.apart[(int64_t)(I * FF_STRIDE + B2) * 128 + i] : fa.apart[(int64_t)(B2 * FF_STRIDE + I) * 128 + 64 + i];
   al += __shfl_xor(al, 1, 64);
   al += __shfl_xor(al, 2, 64);
   double v = 0.0, gm = 0.0;
@@ -457,9 +462,9 @@ __device__ __forceinline__ bool ff_role_vec(const FlowArgs& fa, FlowShared& sh, 
   }
   __syncthreads();
   if (t == 0) {
-    fa.misc[64 + I] = (sh.red[0][0] + sh.red[1][0]) + (sh.red[2][0] + sh.red[3][0]);
-    fa.misc[80 + I] = (sh.red[0][1] + sh.red[1][1]) + (sh.red[2][1] + sh.red[3][1]);
-    if (fa.tail_only) fa.misc[2 + I] = 0.0;
+    fa.misc[FF_MISC_VALUE + I] = (sh.red[0][0] + sh.red[1][0]) + (sh.red[2][0] + sh.red[3][0]);
+    fa.misc[FF_MISC_MEANG + I] = (sh.red[0][1] + sh.red[1][1]) + (sh.red[2][1] + sh.red[3][1]);
+    if (fa.tail_only) fa.misc[FF_MISC_LOGDET + I] = 0.0;
   }
   pd_publish(&fa.flagsV[I], fa.epoch);
   if (t == 0) atomicAdd(&fa.counters[4], 1);
@@ -483,9 +488,9 @@ __device__ __forceinline__ bool ff_role_qvec(const FlowArgs& fa, FlowShared& sh,
   __syncthreads();
   if (t < 64) {
     const double s = ff_wave_sum(sh.vr[t]);
-    if (t == 0) fa.misc[32 + I] = s;
+    if (t == 0) fa.misc[FF_MISC_QSUM + I] = s;
   }
-  pd_publish(&fa.flagsV[16 + I], fa.epoch);
+  pd_publish(&fa.flagsV[FF_STRIDE + I], fa.epoch);
   return true;
 }
 
@@ -562,7 +567,7 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
   ff_stage_meta(sh, fa, I, J);
   const bool lz = !fa.tail_only;
   if (!ff_wait(&fa.flagsV[I], fa, false, lz) || (I != J && !ff_wait(&fa.flagsV[J], fa, false, lz))) return false;
-  if (loo && (!ff_wait(&fa.flagsQ[I * FF_STRIDE + J], fa, false, lz) || !ff_wait(&fa.flagsV[16 + I], fa, false, lz) || !ff_wait(&fa.flagsV[16 + J], fa, false, lz))) return false;
+  if (loo && (!ff_wait(&fa.flagsQ[I * FF_STRIDE + J], fa, false, lz) || !ff_wait(&fa.flagsV[FF_STRIDE + I], fa, false, lz) || !ff_wait(&fa.flagsV[FF_STRIDE + J], fa, false, lz))) return false;
   if (fa.dbg && t == 0) fa.dbg[8 * (fa.role_lo + sh.ticket) + 1] = wall_clock64();
   {
     const double* src = (loo ? fa.Q : fa.M) + (int64_t)(I * 64 + 16 * qd) * fa.np + J * 64;
@@ -701,9 +706,9 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
         if (slot == 1) {  // constant mean: sum of alpha (MLL) / of q (LOO)
           tot = 0.0;
           if (loo)
-            for (int B2 = 0; B2 < fa.nbk; B2++) tot += fa.misc[32 + B2];
+            for (int B2 = 0; B2 < fa.nbk; B2++) tot += fa.misc[FF_MISC_QSUM + B2];
           else
-            for (int B2 = 0; B2 < fa.nbk; B2++) tot += fa.misc[80 + B2];
+            for (int B2 = 0; B2 < fa.nbk; B2++) tot += fa.misc[FF_MISC_MEANG + B2];
         }
         fa.out[1 + slot] = tot;
       }
@@ -711,9 +716,9 @@ __device__ __forceinline__ bool ff_role_gtile(const FlowArgs& fa, FlowShared& sh
   }
   if (t == 0) {
     double v = 0.0;
-    for (int B2 = 0; B2 < fa.nbk; B2++) v += fa.misc[64 + B2];
+    for (int B2 = 0; B2 < fa.nbk; B2++) v += fa.misc[FF_MISC_VALUE + B2];
     if (!loo)
-      for (int B2 = 0; B2 < fa.nbk; B2++) v -= fa.misc[2 + B2];
+      for (int B2 = 0; B2 < fa.nbk; B2++) v -= fa.misc[FF_MISC_LOGDET + B2];
     fa.out[0] = v - 0.5 * (double)fa.n * 1.8378770664093453;  // log(2 pi)
     const int inf = __atomic_load_n(fa.info, __ATOMIC_RELAXED);
     *fa.info_out = inf;
@@ -800,9 +805,9 @@ struct bbh_flow_state {
   int nroles = 0, nM = 0, nG = 0, grid = 0;
   int* d_roles = nullptr;
   int* d_flags = nullptr;     // 4 x 256 tile flags + 32 vector flags + 4 counters
-  double* d_apart = nullptr;  // [256][128]
+  double* d_apart = nullptr;  // [FF_FLAGS][128]
   double* d_gpart = nullptr;  // [nG][tl]
-  double* d_misc = nullptr;   // [64]
+  double* d_misc = nullptr;   // [4][FF_STRIDE]
   long long* d_dbg = nullptr; // BBH_FLOW_TRACE=1
   int epoch = 0, ticket_base = 0, doneM_base = 0, doneG_base = 0, doneV_base = 0;
   bool failed = false, tail_only = false, split = false;
@@ -832,7 +837,7 @@ void bbh_flow_mark_failed(bbh_handle* h) {
 bool bbh_fit_flow_eligible(bbh_handle* h) {
   const int64_t np = h->np;
   const bbh_flow_state* st = (const bbh_flow_state*)h->flow_state;
-  return h->fit_flow && np > 64 && np <= 1024 && h->F <= 1 && !h->hadamard && h->dn <= FF_MAXD && h->T <= FF_MAXT && bbh_theta_len(h) <= 49 &&
+  return h->fit_flow && np > 64 && np <= 64 * FF_MAXBLK && h->F <= 1 && !h->hadamard && h->dn <= FF_MAXD && h->T <= FF_MAXT && bbh_theta_len(h) <= 49 &&
          h->desc.kernel_kind != BBH_KERNEL_PERIODIC && !h->fit_graph_mode && !(h->fit_stream && h->stream == h->fit_stream) && !(st && st->failed);
 }
 
@@ -847,7 +852,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   const int64_t np = h->np;
   const int nbk = (int)(np / 64);
   const int64_t tl = bbh_theta_len(h);
-  if (!bbh_fit_flow_eligible(h) || nbk > 16) return false;
+  if (!bbh_fit_flow_eligible(h) || nbk > FF_MAXBLK || (tail_only && nbk > 16)) return false;
   const size_t lds = sizeof(double) * (tail_only ? 2 : 4) * 64 * PD_LD;  // (the roles after the factorisation need two tile buffers: two workgroups per CU)
   bbh_flow_state* st = (bbh_flow_state*)h->flow_state;
   if (st && st->failed) return false;
@@ -900,11 +905,11 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
                           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)bbh_fit_post_kernel, 256, lds_b) == hipSuccess && per_cu_b >= 1)) &&
               hipMalloc((void**)&st->d_roles, sizeof(int) * roles.size()) == hipSuccess &&
               hipMemcpy(st->d_roles, roles.data(), sizeof(int) * roles.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMalloc((void**)&st->d_flags, sizeof(int) * (4 * 256 + 32 + 8)) == hipSuccess &&
-              hipMemset(st->d_flags, 0, sizeof(int) * (4 * 256 + 32 + 8)) == hipSuccess &&
-              hipMalloc((void**)&st->d_apart, sizeof(double) * 256 * 128) == hipSuccess &&
+              hipMalloc((void**)&st->d_flags, sizeof(int) * (FF_COUNTERS + 8)) == hipSuccess &&
+              hipMemset(st->d_flags, 0, sizeof(int) * (FF_COUNTERS + 8)) == hipSuccess &&
+              hipMalloc((void**)&st->d_apart, sizeof(double) * FF_FLAGS * 128) == hipSuccess &&
               hipMalloc((void**)&st->d_gpart, sizeof(double) * (size_t)st->nG * 64) == hipSuccess /* (nG counts the quarter roles) */ &&
-              hipMalloc((void**)&st->d_misc, sizeof(double) * 128) == hipSuccess &&
+              hipMalloc((void**)&st->d_misc, sizeof(double) * 4 * FF_STRIDE) == hipSuccess &&
               // (tail mode: the factorisation already on the stream owns the flag - clearing it here would erase its verdict)
               (tail_only || hipMemset(h->d_info, 0, sizeof(int)) == hipSuccess);
     if (!ok) {
@@ -922,7 +927,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   }
   if (prepare_only) return true;
   if (st->ticket_base > (1 << 30)) {  // cumulative counters: start over long before they wrap
-    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemset(st->d_flags + 4 * 256 + 32, 0, sizeof(int) * 8) != hipSuccess) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemset(st->d_flags + FF_COUNTERS, 0, sizeof(int) * 8) != hipSuccess) {
       st->failed = true;
       return false;
     }
@@ -959,11 +964,11 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   fa.gpart = st->d_gpart;
   fa.misc = st->d_misc;
   fa.flagsL = st->d_flags;
-  fa.flagsX = st->d_flags + 256;
-  fa.flagsM = st->d_flags + 512;
-  fa.flagsQ = st->d_flags + 768;
-  fa.flagsV = st->d_flags + 1024;
-  fa.counters = st->d_flags + 1024 + 32;
+  fa.flagsX = st->d_flags + FF_FLAGS;
+  fa.flagsM = st->d_flags + 2 * FF_FLAGS;
+  fa.flagsQ = st->d_flags + 3 * FF_FLAGS;
+  fa.flagsV = st->d_flags + 4 * FF_FLAGS;
+  fa.counters = st->d_flags + FF_COUNTERS;
   fa.ticket_base = st->ticket_base;
   fa.doneM_base = st->doneM_base;
   fa.doneG_base = st->doneG_base;
@@ -976,7 +981,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   fa.spin = h->flow_spin_limit;
   fa.tail_only = tail_only ? 1 : 0;
   fa.info = h->d_info;
-  fa.abort = tail_only ? st->d_flags + 1024 + 32 + 3 : h->d_info;
+  fa.abort = tail_only ? st->d_flags + FF_COUNTERS + 3 : h->d_info;
   fa.out = out_dev;
   fa.info_out = info_dev;
   if (getenv("BBH_FLOW_TRACE")) {
@@ -993,7 +998,7 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     fb.nroles = st->nroles - st->nA;
     fb.ticket_base = st->ticket_base + st->nA + st->gridA;
     fb.tail_only = 1;
-    fb.abort = st->d_flags + 1024 + 32 + 3;
+    fb.abort = st->d_flags + FF_COUNTERS + 3;
     hipLaunchKernelGGL(bbh_fit_post_kernel, dim3((unsigned)st->gridB), dim3(256), sizeof(double) * 2 * 64 * PD_LD, h->stream, fb);
     if (hipGetLastError() != hipSuccess) {
       st->failed = true;
@@ -1067,7 +1072,7 @@ void bbh_fit_flow_reset(bbh_handle* h) {
   bbh_flow_state* st = (bbh_flow_state*)h->flow_state;
   if (!st) return;
   hipStreamSynchronize(h->stream);
-  if (st->d_flags) hipMemset(st->d_flags, 0, sizeof(int) * (4 * 256 + 32 + 8));
+  if (st->d_flags) hipMemset(st->d_flags, 0, sizeof(int) * (FF_COUNTERS + 8));
   hipMemset(h->d_info, 0, sizeof(int));
   st->ticket_base = st->doneM_base = st->doneG_base = st->doneV_base = 0;
   st->failed = true;
@@ -1090,8 +1095,8 @@ bool bbh_fit_flow_mt_args(bbh_handle* h, void* out) {
   ma->cmean = 0.0;  // (the Gram-building launch has theta in LDS)
   ma->n = (int)h->n;
   ma->loo = h->desc.criterion == BBH_CRITERION_LOO;
-  ma->flagsM = st->d_flags + 512;
-  ma->doneM = st->d_flags + 1024 + 32 + 1;
+  ma->flagsM = st->d_flags + 2 * FF_FLAGS;
+  ma->doneM = st->d_flags + FF_COUNTERS + 1;
   ma->flow_epoch = st->epoch + 1;
   return true;
 }

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void bbh_potrf_tiles_kernel(double* A, int64_t
       (void)pd_mtile_core(a, b, vr, vr + 64, I, J, nbk, D, X, ldx, ma, cmean, wait);
       __syncthreads();  // (consumers run in the next launch: the kernel boundary publishes the tile; the flag and the count only say "done")
       if (threadIdx.x == 0) {
-        __hip_atomic_store(&ma.flagsM[I * 16 + J], ma.flow_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ma.flagsM[I * PD_MT_STRIDE + J], ma.flow_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(ma.doneM, 1);
       }
       return;

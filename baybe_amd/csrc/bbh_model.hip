@@ -684,11 +684,16 @@ static int bbh_fit_enqueue(bbh_handle* h) {
   }
   {  // 64 < np <= 1024: the whole evaluation as one dataflow launch (bbh_fitflow.hip), the same zero-copy staging
     void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
-    if ((h->fit_flow == 2 || h->fit_flow == 3) && h->np > 64 && h->np <= 1024 && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
+    // BBH_FIT_FLOW=2 / 3: this form for every eligible size (A/B).  Default (1): for 1024 < np <= 2048 only - the tile-dataflow
+    // factorisation of the two-launch default needs all its tiles co-resident, which ends at 16 block rows on 256 CUs; the ticketed
+    // roles of the one-launch form have no such requirement (launch by launch an evaluation at np = 1088 was 1.36 ms against 0.46 ms
+    // at np = 1024: profiles/r06_fit_eval_beyond_1024.log)
+    const bool one_launch = (h->fit_flow == 2 || h->fit_flow == 3) ? h->np <= 1024 : (h->fit_flow == 1 && h->np > 1024 && bbh_fit_flow_eligible(h));
+    if (one_launch && h->np > 64 && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
         hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess && hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
       *h->pin_info = -99;  // (sentinel: the kernel's last role writes the flag; a launch that gave up never does)
       // (theta as kernel arguments when it fits: ~250 workgroups fetching it from the host-mapped buffer is the slower way)
-      if (bbh_fit_flow_launch(h, tl <= 52 ? nullptr : (const double*)th_dev, (double*)out_dev, (int*)info_dev, false, h->pin_theta, h->fit_flow == 3)) {
+      if (bbh_fit_flow_launch(h, tl <= 52 ? nullptr : (const double*)th_dev, (double*)out_dev, (int*)info_dev, false, h->pin_theta, h->fit_flow == 3 && h->np <= 1024)) {
         h->flow_in_flight = true;
         return 0;
       }
@@ -698,7 +703,7 @@ static int bbh_fit_enqueue(bbh_handle* h) {
   {  // default for 64 < np <= 1024, zero copies: the tile-dataflow factorisation builds its Gram tiles itself, the dataflow tail reads the
      // factor - theta from, results into the host-mapped staging buffers (two launches)
     void *th_dev = nullptr, *out_dev = nullptr, *info_dev = nullptr;
-    if (h->fit_flow == 1 && h->tile_gram && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
+    if (h->fit_flow == 1 && h->np <= 1024 && h->tile_gram && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&th_dev, h->pin_theta, 0) == hipSuccess &&
         hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess && hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
       // (theta through one H2D copy, not read from the host-mapped buffer by every workgroup: ~100 workgroups fetching it over the
       // host link at the same moment took 30 us - profiles/r05_tile_gram.log)
@@ -736,7 +741,7 @@ static int bbh_fit_enqueue(bbh_handle* h) {
      // (LOO: q, Q), value, gradient pairs, their sums - as ONE dataflow launch writing the results into the pinned buffers
      // (7-10 kernels, a memset and two copies before)
     void *out_dev = nullptr, *info_dev = nullptr;
-    if (h->fit_flow == 1 && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess &&
+    if (h->fit_flow == 1 && h->np <= 1024 && bbh_fit_flow_eligible(h) && hipHostGetDevicePointer(&out_dev, h->pin_out, 0) == hipSuccess &&
         hipHostGetDevicePointer(&info_dev, h->pin_info, 0) == hipSuccess) {
       bbh_launch_gram(h, 0.0, 0.0);
       h->skip_x_memset = true;  // (the tail reads the lower tiles of L^-1 only)

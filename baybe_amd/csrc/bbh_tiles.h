@@ -645,16 +645,17 @@ __device__ __forceinline__ void pd_gemm64(double (*c)[PD_LD], const double (*a)[
 // factorisation's - extra workgroups of bbh_potrf_tiles_kernel: K^-1's tiles are then built while the factorisation runs, as the rows
 // of X appear.  Two LDS tiles for the operands, the sum in MFMA accumulators, the next k-step's operands on their way into registers
 // while this one's MFMAs run.
+#define PD_MT_STRIDE 32  // row pitch of the per-tile tables shared with the dataflow fit evaluation (flagsM, apart): block rows I < 32
 struct pd_mt_args {
   int nM;                // M-tile workgroups appended to the factorisation's grid (0: none)
   double* M;             // [np][ld] lower tiles (LOO: both triangles)
   int64_t ld;
-  double* apart;         // [(I * 16 + J) * 128] alpha partials: row part M_IJ r_J, column part M_IJ^T r_I
+  double* apart;         // [(I * PD_MT_STRIDE + J) * 128] alpha partials: row part M_IJ r_J, column part M_IJ^T r_I
   const double* ystd;    // [np]
   const double* theta;   // null: cmean
   double cmean;          // constant mean (theta[1])
   int n, loo;
-  int* flagsM;           // [I * 16 + J], stamped with flow_epoch
+  int* flagsM;           // [I * PD_MT_STRIDE + J], stamped with flow_epoch
   int* doneM;            // cumulative counter of finished M-tiles
   int flow_epoch;
 };
@@ -750,7 +751,7 @@ __device__ __forceinline__ bool pd_mtile_core(double (*t0)[PD_LD], double (*t1)[
     s2 += __shfl_xor(s2, 1, 64);
     s2 += __shfl_xor(s2, 2, 64);
     if (part == 0) {
-      double* ap = ma.apart + (int64_t)(I * 16 + J) * 128;
+      double* ap = ma.apart + (int64_t)(I * PD_MT_STRIDE + J) * 128;
       ap[row] = s1;
       ap[64 + row] = (I != J) ? s2 : 0.0;
     }

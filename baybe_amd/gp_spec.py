@@ -808,7 +808,11 @@ class FastObjective:
 
     @staticmethod
     def applies(spec: GPSpec) -> bool:
-        return spec.n_tasks == 1 and not spec.factors and not spec.hadamard and not spec.has_subsets and not spec.has_dot_kind and not spec.has_periodic
+        # round 6: also the ICM models of the BAYBE preset (task covariance B = W W^T + diag(v) behind the kernel slots; shared noise and
+        # mean, no unit scaling, no correlation prior) - configs[3]'s fit is ~900 evaluations, 50 us of host each through the general path
+        if spec.n_tasks > 1 and (spec.task_unit_scale or spec.task_prior is not None):
+            return False
+        return not spec.factors and not spec.hadamard and not spec.has_subsets and not spec.has_dot_kind and not spec.has_periodic
 
     def __init__(self, spec: GPSpec, n: int):
         self.n = int(n)
@@ -830,14 +834,19 @@ class FastObjective:
             add(1, 0.0, True, 2, spec.outputscale_prior)
         soft_ls = spec.ls_constraint != "box"
         add(dn, 0.0, soft_ls, 3, spec.ls_prior)
-        if spec.kernel == "rq":
-            add(1, 0.0, True, 3 + dn, None)
+        T = spec.n_tasks if spec.n_tasks > 1 else 0
+        if spec.kernel == "rq":  # (theta: the alpha slot sits behind the task table)
+            add(1, 0.0, True, 3 + dn + T * T, None)
+        self.n_scalar = len(lower)  # raw slots in front of the task factors
+        self.T, self.r = T, int(spec.task_rank or T) if T else 0
+        self.task_soft = T > 0 and spec.task_factor_constraint == "softplus"
+        self.b_off = 3 + dn
         self.lower = np.array(lower, dtype=np.float64)
         self.soft = np.array(transformed, dtype=bool)
         self.any_soft = bool(self.soft.any())
         self.index = np.array(index, dtype=np.int64)
         self.groups = groups
-        self.base = np.zeros(3 + dn + (1 if spec.kernel == "rq" else 0))
+        self.base = np.zeros(3 + dn + T * T + (1 if spec.kernel == "rq" else 0))
         self.base[2] = 1.0
 
     @staticmethod
@@ -854,10 +863,19 @@ class FastObjective:
     def theta(self, raw: np.ndarray):
         """(theta for the device, natural values per raw slot)."""
         nat = np.array(raw, dtype=np.float64)
+        ns = self.n_scalar
         if self.any_soft:
-            nat[self.soft] = self.lower[self.soft] + softplus(nat[self.soft])
+            sc = nat[:ns]
+            sc[self.soft] = self.lower[self.soft] + softplus(sc[self.soft])
         theta = self.base.copy()
-        theta[self.index] = nat
+        theta[self.index] = nat[:ns]
+        if self.T:
+            T, r = self.T, self.r
+            if self.task_soft:
+                nat[ns : ns + T * r] = softplus(nat[ns : ns + T * r])
+            nat[ns + T * r :] = softplus(nat[ns + T * r :])
+            W = nat[ns : ns + T * r].reshape(T, r)
+            theta[self.b_off : self.b_off + T * T] = (W @ W.T + np.diag(nat[ns + T * r :])).reshape(-1)
         return theta, nat
 
     def objective(self, raw: np.ndarray, nat: np.ndarray, value: float, grad_theta: np.ndarray):
@@ -879,5 +897,13 @@ class FastObjective:
                 total += float((const - lx - 0.5 * z * z).sum())
                 g[sl] += (-1.0 - z / b) / x
         if self.any_soft:
-            g[self.soft] *= sigmoid(np.asarray(raw)[self.soft])
+            g[self.soft] *= sigmoid(np.asarray(raw)[: self.n_scalar][self.soft])
+        if self.T:
+            T, r, ns = self.T, self.r, self.n_scalar
+            raw = np.asarray(raw)
+            S = grad_theta[self.b_off : self.b_off + T * T].reshape(T, T)  # dL/dB
+            gW = (S + S.T) @ nat[ns : ns + T * r].reshape(T, r)
+            if self.task_soft:
+                gW = gW * sigmoid(raw[ns : ns + T * r]).reshape(T, r)
+            g = np.concatenate([g, gW.reshape(-1), np.diag(S) * sigmoid(raw[ns + T * r :])])
         return -total / self.n, -g / self.n

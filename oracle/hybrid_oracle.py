@@ -77,12 +77,13 @@ def optimize_acqf_mixed_qlogei(model, D, cb, q: int, seed: int, S: int = 512, si
     d = D.shape[1] + cb.shape[1]
     best_f = go.best_f_from_model(model, sign) if best_f is None else best_f
     base = np.zeros((0, d)) if X_pending is None else np.atleast_2d(X_pending)
-    picks, values, rows = [], [], []
+    chosen = np.zeros((0, d))
+    values, rows = [], []
     for _ in range(q):
-        pend = np.vstack([base] + picks) if picks else base
-        z = go.sobol_normal_base_samples(S, 1 + len(pend), seed)
-        i, c, val, _ = mixed_step(model, D, cb, pend, z, best_f, sign)
-        picks.append(np.concatenate([D[i], c])[None, :])
+        in_batch = np.concatenate([base, chosen], axis=0)  # X_pending of this round: the caller's pending points, then earlier winners
+        z = go.sobol_normal_base_samples(S, 1 + len(in_batch), seed)
+        i, c, val, _ = mixed_step(model, D, cb, in_batch, z, best_f, sign)
+        chosen = np.concatenate([chosen, np.concatenate([D[i], c])[None, :]], axis=0)
         values.append(val)
         rows.append(i)
-    return np.vstack(picks), values, rows
+    return chosen, values, rows

@@ -1093,7 +1093,10 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
              ("rbf", ScaleKernel(RBFKernel(GammaPrior(3, 1)), GammaPrior(2, 0.5)), 8, 130, 1), ("rq", RQKernel(GammaPrior(3, 1)), 4, 200, 1),
              ("m12", MaternKernel(0.5, GammaPrior(3, 1)), 3, 100, 1),
              ("subset", ScaleKernel(MaternKernel(1.5, GammaPrior(3, 1), parameter_names=["x0", "x2", "x3"])), 5, 150, 1),
-             ("icm-loo", None, 15, 256, 4), ("icm-loo", None, 15, 1024, 4), ("icm-mll", None, 6, 200, 3)]
+             ("icm-loo", None, 15, 256, 4), ("icm-loo", None, 15, 1024, 4), ("icm-mll", None, 6, 200, 3),
+             # round 6: 1024 < np <= 2048 - the one-launch form is the default there (its ticketed roles need no co-residency; the
+             # tile-dataflow factorisation of the two-launch form ends at 16 block rows), configs[3] one batch of measurements later
+             ("preset", None, 20, 1088, 1), ("preset", None, 12, 1500, 1), ("icm-loo", None, 15, 1040, 4), ("preset", None, 8, 2048, 1)]
     for tag, kern, d, n, T in cases:
         if T == 1:
             X, Xt, y = make_problem(4096, d, n, seed=100 + n)
@@ -1118,6 +1121,8 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
         # the suffixed forms switch one of these off each; "3": the split form (factorisation + K^-1 as one ticketed launch, then the rest)
         variants = {"0": {}, "1": {}, "2": {}, "3": {}, "1-mt0": {"BBH_TILE_MT": "0"}, "1-gram0": {"BBH_TILE_GRAM": "0"},
                     "1-wt0": {"BBH_TILE_WT": "0"}, "1-copy": {"BBH_TILE_GRAM_THETA": "copy"}}
+        if n > 1024:  # (forms 2 / 3 are A/B switches for np <= 1024; beyond it the default IS the one-launch form)
+            variants = {"0": {}, "1": {}}
         for mode, extra in variants.items():
             monkeypatch.setenv("BBH_FIT_FLOW", mode[0])
             for k_, v_ in extra.items():
@@ -1144,8 +1149,10 @@ def test_fit_evaluation_in_one_launch_matches_the_launch_path(monkeypatch):
         if out["0"][1] is not None:
             f0, f1 = out["0"][1], out["1"][1]
             assert abs(f0.fun - f1.fun) <= 2e-6 * max(1.0, abs(f0.fun)), (tag, f0.fun, f1.fun)
-        print(f"   {tag} d={d} n={n} T={T}: evaluation launch by launch {out['0'][2]:.3f} ms, factorisation + one dataflow launch {out['1'][2]:.3f} ms, "
-              f"one launch {out['2'][2]:.3f} ms")
+        print(f"   {tag} d={d} n={n} T={T}: evaluation launch by launch {out['0'][2]:.3f} ms, default dataflow form {out['1'][2]:.3f} ms"
+              + (f", one launch {out['2'][2]:.3f} ms" if "2" in out else ""))
+        if n > 1024:
+            assert out["1"][2] < 0.8 * out["0"][2], (tag, n, out["0"][2], out["1"][2])  # (it is the dataflow form that ran)
     # a poll budget of zero: the waiting roles give up at once, the launch never reports, the handle falls back to the launch path
     for mode in ("1", "2", "3"):
         monkeypatch.setenv("BBH_FIT_FLOW", mode)

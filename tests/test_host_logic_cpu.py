@@ -302,8 +302,38 @@ def test_fast_objective_equals_the_general_functions_for_every_single_kernel_mod
         f0, g0 = gp_spec.objective_from_data_term(spec, raw, n, val, grad_theta.copy())
         f1, g1 = fast.objective(raw, nat, val, grad_theta.copy())
         assert math.isclose(f0, f1, rel_tol=1e-14, abs_tol=1e-15) and np.allclose(g0, g1, rtol=1e-14, atol=1e-16)
-    tl = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=2)
-    assert not gp_spec.FastObjective.applies(tl)
+    # round 6: the ICM models of the BAYBE preset take the vectorised assembly too (task factors behind the kernel slots); per-task
+    # noise / mean, unit scaling and correlation priors stay on the general functions
+    from baybe_amd.kernels import ICMKernelFactory, IndexKernel, ProductKernel
+
+    class Space:
+        comp_rep_columns = tuple(f"x{j}" for j in range(d - 1)) + ("task",)
+        task_idx, n_tasks = d - 1, 3
+
+    tls = [gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=T) for T in (2, 4)]
+    free = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=3)
+    apply_kernel_spec(free, ProductKernel([IndexKernel(num_tasks=3, rank=2, parameter_names=["task"]), RQKernel(GammaPrior(2, 2))]), Space())
+    for spec in tls + [free]:
+        assert gp_spec.FastObjective.applies(spec)
+        fast = gp_spec.FastObjective(spec, n)
+        import torch
+
+        torch.manual_seed(2)
+        raw = gp_spec.pack_raw(spec, gp_spec.initial_params(spec)) + 0.3 * rng.standard_normal(len(gp_spec.raw_bounds(spec)))
+        for i, (lo, _) in enumerate(gp_spec.raw_bounds(spec)):
+            if lo is not None:
+                raw[i] = lo + abs(raw[i] - lo) + 1e-3
+        theta, nat = fast.theta(raw)
+        ref_theta = gp_spec.theta_from_params(spec, gp_spec.unpack_raw(spec, raw))
+        assert theta.shape == ref_theta.shape and np.allclose(theta, ref_theta, rtol=1e-15, atol=0)
+        val, grad_theta = float(rng.standard_normal()), rng.standard_normal(len(theta))
+        f0, g0 = gp_spec.objective_from_data_term(spec, raw, n, val, grad_theta.copy())
+        f1, g1 = fast.objective(raw, nat, val, grad_theta.copy())
+        assert g0.shape == g1.shape
+        assert math.isclose(f0, f1, rel_tol=1e-14, abs_tol=1e-15) and np.allclose(g0, g1, rtol=1e-13, atol=1e-16)
+    scaled = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d), task_idx=d - 1, n_tasks=2)
+    scaled.task_unit_scale = True
+    assert not gp_spec.FastObjective.applies(scaled)
 
 
 # ---- backtesting driver: lookup semantics (simulation/lookup.py:19-150), no device needed ---------------
