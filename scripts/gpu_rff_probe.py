@@ -45,6 +45,6 @@ def run(tag, kern):
           f"(HIP events; wall {wall:6.3f}) form {g.posterior_kernel_form()}; greedy q = 5: {tg:6.2f} ms", flush=True)
     g.close()
 
-for D in (5, 16, 32, 64):
+for D in (5, 16, 32, 64, 100, 128, 256):  # (beyond 64: the chunked candidate form and the blocked m x m factorisation, round 6)
     run(f"rff D={D}", ScaleKernel(RFFKernel(D, GammaPrior(3, 2)), GammaPrior(2, 0.5)))
 run("rbf (n x n form)", ScaleKernel(RBFKernel(GammaPrior(3, 2)), GammaPrior(2, 0.5)))
