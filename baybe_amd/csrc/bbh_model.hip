@@ -14,6 +14,32 @@
 
 #include "bbh_common.h"
 
+// Up to four byte ranges of a (host-mapped, pinned) staging buffer into their device arrays, and one range cleared: blockIdx.y selects
+// the range, 8 bytes per thread (every range is a multiple of 4 bytes and 8-byte aligned at both ends; the tail is copied as words).
+struct bbh_scatter_args {
+  const unsigned char* src;
+  unsigned char* dst[4];
+  size_t off[4], bytes[4];
+  unsigned char* zero;
+  size_t zero_bytes;
+  int* flag;       // diagnostics (BBH_SETMODEL_TRACE): host-mapped word the kernel stamps when it starts executing
+  int flag_value;
+};
+__global__ __launch_bounds__(256) void bbh_scatter_kernel(const bbh_scatter_args a) {
+  const int r = blockIdx.y;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (a.flag && r == 0 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (r == 4) {
+    if (i + 8 <= a.zero_bytes) *(unsigned long long*)(a.zero + i) = 0ull;
+    return;
+  }
+  if (i + 8 <= a.bytes[r]) {
+    *(unsigned long long*)(a.dst[r] + i) = *(const unsigned long long*)(a.src + a.off[r] + i);
+  } else if (i + 4 <= a.bytes[r]) {
+    *(unsigned int*)(a.dst[r] + i) = *(const unsigned int*)(a.src + a.off[r] + i);
+  }
+}
+
 // (bbh_gfun: bbh_common.h)
 #define TH_NOISE 0
 #define TH_MEAN 1
@@ -435,11 +461,32 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
   }
   BBH_HIP_TRY(h, hipSetDevice(h->device));
   // BBH_SETMODEL_TRACE=1: wall-clock stamps of the stages below on stderr (scripts/gpu_set_model_probe.py)
-  static const bool sm_trace = getenv("BBH_SETMODEL_TRACE") != nullptr;
+  // (=2: the stamps are kept and printed in one piece when the call returns - a write per stage shifts the timing of what follows:
+  // with per-stage prints the call measured 0.2 ms, without them 18 ms, profiles/r06_small_space_latency*.log)
+  static const char* sm_env = getenv("BBH_SETMODEL_TRACE");
+  static const bool sm_trace = sm_env != nullptr, sm_quiet = sm_env && sm_env[0] == '2';
   const auto sm_t0 = std::chrono::steady_clock::now();
+  struct sm_rec { const char* what; double us; };
+  sm_rec sm_log[16];
+  int sm_n = 0;
   auto sm_stamp = [&](const char* what) {
-    if (sm_trace) fprintf(stderr, "bbh_set_model %-10s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - sm_t0).count());
+    if (!sm_trace) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - sm_t0).count();
+    if (sm_quiet) {
+      if (sm_n < 16) sm_log[sm_n++] = {what, us};
+    } else {
+      fprintf(stderr, "bbh_set_model %-10s %8.1f us\n", what, us);
+    }
   };
+  struct sm_flush_t {
+    sm_rec* log; int* n;
+    ~sm_flush_t() {
+      if (*n == 0) return;
+      char buf[1024]; int o = 0;
+      for (int k = 0; k < *n && o < 900; k++) o += snprintf(buf + o, sizeof(buf) - o, " %s %.1f", log[k].what, log[k].us);
+      fprintf(stderr, "bbh_set_model stages (us):%s\n", buf);
+    }
+  } sm_flush{sm_log, &sm_n};
   // A campaign re-fits after every batch of measurements: the model description is the same and the padded size np changes only
   // every 64 measurements.  Then every device buffer keeps its size - freeing and re-allocating ~40 of them (hipFree synchronises
   // the device) was 1 ms of a 6.8 ms small-space recommend().  Buffers are kept when the shape signature is unchanged.
@@ -605,18 +652,60 @@ extern "C" int bbh_set_model_ex(bbh_handle* h, const bbh_model_desc* desc, int64
     memcpy(stage + o_y, ypad.data(), b_y);
     memcpy(stage + o_t, tpad.data(), b_t);
     hipStream_t s = h->stream;
-    BBH_HIP_TRY(h, hipMemsetAsync(h->d_pendT, 0, sizeof(double) * h->dn * 16, s));
-    sm_stamp("memset");
-    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_xnT, stage + o_x, b_x, hipMemcpyHostToDevice, s));
-    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_nmask, stage + o_m, b_m, hipMemcpyHostToDevice, s));
-    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_ystd, stage + o_y, b_y, hipMemcpyHostToDevice, s));
-    BBH_HIP_TRY(h, hipMemcpyAsync(h->d_task, stage + o_t, b_t, hipMemcpyHostToDevice, s));
+    // BBH_SETMODEL_UPLOAD=copy: four hipMemcpyAsync from the staging buffer (copy engine); default: ONE kernel reads the staging buffer
+    // through its device mapping and scatters the four arrays (and clears d_pendT) - no copy-engine command on this path
+    static const char* up_env = getenv("BBH_SETMODEL_UPLOAD");
+    static const char* sync_env = getenv("BBH_SETMODEL_SYNC");
+    void* stage_dev = nullptr;
+    const bool by_kernel = !(up_env && up_env[0] == 'c') && hipHostGetDevicePointer(&stage_dev, stage, 0) == hipSuccess;
+    if (by_kernel) {
+      bbh_scatter_args sa{};
+      sa.src = (const unsigned char*)stage_dev;
+      sa.dst[0] = (unsigned char*)h->d_xnT;   sa.off[0] = o_x; sa.bytes[0] = b_x;
+      sa.dst[1] = (unsigned char*)h->d_nmask; sa.off[1] = o_m; sa.bytes[1] = b_m;
+      sa.dst[2] = (unsigned char*)h->d_ystd;  sa.off[2] = o_y; sa.bytes[2] = b_y;
+      sa.dst[3] = (unsigned char*)h->d_task;  sa.off[3] = o_t; sa.bytes[3] = b_t;
+      sa.zero = (unsigned char*)h->d_pendT;   sa.zero_bytes = sizeof(double) * (size_t)h->dn * 16;
+      const size_t longest = b_x > b_m ? b_x : b_m;
+      static int sm_seq = 0;
+      volatile int* flag_host = nullptr;
+      if (sm_trace && h->pin_info) {  // (the Cholesky flag's pinned word is idle here: borrowed as the kernel's "I am running" stamp)
+        void* fd = nullptr;
+        if (hipHostGetDevicePointer(&fd, h->pin_info, 0) == hipSuccess) {
+          sa.flag = (int*)fd;
+          sa.flag_value = 0x5a000000 | (++sm_seq & 0xffffff);
+          flag_host = h->pin_info;
+        }
+      }
+      hipLaunchKernelGGL(bbh_scatter_kernel, dim3((unsigned)((longest / 8 + 255) / 256), 5), dim3(256), 0, s, sa);
+      sm_stamp("memset");
+      if (flag_host) {  // busy-poll plain memory: when does the GPU actually start the kernel, independent of the runtime's waits?
+        const auto t_poll = std::chrono::steady_clock::now();
+        while (*flag_host != sa.flag_value && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count() < 0.2) {}
+        sm_stamp("kernel-ran");
+      }
+    } else {
+      (void)hipGetLastError();
+      BBH_HIP_TRY(h, hipMemsetAsync(h->d_pendT, 0, sizeof(double) * h->dn * 16, s));
+      sm_stamp("memset");
+      BBH_HIP_TRY(h, hipMemcpyAsync(h->d_xnT, stage + o_x, b_x, hipMemcpyHostToDevice, s));
+      BBH_HIP_TRY(h, hipMemcpyAsync(h->d_nmask, stage + o_m, b_m, hipMemcpyHostToDevice, s));
+      BBH_HIP_TRY(h, hipMemcpyAsync(h->d_ystd, stage + o_y, b_y, hipMemcpyHostToDevice, s));
+      BBH_HIP_TRY(h, hipMemcpyAsync(h->d_task, stage + o_t, b_t, hipMemcpyHostToDevice, s));
+    }
     int rc_stage = bbh_stage_done(h);
     if (rc_stage) return rc_stage;
     // (complete before the call returns, as the synchronous copies were: the handle's stream may be changed before the model is used -
     // bbh_set_stream, the captured-graph stream of BBH_FIT_GRAPH - and the side streams are not ordered behind h->stream)
     sm_stamp("enqueued");
-    BBH_HIP_TRY(h, hipStreamSynchronize(s));
+    if (sync_env && sync_env[0] == 'p') {  // poll
+      hipError_t q;
+      while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+      (void)hipGetLastError();
+    } else if (!(sync_env && sync_env[0] == '0')) {
+      BBH_HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    sm_stamp("synced");
   }
   sm_stamp("copies");
   h->xraw_host.assign(X_train_host, X_train_host + n * d);
