@@ -366,6 +366,15 @@ def run(args):
             torch.cuda.synchronize()
             ts_setup.append((time.perf_counter() - t0) * 1e3)
         extra["nehvi_setup_ms"] = float(np.median(ts_setup))
+        # pruning as every later recommend() pays it (the acquisition function is rebuilt per call, acqfs.py:477-484): a second object's
+        # first prepare - without the process's one-off costs (self-check of the native generator, the engine's direction numbers)
+        nehvi2 = HipNEHVI(engines, np.ones(len(ys)), Xt, ref, n_mc_samples=S, prune_baseline=True, device=local_rank)
+        torch.cuda.synchronize()
+        nehvi2.prepare(1234, prune_seed=4321)
+        torch.cuda.synchronize()
+        extra["nehvi_prune_ms_steady"] = nehvi2.last_setup_ms.get("prune")
+        extra["nehvi_prune_parts_ms_steady"] = {k: round(v, 3) for k, v in getattr(nehvi2, "last_prune_ms", {}).items()}
+        del nehvi2
         extra["nehvi_setup_parts_ms"] = {k: round(v, 3) for k, v in nehvi.last_setup_ms.items()}
         extra["nehvi_baseline_points"] = int(len(nehvi.X_b_current))
         extra["nehvi_cells_per_sample"] = float(nehvi.n_cells) / S
