@@ -523,11 +523,12 @@ class HipGP:
             mask = np.ascontiguousarray(noise_mask, dtype=np.uint8)
             mask_p = mask.ctypes.data_as(C.POINTER(C.c_uint8))
         given, yb, ys = (1, float(standardization[0]), float(standardization[1])) if standardization else (0, 0.0, 1.0)
-        self._check(
-            self._lib.bbh_set_model_ex(self._h, C.byref(desc), X.shape[0], _dp(X), _dp(y), _dp(lo), _dp(hi), mask_p,
-                                       given, yb, ys),
-            "bbh_set_model_ex",
-        )
+        with self._on_thread_stream():  # (the uploads complete inside the call: bbh_set_model_ex synchronises its stream)
+            self._check(
+                self._lib.bbh_set_model_ex(self._h, C.byref(desc), X.shape[0], _dp(X), _dp(y), _dp(lo), _dp(hi), mask_p,
+                                           given, yb, ys),
+                "bbh_set_model_ex",
+            )
         a, b = C.c_double(), C.c_double()
         self._check(self._lib.bbh_get_standardization(self._h, C.byref(a), C.byref(b)), "bbh_get_standardization")
         self.spec, self.n, self.ybar, self.ysd = spec, X.shape[0], a.value, b.value
@@ -588,20 +589,28 @@ class HipGP:
         Like BoTorch's ``_fit_fallback`` the fit is retried (up to ``max_attempts`` times) from
         hyper-parameters re-sampled from their priors when an attempt ends abnormally or at a
         non-finite point; ``ModelFittingError`` is raised when every attempt fails."""
+        with self._on_thread_stream():
+            return self._fit(p0, maxiter, max_attempts)
+
+    @contextlib.contextmanager
+    def _on_thread_stream(self):
+        """Fits side by side (the targets of a CompositeSurrogate, one host thread each): on the handles' default stream - the legacy
+        null stream, ONE queue per device - their evaluations would run one after the other however many threads submit them (round 5:
+        50.6 ms for three fits against 56.6 ms in sequence).  Inside ``private_fit_stream`` the handle enqueues on the thread's private
+        stream for the duration of the block; ``set_model``, every evaluation and the final factorisation end with a synchronisation
+        of that stream, so nothing is in flight on it when the handle goes back to its own."""
         st = getattr(_FIT_TLS, "stream", None)
-        if st is not None:
-            # Fits side by side (the targets of a CompositeSurrogate, one host thread each): on the handles' default stream - the
-            # legacy null stream, ONE queue per device - their evaluations would run one after the other however many threads
-            # submit them (round 5: 50.6 ms for three fits against 56.6 ms in sequence).  For the duration of the fit the handle
-            # enqueues on the thread's private stream; every evaluation ends with a synchronisation of that stream, so nothing is
-            # in flight on it when the handle goes back to its own.
-            prev = getattr(self, "_stream_ptr", 0)
-            self._check(self._lib.bbh_set_stream(self._h, C.c_void_p(int(st.cuda_stream))), "bbh_set_stream")
-            try:
-                return self._fit(p0, maxiter, max_attempts)
-            finally:
-                self._check(self._lib.bbh_set_stream(self._h, C.c_void_p(prev)), "bbh_set_stream")
-        return self._fit(p0, maxiter, max_attempts)
+        if st is None or getattr(self, "_thread_stream_depth", 0) > 0:
+            yield
+            return
+        prev = getattr(self, "_stream_ptr", 0)
+        self._check(self._lib.bbh_set_stream(self._h, C.c_void_p(int(st.cuda_stream))), "bbh_set_stream")
+        self._thread_stream_depth = 1
+        try:
+            yield
+        finally:
+            self._thread_stream_depth = 0
+            self._check(self._lib.bbh_set_stream(self._h, C.c_void_p(prev)), "bbh_set_stream")
 
     def _fit(self, p0, maxiter, max_attempts) -> FitInfo:
         spec = self.spec

@@ -220,6 +220,10 @@ class HipGPSurrogateImpl:
             spec.criterion = criterion
         if self._engine is None:
             self._engine = HipGP(self.device)
+        self._fit_on_engine(spec, train_x, train_y)
+        self._searchspace, self._objective, self._measurements_hash = searchspace, objective, mhash
+
+    def _fit_on_engine(self, spec, train_x, train_y):
         self._engine.set_model(spec, train_x, train_y)
         if self.fixed_hyperparameters is not None:
             self._engine.factorize(self.fixed_hyperparameters)
@@ -238,7 +242,6 @@ class HipGPSurrogateImpl:
                 if prev is None:
                     raise
                 self._fit_info = self._engine.fit()
-        self._searchspace, self._objective, self._measurements_hash = searchspace, objective, mhash
 
     def to_botorch(self):
         raise IncompatibilityError(
