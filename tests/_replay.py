@@ -134,6 +134,9 @@ def check_repins(kind: str, name: str, repinned: list, n_calls: int) -> None:
         if "gap" in e:
             lim = allowed[e["key"]].get("max_gap", 0.0)
             assert 0.0 <= e["gap"] + 1e-12 and e["gap"] <= lim, (kind, name, e, lim)
+        if "max_abs_value_diff_under_the_device_fit" in e:  # read-back values under two valid fits of a flat criterion
+            lim = allowed[e["key"]].get("max_value_diff", 0.0)
+            assert e["max_abs_value_diff_under_the_device_fit"] <= lim, (kind, name, e, lim)
 
 
 def load_traces():
@@ -239,13 +242,34 @@ def replay_events(recommender, events, data):
     out = []
     frames = {}
     repinned = replay_events.repinned = []
+    last_fit = None  # the last recommend event with recorded hyper-parameters: (key, arguments) - what a read-back's model was fitted on
+    pinned_keys = set()
+
+    def values_on_recorded_fit(kind, k, want, got, again):
+        """A read-back follows the model of the last ``recommend``.  Where that model was fitted on a flat criterion (LOO over few points)
+        the device's own fit and the recorded one are different valid end points, and the read-back values differ by what the two fits
+        disagree about - even when both return the same labels.  Then, and only with an allow-list entry, the recorded hyper-parameters are
+        installed (``recommend_on_recorded_fit``: it first holds the device's fit to its objective value) and the read-back is repeated."""
+        got = np.asarray(got, dtype=np.float64)
+        if np.allclose(got, want, rtol=1e-6, atol=1e-8) or last_fit is None or last_fit[0] in pinned_keys:
+            return got
+        fk, args = last_fit
+        diff = float(np.abs(got - want).max())
+        labels = recommend_on_recorded_fit(recommender, data, fk, *args)
+        assert labels == data[fk + "_out"].tolist()
+        pinned_keys.add(fk)
+        repinned.append({"key": fk, "kind": f"values of the {kind} read-back {k}", "max_abs_value_diff_under_the_device_fit": diff})
+        return np.asarray(again(), dtype=np.float64)
+
     for ev in events:
         k, kind = ev["key"], ev["kind"]
         if kind == "posterior_stats":
             cand = pd.DataFrame(data[k + "_cand"], columns=ev["columns"])
             got = recommender._surrogate_model.posterior_stats(cand)
             assert list(got.columns) == ev["stat_columns"]
-            out.append((kind, data[k + "_out"], got.to_numpy(dtype=np.float64)))
+            vals = values_on_recorded_fit(kind, k, data[k + "_out"], got.to_numpy(dtype=np.float64),
+                                          lambda: recommender._surrogate_model.posterior_stats(cand).to_numpy(dtype=np.float64))
+            out.append((kind, data[k + "_out"], vals))
             continue
         comp_values = data[k + "_comp"]
         fkey = (comp_values.shape, comp_values.tobytes())
@@ -262,16 +286,27 @@ def replay_events(recommender, events, data):
         if kind == "recommend":
             got = recommender.recommend(ev["batch_size"], space, objective, meas, pend)
             labels = list(got.index)
+            if f"{k}_raw0" in data.files:
+                last_fit = (k, (ev["batch_size"], space, objective, meas, pend))
             if labels != data[k + "_out"].tolist() and f"{k}_raw0" in data.files:
                 note_repin(repinned, recommender, frames[fkey], data, k, data[k + "_out"].tolist(), labels, space, objective, meas, pend)
                 labels = recommend_on_recorded_fit(recommender, data, k, ev["batch_size"], space, objective, meas, pend)
+                pinned_keys.add(k)
             out.append((kind, data[k + "_out"].tolist(), labels))
         elif kind == "acquisition_values":
             cand = pd.DataFrame(data[k + "_cand"], columns=ev["columns"])
-            got = recommender.acquisition_values(cand, space, objective, meas, pend)
-            out.append((kind, data[k + "_out"], got.to_numpy(dtype=np.float64)))
+
+            def acq_values():
+                torch.set_rng_state(torch.from_numpy(data[k + "_rng"].copy()))
+                return recommender.acquisition_values(cand, space, objective, meas, pend).to_numpy(dtype=np.float64)
+
+            out.append((kind, data[k + "_out"], values_on_recorded_fit(kind, k, data[k + "_out"], acq_values(), acq_values)))
         else:
             cand = pd.DataFrame(data[k + "_cand"], columns=ev["columns"])
-            got = recommender.joint_acquisition_value(cand, space, objective, meas, pend)
-            out.append((kind, data[k + "_out"], np.asarray([float(got)])))
+
+            def joint_value():
+                torch.set_rng_state(torch.from_numpy(data[k + "_rng"].copy()))
+                return np.asarray([float(recommender.joint_acquisition_value(cand, space, objective, meas, pend))])
+
+            out.append((kind, data[k + "_out"], values_on_recorded_fit(kind, k, data[k + "_out"], joint_value(), joint_value)))
     return out
