@@ -463,8 +463,8 @@ bool pd_ledger_reserve(int device, hipStream_t s, int tiles, int cap) {
       std::lock_guard<std::mutex> lk(L.mu);
       int in_flight = 0;
       for (size_t k = 0; k < L.live.size();) {
-        if (L.live[k].stream == s || hipEventQuery(L.live[k].evt) == hipSuccess) {
-          L.spare.push_back(L.live[k].evt);
+        if (L.live[k].stream == s || (L.live[k].evt && hipEventQuery(L.live[k].evt) == hipSuccess)) {
+          if (L.live[k].evt) L.spare.push_back(L.live[k].evt);
           L.live[k] = L.live.back();
           L.live.pop_back();
         } else {
