@@ -983,3 +983,29 @@ def test_qlognehvi_refuses_rff_surrogates_before_touching_a_device():
     engines = [SimpleNamespace(spec=SimpleNamespace(kernel="matern52")), SimpleNamespace(spec=SimpleNamespace(kernel="rff"))]
     with pytest.raises(IncompatibilityError, match="RFFKernel"):
         HipNEHVI(engines, [1.0, 1.0], np.zeros((3, 2)), np.zeros(2))
+
+
+def test_fits_side_by_side_fall_back_to_a_sequence_without_a_device(monkeypatch):
+    """``engine.fit_side_by_side`` (what ``HipCompositeImpl.fit`` runs) needs streams: where no device is visible - the CPU double of the
+    handle in these tests - the jobs run in order on the calling thread; ``BBH_FIT_SIDE_BY_SIDE=0`` forces that everywhere."""
+    import threading
+
+    import torch
+
+    from baybe_amd import engine
+
+    seen = []
+
+    def job(k):
+        def run():
+            seen.append((k, threading.current_thread().name, getattr(engine._FIT_TLS, "stream", None)))
+            return k * k
+        return run
+
+    if not torch.cuda.is_available():
+        assert engine.fit_side_by_side([job(k) for k in range(3)]) == [0, 1, 4]
+        assert [s[0] for s in seen] == [0, 1, 2] and {s[1] for s in seen} == {threading.current_thread().name} and all(s[2] is None for s in seen)
+    seen.clear()
+    monkeypatch.setenv("BBH_FIT_SIDE_BY_SIDE", "0")
+    assert engine.fit_side_by_side([job(k) for k in range(2)]) == [0, 1] and [s[0] for s in seen] == [0, 1]
+    assert engine.fit_side_by_side([]) == [] and engine.fit_side_by_side([job(7)]) == [49]
