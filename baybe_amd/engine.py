@@ -159,11 +159,26 @@ def fit_side_by_side(jobs, device: int = 0):
         _FIT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="bbh-fit")
 
     def run(slot, job):
-        with private_fit_stream(device, slot):
-            return job()
+        _FIT_TLS.no_global_generator = True
+        try:
+            with private_fit_stream(device, slot):
+                return job()
+        finally:
+            _FIT_TLS.no_global_generator = False
 
     futures = [_FIT_POOL.submit(run, k % 4, job) for k, job in enumerate(jobs)]
-    return [f.result() for f in futures]
+    results, rerun = [], False
+    for f in futures:  # (every job is waited for before anything is decided: none may still be running when the sequence starts)
+        try:
+            results.append(f.result())
+        except _FitNeedsTheGlobalGenerator:
+            results.append(None)
+            rerun = True
+    if rerun:
+        # a fit wants torch's global generator: side by side its state would depend on which thread draws first.  Nothing has drawn
+        # from it yet (the parallel attempts started from the deterministic prior modes), so the whole group is fitted again in order
+        return [job() for job in jobs]
+    return results
 
 
 _NATIVE_SOBOL = None  # None: unchecked, True / False after the first use
@@ -332,6 +347,12 @@ class GreedyResult:
 
 class ModelFittingError(RuntimeError):
     """Hyper-parameter fit / factorisation failed (mirrors baybe.exceptions.ModelFittingError)."""
+
+
+class _FitNeedsTheGlobalGenerator(ModelFittingError):
+    """Raised inside ``fit_side_by_side`` by a fit that would have to draw from torch's global generator (a retry from re-sampled
+    hyper-parameters, random start values of a free task factor): the group is then fitted in sequence, so that the generator is
+    consumed in the reference's order (surrogates/composite.py:101-134 fits target by target)."""
 
 
 # Device handles of closed / collected HipGP objects, per device ordinal: a backtesting run creates (and drops) one
@@ -632,7 +653,12 @@ class HipGP:
             return objective_from_data_term(spec, raw, n, val, g, params=p)
 
         last_msg = ""
+        no_rng = bool(getattr(_FIT_TLS, "no_global_generator", False))  # (inside fit_side_by_side: see _FitNeedsTheGlobalGenerator)
+        if no_rng and p0 is None and spec.n_tasks > 1 and getattr(spec, "task_factor_constraint", "softplus") == "none":
+            raise _FitNeedsTheGlobalGenerator("random start values of the task factor")
         for attempt in range(max_attempts):
+            if attempt > 0 and no_rng:
+                raise _FitNeedsTheGlobalGenerator(f"retry after: {last_msg}")
             start = p0 if (attempt == 0 and p0 is not None) else (
                 initial_params(spec) if attempt == 0 else sample_params_from_priors(spec))
             res = lbfgsb_minimize(fun, pack_raw(spec, start), raw_bounds(spec), maxiter)

@@ -1009,3 +1009,42 @@ def test_fits_side_by_side_fall_back_to_a_sequence_without_a_device(monkeypatch)
     monkeypatch.setenv("BBH_FIT_SIDE_BY_SIDE", "0")
     assert engine.fit_side_by_side([job(k) for k in range(2)]) == [0, 1] and [s[0] for s in seen] == [0, 1]
     assert engine.fit_side_by_side([]) == [] and engine.fit_side_by_side([job(7)]) == [49]
+
+
+def test_side_by_side_fits_that_need_the_global_generator_are_redone_in_sequence(monkeypatch):
+    """A retry from re-sampled hyper-parameters (or a free task factor's random start) draws from torch's global generator; side by side
+    the state after the group would depend on thread timing.  Such a fit raises inside the parallel phase - before anything has been
+    drawn - and the whole group is fitted again target by target, as the reference does (surrogates/composite.py:101-134)."""
+    import torch
+
+    from baybe_amd import engine
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+
+    class _NoStream:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(engine, "private_fit_stream", lambda device, slot: _NoStream())
+    calls = []
+
+    def job(k, needs_rng):
+        def run():
+            inside = bool(getattr(engine._FIT_TLS, "no_global_generator", False))
+            calls.append((k, inside))
+            if needs_rng and inside:
+                raise engine._FitNeedsTheGlobalGenerator("retry")
+            return (k, float(torch.rand(1)) if needs_rng else None)
+        return run
+
+    torch.manual_seed(0)
+    want = float(torch.rand(1))
+    torch.manual_seed(0)
+    out = engine.fit_side_by_side([job(0, False), job(1, True), job(2, False)])
+    assert [o[0] for o in out] == [0, 1, 2] and out[1][1] == want  # the draw happened once, in the sequential pass
+    assert sorted(calls[:3]) == [(0, True), (1, True), (2, True)] and calls[3:] == [(0, False), (1, False), (2, False)]
+    calls.clear()
+    assert [o[0] for o in engine.fit_side_by_side([job(0, False), job(1, False)])] == [0, 1] and len(calls) == 2  # (no rerun without need)
