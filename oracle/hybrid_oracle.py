@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE (oracle): restatement of the hybrid-space enumeration of
 ``baybe/recommenders/pure/bayesian/botorch/hybrid.py:30-163`` -> ``botorch.optim.optimize_acqf_mixed`` [UPSTREAM, botorch 0.16.1] for
 qLogEI.  Only ``tests/`` may import this module; the product's hybrid search (``baybe_amd/recommenders.py::_recommend_hybrid``) is
-compared with it by the acquisition value it reaches.
+compared with it by the acquisition value it reaches.  PARITY UNPINNED: botorch is not importable here and the reference's tests hold no
+vectors for this path (tests/hypothesis_strategies / test_searchspace only build hybrid spaces) - ``optimize_acqf_mixed``'s control flow is
+restated from botorch 0.16.1 as recalled; the acquisition arithmetic is ``oracle/gp_oracle.py``'s (its own header says what pins it).
 
 What the reference does (hybrid.py:95-136): every row of the (possibly subsampled) discrete candidate set becomes one
 ``fixed_features`` dictionary; ``optimize_acqf_mixed`` then
