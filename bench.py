@@ -874,10 +874,23 @@ def run(args):
             "cpu_fit_ms": per_eval * nfev_tot, "note": "oracle fit objective (value + autograd gradient) x the device fit's evaluation count"
                                                        + (" (three targets)" if cfg == "cfg5" else ""),
         }
-    if rank == 0:
-        print(json.dumps(out))
+    # The JSON line is the LAST thing on rank 0's stdout: RCCL prints a version banner through C stdio (buffered when stdout is a pipe, so
+    # it used to come out at exit, BEHIND the line); the process group goes first, C stdio is flushed, then the line.
     if dist_on:
+        try:
+            dist.barrier()
+        except Exception:  # noqa: BLE001
+            pass
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
