@@ -271,3 +271,43 @@ def test_fits_side_by_side_equal_fits_in_sequence():
         assert np.array_equal(a.params.lengthscale, b.params.lengthscale) and a.params.noise == b.params.noise
     for g in engines:
         g.close()
+
+
+def test_installed_columns_are_invalidated_not_freed_by_a_refit():
+    """a same-shape ``set_model`` keeps the (N-independent) column buffers of ``bbh_set_mean_columns`` and only
+    invalidates what they hold - ``bbh_posterior_columns`` refuses until new columns are installed, and the re-installed ones give what a
+    fresh handle gives (the refit path has no ``hipFree`` and with it no device-wide synchronisation)."""
+    import torch
+
+    from baybe_amd import engine, gp_spec
+    from baybe_amd.engine import HipError
+
+    rng = np.random.default_rng(4)
+    d, n, S, N = 4, 90, 24, 700
+    X = rng.random((N, d))
+    Xt = rng.random((n, d))
+    y = np.sin(3 * Xt[:, 0]) + Xt[:, 1:].sum(1) + 0.05 * rng.standard_normal(n)
+    spec = gp_spec.GPSpec.baybe_default(d, np.zeros(d), np.ones(d))
+    params = gp_spec.GPParams(np.full(d, 0.6), 0.01, 0.1)
+    Y = y[:, None] + 0.1 * rng.standard_normal((n, S))
+    g = engine.HipGP(0)
+    g.set_model(spec, Xt, y)
+    g.factorize(params)
+    g.set_mean_columns(Y)
+    want = g.posterior_columns(torch.from_numpy(X).cuda()).cpu().numpy()
+    # a refit of the same shape: new measurements, same padded size
+    y2 = y + 0.01
+    g.set_model(spec, Xt, y2)
+    g.factorize(params)
+    with pytest.raises(HipError):
+        g.posterior_columns(torch.from_numpy(X).cuda())  # the old columns belong to the old model
+    g.set_mean_columns(Y)
+    got = g.posterior_columns(torch.from_numpy(X).cuda()).cpu().numpy()
+    fresh = engine.HipGP(0)
+    fresh.set_model(spec, Xt, y2)
+    fresh.factorize(params)
+    fresh.set_mean_columns(Y)
+    ref = fresh.posterior_columns(torch.from_numpy(X).cuda()).cpu().numpy()
+    assert np.array_equal(got, ref) and got.shape == want.shape == (N, S)
+    g.close()
+    fresh.close()
