@@ -468,13 +468,7 @@ class HipRecommenderImpl:
             Dcomp = disc.comp_rep.loc[candidates_exp.index]
             n_keep = int(np.ceil(self.sampling_percentage * len(Dcomp)))
             if self.hybrid_sampler is not None and n_keep < len(Dcomp):
-                name = str(getattr(self.hybrid_sampler, "value", self.hybrid_sampler))
-                if name != "Random":
-                    raise IncompatibilityError("hybrid_sampler='FPS' is not on the HIP path; use 'Random' or sampling_percentage=1.")
-                # (under row shards every rank must draw the same subsample: the agreed sampler seed instead of numpy's global state)
-                pick = (np.random.default_rng(self._sampler_seed()).choice(len(Dcomp), n_keep, replace=False) if self.shard is not None
-                        else np.random.choice(len(Dcomp), n_keep, replace=False))
-                Dcomp = Dcomp.iloc[np.sort(pick)]
+                Dcomp = Dcomp.iloc[self._sample_discrete_rows(Dcomp, n_keep)]
             D = np.ascontiguousarray(Dcomp.to_numpy(dtype=np.float64))
             labels = Dcomp.index
         else:
@@ -513,6 +507,27 @@ class HipRecommenderImpl:
             out_cont.index = rec_disc.index
             return pd.concat([rec_disc, out_cont], axis=1)
         return out_cont
+
+    def _sample_discrete_rows(self, Dcomp: pd.DataFrame, n_keep: int) -> list:
+        """Positions of the discrete rows a hybrid recommendation enumerates: ``sample_numerical_df(candidates_comp, n, method=
+        hybrid_sampler)`` of the reference (botorch/hybrid.py:92-96, utils/sampling_algorithms.py:185-229) - "Random" is pandas' own
+        ``DataFrame.sample`` (numpy's global generator, the same draw as the reference's), "FPS" the reference's
+        ``farthest_point_sampling`` itself where BayBE is importable (the plug-in lives inside it)."""
+        name = str(getattr(self.hybrid_sampler, "value", self.hybrid_sampler))
+        if self.shard is not None:  # row shards: every rank must draw the same subsample - the agreed sampler seed, not a global state
+            if name != "Random":
+                raise IncompatibilityError("hybrid_sampler='FPS' under row shards is not on the HIP path; use 'Random'.")
+            return np.random.default_rng(self._sampler_seed()).choice(len(Dcomp), n_keep, replace=False).tolist()
+        if name == "Random":
+            return Dcomp.reset_index(drop=True).sample(n_keep).index.tolist()
+        if name == "FPS":
+            try:
+                from baybe.utils.sampling_algorithms import farthest_point_sampling  # type: ignore
+            except Exception as ex:  # noqa: BLE001
+                raise IncompatibilityError("hybrid_sampler='FPS' needs BayBE's own farthest_point_sampling (baybe is not importable here); "
+                                           "use 'Random' or sampling_percentage=1.") from ex
+            return list(farthest_point_sampling(Dcomp.to_numpy(), n_keep))
+        raise ValueError(f"Unrecognized sampling method: '{name}'.")
 
     def _mc_or_analytic(self, eng, acqf, X, mean, var, pend, seed, sign):
         if acqf.is_analytic:

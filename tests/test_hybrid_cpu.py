@@ -98,3 +98,23 @@ def test_continuous_space_and_unsupported_constraints(ref):
                                                                                            coefficients=[1.0, 1.0], rhs=1.5)])
     with pytest.raises(IncompatibilityError, match="box-bounded"):
         R().recommend(1, constrained, NumericalTarget("y").to_objective(), meas)
+
+
+@pytest.mark.parametrize("method", ["Random", "FPS"])
+def test_hybrid_subsampling_is_the_references(ref, method):
+    """``hybrid_sampler`` / ``sampling_percentage`` (botorch/hybrid.py:87-96): the discrete rows a hybrid recommendation enumerates are the
+    ones ``baybe.utils.sampling_algorithms.sample_numerical_df`` picks from the same generator state - pandas' ``sample`` for "Random", the
+    reference's own farthest-point sampling for "FPS" (it used to be refused)."""
+    S, C, R, Eng = ref
+    from baybe.utils.sampling_algorithms import DiscreteSamplingMethod, sample_numerical_df
+
+    rng = np.random.default_rng(3)
+    comp = pd.DataFrame(rng.random((40, 3)), columns=["a", "b", "c"], index=pd.RangeIndex(100, 140))
+    rec = R(hybrid_sampler=method, sampling_percentage=0.3)
+    n_keep = int(np.ceil(0.3 * len(comp)))
+    np.random.seed(11)
+    got = comp.iloc[rec._sample_discrete_rows(comp, n_keep)]
+    np.random.seed(11)
+    want = sample_numerical_df(comp, n_keep, method=DiscreteSamplingMethod(method))
+    assert list(got.index) == list(want.index) and np.array_equal(got.to_numpy(), want.to_numpy())
+    assert len(got) == n_keep == 12 and got.index.is_unique
