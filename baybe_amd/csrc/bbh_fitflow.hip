@@ -798,6 +798,10 @@ __global__ __launch_bounds__(256) void bbh_fit_flow_kernel(const FlowArgs fa) { 
 __global__ __launch_bounds__(256, 2) void bbh_fit_tail_kernel(const FlowArgs fa) { ff_kernel_body<1>(fa); }
 __global__ __launch_bounds__(256) void bbh_fit_factor_kernel(const FlowArgs fa) { ff_kernel_body<2>(fa); }
 __global__ __launch_bounds__(256, 2) void bbh_fit_post_kernel(const FlowArgs fa) { ff_kernel_body<3>(fa); }
+// The same roles without the 256-register cap (60 spilled VGPRs, 244 B of scratch per lane in the two-per-CU form): one workgroup per CU,
+// for launches whose roles all find a slot that way (n <= 640: 8 ... 10 VEC roles + 4 G-roles per tile <= 256).
+__global__ __launch_bounds__(256) void bbh_fit_post1_kernel(const FlowArgs fa) { ff_kernel_body<3>(fa); }
+__global__ __launch_bounds__(256) void bbh_fit_tail1_kernel(const FlowArgs fa) { ff_kernel_body<1>(fa); }  // (default since round 6; BBH_FIT_TAIL1=0: the form above)
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 struct bbh_flow_state {
@@ -1030,9 +1034,12 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
   if (skip_mt >= st->nM) {  // the table starts with the nM M-tile roles: begin behind them (their count was added by the factorisation's workgroups)
     int per_cu_b = 0;
     const int nB = st->nroles - st->nA;
+    static const bool post1_ok = !(getenv("BBH_FIT_POST1") && getenv("BBH_FIT_POST1")[0] == '0');  // (A/B)
+    const bool one_per_cu = post1_ok && nB <= h->num_cu;
+    const void* pk = one_per_cu ? (const void*)bbh_fit_post1_kernel : (const void*)bbh_fit_post_kernel;
     if (!st->gridB) {
-      if (hipFuncSetAttribute((const void*)bbh_fit_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)bbh_fit_post_kernel, 256, lds) != hipSuccess || per_cu_b < 1) {
+      if (hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, pk, 256, lds) != hipSuccess || per_cu_b < 1) {
         (void)hipGetLastError();
         return false;
       }
@@ -1041,12 +1048,37 @@ bool bbh_fit_flow_launch(bbh_handle* h, const double* theta_dev, double* out_dev
     fa.roles = st->d_roles + st->nA;
     fa.role_lo = st->nA;
     fa.nroles = nB;
-    hipLaunchKernelGGL(bbh_fit_post_kernel, dim3((unsigned)st->gridB), dim3(256), lds, h->stream, fa);
+    if (one_per_cu)
+      hipLaunchKernelGGL(bbh_fit_post1_kernel, dim3((unsigned)st->gridB), dim3(256), lds, h->stream, fa);
+    else
+      hipLaunchKernelGGL(bbh_fit_post_kernel, dim3((unsigned)st->gridB), dim3(256), lds, h->stream, fa);
     if (hipGetLastError() != hipSuccess) {
       st->failed = true;
       return false;
     }
     st->ticket_base += nB + st->gridB;
+    st->doneM_base += st->nM;
+    st->doneG_base += st->nG;
+    st->doneV_base += nbk;
+    return true;
+  }
+  // one workgroup per CU without the 256-register cap (the two-per-CU form spills 99 VGPRs: 400 B of scratch per lane); measured at
+  // n = 1024: 464 -> 450 us per evaluation, ICM / LOO 552 -> 537 us although its 848 roles then share 256 slots instead of 512
+  // (profiles/r06_fit_eval_post1_tail1.log).  BBH_FIT_TAIL1=0: the two-per-CU form (A/B)
+  static const bool tail1 = !(getenv("BBH_FIT_TAIL1") && getenv("BBH_FIT_TAIL1")[0] == '0');
+  if (tail_only && tail1) {
+    static bool attr1 = false;
+    if (!attr1) {
+      hipFuncSetAttribute((const void*)bbh_fit_tail1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr1 = true;
+    }
+    const int g1 = st->nroles < h->num_cu ? st->nroles : h->num_cu;
+    hipLaunchKernelGGL(bbh_fit_tail1_kernel, dim3((unsigned)g1), dim3(256), lds, h->stream, fa);
+    if (hipGetLastError() != hipSuccess) {
+      st->failed = true;
+      return false;
+    }
+    st->ticket_base += st->nroles + g1;
     st->doneM_base += st->nM;
     st->doneG_base += st->nG;
     st->doneV_base += nbk;
